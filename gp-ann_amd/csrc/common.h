@@ -1,0 +1,120 @@
+// common.h — shared host/device helpers of libgpann_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "../../include/gpann.h"
+
+// All distance arithmetic in this library must be the reference's strict binary32 sequence: no FMA contraction.
+// The translation units are compiled with -ffp-contract=off; this pragma makes it explicit per file as well.
+#pragma clang fp contract(off)
+
+namespace gpann {
+
+constexpr int kWave = 64;
+constexpr uint32_t kNoId = GPANN_NO_ID;
+
+// ---- error plumbing ---------------------------------------------------------------------------------------------
+void SetLastError(const char* fmt, ...);
+
+#define GPANN_HIP_TRY(expr)                                                                                   \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) {                                                                               \
+            ::gpann::SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP;                                 \
+        }                                                                                                     \
+    } while (0)
+
+#define GPANN_REQUIRE(cond, msg)                                                        \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            ::gpann::SetLastError("invalid argument: %s (%s:%d)", msg, __FILE__, __LINE__); \
+            return GPANN_ERR_INVALID;                                                   \
+        }                                                                               \
+    } while (0)
+
+#define GPANN_TRY(expr)                      \
+    do {                                     \
+        gpann_status _s = (expr);            \
+        if (_s != GPANN_OK) return _s;       \
+    } while (0)
+
+gpann_status EnsureDevice(int device);
+
+// Growable device buffer owned by a handle.
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    gpann_status Reserve(size_t need) {
+        if (need <= bytes) return GPANN_OK;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            ptr = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) {
+                SetLastError("hipFree failed: %s", hipGetErrorString(e));
+                return GPANN_ERR_HIP;
+            }
+        }
+        size_t grow = need + need / 8;
+        hipError_t e = hipMalloc(&ptr, grow);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            SetLastError("hipMalloc(%zu bytes) failed: %s", grow, hipGetErrorString(e));
+            return GPANN_ERR_OOM;
+        }
+        bytes = grow;
+        return GPANN_OK;
+    }
+    void Release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(ptr); }
+};
+
+inline uint32_t RoundUp4(uint32_t d) { return (d + 3u) & ~3u; }
+
+// ---- device-side exact distance -----------------------------------------------------------------------------------
+// The reference's scalar sequences (src/dist.cpp:17-37 L2, :42-52 MIPS), one (point,query) pair, rows in global memory.
+// `p` and `q` need only 4-byte alignment here; used by the router walk, rescoring and the small helper kernels.
+template <int METRIC>
+__device__ __forceinline__ float ExactDistance(const float* __restrict__ p, const float* __restrict__ q, uint32_t d) {
+    float result = 0.f;
+    if (METRIC == GPANN_METRIC_L2) {
+        uint32_t i = 0;
+        for (; i + 4 <= d; i += 4) {
+            float d0 = p[i] - q[i];
+            float d1 = p[i + 1] - q[i + 1];
+            float d2 = p[i + 2] - q[i + 2];
+            float d3 = p[i + 3] - q[i + 3];
+            float s = d0 * d0 + d1 * d1;
+            s = s + d2 * d2;
+            s = s + d3 * d3;
+            result = result + s;
+        }
+        for (; i < d; ++i) {
+            float d0 = p[i] - q[i];
+            result = result + d0 * d0;
+        }
+        return result;
+    } else {
+        for (uint32_t i = 0; i < d; ++i) result = result + q[i] * p[i];
+        return 1.0f - result;
+    }
+}
+
+// lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
+__device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
+
+}  // namespace gpann

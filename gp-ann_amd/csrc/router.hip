@@ -1,0 +1,421 @@
+// router.hip — KMeansTreeRouter::Query on the GPU (reference src/kmeans_tree_router.cpp:93-130).
+//
+// Per query the reference runs a best-first walk over S k-means trees: a min-priority queue keyed on centroid distance,
+// every popped node has ALL its centroids evaluated (distance(), src/dist.cpp:75-81), `min_dist[shard]` is lowered and
+// the children of the node are pushed; the walk stops when the distance-evaluation budget is used up.  The result is
+// the shard order by ascending min_dist.
+//
+// Here: one wavefront per query.
+//   * distance evaluation is wave-parallel: the <=64 centroid rows of a node are fetched with coalesced 16-byte loads in
+//     32-dim chunks, transposed through a wave-private LDS tile, and lane i accumulates centroid i with the reference's
+//     exact unfused sequence (same arithmetic as the scan kernel) against the query row held in LDS.
+//   * the priority queue is the reference's std::priority_queue<PQEntry, vector, greater<>>: lane 0 runs libstdc++'s
+//     __push_heap / __adjust_heap index arithmetic (bits/stl_heap.h) on a per-wave array, so the pop order is identical
+//     even among equal keys (e.g. the S roots, all pushed with key lowest(), kmeans_tree_router.cpp:103-110).
+//   * min_dist is returned to the host, where the final std::sort is the same libstdc++ call the reference makes
+//     (:125-127), so the order among equal min_dist (unvisited shards = FLT_MAX) is inherited, not imitated.
+#include "common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <numeric>
+#include <vector>
+
+struct gpann_router {
+    int device = 0;
+    int metric = 0;
+    uint32_t d = 0, ld = 0, S = 0, n_nodes = 0;
+    uint64_t n_centroids = 0;
+    uint32_t max_children = 0;
+    float* centroids = nullptr;          // [n_centroids][ld]
+    int32_t* node_shard = nullptr;
+    uint32_t* node_cent_first = nullptr; // [n_nodes+1]
+    uint32_t* node_child_first = nullptr;
+    uint32_t* node_child_count = nullptr;
+    uint32_t* shard_root = nullptr;
+    gpann::DeviceBuffer ws_queries, ws_heap, ws_out;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace gpann {
+
+constexpr int kRDC = 32;                 // dims per staged chunk
+constexpr int kRStride = kRDC + 4;       // LDS row stride (floats)
+constexpr int kRWaves = 4;               // wavefronts (= queries in flight) per workgroup
+
+struct RouterArgs {
+    const float* centroids;
+    const int32_t* node_shard;
+    const uint32_t* node_cent_first;
+    const uint32_t* node_child_first;
+    const uint32_t* node_child_count;
+    const uint32_t* shard_root;
+    const float* queries;     // [nq][ld]
+    float* heap_key;          // [slots][heap_cap]
+    uint32_t* heap_node;      // [slots][heap_cap]
+    float* out_min_dist;      // [nq][S]
+    uint32_t d, ld, S, nq;
+    uint64_t heap_cap;
+    int32_t budget;
+};
+
+// comp(a, b) of std::greater<PQEntry> with PQEntry::operator> comparing dist only (kmeans_tree_router.cpp:98)
+__device__ __forceinline__ bool HeapComp(float a, float b) { return a > b; }
+
+// libstdc++ std::__push_heap (bits/stl_heap.h:135-148)
+__device__ __forceinline__ void PushHeap(float* key, uint32_t* node, int64_t hole, int64_t top, float vkey, uint32_t vnode) {
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && HeapComp(key[parent], vkey)) {
+        key[hole] = key[parent];
+        node[hole] = node[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    key[hole] = vkey;
+    node[hole] = vnode;
+}
+
+// libstdc++ std::__adjust_heap (bits/stl_heap.h:219-245)
+__device__ __forceinline__ void AdjustHeap(float* key, uint32_t* node, int64_t hole, int64_t len, float vkey, uint32_t vnode) {
+    const int64_t top = hole;
+    int64_t second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (HeapComp(key[second], key[second - 1])) second--;
+        key[hole] = key[second];
+        node[hole] = node[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        key[hole] = key[second - 1];
+        node[hole] = node[second - 1];
+        hole = second - 1;
+    }
+    PushHeap(key, node, hole, top, vkey, vnode);
+}
+
+template <int METRIC>
+__device__ __forceinline__ float TailStep(float r, float pe, float qe) {
+    if (METRIC == GPANN_METRIC_L2) {
+        float d0 = pe - qe;
+        return r + d0 * d0;
+    }
+    return r + qe * pe;
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
+    extern __shared__ float4 rsmem4[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t d = a.d, ld = a.ld, S = a.S;
+    // wave-private LDS: query row [ld] | centroid chunk tile [64][36] | node distances [64] | min_dist [S]
+    const size_t per_wave = (size_t)ld + 64 * kRStride + 64 + S;
+    float* sQ = reinterpret_cast<float*>(rsmem4) + (size_t)wave * ((per_wave + 3) & ~(size_t)3);
+    float* sC = sQ + ld;
+    float* sDist = sC + 64 * kRStride;
+    float* sMin = sDist + 64;
+
+    const uint32_t slot = blockIdx.x * kRWaves + wave;
+    const uint32_t n_slots = gridDim.x * kRWaves;
+    float* hkey = a.heap_key + (size_t)slot * a.heap_cap;
+    uint32_t* hnode = a.heap_node + (size_t)slot * a.heap_cap;
+    const uint32_t full_groups = d >> 2;
+    const int tail = (int)(d & 3u);
+    const uint32_t nchunks = (ld + kRDC - 1) / kRDC;
+
+    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        for (uint32_t c = lane; c < ld; c += 64) sQ[c] = a.queries[(size_t)q * ld + c];
+        for (uint32_t b = lane; b < S; b += 64) sMin[b] = FLT_MAX;   // :101
+        int64_t size = 0;
+        if (lane == 0) {
+            for (uint32_t r = 0; r < S; ++r) {   // :103-110, key = numeric_limits<float>::lowest()
+                PushHeap(hkey, hnode, size, 0, -FLT_MAX, a.shard_root[r]);
+                size++;
+            }
+        }
+        size = S;
+        __builtin_amdgcn_wave_barrier();
+        int32_t budget = a.budget;
+        while (size > 0 && budget > 0) {   // :112
+            uint32_t node = 0;
+            if (lane == 0) {
+                node = hnode[0];   // pq.top()
+                if (size > 1) {    // std::pop_heap
+                    float vk = hkey[size - 1];
+                    uint32_t vn = hnode[size - 1];
+                    hkey[size - 1] = hkey[0];
+                    hnode[size - 1] = hnode[0];
+                    AdjustHeap(hkey, hnode, 0, size - 1, vk, vn);
+                }
+            }
+            size--;
+            node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const uint32_t c_first = a.node_cent_first[node];
+            const uint32_t n = a.node_cent_first[node + 1] - c_first;
+            const uint32_t n_child = a.node_child_count[node];
+            const uint32_t child_first = a.node_child_first[node];
+            const int shard = a.node_shard[node];
+            budget -= (int32_t)n;   // :115
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t m = min(64u, n - base);
+                float acc = 0.f;
+                for (uint32_t ch = 0; ch < nchunks; ++ch) {
+                    // stage [m rows][32 dims] of the node's centroids: lane handles float4 #(lane + 64 i) of 512
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int f = lane + 64 * i;
+                        const uint32_t row = (uint32_t)(f >> 3);
+                        const uint32_t c = ch * kRDC + 4u * (uint32_t)(f & 7);
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row < m && c < ld) v = *reinterpret_cast<const float4*>(a.centroids + (size_t)(c_first + base + row) * ld + c);
+                        *reinterpret_cast<float4*>(sC + row * kRStride + 4 * (f & 7)) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t g0 = ch * (kRDC / 4);
+                    for (int g = 0; g < kRDC / 4; ++g) {
+                        const uint32_t G = g0 + g;
+                        if (G > full_groups || (G == full_groups && tail == 0)) break;
+                        const float4 pv = *reinterpret_cast<const float4*>(sC + lane * kRStride + 4 * g);
+                        const float4 qv = *reinterpret_cast<const float4*>(sQ + 4 * G);
+                        if (G < full_groups) {
+                            if (METRIC == GPANN_METRIC_L2) {
+                                float d0 = pv.x - qv.x, d1 = pv.y - qv.y, d2 = pv.z - qv.z, d3 = pv.w - qv.w;
+                                float s = d0 * d0 + d1 * d1;
+                                s = s + d2 * d2;
+                                s = s + d3 * d3;
+                                acc = acc + s;
+                            } else {
+                                acc = acc + qv.x * pv.x;
+                                acc = acc + qv.y * pv.y;
+                                acc = acc + qv.z * pv.z;
+                                acc = acc + qv.w * pv.w;
+                            }
+                        } else {
+                            if (tail > 0) acc = TailStep<METRIC>(acc, pv.x, qv.x);
+                            if (tail > 1) acc = TailStep<METRIC>(acc, pv.y, qv.y);
+                            if (tail > 2) acc = TailStep<METRIC>(acc, pv.z, qv.z);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                float dist = METRIC == GPANN_METRIC_MIPS ? 1.0f - acc : acc;
+                if ((uint32_t)lane >= m) dist = FLT_MAX;
+                sDist[lane] = dist;
+                // min over the node's centroids (:118; std::min keeps the old value on ties and ignores NaN the same way)
+                float mn = dist;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    if (mn < sMin[shard]) sMin[shard] = mn;
+                    // children of centroids base .. base+m) in centroid order (:119-121)
+                    for (uint32_t i = base; i < base + m && i < n_child; ++i) {
+                        PushHeap(hkey, hnode, size + (int64_t)(i - base), 0, sDist[i - base], child_first + i);
+                    }
+                }
+                if (n_child > base) size += (int64_t)(min(n_child, base + m) - base);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = sMin[b];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace gpann
+
+using namespace gpann;
+
+extern "C" {
+
+gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_nodes, const int32_t* node_shard,
+                                 const uint32_t* node_cent_first, const uint32_t* node_child_first, const uint32_t* node_child_count,
+                                 const uint32_t* shard_root, const float* centroids, int device, gpann_router** out) {
+    GPANN_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    GPANN_REQUIRE(d > 0 && S > 0 && n_nodes >= S, "d, S must be positive and n_nodes >= S");
+    GPANN_REQUIRE(node_shard && node_cent_first && node_child_first && node_child_count && shard_root && centroids, "null tree array");
+    GPANN_REQUIRE(metric == GPANN_METRIC_L2 || metric == GPANN_METRIC_MIPS, "unknown metric");
+    GPANN_REQUIRE(node_cent_first[0] == 0, "node_cent_first[0] must be 0");
+    uint32_t max_children = 0;
+    for (uint32_t u = 0; u < n_nodes; ++u) {
+        GPANN_REQUIRE(node_cent_first[u] <= node_cent_first[u + 1], "node_cent_first not monotone");
+        GPANN_REQUIRE(node_shard[u] >= 0 && (uint32_t)node_shard[u] < S, "node_shard out of range");
+        const uint32_t nc = node_cent_first[u + 1] - node_cent_first[u];
+        GPANN_REQUIRE(node_child_count[u] <= nc, "a node has more children than centroids");
+        GPANN_REQUIRE(node_child_count[u] == 0 || (uint64_t)node_child_first[u] + node_child_count[u] <= n_nodes, "child index out of range");
+        max_children = std::max(max_children, node_child_count[u]);
+    }
+    for (uint32_t b = 0; b < S; ++b) GPANN_REQUIRE(shard_root[b] < n_nodes, "shard_root out of range");
+    GPANN_TRY(EnsureDevice(device));
+
+    auto* r = new gpann_router();
+    r->device = device;
+    r->metric = metric;
+    r->d = d;
+    r->ld = RoundUp4(d);
+    r->S = S;
+    r->n_nodes = n_nodes;
+    r->n_centroids = node_cent_first[n_nodes];
+    r->max_children = max_children;
+    auto fail = [&](gpann_status st) {
+        gpann_router_destroy(r);
+        return st;
+    };
+#define TRY_OR_FAIL(expr)                                                                            \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return fail(_e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP);                  \
+        }                                                                                            \
+    } while (0)
+    const size_t nc = r->n_centroids;
+    TRY_OR_FAIL(hipMalloc(&r->centroids, std::max<size_t>(nc * r->ld * sizeof(float), 256)));
+    TRY_OR_FAIL(hipMalloc(&r->node_shard, n_nodes * 4));
+    TRY_OR_FAIL(hipMalloc(&r->node_cent_first, (n_nodes + 1) * 4));
+    TRY_OR_FAIL(hipMalloc(&r->node_child_first, n_nodes * 4));
+    TRY_OR_FAIL(hipMalloc(&r->node_child_count, n_nodes * 4));
+    TRY_OR_FAIL(hipMalloc(&r->shard_root, S * 4));
+    if (r->ld != d) TRY_OR_FAIL(hipMemset(r->centroids, 0, nc * r->ld * sizeof(float)));
+    if (nc) TRY_OR_FAIL(hipMemcpy2D(r->centroids, (size_t)r->ld * 4, centroids, (size_t)d * 4, (size_t)d * 4, nc, hipMemcpyHostToDevice));
+    TRY_OR_FAIL(hipMemcpy(r->node_shard, node_shard, n_nodes * 4, hipMemcpyHostToDevice));
+    TRY_OR_FAIL(hipMemcpy(r->node_cent_first, node_cent_first, (n_nodes + 1) * 4, hipMemcpyHostToDevice));
+    TRY_OR_FAIL(hipMemcpy(r->node_child_first, node_child_first, n_nodes * 4, hipMemcpyHostToDevice));
+    TRY_OR_FAIL(hipMemcpy(r->node_child_count, node_child_count, n_nodes * 4, hipMemcpyHostToDevice));
+    TRY_OR_FAIL(hipMemcpy(r->shard_root, shard_root, S * 4, hipMemcpyHostToDevice));
+    for (auto& e : r->ev) TRY_OR_FAIL(hipEventCreate(&e));
+#undef TRY_OR_FAIL
+    *out = r;
+    return GPANN_OK;
+}
+
+gpann_status gpann_router_destroy(gpann_router* r) {
+    if (!r) return GPANN_OK;
+    (void)hipSetDevice(r->device);
+    for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
+                    (void*)r->node_child_count, (void*)r->shard_root})
+        if (p) (void)hipFree(p);
+    r->ws_queries.Release();
+    r->ws_heap.Release();
+    r->ws_out.Release();
+    for (auto& e : r->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete r;
+    return GPANN_OK;
+}
+
+gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
+                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
+    GPANN_TRY(EnsureDevice(r->device));
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (nq == 0) return GPANN_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t S = r->S, ld = r->ld;
+
+    const size_t qbytes = (size_t)nq * ld * sizeof(float);
+    GPANN_TRY(r->ws_queries.Reserve(qbytes));
+    if (ld != r->d) GPANN_HIP_TRY(hipMemsetAsync(r->ws_queries.ptr, 0, qbytes, st));
+    GPANN_HIP_TRY(hipMemcpy2DAsync(r->ws_queries.ptr, (size_t)ld * 4, queries, (size_t)r->d * 4, (size_t)r->d * 4, nq,
+                                   (flags & GPANN_QUERIES_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+
+    // every node enters the queue at most once (when its parent is popped), so n_nodes bounds the queue; so does
+    // S + (#pops <= budget) * max_children
+    uint64_t cap = r->n_nodes;
+    if (budget > 0) cap = std::min<uint64_t>(cap, (uint64_t)S + (uint64_t)budget * std::max<uint32_t>(1, r->max_children));
+    cap = std::max<uint64_t>(cap, S);
+    const size_t per_wave_lds = (((size_t)ld + 64 * kRStride + 64 + S) + 3) & ~(size_t)3;
+    const size_t lds = per_wave_lds * kRWaves * sizeof(float);
+    if (lds > 160 * 1024) {
+        SetLastError("router needs %zu bytes of LDS per workgroup (d = %u, S = %u): unsupported", lds, r->d, S);
+        return GPANN_ERR_UNSUPPORTED;
+    }
+    hipDeviceProp_t prop;
+    GPANN_HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+    uint32_t grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * blocks_per_cu);
+    // keep the queue workspace bounded (<= 4 GiB)
+    while (grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
+    const uint64_t slots = (uint64_t)grid * kRWaves;
+    GPANN_TRY(r->ws_heap.Reserve(slots * cap * 8));
+    GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
+
+    RouterArgs a;
+    a.centroids = r->centroids;
+    a.node_shard = r->node_shard;
+    a.node_cent_first = r->node_cent_first;
+    a.node_child_first = r->node_child_first;
+    a.node_child_count = r->node_child_count;
+    a.shard_root = r->shard_root;
+    a.queries = r->ws_queries.as<float>();
+    a.heap_key = r->ws_heap.as<float>();
+    a.heap_node = reinterpret_cast<uint32_t*>(a.heap_key + slots * cap);
+    a.out_min_dist = r->ws_out.as<float>();
+    a.d = r->d;
+    a.ld = ld;
+    a.S = S;
+    a.nq = nq;
+    a.heap_cap = cap;
+    a.budget = budget;
+    GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
+    if (r->metric == GPANN_METRIC_L2)
+        hipLaunchKernelGGL(RouterWalkKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64 * kRWaves), lds, st, a);
+    else
+        hipLaunchKernelGGL(RouterWalkKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64 * kRWaves), lds, st, a);
+    GPANN_HIP_TRY(hipGetLastError());
+    GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
+
+    std::vector<float> local_min;
+    float* md = out_min_dist;
+    if (!md) {
+        local_min.resize((size_t)nq * S);
+        md = local_min.data();
+    }
+    GPANN_HIP_TRY(hipMemcpyAsync(md, a.out_min_dist, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
+
+    if (out_probes) {
+        // kmeans_tree_router.cpp:125-127 — the reference's own call, on the GPU-computed min_dist
+        std::vector<int> probes(S);
+        for (uint32_t q = 0; q < nq; ++q) {
+            const float* min_dist = md + (size_t)q * S;
+            std::iota(probes.begin(), probes.end(), 0);
+            std::sort(probes.begin(), probes.end(), [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
+            std::copy(probes.begin(), probes.end(), out_probes + (size_t)q * S);
+        }
+    }
+    return GPANN_OK;
+}
+
+// DedupNeighbors (small_scale_queries.cpp:15-23) over per-slot result lists; host-side, libstdc++ sorts as the reference.
+gpann_status gpann_merge_dedup(const float* in_dist, const uint32_t* in_ids, uint32_t nq, uint32_t nprobe, uint32_t nprobe_used, uint32_t k,
+                               float* out_dist, uint32_t* out_ids, uint32_t* out_count) {
+    GPANN_REQUIRE(nq == 0 || (in_dist && in_ids && out_dist && out_ids), "null argument");
+    GPANN_REQUIRE(nprobe_used <= nprobe, "nprobe_used > nprobe");
+    std::vector<std::pair<float, uint32_t>> n;
+    for (uint32_t q = 0; q < nq; ++q) {
+        n.clear();
+        for (uint32_t j = 0; j < nprobe_used; ++j)
+            for (uint32_t x = 0; x < k; ++x) {
+                const size_t idx = ((size_t)q * nprobe + j) * k + x;
+                if (in_ids[idx] != GPANN_NO_ID) n.emplace_back(in_dist[idx], in_ids[idx]);
+            }
+        std::sort(n.begin(), n.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
+        n.erase(std::unique(n.begin(), n.end()), n.end());
+        std::sort(n.begin(), n.end());
+        n.resize(std::min<size_t>(n.size(), k));
+        for (uint32_t x = 0; x < k; ++x) {
+            out_dist[(size_t)q * k + x] = x < n.size() ? n[x].first : std::numeric_limits<float>::infinity();
+            out_ids[(size_t)q * k + x] = x < n.size() ? n[x].second : GPANN_NO_ID;
+        }
+        if (out_count) out_count[q] = (uint32_t)n.size();
+    }
+    return GPANN_OK;
+}
+
+}  // extern "C"

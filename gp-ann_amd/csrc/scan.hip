@@ -1,0 +1,732 @@
+// scan.hip — the per-shard exact distance scan with top-k selection (gfx950).
+//
+// Replaces the reference's brute-force loops  InvertedIndex::QueryBucket / Query (src/inverted_index.h:43-75) and
+// ComputeGroundTruth (src/recall.h:25-39):  for one query, stream every row of a shard, evaluate distance(), keep the
+// k lexicographically smallest (distance, row) pairs (TopN, src/topn.h:12-19).
+//
+// MI355X design:
+//   * the caller's (query, probe-slot) pairs are grouped by shard into TASKS; a work UNIT is (<=64 tasks of one shard) x
+//     (one contiguous row segment of that shard); one 256-thread workgroup per unit, thousands of units per launch.
+//   * a workgroup walks its segment in tiles of 64 rows.  Point rows stream from HBM in 32-dim chunks (coalesced 16-byte
+//     loads, 128 contiguous bytes per row), are staged in LDS together with the matching chunk of the 64 query rows, and
+//     each thread accumulates a 4x4 (query x point) register tile with the reference's exact op sequence:
+//     per 4 dims  acc += ((d0*d0 + d1*d1) + d2*d2) + d3*d3   (unfused: v_sub, v_mul, v_add only — no FMA).
+//     Every row loaded from HBM is reused by 64 queries, every LDS operand by 4 pairs.
+//   * the 64x64 distance tile goes through LDS to the selection stage: each wavefront owns 16 queries and keeps their
+//     running top-k lists in registers, one list entry per lane (k <= 64).  A row enters the insert path only if it beats
+//     the current k-th entry (ballot over the 64 rows of the tile); after warm-up that is rare.
+//   * a second kernel merges the per-segment lists of a task, maps rows to global ids through `permutation`
+//     (inverted_index.h:56-58) and writes the caller's [nq][nprobe][k] arrays.
+#include "shards.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace gpann {
+
+constexpr int kQT = 64;          // queries (tasks) per unit
+constexpr int kPT = 64;          // rows per tile
+constexpr int kDC = 32;          // dims per staged chunk
+constexpr int kLdsStride = kDC + 4;   // floats; +4 keeps the 16 row addresses of a ds_read_b128 lane group on distinct banks
+constexpr int kThreads = 256;
+constexpr int kQueriesPerWave = kQT / 4;
+
+struct ScanArgs {
+    const float* points;        // [rows][ld]
+    const float* queries;       // [nq][ld]  (repacked, zero padded)
+    const ScanUnit* units;
+    const uint32_t* task_query; // [tasks]
+    const uint32_t* task_part;  // [tasks] index of the task's first partial list
+    float* part_dist;           // [lists][k]
+    uint32_t* part_row;         // [lists][k]
+    uint32_t d, ld, k;
+};
+
+// insert candidate (cd, cr) — known to be < entry k-1 — into the sorted list held one entry per lane
+__device__ __forceinline__ void ListInsert(float& ld_, uint32_t& lr_, float cd, uint32_t cr, uint32_t k, int lane) {
+    bool less = (lane >= (int)k) || PairLess(cd, cr, ld_, lr_);
+    unsigned long long m = __ballot(less);
+    int pos = __builtin_ctzll(m);
+    float up_d = __shfl_up(ld_, 1);
+    uint32_t up_r = __shfl_up(lr_, 1);
+    if (lane == pos) {
+        ld_ = cd;
+        lr_ = cr;
+    } else if (lane > pos) {
+        ld_ = up_d;
+        lr_ = up_r;
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ void AccumulateGroup(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (METRIC == GPANN_METRIC_L2) {
+                // src/dist.cpp:23-31: diffN = a[N] - b[N] (a = point, b = query); result += d0*d0 + d1*d1 + d2*d2 + d3*d3
+                float d0 = pv[j].x - qv[i].x;
+                float d1 = pv[j].y - qv[i].y;
+                float d2 = pv[j].z - qv[i].z;
+                float d3 = pv[j].w - qv[i].w;
+                float s = d0 * d0 + d1 * d1;
+                s = s + d2 * d2;
+                s = s + d3 * d3;
+                acc[i][j] = acc[i][j] + s;
+            } else {
+                // src/dist.cpp:44-46: result += q[i] * p[i], one dimension after the other
+                float r = acc[i][j];
+                r = r + qv[i].x * pv[j].x;
+                r = r + qv[i].y * pv[j].y;
+                r = r + qv[i].z * pv[j].z;
+                r = r + qv[i].w * pv[j].w;
+                acc[i][j] = r;
+            }
+        }
+    }
+}
+
+// the 0..3 trailing dimensions (src/dist.cpp:33-36): one at a time
+template <int METRIC>
+__device__ __forceinline__ float TailStep(float r, float pe, float qe) {
+    if (METRIC == GPANN_METRIC_L2) {
+        float d0 = pe - qe;
+        return r + d0 * d0;
+    }
+    return r + qe * pe;
+}
+
+template <int METRIC>
+__device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4], int tail) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = acc[i][j];
+            if (tail > 0) r = TailStep<METRIC>(r, pv[j].x, qv[i].x);
+            if (tail > 1) r = TailStep<METRIC>(r, pv[j].y, qv[i].y);
+            if (tail > 2) r = TailStep<METRIC>(r, pv[j].z, qv[i].z);
+            acc[i][j] = r;
+        }
+    }
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
+    extern __shared__ float4 smem4[];
+    float* sQ = reinterpret_cast<float*>(smem4);          // [64][36]
+    float* sP = sQ + kQT * kLdsStride;                    // [64][36]
+    float* sD = sP + kPT * kLdsStride;                    // [64][64] distances of the current tile
+
+    // (fields are read one by one: a by-value struct copy ends up in scratch memory)
+    struct {
+        int64_t row_begin, row_end;
+        uint32_t task_begin, task_count, seg;
+    } u;
+    u.row_begin = a.units[blockIdx.x].row_begin;
+    u.row_end = a.units[blockIdx.x].row_end;
+    u.task_begin = a.units[blockIdx.x].task_begin;
+    u.task_count = a.units[blockIdx.x].task_count;
+    u.seg = a.units[blockIdx.x].seg;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int ty = tid >> 4;   // query group 0..15 : queries ty + 16 i
+    const int tx = tid & 15;   // point group 0..15 : rows    tx + 16 j
+    const uint32_t d = a.d, ld = a.ld, k = a.k;
+    const uint32_t full_groups = d >> 2;        // groups of 4 complete dims
+    const int tail = (int)(d & 3u);
+    const uint32_t nchunks = (ld + kDC - 1) / kDC;
+
+    // staging role: float4 #f of a [64 rows][8 float4] chunk, f = tid and tid + 256
+    const int st_row0 = tid >> 3, st_row1 = (tid + 256) >> 3;
+    const int st_c4 = tid & 7;
+    const uint32_t tq0 = u.task_begin + min((uint32_t)st_row0, u.task_count - 1);
+    const uint32_t tq1 = u.task_begin + min((uint32_t)st_row1, u.task_count - 1);
+    const float* qrow0 = a.queries + (size_t)a.task_query[tq0] * ld;
+    const float* qrow1 = a.queries + (size_t)a.task_query[tq1] * ld;
+
+    // running top-k lists of this wave's 16 queries: lane i holds entry i
+    float list_d[kQueriesPerWave];
+    uint32_t list_r[kQueriesPerWave];
+#pragma unroll
+    for (int j = 0; j < kQueriesPerWave; ++j) {
+        list_d[j] = INFINITY;
+        list_r[j] = kNoId;
+    }
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row0 = u.row_begin; row0 < u.row_end; row0 += kPT) {
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+        const int64_t pr0 = min(row0 + st_row0, u.row_end - 1);
+        const int64_t pr1 = min(row0 + st_row1, u.row_end - 1);
+        const float* prow0 = a.points + (size_t)pr0 * ld;
+        const float* prow1 = a.points + (size_t)pr1 * ld;
+
+        // prefetch chunk 0 into registers
+        float4 gq0, gq1, gp0, gp1;
+        {
+            const uint32_t c = 4u * st_c4;
+            const bool in = c < ld;
+            gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
+            gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
+            gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
+            gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+        }
+        for (uint32_t ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();   // previous chunk's LDS reads (and the previous tile's selection reads of sD) are done
+            *reinterpret_cast<float4*>(sQ + st_row0 * kLdsStride + 4 * st_c4) = gq0;
+            *reinterpret_cast<float4*>(sQ + st_row1 * kLdsStride + 4 * st_c4) = gq1;
+            *reinterpret_cast<float4*>(sP + st_row0 * kLdsStride + 4 * st_c4) = gp0;
+            *reinterpret_cast<float4*>(sP + st_row1 * kLdsStride + 4 * st_c4) = gp1;
+            __syncthreads();
+            if (ch + 1 < nchunks) {   // issue the next chunk's global loads; they complete under the arithmetic below
+                const uint32_t c = (ch + 1) * kDC + 4u * st_c4;
+                const bool in = c < ld;
+                gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
+                gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
+                gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
+                gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+            }
+            const uint32_t g0 = ch * (kDC / 4);                        // first group index of this chunk
+            const float* q_base = sQ + ty * kLdsStride;
+            const float* p_base = sP + tx * kLdsStride;
+            if (g0 + kDC / 4 <= full_groups) {
+                // fast path: 8 complete groups (unroll 2: two groups of LDS operands in flight keeps the tile under 168 VGPRs)
+#pragma unroll 2
+                for (int g = 0; g < kDC / 4; ++g) {
+                    float4 qv[4], pv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kLdsStride + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kLdsStride + 4 * g);
+                    AccumulateGroup<METRIC>(acc, qv, pv);
+                }
+            } else {
+                for (int g = 0; g < kDC / 4; ++g) {
+                    const uint32_t G = g0 + g;
+                    if (G > full_groups || (G == full_groups && tail == 0)) break;
+                    float4 qv[4], pv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kLdsStride + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kLdsStride + 4 * g);
+                    if (G < full_groups) AccumulateGroup<METRIC>(acc, qv, pv);
+                    else AccumulateTail<METRIC>(acc, qv, pv, tail);
+                }
+            }
+        }
+
+        // publish the 64x64 distance tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[i][j];
+                if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;   // src/dist.cpp:50-52
+                sD[(ty + 16 * i) * kPT + tx + 16 * j] = v;
+            }
+        __syncthreads();
+
+        // selection: this wave's 16 queries, lane = row of the tile
+        const uint32_t my_row = (uint32_t)(row0 + lane);
+        const bool row_valid = row0 + lane < u.row_end;
+#pragma unroll
+        for (int j = 0; j < kQueriesPerWave; ++j) {
+            const int ql = wave * kQueriesPerWave + j;
+            const float v = sD[ql * kPT + lane];
+            float td = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(list_d[j]), k - 1));
+            uint32_t tr = (uint32_t)__builtin_amdgcn_readlane((int)list_r[j], k - 1);
+            bool pass = row_valid && PairLess(v, my_row, td, tr);
+            unsigned long long mask = __ballot(pass);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                const float cd = __shfl(v, l);
+                const uint32_t cr = (uint32_t)(row0 + l);
+                ListInsert(list_d[j], list_r[j], cd, cr, k, lane);
+                td = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(list_d[j]), k - 1));
+                tr = (uint32_t)__builtin_amdgcn_readlane((int)list_r[j], k - 1);
+                pass = pass && lane > l && PairLess(v, my_row, td, tr);
+                mask = __ballot(pass);
+            }
+        }
+        // no barrier needed here: sD is next written after two more __syncthreads of the following tile
+    }
+
+    // write this unit's partial lists
+#pragma unroll
+    for (int j = 0; j < kQueriesPerWave; ++j) {
+        const uint32_t ql = wave * kQueriesPerWave + j;
+        if (ql < u.task_count && lane < (int)k) {
+            const size_t list = (size_t)a.task_part[u.task_begin + ql] + u.seg;
+            a.part_dist[list * k + lane] = list_d[j];
+            a.part_row[list * k + lane] = list_r[j];
+        }
+    }
+}
+
+// ---- merge ---------------------------------------------------------------------------------------------------------
+// One wavefront per output list.  MODE 0: merge the per-segment partial lists of a task -> out[task_out[t]].
+// MODE 1: merge the first nprobe per-slot lists of a query (InvertedIndex::Query: one TopN over all probed shards).
+struct MergeArgs {
+    const float* in_dist;       // lists of k entries, ascending
+    const uint32_t* in_row;
+    const uint32_t* first_list; // [n_out] index of the first input list (MODE 0) ; unused in MODE 1
+    const uint32_t* n_lists;    // [n_out] number of input lists (MODE 0)
+    const uint32_t* out_index;  // [n_out] destination list index (MODE 0)
+    const uint32_t* permutation;
+    float* out_dist;            // may be null
+    uint32_t* out_ids;          // may be null
+    uint32_t* out_rows;         // may be null
+    uint32_t n_out, k, lists_per_out;   // lists_per_out: MODE 1 (nprobe)
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) MergeListsKernel(MergeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= a.n_out) return;
+    const uint32_t k = a.k;
+    const size_t first = MODE == 0 ? a.first_list[o] : (size_t)o * a.lists_per_out;
+    const uint32_t n = MODE == 0 ? a.n_lists[o] : a.lists_per_out;
+    float ld_ = INFINITY;
+    uint32_t lr_ = kNoId;
+    if (n > 0 && lane < (int)k) {
+        ld_ = a.in_dist[first * k + lane];
+        lr_ = a.in_row[first * k + lane];
+    }
+    for (uint32_t s = 1; s < n; ++s) {
+        // candidates of list s in ascending order; stop at the first one that does not beat the current k-th entry
+        float cd_l = INFINITY;
+        uint32_t cr_l = kNoId;
+        if (lane < (int)k) {
+            cd_l = a.in_dist[(first + s) * k + lane];
+            cr_l = a.in_row[(first + s) * k + lane];
+        }
+        for (uint32_t e = 0; e < k; ++e) {
+            const float cd = __shfl(cd_l, e);
+            const uint32_t cr = __shfl(cr_l, e);
+            const float td = __shfl(ld_, k - 1);
+            const uint32_t tr = __shfl(lr_, k - 1);
+            if (!PairLess(cd, cr, td, tr)) break;
+            ListInsert(ld_, lr_, cd, cr, k, lane);
+        }
+    }
+    if (lane < (int)k) {
+        const size_t dst = (size_t)(MODE == 0 ? a.out_index[o] : o) * k + lane;
+        if (a.out_dist) a.out_dist[dst] = ld_;
+        if (a.out_rows) a.out_rows[dst] = lr_;
+        if (a.out_ids) a.out_ids[dst] = lr_ == kNoId ? kNoId : a.permutation[lr_];
+    }
+}
+
+__global__ void FillKernel(float* dist, uint32_t* ids, uint32_t* rows, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (dist) dist[i] = INFINITY;
+        if (ids) ids[i] = kNoId;
+        if (rows) rows[i] = kNoId;
+    }
+}
+
+// RunInShardSearches hit lists: from per-(q, shard) ascending lists keep entries with dist <= kth[q], emit ids descending.
+__global__ void ShardHitsKernel(const float* dist, const uint32_t* ids, const float* kth, uint32_t nq, uint32_t S, uint32_t k,
+                                uint32_t* out_ids, uint32_t* out_count) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;   // t = q * S + b
+    if (t >= (size_t)nq * S) return;
+    const uint32_t q = (uint32_t)(t / S), b = (uint32_t)(t % S);
+    const float thr = kth[q];
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        if (ids[t * k + i] != kNoId && dist[t * k + i] <= thr) c++;
+        else break;
+    }
+    uint32_t* o = out_ids + ((size_t)b * nq + q) * k;
+    for (uint32_t i = 0; i < k; ++i) o[i] = i < c ? ids[t * k + (c - 1 - i)] : kNoId;
+    out_count[(size_t)b * nq + q] = c;
+}
+
+// ---- host orchestration -------------------------------------------------------------------------------------------
+static uint32_t EnvU32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    long x = std::strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
+// Group the (query, slot) pairs by shard and cut every shard into row segments so that the launch has enough
+// workgroups to fill 256 CUs several times over while each unit still amortises its list warm-up.
+static gpann_status BuildPlan(const gpann_shards* s, uint32_t nq, const int32_t* probes, uint32_t probe_stride, uint32_t nprobe,
+                              ScanPlan& plan) {
+    const uint32_t S = s->S;
+    std::vector<uint32_t> count(S + 1, 0);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t j = 0; j < nprobe; ++j) {
+            int32_t b = probes[(size_t)q * probe_stride + j];
+            if (b < 0) continue;
+            GPANN_REQUIRE((uint32_t)b < S, "probe shard id out of range");
+            count[b + 1]++;
+        }
+    for (uint32_t b = 0; b < S; ++b) count[b + 1] += count[b];
+    const uint32_t T = count[S];
+    plan.task_query.resize(T);
+    plan.task_out.resize(T);
+    plan.task_part.resize(T);
+    plan.task_nseg.resize(T);
+    std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t j = 0; j < nprobe; ++j) {
+            int32_t b = probes[(size_t)q * probe_stride + j];
+            if (b < 0) continue;
+            uint32_t t = cursor[b]++;
+            plan.task_query[t] = q;
+            plan.task_out[t] = q * nprobe + j;
+        }
+
+    // total tile work, to size segments
+    uint64_t tile_rows = 0;
+    for (uint32_t b = 0; b < S; ++b) {
+        uint32_t tb = count[b + 1] - count[b];
+        uint64_t nb = (uint64_t)(s->offsets[b + 1] - s->offsets[b]);
+        tile_rows += (uint64_t)((tb + kQT - 1) / kQT) * nb;
+        plan.pairs += (uint64_t)tb * nb;
+    }
+    const uint32_t target_units = EnvU32("GPANN_SCAN_TARGET_UNITS", 8192);
+    const uint32_t min_seg_rows = EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 2048);
+    uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
+    seg_rows = (seg_rows + kPT - 1) / kPT * kPT;
+
+    uint64_t lists = 0;
+    for (uint32_t b = 0; b < S; ++b) {
+        const uint32_t tb = count[b + 1] - count[b];
+        if (tb == 0) continue;
+        const int64_t r0 = s->offsets[b], r1 = s->offsets[b + 1];
+        const uint64_t nb = (uint64_t)(r1 - r0);
+        const uint32_t nseg = nb == 0 ? 0 : (uint32_t)((nb + seg_rows - 1) / seg_rows);
+        for (uint32_t t = count[b]; t < count[b + 1]; ++t) {
+            plan.task_part[t] = (uint32_t)lists;
+            plan.task_nseg[t] = nseg;
+            lists += nseg;
+        }
+        GPANN_REQUIRE(lists < 0xFFFFFFFFull, "too many partial lists");
+        if (nseg == 0) continue;
+        // equal segments (multiples of the tile height) rather than seg_rows + remainder
+        uint64_t per = ((nb + nseg - 1) / nseg + kPT - 1) / kPT * kPT;
+        const uint32_t ntiles_q = (tb + kQT - 1) / kQT;
+        for (uint32_t qt = 0; qt < ntiles_q; ++qt) {
+            // balanced query tiles: e.g. 65 tasks -> 33 + 32 instead of 64 + 1
+            uint32_t tbeg = count[b] + (uint32_t)((uint64_t)tb * qt / ntiles_q);
+            uint32_t tend = count[b] + (uint32_t)((uint64_t)tb * (qt + 1) / ntiles_q);
+            for (uint32_t sg = 0; sg < nseg; ++sg) {
+                ScanUnit u;
+                u.row_begin = r0 + (int64_t)(sg * per);
+                u.row_end = std::min<int64_t>(r1, u.row_begin + (int64_t)per);
+                if (u.row_begin >= u.row_end) {
+                    // cannot happen for sg < nseg with per >= nb/nseg, but keep lists well-defined
+                    u.row_begin = u.row_end = r1;
+                }
+                u.task_begin = tbeg;
+                u.task_count = tend - tbeg;
+                u.seg = sg;
+                u.pad = 0;
+                plan.units.push_back(u);
+                plan.padded_pairs += (uint64_t)kQT * (uint64_t)(((u.row_end - u.row_begin) + kPT - 1) / kPT * kPT);
+            }
+        }
+    }
+    plan.n_lists = lists;
+    return GPANN_OK;
+}
+
+// queries (host or device, stride d) -> device workspace with stride ld, zero padded
+static gpann_status StageQueries(gpann_shards* s, const float* queries, uint32_t nq, bool on_device, hipStream_t st, const float** out) {
+    const size_t bytes = (size_t)nq * s->ld * sizeof(float);
+    GPANN_TRY(s->ws_queries.Reserve(std::max<size_t>(bytes, 256)));
+    float* dst = s->ws_queries.as<float>();
+    if (s->ld != s->d) GPANN_HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
+    GPANN_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(float), queries, (size_t)s->d * sizeof(float), (size_t)s->d * sizeof(float), nq,
+                                   on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    *out = dst;
+    return GPANN_OK;
+}
+
+struct DeviceLists {   // per-(query, slot) result lists on the device: [nq*nprobe][k]
+    float* dist = nullptr;
+    uint32_t* ids = nullptr;
+    uint32_t* rows = nullptr;
+};
+
+// Runs plan + scan + merge; results land in device arrays (caller-provided or workspace).
+static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
+                                 uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
+    ScanPlan& plan = s->plan;
+    plan.Clear();
+    GPANN_TRY(BuildPlan(s, nq, probes, probe_stride, nprobe, plan));
+    const uint32_t T = (uint32_t)plan.task_query.size();
+    const size_t n_out = (size_t)nq * nprobe;
+
+    const float* d_queries = nullptr;
+    GPANN_TRY(StageQueries(s, queries, nq, (flags & GPANN_QUERIES_ON_DEVICE) != 0, st, &d_queries));
+
+    // task arrays: query | out | part | nseg
+    GPANN_TRY(s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 4 * sizeof(uint32_t), 256)));
+    uint32_t* d_task_query = s->ws_tasks.as<uint32_t>();
+    uint32_t* d_task_out = d_task_query + T;
+    uint32_t* d_task_part = d_task_out + T;
+    uint32_t* d_task_nseg = d_task_part + T;
+    GPANN_TRY(s->ws_units.Reserve(std::max<size_t>(plan.units.size() * sizeof(ScanUnit), 256)));
+    GPANN_TRY(s->ws_partials.Reserve(std::max<size_t>(plan.n_lists * k * 8, 256)));
+    float* d_part_dist = s->ws_partials.as<float>();
+    uint32_t* d_part_row = reinterpret_cast<uint32_t*>(d_part_dist + plan.n_lists * k);
+    if (T) {
+        GPANN_HIP_TRY(hipMemcpyAsync(d_task_query, plan.task_query.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(d_task_out, plan.task_out.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(d_task_part, plan.task_part.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(d_task_nseg, plan.task_nseg.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice, st));
+    }
+    // (the plan's host arrays live in the handle until the next scan call, so the async uploads above stay valid)
+
+    {   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID)
+        size_t n = n_out * k;
+        int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+        if (n) hipLaunchKernelGGL(FillKernel, dim3(grid), dim3(256), 0, st, out.dist, out.ids, out.rows, n);
+    }
+
+    GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
+    if (!plan.units.empty()) {
+        ScanArgs a;
+        a.points = s->points;
+        a.queries = d_queries;
+        a.units = s->ws_units.as<ScanUnit>();
+        a.task_query = d_task_query;
+        a.task_part = d_task_part;
+        a.part_dist = d_part_dist;
+        a.part_row = d_part_row;
+        a.d = s->d;
+        a.ld = s->ld;
+        a.k = k;
+        const size_t lds = (size_t)(kQT * kLdsStride + kPT * kLdsStride + kQT * kPT) * sizeof(float);
+        if (s->metric == GPANN_METRIC_L2)
+            hipLaunchKernelGGL(ScanTileKernel<GPANN_METRIC_L2>, dim3((uint32_t)plan.units.size()), dim3(kThreads), lds, st, a);
+        else
+            hipLaunchKernelGGL(ScanTileKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)plan.units.size()), dim3(kThreads), lds, st, a);
+        GPANN_HIP_TRY(hipGetLastError());
+    }
+    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+    if (T) {
+        MergeArgs m{};
+        m.in_dist = d_part_dist;
+        m.in_row = d_part_row;
+        m.first_list = d_task_part;
+        m.n_lists = d_task_nseg;
+        m.out_index = d_task_out;
+        m.permutation = s->permutation;
+        m.out_dist = out.dist;
+        m.out_ids = out.ids;
+        m.out_rows = out.rows;
+        m.n_out = T;
+        m.k = k;
+        m.lists_per_out = 0;
+        hipLaunchKernelGGL(MergeListsKernel<0>, dim3((T + 3) / 4), dim3(256), 0, st, m);
+        GPANN_HIP_TRY(hipGetLastError());
+    }
+    GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
+
+    s->stats = gpann_scan_stats{};
+    s->stats.pairs = plan.pairs;
+    s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)T * k * 8ull;
+    s->stats.tasks = T;
+    s->stats.units = plan.units.size();
+    s->stats.padded_pairs = plan.padded_pairs;
+    return GPANN_OK;
+}
+
+static gpann_status FinishTiming(gpann_shards* s, float* elapsed_ms) {
+    GPANN_HIP_TRY(hipEventSynchronize(s->ev[2]));
+    float a = 0.f, b = 0.f;
+    GPANN_HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    GPANN_HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    s->stats.scan_ms = a;
+    s->stats.merge_ms = b;
+    if (elapsed_ms) *elapsed_ms = a + b;
+    return GPANN_OK;
+}
+
+static gpann_status CheckScanArgs(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t nprobe,
+                                  uint32_t probe_stride) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    GPANN_REQUIRE(k >= 1, "k must be >= 1");
+    if (k > GPANN_MAX_K) {
+        SetLastError("k = %u exceeds GPANN_MAX_K = %u", k, GPANN_MAX_K);
+        return GPANN_ERR_UNSUPPORTED;
+    }
+    GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
+    GPANN_REQUIRE(nq == 0 || nprobe == 0 || probes != nullptr, "probes is null");
+    GPANN_REQUIRE(probe_stride >= nprobe, "probe_stride < nprobe");
+    GPANN_REQUIRE((uint64_t)nq * nprobe < 0xFFFFFFFFull, "nq * nprobe must fit 32 bits");
+    return EnsureDevice(s->device);
+}
+
+}  // namespace gpann
+
+using namespace gpann;
+
+extern "C" {
+
+gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t probe_stride,
+                                uint32_t nprobe, uint32_t* out_ids, float* out_dist, uint32_t* out_rows, int flags, void* stream,
+                                float* elapsed_ms) {
+    GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
+    GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)nq * nprobe * k;
+    if (n == 0) {
+        if (elapsed_ms) *elapsed_ms = 0.f;
+        return GPANN_OK;
+    }
+    DeviceLists dl;
+    const bool dev_out = (flags & GPANN_OUTPUT_ON_DEVICE) != 0;
+    if (dev_out) {
+        dl.ids = out_ids;
+        dl.dist = out_dist;
+        dl.rows = out_rows;
+    } else {
+        GPANN_TRY(s->ws_out.Reserve(n * 12));
+        dl.dist = s->ws_out.as<float>();
+        dl.ids = reinterpret_cast<uint32_t*>(dl.dist + n);
+        dl.rows = dl.ids + n;
+    }
+    GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags, st, dl));
+    if (!dev_out) {
+        GPANN_HIP_TRY(hipMemcpyAsync(out_ids, dl.ids, n * 4, hipMemcpyDeviceToHost, st));
+        if (out_dist) GPANN_HIP_TRY(hipMemcpyAsync(out_dist, dl.dist, n * 4, hipMemcpyDeviceToHost, st));
+        if (out_rows) GPANN_HIP_TRY(hipMemcpyAsync(out_rows, dl.rows, n * 4, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+        GPANN_TRY(FinishTiming(s, elapsed_ms));
+    } else if (elapsed_ms) {
+        GPANN_TRY(FinishTiming(s, elapsed_ms));
+    }
+    return GPANN_OK;
+}
+
+gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t probe_stride,
+                               uint32_t nprobe, uint32_t* out_ids, float* out_dist, int flags, void* stream, float* elapsed_ms) {
+    GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
+    GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n_slot = (size_t)nq * nprobe * k, n = (size_t)nq * k;
+    if (n == 0) {
+        if (elapsed_ms) *elapsed_ms = 0.f;
+        return GPANN_OK;
+    }
+    // per-slot lists (dist,rows) in workspace, then one more merge across the slots of a query
+    GPANN_TRY(s->ws_out.Reserve(n_slot * 8 + n * 8 + 256));
+    DeviceLists slot;
+    slot.dist = s->ws_out.as<float>();
+    slot.rows = reinterpret_cast<uint32_t*>(slot.dist + n_slot);
+    slot.ids = nullptr;
+    float* d_out_dist = reinterpret_cast<float*>(slot.rows + n_slot);
+    uint32_t* d_out_ids = reinterpret_cast<uint32_t*>(d_out_dist + n);
+    const bool dev_out = (flags & GPANN_OUTPUT_ON_DEVICE) != 0;
+    if (nprobe == 0) {
+        hipLaunchKernelGGL(FillKernel, dim3(64), dim3(256), 0, st, dev_out ? out_dist : d_out_dist, dev_out ? out_ids : d_out_ids,
+                           (uint32_t*)nullptr, n);
+    } else {
+        GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags, st, slot));
+        MergeArgs m{};
+        m.in_dist = slot.dist;
+        m.in_row = slot.rows;
+        m.permutation = s->permutation;
+        m.out_dist = dev_out ? out_dist : d_out_dist;
+        m.out_ids = dev_out ? out_ids : d_out_ids;
+        m.out_rows = nullptr;
+        m.n_out = nq;
+        m.k = k;
+        m.lists_per_out = nprobe;
+        hipLaunchKernelGGL(MergeListsKernel<1>, dim3((nq + 3) / 4), dim3(256), 0, st, m);
+        GPANN_HIP_TRY(hipGetLastError());
+        GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
+    }
+    if (!dev_out) {
+        GPANN_HIP_TRY(hipMemcpyAsync(out_ids, d_out_ids, n * 4, hipMemcpyDeviceToHost, st));
+        if (out_dist) GPANN_HIP_TRY(hipMemcpyAsync(out_dist, d_out_dist, n * 4, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (nprobe && (!dev_out || elapsed_ms)) GPANN_TRY(FinishTiming(s, elapsed_ms));
+    return GPANN_OK;
+}
+
+gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const float* distance_to_kth,
+                                     uint32_t* out_ids, uint32_t* out_count, int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    const uint32_t S = s->S;
+    std::vector<int32_t> probes((size_t)nq * S);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t b = 0; b < S; ++b) probes[(size_t)q * S + b] = (int32_t)b;
+    GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes.data(), S, S));
+    GPANN_REQUIRE(out_ids != nullptr && out_count != nullptr && distance_to_kth != nullptr, "null output / threshold pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)nq * S * k;
+    if (n == 0) return GPANN_OK;
+    // workspace: slot dist | slot ids | hits ids | hits count | kth
+    GPANN_TRY(s->ws_out.Reserve(n * 12 + (size_t)nq * S * 4 + (size_t)nq * 4 + 256));
+    DeviceLists slot;
+    slot.dist = s->ws_out.as<float>();
+    slot.ids = reinterpret_cast<uint32_t*>(slot.dist + n);
+    slot.rows = nullptr;
+    uint32_t* d_hits = slot.ids + n;
+    uint32_t* d_count = d_hits + n;
+    float* d_kth = reinterpret_cast<float*>(d_count + (size_t)nq * S);
+    GPANN_HIP_TRY(hipMemcpyAsync(d_kth, distance_to_kth, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    GPANN_TRY(ScanToDevice(s, queries, nq, k, probes.data(), S, S, flags & GPANN_QUERIES_ON_DEVICE, st, slot));
+    const size_t tt = (size_t)nq * S;
+    hipLaunchKernelGGL(ShardHitsKernel, dim3((uint32_t)((tt + 255) / 256)), dim3(256), 0, st, slot.dist, slot.ids, d_kth, nq, S, k, d_hits, d_count);
+    GPANN_HIP_TRY(hipGetLastError());
+    GPANN_HIP_TRY(hipMemcpyAsync(out_ids, d_hits, n * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipMemcpyAsync(out_count, d_count, tt * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    GPANN_TRY(FinishTiming(s, elapsed_ms));
+    return GPANN_OK;
+}
+
+gpann_status gpann_ground_truth(gpann_shards* s_all, const float* points, uint64_t n, uint32_t d, int metric, const float* queries,
+                                uint32_t nq, uint32_t k, uint32_t* out_ids, float* out_dist, int device, int flags, void* stream,
+                                float* elapsed_ms) {
+    gpann_shards* s = s_all;
+    bool temp = false;
+    if (!s) {
+        GPANN_REQUIRE(points != nullptr, "points is null and no store given");
+        GPANN_REQUIRE(n < 0xFFFFFFFFull, "n must fit 32 bits");
+        std::vector<uint32_t> ids(n);
+        for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)i;
+        uint64_t offs[2] = {0, n};
+        GPANN_TRY(gpann_shards_create(points, n, d, metric, ids.data(), offs, 1, device, flags & GPANN_POINTS_ON_DEVICE, &s));
+        temp = true;
+    } else {
+        GPANN_REQUIRE(s->S == 1, "ground truth needs a 1-shard store over all points");
+    }
+    std::vector<int32_t> probes(nq, 0);
+    gpann_status st = gpann_scan_buckets(s, queries, nq, k, probes.data(), 1, 1, out_ids, out_dist, nullptr,
+                                         flags & (GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE), stream, elapsed_ms);
+    if (temp) {
+        if (st == GPANN_OK && (flags & GPANN_OUTPUT_ON_DEVICE)) (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+        gpann_shards_destroy(s);
+    }
+    return st;
+}
+
+gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out) {
+    GPANN_REQUIRE(s != nullptr && out != nullptr, "null argument");
+    *out = s->stats;
+    return GPANN_OK;
+}
+
+}  // extern "C"

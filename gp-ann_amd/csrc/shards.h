@@ -1,0 +1,55 @@
+// shards.h — the device-resident shard store (InvertedIndex layout, reference src/inverted_index.h:8-41).
+#pragma once
+
+#include <vector>
+
+#include "common.h"
+
+namespace gpann {
+
+// One scan workgroup's job: <= 64 tasks of one shard x one contiguous row segment (see scan.hip).
+struct ScanUnit {
+    int64_t row_begin;
+    int64_t row_end;
+    uint32_t task_begin;   // index into the shard-sorted task arrays
+    uint32_t task_count;   // 1..64
+    uint32_t seg;          // segment number within the shard
+    uint32_t pad;
+};
+
+// Host-side launch plan of one scan call; kept alive in the handle until the next call because its arrays are the
+// sources of asynchronous uploads.
+struct ScanPlan {
+    std::vector<uint32_t> task_query, task_out, task_part, task_nseg;
+    std::vector<ScanUnit> units;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0;
+    void Clear() {
+        task_query.clear();
+        task_out.clear();
+        task_part.clear();
+        task_nseg.clear();
+        units.clear();
+        n_lists = pairs = padded_pairs = 0;
+    }
+};
+
+}  // namespace gpann
+
+struct gpann_shards {
+    int device = 0;
+    int metric = 0;
+    uint32_t d = 0;      // true dimension
+    uint32_t ld = 0;     // row stride in floats (d rounded up to 4; pad floats are zero and never enter the arithmetic)
+    uint32_t S = 0;
+    uint64_t rows = 0;   // sum of shard sizes
+    float* points = nullptr;         // [rows][ld]   HBM, shard-contiguous
+    uint32_t* permutation = nullptr; // [rows]       row -> global id
+    int64_t* d_offsets = nullptr;    // [S+1]        device copy
+    std::vector<int64_t> offsets;    // [S+1]        host copy
+
+    // per-call workspace, grown on demand and reused
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    gpann_scan_stats stats{};
+    gpann::ScanPlan plan;
+};

@@ -1,0 +1,218 @@
+// shards.hip — building and querying metadata of the device-resident shard store.
+//
+// Replaces InvertedIndex::InvertedIndex (reference src/inverted_index.h:12-41): the points of every shard are gathered
+// into one shard-contiguous row-major array so that a shard is one coalesced HBM stream; offsets[S+1] and
+// permutation[row] -> global id are kept exactly as the reference keeps them.
+#include "shards.h"
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace gpann {
+
+thread_local std::string g_last_error;
+
+void SetLastError(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+gpann_status EnsureDevice(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        SetLastError("no usable HIP device (hipGetDeviceCount: %s, count %d) — libgpann_hip has no CPU fallback",
+                     hipGetErrorString(e), count);
+        return GPANN_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        SetLastError("device %d out of range (count %d)", device, count);
+        return GPANN_ERR_INVALID;
+    }
+    GPANN_HIP_TRY(hipSetDevice(device));
+    return GPANN_OK;
+}
+
+// One thread per float4 of the destination: dst row r <- src row ids[r].  Source rows have stride d (caller layout),
+// destination rows stride ld (multiple of 4, zero padded).
+__global__ void __launch_bounds__(256) GatherRowsKernel(const float* __restrict__ src, const uint32_t* __restrict__ ids, uint64_t rows,
+                                                        uint32_t d, uint32_t ld, float* __restrict__ dst) {
+    const uint32_t vec_per_row = ld / 4;
+    const uint64_t total = rows * vec_per_row;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = i / vec_per_row;
+        uint32_t c = (uint32_t)(i % vec_per_row) * 4;
+        const float* s = src + (uint64_t)ids[r] * d;
+        float4 v;
+        v.x = c + 0 < d ? s[c + 0] : 0.f;
+        v.y = c + 1 < d ? s[c + 1] : 0.f;
+        v.z = c + 2 < d ? s[c + 2] : 0.f;
+        v.w = c + 3 < d ? s[c + 3] : 0.f;
+        *reinterpret_cast<float4*>(dst + r * ld + c) = v;
+    }
+}
+
+}  // namespace gpann
+
+using namespace gpann;
+
+extern "C" {
+
+const char* gpann_last_error(void) { return g_last_error.c_str(); }
+
+const char* gpann_version(void) { return "gpann-hip 0.1 (gfx950)"; }
+
+gpann_status gpann_device_count(int* count) {
+    GPANN_REQUIRE(count != nullptr, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) c = 0;
+    *count = c;
+    return GPANN_OK;
+}
+
+gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, int metric, const uint32_t* ids_concat,
+                                 const uint64_t* shard_offsets, uint32_t S, int device, int flags, gpann_shards** out) {
+    GPANN_REQUIRE(out != nullptr, "out is null");
+    *out = nullptr;
+    GPANN_REQUIRE(points != nullptr && shard_offsets != nullptr, "points/shard_offsets null");
+    GPANN_REQUIRE(d > 0 && S > 0, "d and S must be positive");
+    GPANN_REQUIRE(metric == GPANN_METRIC_L2 || metric == GPANN_METRIC_MIPS, "unknown metric");
+    GPANN_REQUIRE(shard_offsets[0] == 0, "shard_offsets[0] must be 0");
+    const uint64_t rows = shard_offsets[S];
+    GPANN_REQUIRE(rows < 0xFFFFFFFFull, "total rows must fit the reference's 32-bit row index (inverted_index.h:9)");
+    GPANN_REQUIRE(rows == 0 || ids_concat != nullptr, "ids_concat null");
+    for (uint32_t b = 0; b < S; ++b) GPANN_REQUIRE(shard_offsets[b] <= shard_offsets[b + 1], "shard_offsets not monotone");
+    for (uint64_t i = 0; i < rows; ++i) GPANN_REQUIRE(ids_concat[i] < n, "point id out of range");
+    GPANN_TRY(EnsureDevice(device));
+
+    auto* s = new gpann_shards();
+    s->device = device;
+    s->metric = metric;
+    s->d = d;
+    s->ld = RoundUp4(d);
+    s->S = S;
+    s->rows = rows;
+    s->offsets.assign(shard_offsets, shard_offsets + S + 1);
+    auto fail = [&](gpann_status st) {
+        gpann_shards_destroy(s);
+        return st;
+    };
+#define TRY_OR_FAIL(expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+            return fail(_e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP);                        \
+        }                                                                                                  \
+    } while (0)
+
+    const size_t row_bytes = (size_t)s->ld * sizeof(float);
+    TRY_OR_FAIL(hipMalloc(&s->points, std::max<size_t>(rows * row_bytes, 256)));
+    TRY_OR_FAIL(hipMalloc(&s->permutation, std::max<size_t>(rows * sizeof(uint32_t), 256)));
+    TRY_OR_FAIL(hipMalloc(&s->d_offsets, (S + 1) * sizeof(int64_t)));
+    TRY_OR_FAIL(hipMemcpy(s->d_offsets, s->offsets.data(), (S + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (rows) TRY_OR_FAIL(hipMemcpy(s->permutation, ids_concat, rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (auto& e : s->ev) TRY_OR_FAIL(hipEventCreate(&e));
+
+    if (rows) {
+        if (flags & GPANN_POINTS_ON_DEVICE) {
+            uint64_t total_vec = rows * (s->ld / 4);
+            int grid = (int)std::min<uint64_t>((total_vec + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(GatherRowsKernel, dim3(grid), dim3(256), 0, 0, points, s->permutation, rows, d, s->ld, s->points);
+            TRY_OR_FAIL(hipGetLastError());
+            TRY_OR_FAIL(hipDeviceSynchronize());
+        } else {
+            // Host points: gather on the host into pinned staging chunks (what the reference's constructor does with
+            // parlay, inverted_index.h:27-40) and stream them up; needs no second device copy of the whole point set.
+            const size_t chunk_rows = std::max<size_t>(1, (64u << 20) / row_bytes);
+            float* staging[2] = {nullptr, nullptr};
+            hipEvent_t done[2];
+            for (int i = 0; i < 2; ++i) {
+                TRY_OR_FAIL(hipHostMalloc((void**)&staging[i], chunk_rows * row_bytes, hipHostMallocDefault));
+                TRY_OR_FAIL(hipEventCreate(&done[i]));
+            }
+            unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+            int buf = 0;
+            for (uint64_t r0 = 0; r0 < rows; r0 += chunk_rows, buf ^= 1) {
+                uint64_t r1 = std::min<uint64_t>(rows, r0 + chunk_rows);
+                TRY_OR_FAIL(hipEventSynchronize(done[buf]));
+                float* st = staging[buf];
+                auto work = [&](uint64_t a, uint64_t b) {
+                    for (uint64_t r = a; r < b; ++r) {
+                        const float* src = points + (uint64_t)ids_concat[r] * d;
+                        float* dst = st + (r - r0) * s->ld;
+                        std::memcpy(dst, src, d * sizeof(float));
+                        for (uint32_t c = d; c < s->ld; ++c) dst[c] = 0.f;
+                    }
+                };
+                uint64_t cnt = r1 - r0;
+                unsigned T = (unsigned)std::min<uint64_t>(hw, std::max<uint64_t>(1, cnt / 4096));
+                if (T <= 1) {
+                    work(r0, r1);
+                } else {
+                    std::vector<std::thread> th;
+                    for (unsigned t = 0; t < T; ++t) th.emplace_back(work, r0 + cnt * t / T, r0 + cnt * (t + 1) / T);
+                    for (auto& x : th) x.join();
+                }
+                TRY_OR_FAIL(hipMemcpyAsync(s->points + r0 * s->ld, st, cnt * row_bytes, hipMemcpyHostToDevice, 0));
+                TRY_OR_FAIL(hipEventRecord(done[buf], 0));
+            }
+            TRY_OR_FAIL(hipDeviceSynchronize());
+            for (int i = 0; i < 2; ++i) {
+                (void)hipHostFree(staging[i]);
+                (void)hipEventDestroy(done[i]);
+            }
+        }
+    }
+#undef TRY_OR_FAIL
+    *out = s;
+    return GPANN_OK;
+}
+
+gpann_status gpann_shards_destroy(gpann_shards* s) {
+    if (!s) return GPANN_OK;
+    (void)hipSetDevice(s->device);
+    if (s->points) (void)hipFree(s->points);
+    if (s->permutation) (void)hipFree(s->permutation);
+    if (s->d_offsets) (void)hipFree(s->d_offsets);
+    s->ws_queries.Release();
+    s->ws_tasks.Release();
+    s->ws_units.Release();
+    s->ws_partials.Release();
+    s->ws_out.Release();
+    s->ws_misc.Release();
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+    return GPANN_OK;
+}
+
+gpann_status gpann_shards_info(const gpann_shards* s, uint64_t* rows, uint32_t* d, uint32_t* S, int* metric, int* device) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    if (rows) *rows = s->rows;
+    if (d) *d = s->d;
+    if (S) *S = s->S;
+    if (metric) *metric = s->metric;
+    if (device) *device = s->device;
+    return GPANN_OK;
+}
+
+gpann_status gpann_shards_export(const gpann_shards* s, int64_t* offsets, uint32_t* permutation, float* clustered) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    GPANN_TRY(EnsureDevice(s->device));
+    if (offsets) std::copy(s->offsets.begin(), s->offsets.end(), offsets);
+    if (permutation && s->rows) GPANN_HIP_TRY(hipMemcpy(permutation, s->permutation, s->rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (clustered && s->rows) {
+        GPANN_HIP_TRY(hipMemcpy2D(clustered, (size_t)s->d * sizeof(float), s->points, (size_t)s->ld * sizeof(float),
+                                  (size_t)s->d * sizeof(float), s->rows, hipMemcpyDeviceToHost));
+    }
+    return GPANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+/* gpann.h — C-ABI of libgpann_hip.so: the MI355X (gfx950) implementation of gp-ann's route + shard-scan hot path.
+ *
+ * This is the drop-in boundary.  The reference is a single-process C++ program with no FFI; the
+ * entry points below are what a binding for this path would have to cover, one per reference interface:
+ *
+ *   gpann_shards_create            <- InvertedIndex::InvertedIndex(PointSet&, const Clusters&)      src/inverted_index.h:12-41
+ *   gpann_scan_buckets             <- InvertedIndex::QueryBucket(float*, int k, int bucket)         src/inverted_index.h:62-75
+ *                                     batched over (query, probe slot), as driven by small_scale_queries.cpp:149-155
+ *   gpann_scan_merged              <- InvertedIndex::Query(float*, int k, probes, nprobe)           src/inverted_index.h:43-60
+ *   gpann_ground_truth             <- ComputeGroundTruth(points, queries, k)                        src/recall.h:25-39
+ *   gpann_shard_search_hits        <- RunInShardSearches(...) hit lists (exact scan instead of HNSW) src/shard_searches.cpp:11-104
+ *   gpann_router_create            <- KMeansTreeRouter (trained tree, flattened as ExtractPoints)    src/kmeans_tree_router.cpp:174-201
+ *   gpann_router_query_batch       <- KMeansTreeRouter::Query(float* Q, int budget)                 src/kmeans_tree_router.cpp:93-130
+ *   gpann_merge_dedup              <- DedupNeighbors(neighbors, k)                                  small_scale_queries.cpp:15-23
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns a gpann_status (0 = OK) and never
+ * throws; outputs are caller-allocated.  `metric`: 0 = squared L2, 1 = MIPS distance 1 - <p,q> (the reference's
+ * compile-time MIPS_DISTANCE switch, src/dist.cpp:75-81, is a runtime argument here).  Distances are evaluated in
+ * strict IEEE binary32 in the reference's scalar operation order (src/dist.cpp:17-37, :42-52), so returned ids and
+ * distances are bit-identical to the reference's CPU path built without -ffast-math/AVX.
+ *
+ * Memory spaces: pointer arguments documented as "host|device" are interpreted according to the GPANN_*_ON_DEVICE bits
+ * in `flags`; all other pointers are host pointers.  `stream` is a hipStream_t (NULL = default stream).  Calls that
+ * return results to host memory synchronise the stream before returning.
+ *
+ * There is no CPU fallback: if no gfx950 device is usable every entry point returns GPANN_ERR_NO_DEVICE.
+ */
+#ifndef GPANN_H
+#define GPANN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gpann_status {
+    GPANN_OK = 0,
+    GPANN_ERR_INVALID = 1,     /* bad argument (null pointer, k == 0 or k > GPANN_MAX_K, shard id out of range ...) */
+    GPANN_ERR_NO_DEVICE = 2,   /* no usable HIP device */
+    GPANN_ERR_HIP = 3,         /* a HIP runtime call failed; see gpann_last_error() */
+    GPANN_ERR_OOM = 4,         /* device or host allocation failed */
+    GPANN_ERR_UNSUPPORTED = 5
+} gpann_status;
+
+enum {
+    GPANN_METRIC_L2 = 0,
+    GPANN_METRIC_MIPS = 1
+};
+
+enum {
+    GPANN_QUERIES_ON_DEVICE = 1 << 0,  /* `queries` is a device pointer */
+    GPANN_OUTPUT_ON_DEVICE = 1 << 1,   /* out_* are device pointers (no synchronisation on return) */
+    GPANN_POINTS_ON_DEVICE = 1 << 2    /* `points` is a device pointer (gpann_shards_create) */
+};
+
+#define GPANN_MAX_K 64u                 /* top-k lists are held one entry per wavefront lane */
+#define GPANN_NO_ID 0xFFFFFFFFu         /* id / row written to unused result slots; their distance is +inf */
+
+typedef struct gpann_shards gpann_shards;   /* device-resident shard store (the InvertedIndex layout) */
+typedef struct gpann_router gpann_router;   /* device-resident flattened k-means tree router */
+
+/* thread-local, human-readable description of the last failure in the calling thread */
+const char* gpann_last_error(void);
+const char* gpann_version(void);
+gpann_status gpann_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------------ shard store */
+/* Gathers the points of every shard into one shard-contiguous row-major array in HBM (row stride = d rounded up to
+ * 4 floats), plus offsets[S+1] and permutation[row] -> global id, exactly the InvertedIndex layout.
+ *   points          host|device, n x d float32 row-major
+ *   ids_concat      host, concatenation of Clusters[0..S) (global ids, may repeat across shards)
+ *   shard_offsets   host, S+1 prefix offsets into ids_concat
+ */
+gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, int metric, const uint32_t* ids_concat,
+                                 const uint64_t* shard_offsets, uint32_t S, int device, int flags, gpann_shards** out);
+gpann_status gpann_shards_destroy(gpann_shards* s);
+/* rows = sum of shard sizes; any out pointer may be NULL */
+gpann_status gpann_shards_info(const gpann_shards* s, uint64_t* rows, uint32_t* d, uint32_t* S, int* metric, int* device);
+/* copies offsets (S+1 x int64) / permutation (rows x u32) / clustered points (rows x d f32, unpadded) to host */
+gpann_status gpann_shards_export(const gpann_shards* s, int64_t* offsets, uint32_t* permutation, float* clustered);
+
+/* Batched QueryBucket.  For q < nq, j < nprobe: exact top-k of shard probes[q*probe_stride + j] (negative = skip).
+ *   queries   host|device nq x d
+ *   probes    host, int32
+ *   out_ids   host|device [nq][nprobe][k] global ids, ascending by (distance, row); unused slots GPANN_NO_ID
+ *   out_dist  host|device [nq][nprobe][k] (may be NULL); unused slots +inf
+ *   out_rows  host|device [nq][nprobe][k] row index in the clustered layout = the reference's TopN key (may be NULL)
+ *   elapsed_ms  (may be NULL) device time of the scan + merge kernels, measured with HIP events on `stream`
+ */
+gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
+                                uint32_t probe_stride, uint32_t nprobe, uint32_t* out_ids, float* out_dist, uint32_t* out_rows,
+                                int flags, void* stream, float* elapsed_ms);
+
+/* Batched InvertedIndex::Query: ONE top-k over the union of the first nprobe probed shards (no dedupe), [nq][k]. */
+gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
+                               uint32_t probe_stride, uint32_t nprobe, uint32_t* out_ids, float* out_dist, int flags, void* stream,
+                               float* elapsed_ms);
+
+/* RunInShardSearches with the exact scan: every query against every shard; for shard b and query q the global ids whose
+ * distance <= distance_to_kth[q], in DESCENDING distance order (the reference pops a max-heap, shard_searches.cpp:78-89).
+ *   out_ids    host [S][nq][k], unused slots GPANN_NO_ID;  out_count host [S][nq]
+ */
+gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const float* distance_to_kth,
+                                     uint32_t* out_ids, uint32_t* out_count, int flags, void* stream, float* elapsed_ms);
+
+/* ComputeGroundTruth: exact k-NN of every query over ALL n points, ids are global point ids, ascending (dist, id).
+ * points: host|device.  Requires nothing to be resident; builds a temporary 1-shard store unless `s_all` (a store
+ * created with S = 1 and ids = 0..n-1) is passed, in which case `points` may be NULL. */
+gpann_status gpann_ground_truth(gpann_shards* s_all, const float* points, uint64_t n, uint32_t d, int metric, const float* queries,
+                                uint32_t nq, uint32_t k, uint32_t* out_ids, float* out_dist, int device, int flags, void* stream,
+                                float* elapsed_ms);
+
+/* Statistics of the most recent scan call on this store (for roofline accounting). */
+typedef struct gpann_scan_stats {
+    uint64_t pairs;              /* (query, point) distance evaluations requested by the caller: sum over tasks of shard rows */
+    uint64_t algorithmic_bytes;  /* pairs * d * 4  +  tasks * k * 8    */
+    uint64_t tasks;              /* (query, probe slot) pairs with a valid shard */
+    uint64_t units;              /* workgroups launched by the scan kernel */
+    uint64_t padded_pairs;       /* distance evaluations actually executed (tile padding included) */
+    float scan_ms;               /* scan kernel, HIP events */
+    float merge_ms;              /* merge kernel(s), HIP events */
+} gpann_scan_stats;
+gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
+
+/* ------------------------------------------------------------------------------------------------------ router */
+/* Flattened KMeansTreeRouter.  Nodes are numbered per shard in BFS order (the order of ExtractPoints); the centroids of
+ * node u are rows node_cent_first[u] .. node_cent_first[u+1]) of `centroids`; child i of node u (it exists iff
+ * i < node_child_count[u]) is node node_child_first[u] + i and belongs to centroid i (kmeans_tree_router.cpp:119-121).
+ * All arrays are host pointers and are copied. */
+gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_nodes, const int32_t* node_shard,
+                                 const uint32_t* node_cent_first, const uint32_t* node_child_first, const uint32_t* node_child_count,
+                                 const uint32_t* shard_root, const float* centroids, int device, gpann_router** out);
+gpann_status gpann_router_destroy(gpann_router* r);
+
+/* Batched KMeansTreeRouter::Query.  The best-first walk (all distance evaluations, the priority queue and the budget
+ * rule) runs on the GPU; the final order is std::sort over min_dist on the host, the very call the reference makes
+ * (kmeans_tree_router.cpp:125-127), so tie order is inherited from libstdc++.
+ *   queries       host|device nq x d
+ *   out_probes    host [nq][S] shard ids by ascending min_dist            (may be NULL)
+ *   out_min_dist  host [nq][S]; FLT_MAX for shards whose root was never opened (may be NULL)
+ */
+gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
+                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms);
+
+/* ------------------------------------------------------------------------------------------------------- merge */
+/* DedupNeighbors over per-slot results: for each query, the first `nprobe_used` slots of in_* [nq][nprobe][k] are
+ * concatenated, sorted by id, de-duplicated on (dist,id), sorted by (dist,id) and cut to k.  Host arrays.
+ * out_* [nq][k]; out_count[nq] (may be NULL). */
+gpann_status gpann_merge_dedup(const float* in_dist, const uint32_t* in_ids, uint32_t nq, uint32_t nprobe, uint32_t nprobe_used,
+                               uint32_t k, float* out_dist, uint32_t* out_ids, uint32_t* out_count);
+
+/* ---------------------------------------------------------------------------------- synthetic inputs (bench support) */
+/* Fills `out` (DEVICE pointer, nrows x d) with rows row0.. of the Gaussian-mixture generator of include/gpann_synth.h. */
+gpann_status gpann_synth_rows_device(uint64_t seed, uint64_t center_seed, uint32_t n_centers, float sigma, uint64_t row0,
+                                     uint64_t nrows, uint32_t d, float* out, void* stream);
+/* For every row of `points` (DEVICE, n x d) the index of the nearest of `centroids` (DEVICE, c x d) under `metric`
+ * (first minimum wins, kmeans.cpp:12-23 Top1Neighbor) -> out_assign (DEVICE int32[n]).  Used to shard synthetic data. */
+gpann_status gpann_nearest_centroid_device(const float* points, uint64_t n, uint32_t d, int metric, const float* centroids, uint32_t c,
+                                           int32_t* out_assign, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPANN_H */

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The strict CPU oracle (oracle/liboracle.so) — the checker, never the thing under test in -m gpu tests."""
+    import pyoracle
+    pyoracle.build()
+    return pyoracle.Oracle("strict")
+
+
+@pytest.fixture(scope="session")
+def gp():
+    """The product binding; GPU tests fail loudly (no fallback) if the HIP library is missing."""
+    import pygpann
+    pygpann.lib()
+    return pygpann
+
+
+def make_mixture(orc, n, d, seed=555, n_centers=16, sigma=0.35, center_seed=7):
+    return orc.synth_rows(seed, center_seed, n_centers, sigma, 0, n, d, nthreads=4)
+
+
+def random_clusters(rng, n, S, overlap=0.0, empty_shard=False):
+    """Random shard membership lists in random order (ids may repeat across shards when overlap > 0)."""
+    part = rng.integers(0, S - (1 if empty_shard else 0), size=n)
+    clusters = [list(np.flatnonzero(part == b)) for b in range(S)]
+    if overlap > 0:
+        extra = rng.choice(n, size=int(n * overlap), replace=False)
+        for i in extra:
+            b = int(rng.integers(0, S - (1 if empty_shard else 0)))
+            if part[i] != b:
+                clusters[b].append(int(i))
+    out = []
+    for c in clusters:
+        c = np.asarray(c, dtype=np.uint32)
+        rng.shuffle(c)
+        out.append(c)
+    return out

@@ -1,0 +1,105 @@
+"""GPU parity: KMeansTreeRouter::Query on the GPU against the CPU oracle — min_dist bit-exact, probes identical."""
+import numpy as np
+import pytest
+
+from conftest import make_mixture, random_clusters
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree(orc, n, d, S, metric, num_centroids, min_cluster, budget, seed=1):
+    rng = np.random.default_rng(seed)
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=num_centroids, min_cluster_size=min_cluster, budget=budget, metric=metric, nthreads=4)
+    return pts, clusters, tree
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d,num_centroids", [(32, 16), (100, 8), (7, 64)])
+def test_router_matches_oracle(orc, gp, metric, d, num_centroids):
+    pts, clusters, tree = _tree(orc, 12000, d, 5, metric, num_centroids, 40, 1500)
+    assert tree.n_nodes > 5
+    queries = make_mixture(orc, 200, d, seed=556, n_centers=24)
+    router = gp.Router(tree.flat(), metric, 0)
+    for budget in (1, 37, 300, 100000):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget, nthreads=4)
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), budget
+        assert np.array_equal(probes, wp), budget
+
+
+def test_router_unvisited_shards_and_zero_budget(orc, gp):
+    pts, clusters, tree = _tree(orc, 8000, 16, 8, 0, 16, 30, 2000)
+    queries = make_mixture(orc, 64, 16, seed=556, n_centers=24)
+    router = gp.Router(tree.flat(), 0, 0)
+    FLT_MAX = np.finfo(np.float32).max
+    # budget too small to open every root: unopened shards keep FLT_MAX and the order among them is libstdc++'s
+    probes, md, _ = router.query_batch(queries, 20)
+    wp, wm = tree.query_batch(queries, 20, nthreads=2)
+    assert (md == FLT_MAX).any()
+    assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+    for budget in (0, -5):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget)
+        assert (md == FLT_MAX).all() and np.array_equal(probes, wp)
+
+
+def test_router_duplicate_centroids_tie_order(orc, gp):
+    """equal priority-queue keys: the pop order must be libstdc++'s (reference kmeans_tree_router.cpp:94-100)"""
+    n, d, S = 6000, 8, 4
+    rng = np.random.default_rng(4)
+    base = make_mixture(orc, 50, d, n_centers=4)
+    pts = base[rng.integers(0, 50, size=n)]          # only 50 distinct points -> duplicated centroids, equal distances
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=16, min_cluster_size=20, budget=1200, metric=0, nthreads=4)
+    queries = base[rng.integers(0, 50, size=100)]
+    router = gp.Router(tree.flat(), 0, 0)
+    for budget in (30, 100, 400):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget)
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+
+
+def test_router_wide_nodes(orc, gp):
+    """nodes with more than 64 centroids (the reference also uses 128, routes.cpp:130-157)"""
+    pts, clusters, tree = _tree(orc, 20000, 24, 3, 0, 128, 60, 3000)
+    f = tree.flat()
+    assert np.max(np.diff(f["node_cent_first"])) > 64
+    queries = make_mixture(orc, 80, 24, seed=556, n_centers=24)
+    router = gp.Router(f, 0, 0)
+    for budget in (200, 5000):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget, nthreads=4)
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+
+
+def test_end_to_end_route_scan_merge_recall(orc, gp):
+    """small_scale_queries.cpp:93-165 end to end: route -> QueryBucket per probe -> DedupNeighbors -> Recall"""
+    n, d, S, nq, k = 20000, 32, 6, 200, 10
+    pts = make_mixture(orc, n, d, n_centers=32)
+    part, _ = orc.kmeans(pts, S, 555, 0, nthreads=4)
+    clusters = orc.partition_to_clusters(part)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=32, min_cluster_size=200, budget=2000, metric=0, nthreads=4)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=32)
+    router = gp.Router(tree.flat(), 0, 0)
+    probes, _, _ = router.query_batch(queries, 5000)
+    wp, _ = tree.query_batch(queries, 5000, nthreads=4)
+    assert np.array_equal(probes, wp)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
+    gt_ids, gt_dist, _ = gp.ground_truth(pts, queries, k, 0)
+    kth = gt_dist[:, k - 1]
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, wp, S, 0, nthreads=4)
+    prev = 0.0
+    for nprobe in range(1, S + 1):
+        md, mi, mc = gp.merge_dedup(dist, ids, nprobe, k)
+        # oracle merge over the same prefix
+        offs = np.arange(nq + 1, dtype=np.uint64) * (nprobe * k)
+        od, oi, oc = orc.dedup_neighbors(wd[:, :nprobe].reshape(-1), wi[:, :nprobe].reshape(-1), offs, k)
+        assert np.array_equal(mi, oi) and np.array_equal(md.view(np.uint32), od.view(np.uint32)) and np.array_equal(mc, oc)
+        rec = orc.recall(md.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * k, kth, k)
+        assert rec >= prev - 1e-12
+        prev = rec
+    assert abs(prev - 1.0) < 1e-6        # all shards probed: exact
