@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""bench.py — QPS at recall@10 >= 0.9 of the route + shard-scan hot path on synthetic 100M x 128 float vectors.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch of 10 000 queries that are already resident in HBM:
+    KMeansTreeRouter::Query (GPU walk + host std::sort)  ->  per-(query, probe) exact shard scan + top-k (GPU)
+    ->  [N > 1: all-gather of the per-slot partial results over RCCL]  ->  host merge (DedupNeighbors).
+The workload is BASELINE.json's north-star configuration (SURVEY.md §8 "NS"): 100M x 128 f32 Gaussian-mixture points
+(1024 centres, sigma 0.35, seed 555), 10k queries (seed 556), 40 k-means shards, k = 10, nprobe = the smallest value whose
+recall@10 reaches 0.9 (found by a sweep before the timed region; the ground truth is computed with the same scan kernel).
+With N GPUs the 40 shards are spread over the ranks (LPT by size); total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (the scan kernel: algorithmic bytes / HIP-event kernel time against
+the 8 TB/s HBM peak), `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample of the same
+workload) and `detail`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+POINT_SEED, QUERY_SEED, CENTER_SEED = 555, 556, 7
+N_CENTERS, SIGMA = 1024, 0.35
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
+    """Flat k-means on the device (setup only): nearest-centroid kernel + torch scatter-add updates."""
+    n, d = sample.shape
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    idx = torch.randperm(n, generator=g)[:k].to(sample.device)
+    cent = sample[idx].clone().contiguous()
+    assign = torch.empty(n, dtype=torch.int32, device=sample.device)
+    for _ in range(rounds):
+        pygpann.nearest_centroid_device(sample.data_ptr(), n, d, 0, cent.data_ptr(), cent.shape[0], assign.data_ptr(), stream)
+        a64 = assign.to(torch.int64)
+        sums = torch.zeros_like(cent).index_add_(0, a64, sample)
+        cnt = torch.bincount(a64, minlength=cent.shape[0]).clamp_(min=1).to(sample.dtype)
+        keep = torch.bincount(a64, minlength=cent.shape[0]) > 0
+        cent = torch.where(keep[:, None], sums / cnt[:, None], cent).contiguous()
+    pygpann.nearest_centroid_device(sample.data_ptr(), n, d, 0, cent.data_ptr(), cent.shape[0], assign.data_ptr(), stream)
+    return cent, assign
+
+
+def build_router_tree(torch, pygpann, sample, sample_assign, S, num_centroids, seed, stream):
+    """A depth-1 KMeansTreeRouter (one root of <= num_centroids centroids per shard) trained on a device sample.
+    (The multi-level host trainer is gp-ann_amd/host; the bench only needs *a* valid tree for the fixed workload.)"""
+    d = sample.shape[1]
+    cents, node_shard, cent_first = [], [], [0]
+    for b in range(S):
+        rows = sample[sample_assign == b]
+        kk = int(min(num_centroids, max(1, rows.shape[0])))
+        if rows.shape[0] == 0:
+            c = torch.zeros((1, d), dtype=sample.dtype, device=sample.device)
+        else:
+            c, a = lloyd_gpu(torch, pygpann, rows.contiguous(), kk, 10, seed + b, stream)
+            used = torch.bincount(a.to(torch.int64), minlength=c.shape[0]) > 0
+            c = c[used] if used.any() else c[:1]
+        cents.append(c)
+        node_shard.append(b)
+        cent_first.append(cent_first[-1] + c.shape[0])
+    cen = torch.cat(cents).cpu().numpy()
+    return dict(d=d, S=S, node_shard=np.asarray(node_shard, np.int32), node_cent_first=np.asarray(cent_first, np.uint32),
+                node_child_first=np.zeros(S, np.uint32), node_child_count=np.zeros(S, np.uint32),
+                shard_root=np.arange(S, dtype=np.uint32), centroids=cen)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("GPANN_BENCH_N", 100_000_000)))
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--shards", type=int, default=40)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--target-recall", type=float, default=0.9)
+    ap.add_argument("--search-budget", type=int, default=50000)
+    ap.add_argument("--router-centroids", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pygpann
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, d, nq, S, k = args.n, args.d, args.nq, args.shards, args.k
+
+    t_setup = time.time()
+    # ---------------------------------------------------------------- synthetic inputs, generated straight into HBM
+    queries = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    pygpann.synth_rows_device(queries.data_ptr(), QUERY_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, nq, d, stream)
+    n_sample = min(n, 2_000_000)
+    sample = torch.empty((n_sample, d), dtype=torch.float32, device=dev)
+    pygpann.synth_rows_device(sample.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, n_sample, d, stream)
+    shard_cent, sample_assign = lloyd_gpu(torch, pygpann, sample, S, 20, 555, stream)
+    tree = build_router_tree(torch, pygpann, sample, sample_assign, S, args.router_centroids, 555, stream)
+    del sample
+    log(f"shard centroids + router tree ({tree['centroids'].shape[0]} centroids) ready in {time.time() - t_setup:.1f}s")
+
+    # shard assignment of all rows, chunked; every rank keeps only the rows of the shards it owns
+    chunk = 4_000_000
+    counts = torch.zeros(S, dtype=torch.int64, device=dev)
+    assign_all = torch.empty(n, dtype=torch.int32, device=dev)
+    buf = torch.empty((min(chunk, n), d), dtype=torch.float32, device=dev)
+    for r0 in range(0, n, chunk):
+        m = min(chunk, n - r0)
+        pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
+        pygpann.nearest_centroid_device(buf.data_ptr(), m, d, 0, shard_cent.data_ptr(), S, assign_all[r0:r0 + m].data_ptr(), stream)
+    counts = torch.bincount(assign_all.to(torch.int64), minlength=S).cpu().numpy()
+    # LPT: biggest shard first onto the least loaded rank
+    owner = np.zeros(S, np.int64)
+    load = np.zeros(world, np.int64)
+    for b in np.argsort(-counts, kind="stable"):
+        r = int(np.argmin(load))
+        owner[b] = r
+        load[r] += counts[b]
+    mine = np.flatnonzero(owner == rank)
+    log(f"shard sizes min/max {counts.min()}/{counts.max()}, rank loads {load.tolist()}")
+    # local point set = rows of my shards, in global-id order; Clusters hold GLOBAL ids, local_rows maps them to local rows
+    mine_mask = torch.zeros(S, dtype=torch.bool, device=dev)
+    mine_mask[torch.as_tensor(mine, device=dev)] = True
+    keep = mine_mask[assign_all.to(torch.int64)]
+    my_ids = torch.nonzero(keep).squeeze(1)                      # global ids I own, ascending
+    n_local = int(my_ids.numel())
+    local_points = torch.empty((n_local, d), dtype=torch.float32, device=dev)
+    pos = 0
+    for r0 in range(0, n, chunk):
+        m = min(chunk, n - r0)
+        kc = keep[r0:r0 + m]
+        c = int(kc.sum())
+        if c == 0:
+            continue
+        pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
+        local_points[pos:pos + c] = buf[:m][kc]
+        pos += c
+    del buf, keep
+    my_assign = assign_all[my_ids]
+    del assign_all
+    order = torch.sort(my_assign.to(torch.int64), stable=True).indices       # local rows grouped by shard
+    sorted_assign = my_assign[order].cpu().numpy()
+    local_rows_by_shard = order.to(torch.int32).cpu().numpy().astype(np.uint32)
+    global_ids_by_shard = my_ids[order].cpu().numpy().astype(np.uint32)
+    del order, my_assign
+    # Clusters over the LOCAL point array (all S shards; shards of other ranks are empty here)
+    bounds = np.searchsorted(sorted_assign, np.arange(S + 1))
+    clusters_local = [local_rows_by_shard[bounds[b]:bounds[b + 1]] for b in range(S)]
+    torch.cuda.synchronize()
+    shards = pygpann.Shards(local_points.data_ptr(), clusters_local, 0, local_rank, n=n_local, d=d)
+    del local_points
+    torch.cuda.empty_cache()
+    router = pygpann.Router(tree, 0, local_rank)
+    log(f"rank {rank}: {n_local} rows in {len(mine)} shards resident; setup {time.time() - t_setup:.1f}s")
+
+    def to_global(ids_local):
+        """scan results carry ids of the local point array; map them to the global ids of the synthetic cloud"""
+        out = np.full(ids_local.shape, 0xFFFFFFFF, np.uint32)
+        v = ids_local != 0xFFFFFFFF
+        # permutation: local row id -> global id (my_ids is ascending, local row i = i-th owned global id)
+        out[v] = my_ids_host[ids_local[v]]
+        return out
+
+    my_ids_host = my_ids.cpu().numpy().astype(np.uint32)
+    del my_ids
+
+    owner32 = owner.astype(np.int32)
+
+    def local_probes(probes):
+        """probe lists with the shards of other ranks masked out (-1 = skip)"""
+        p = probes.copy()
+        p[owner32[np.clip(p, 0, S - 1)] != rank] = -1
+        return p
+
+    out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((nq, S, k), dtype=torch.float32, device=dev)
+
+    def scan_slots(probes, nprobe, timed=False):
+        """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
+        lp = local_probes(np.ascontiguousarray(probes[:, :nprobe]))
+        oi = out_ids[:, :nprobe].contiguous() if nprobe != S else out_ids
+        od = out_dist[:, :nprobe].contiguous() if nprobe != S else out_dist
+        ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed)
+        if world > 1:
+            gi = [torch.empty_like(oi) for _ in range(world)]
+            gd = [torch.empty_like(od) for _ in range(world)]
+            # translate to global ids before the exchange
+            ids_h = to_global(oi.cpu().numpy().view(np.uint32))
+            oi.copy_(torch.from_numpy(ids_h.view(np.int32)))
+            dist.all_gather(gi, oi)
+            dist.all_gather(gd, od)
+            gd_h = torch.stack(gd).cpu().numpy()
+            gi_h = torch.stack(gi).cpu().numpy().view(np.uint32)
+            sel = owner32[np.clip(probes[:, :nprobe], 0, S - 1)]                       # [nq, nprobe] owning rank of each slot
+            dist_h = np.take_along_axis(gd_h, sel[None, :, :, None], axis=0)[0]
+            ids_h = np.take_along_axis(gi_h, sel[None, :, :, None], axis=0)[0]
+        else:
+            torch.cuda.current_stream().synchronize()
+            dist_h = od.cpu().numpy()
+            ids_h = to_global(oi.cpu().numpy().view(np.uint32))
+        return dist_h, ids_h, ms
+
+    # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
+    t0 = time.time()
+    all_probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    gt_slot_d, gt_slot_i, _ = scan_slots(all_probes, S)
+    gt_d, gt_i, _ = pygpann.merge_dedup(gt_slot_d, gt_slot_i, S, k)
+    kth = gt_d[:, k - 1].copy()
+    log(f"ground truth over {n} points in {time.time() - t0:.1f}s")
+
+    # nprobe sweep on the host: the ground-truth pass already produced the exact top-k of EVERY (query, shard), so the
+    # result of probing the first j shards of a route is a gather + DedupNeighbors (small_scale_queries.cpp:149-157)
+    probes, _, _ = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+    nprobe, recall_curve = None, []
+    routed_d = np.take_along_axis(gt_slot_d, probes[:, :, None].astype(np.int64), axis=1)
+    routed_i = np.take_along_axis(gt_slot_i, probes[:, :, None].astype(np.int64), axis=1)
+    for np_try in range(1, S + 1):
+        md, mi, _ = pygpann.merge_dedup(routed_d, routed_i, np_try, k)
+        rec = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
+        recall_curve.append(round(rec, 6))
+        if rec >= args.target_recall:
+            nprobe = np_try
+            break
+    if nprobe is None:
+        nprobe = S
+    del routed_d, routed_i, gt_slot_d, gt_slot_i
+    log(f"recall curve {recall_curve} -> nprobe {nprobe}")
+
+    # ---------------------------------------------------------------- the timed hot path
+    def step():
+        pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+        sd, si, s_ms = scan_slots(pr, nprobe, timed=True)
+        md, mi, _ = pygpann.merge_dedup(sd, si, nprobe, k)
+        return md, mi, r_ms, s_ms
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    scan_ms, router_ms, algo_bytes, stats = [], [], [], None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        md, mi, r_ms, s_ms = step()
+        st = shards.stats()
+        scan_ms.append(st["scan_ms"])
+        router_ms.append(r_ms)
+        algo_bytes.append(st["algorithmic_bytes"])
+        stats = st
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
+    qps = nq * args.steps / elapsed
+
+    result = {
+        "metric": "QPS @ recall@10=0.9, 10k batched queries",
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"NS: {n}x{d} f32 Gaussian mixture ({N_CENTERS} centres, sigma {SIGMA}), {nq} queries, {S} k-means shards, "
+                               f"k={k}, KMeansTreeRouter ({tree['centroids'].shape[0]} centroids, search budget {args.search_budget}) + exact "
+                               f"shard scan, nprobe={nprobe}",
+                   "n": n, "d": d, "queries": nq, "shards": S, "k": k, "nprobe": nprobe, "recall_at_k": recall,
+                   "parallelism": f"shards over {world} GPU(s), LPT"},
+    }
+    avg_scan_s = float(np.mean(scan_ms)) / 1000.0
+    achieved = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
+    result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                          "traffic": None, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
+                          "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY §8d) of rank 0 / HIP-event kernel time; "
+                                  "each HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
+                          "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0}
+    result["detail"] = {"recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "scan_kernel_ms": float(np.mean(scan_ms)),
+                        "merge_kernel_ms": stats["merge_ms"], "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"],
+                        "padded_pairs": stats["padded_pairs"], "setup_s": time.time() - t_setup}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts)
+        except Exception as e:   # the baseline must never take the headline number down with it
+            result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts):
+    """Time the strict CPU oracle (oracle/liboracle.so, `kind: port`) on the host cores over a bounded sample of the same
+    workload: the queries whose first `nprobe` probes fall into a few shards, scanned against those shards' real rows."""
+    import pyoracle
+    orc = pyoracle.Oracle("strict")
+    cores = os.cpu_count() or 1
+    S, k, d = args.shards, args.k, args.d
+    # choose shards until the sample holds ~1e10 (query, row) pairs
+    first = probes[:, :nprobe]
+    chosen, sel_q, pairs = [], np.zeros(len(first), bool), 0
+    for b in np.argsort(counts, kind="stable"):
+        qs = np.all(np.isin(first, chosen + [int(b)]), axis=1)
+        chosen.append(int(b))
+        sel_q = qs
+        pairs = int(sum(counts[first[q]].sum() for q in np.flatnonzero(qs)))
+        if pairs >= 1.2e10 or len(chosen) >= 8:
+            break
+    qidx = np.flatnonzero(sel_q)
+    if len(qidx) == 0:
+        return {"value": None, "unit": "queries/s", "cores": cores, "kind": "port", "sample": "no query falls entirely into the sampled shards"}
+    # pull the sampled shards' rows to the host
+    offs = shards.offsets()
+    new_id = {b: i for i, b in enumerate(chosen)}
+    parts = [shards.export_range(int(offs[b]), int(offs[b + 1] - offs[b])) for b in chosen]
+    clustered = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
+    ivf_perm = np.concatenate([p[0] for p in parts]).astype(np.uint32)
+    sizes = np.array([len(p[0]) for p in parts], np.int64)
+    ivf_offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    q_host = queries.cpu().numpy()[qidx]
+    ivf = (np.ascontiguousarray(clustered, np.float32), ivf_offsets, ivf_perm)
+    pr = np.vectorize(new_id.get)(first[qidx]).astype(np.int32)
+    otree = orc.kmtr_from_flat(tree, 0)
+    t0 = time.perf_counter()
+    otree.query_batch(q_host, args.search_budget, nthreads=cores)                         # route
+    od, oi, _ = orc.ivf_query_bucket_batch(ivf, q_host, k, pr, nprobe, 0, nthreads=cores)  # scan
+    offsets = np.arange(len(qidx) + 1, dtype=np.uint64) * (nprobe * k)
+    orc.dedup_neighbors(od.reshape(-1), oi.reshape(-1), offsets, k)                      # merge
+    dt = time.perf_counter() - t0
+    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
+                      f"{pairs:.3g} (query,row) pairs in {dt:.1f}s on {cores} threads; strict build (-O2, no fast-math/FMA/AVX)",
+            "seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

@@ -215,4 +215,18 @@ gpann_status gpann_shards_export(const gpann_shards* s, int64_t* offsets, uint32
     return GPANN_OK;
 }
 
+gpann_status gpann_shards_export_range(const gpann_shards* s, uint64_t row_begin, uint64_t row_count, uint32_t* permutation,
+                                       float* clustered) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    GPANN_REQUIRE(row_begin <= s->rows && row_count <= s->rows - row_begin, "row range out of bounds");
+    GPANN_TRY(EnsureDevice(s->device));
+    if (row_count == 0) return GPANN_OK;
+    if (permutation) GPANN_HIP_TRY(hipMemcpy(permutation, s->permutation + row_begin, row_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (clustered) {
+        GPANN_HIP_TRY(hipMemcpy2D(clustered, (size_t)s->d * sizeof(float), s->points + row_begin * s->ld, (size_t)s->ld * sizeof(float),
+                                  (size_t)s->d * sizeof(float), row_count, hipMemcpyDeviceToHost));
+    }
+    return GPANN_OK;
+}
+
 }  // extern "C"

@@ -27,7 +27,7 @@ _i64p = C.POINTER(C.c_int64)
 
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
-    "gpann_shards_export", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
+    "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
     "gpann_scan_last_stats", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
@@ -71,6 +71,7 @@ def lib():
     L.gpann_shards_destroy.argtypes = [C.c_void_p]
     L.gpann_shards_info.argtypes = [C.c_void_p, _u64p, _u32p, _u32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gpann_shards_export.argtypes = [C.c_void_p, _i64p, _u32p, _f32p]
+    L.gpann_shards_export_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _u32p, _f32p]
     L.gpann_scan_buckets.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _i32p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, _f32p]
     L.gpann_scan_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _i32p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -162,6 +163,17 @@ class Shards:
         pts = np.empty((self.rows, self.d), np.float32)
         _check(lib().gpann_shards_export(self.h, offsets.ctypes.data_as(_i64p), perm.ctypes.data_as(_u32p), pts.ctypes.data_as(_f32p)))
         return offsets, perm, pts
+
+    def offsets(self):
+        offsets = np.empty(self.S + 1, np.int64)
+        _check(lib().gpann_shards_export(self.h, offsets.ctypes.data_as(_i64p), None, None))
+        return offsets
+
+    def export_range(self, row_begin, row_count):
+        perm = np.empty(row_count, np.uint32)
+        pts = np.empty((row_count, self.d), np.float32)
+        _check(lib().gpann_shards_export_range(self.h, row_begin, row_count, perm.ctypes.data_as(_u32p), pts.ctypes.data_as(_f32p)))
+        return perm, pts
 
     def scan_buckets(self, queries, k, probes, nprobe=None, stream=None, want_rows=False):
         """Batched QueryBucket.  queries [nq,d]; probes [nq,stride] int32.  Returns ids, dist [nq,nprobe,k] (+rows), ms."""

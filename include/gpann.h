@@ -80,6 +80,9 @@ gpann_status gpann_shards_destroy(gpann_shards* s);
 gpann_status gpann_shards_info(const gpann_shards* s, uint64_t* rows, uint32_t* d, uint32_t* S, int* metric, int* device);
 /* copies offsets (S+1 x int64) / permutation (rows x u32) / clustered points (rows x d f32, unpadded) to host */
 gpann_status gpann_shards_export(const gpann_shards* s, int64_t* offsets, uint32_t* permutation, float* clustered);
+/* same for the row range [row_begin, row_begin + row_count) only (e.g. one shard): permutation / clustered may be NULL */
+gpann_status gpann_shards_export_range(const gpann_shards* s, uint64_t row_begin, uint64_t row_count, uint32_t* permutation,
+                                       float* clustered);
 
 /* Batched QueryBucket.  For q < nq, j < nprobe: exact top-k of shard probes[q*probe_stride + j] (negative = skip).
  *   queries   host|device nq x d
