@@ -202,12 +202,12 @@ def main():
     out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, S, k), dtype=torch.float32, device=dev)
 
-    def scan_slots(probes, nprobe, timed=False):
+    def scan_slots(probes, nprobe, timed=False, aux=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
         lp = local_probes(np.ascontiguousarray(probes[:, :nprobe]))
         oi = out_ids[:, :nprobe].contiguous() if nprobe != S else out_ids
         od = out_dist[:, :nprobe].contiguous() if nprobe != S else out_dist
-        ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed)
+        ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
         if world > 1:
             gi = [torch.empty_like(oi) for _ in range(world)]
             gd = [torch.empty_like(od) for _ in range(world)]
@@ -230,7 +230,7 @@ def main():
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
     all_probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
-    gt_slot_d, gt_slot_i, _ = scan_slots(all_probes, S)
+    gt_slot_d, gt_slot_i, _ = scan_slots(all_probes, S, aux=True)
     gt_d, gt_i, _ = pygpann.merge_dedup(gt_slot_d, gt_slot_i, S, k)
     kth = gt_d[:, k - 1].copy()
     log(f"ground truth over {n} points in {time.time() - t0:.1f}s")

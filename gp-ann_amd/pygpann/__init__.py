@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1
-QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE = 1, 2, 4
+QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS = 1, 2, 4, 8
 MAX_K = 64
 NO_ID = np.uint32(0xFFFFFFFF)
 
@@ -194,14 +194,15 @@ class Shards:
             return ids, dist, rows, ms.value
         return ids, dist, ms.value
 
-    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False):
+    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False):
         """Same with queries and outputs resident on the device (raw pointers); asynchronous unless timed."""
         probes = _np(probes, np.int32)
         stride = probes.shape[1]
         ms = C.c_float(0)
         _check(lib().gpann_scan_buckets(self.h, C.c_void_p(int(queries_ptr)), nq, k, probes.ctypes.data_as(_i32p), stride, nprobe,
                                         C.c_void_p(int(out_ids_ptr)), C.c_void_p(int(out_dist_ptr)) if out_dist_ptr else None, None,
-                                        QUERIES_ON_DEVICE | OUTPUT_ON_DEVICE, C.c_void_p(stream or 0), C.byref(ms) if timed else None))
+                                        QUERIES_ON_DEVICE | OUTPUT_ON_DEVICE | (AUX_PASS if aux else 0), C.c_void_p(stream or 0),
+                                        C.byref(ms) if timed else None))
         return ms.value
 
     def scan_merged(self, queries, k, probes, nprobe, stream=None):

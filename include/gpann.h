@@ -52,7 +52,9 @@ enum {
 enum {
     GPANN_QUERIES_ON_DEVICE = 1 << 0,  /* `queries` is a device pointer */
     GPANN_OUTPUT_ON_DEVICE = 1 << 1,   /* out_* are device pointers (no synchronisation on return) */
-    GPANN_POINTS_ON_DEVICE = 1 << 2    /* `points` is a device pointer (gpann_shards_create) */
+    GPANN_POINTS_ON_DEVICE = 1 << 2,   /* `points` is a device pointer (gpann_shards_create) */
+    GPANN_AUX_PASS = 1 << 3            /* profiling label: run the identical scan kernel under a second symbol name so that
+                                          auxiliary passes (ground truth) stay out of the hot path's per-kernel statistics */
 };
 
 #define GPANN_MAX_K 64u                 /* top-k lists are held one entry per wavefront lane */
