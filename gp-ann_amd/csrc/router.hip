@@ -54,6 +54,10 @@ struct RouterArgs {
     float* heap_key;          // [slots][heap_cap]
     uint32_t* heap_node;      // [slots][heap_cap]
     float* out_min_dist;      // [nq][S]
+    float* rec_dist;          // optional [nq][rec_cap]: every evaluated centroid distance, in evaluation order (FrequencyQuery)
+    int32_t* rec_shard;       // optional [nq][rec_cap]
+    uint32_t* rec_count;      // optional [nq]
+    uint64_t rec_cap;
     uint32_t d, ld, S, nq;
     uint64_t heap_cap;
     int32_t budget;
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
         size = S;
         __builtin_amdgcn_wave_barrier();
         int32_t budget = a.budget;
+        uint32_t n_rec = 0;
         while (size > 0 && budget > 0) {   // :112
             uint32_t node = 0;
             if (lane == 0) {
@@ -201,6 +206,11 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
                     __builtin_amdgcn_wave_barrier();
                 }
                 float dist = METRIC == GPANN_METRIC_MIPS ? 1.0f - acc : acc;
+                if (a.rec_dist && (uint32_t)lane < m) {   // kmeans_tree_router.cpp:158: every (dist, shard) is offered to the vote list
+                    a.rec_dist[(size_t)q * a.rec_cap + n_rec + lane] = dist;
+                    a.rec_shard[(size_t)q * a.rec_cap + n_rec + lane] = shard;
+                }
+                n_rec += m;
                 if ((uint32_t)lane >= m) dist = FLT_MAX;
                 sDist[lane] = dist;
                 // min over the node's centroids (:118; std::min keeps the old value on ties and ignores NaN the same way)
@@ -220,6 +230,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
             }
         }
         for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = sMin[b];
+        if (a.rec_count && lane == 0) a.rec_count[q] = n_rec;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -307,16 +318,13 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     return GPANN_OK;
 }
 
-gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
-                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
-    GPANN_REQUIRE(r != nullptr, "router handle is null");
-    GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
-    GPANN_TRY(EnsureDevice(r->device));
-    if (elapsed_ms) *elapsed_ms = 0.f;
-    if (nq == 0) return GPANN_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint32_t S = r->S, ld = r->ld;
+namespace {
 
+// Stages the queries, sizes the queue workspace and launches the walk for queries [0, nq); min_dist lands in r->ws_out.
+// rec_* (device, optional) receive every evaluated (distance, shard) pair.
+gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int flags, hipStream_t st, float* rec_dist,
+                        int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap) {
+    const uint32_t S = r->S, ld = r->ld;
     const size_t qbytes = (size_t)nq * ld * sizeof(float);
     GPANN_TRY(r->ws_queries.Reserve(qbytes));
     if (ld != r->d) GPANN_HIP_TRY(hipMemsetAsync(r->ws_queries.ptr, 0, qbytes, st));
@@ -355,6 +363,10 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     a.heap_key = r->ws_heap.as<float>();
     a.heap_node = reinterpret_cast<uint32_t*>(a.heap_key + slots * cap);
     a.out_min_dist = r->ws_out.as<float>();
+    a.rec_dist = rec_dist;
+    a.rec_shard = rec_shard;
+    a.rec_count = rec_count;
+    a.rec_cap = rec_cap;
     a.d = r->d;
     a.ld = ld;
     a.S = S;
@@ -368,6 +380,21 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         hipLaunchKernelGGL(RouterWalkKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64 * kRWaves), lds, st, a);
     GPANN_HIP_TRY(hipGetLastError());
     GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
+    return GPANN_OK;
+}
+
+}  // namespace
+
+gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
+                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
+    GPANN_TRY(EnsureDevice(r->device));
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (nq == 0) return GPANN_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t S = r->S;
+    GPANN_TRY(LaunchWalk(r, queries, nq, budget, flags, st, nullptr, nullptr, nullptr, 0));
 
     std::vector<float> local_min;
     float* md = out_min_dist;
@@ -375,7 +402,7 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         local_min.resize((size_t)nq * S);
         md = local_min.data();
     }
-    GPANN_HIP_TRY(hipMemcpyAsync(md, a.out_min_dist, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipMemcpyAsync(md, r->ws_out.ptr, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
     if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
 
@@ -390,6 +417,77 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         }
     }
     return GPANN_OK;
+}
+
+// KMeansTreeRouter::FrequencyQuery (kmeans_tree_router.cpp:132-172): the same walk; additionally the num_voting smallest
+// (distance, shard) pairs over ALL evaluated centroids (TopN, then FrequencyQueryData::Init sorts them ascending).
+// The walk kernel records every evaluated pair; the selection of the num_voting smallest is done here on the host
+// (order-independent: the result is the set of lexicographically smallest pairs).
+gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t num_voting,
+                                                float* out_min_dist, float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count,
+                                                int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    GPANN_REQUIRE(nq == 0 || (queries && out_min_dist && out_nn_dist && out_nn_shard && out_nn_count), "null argument");
+    GPANN_TRY(EnsureDevice(r->device));
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (nq == 0) return GPANN_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t S = r->S;
+    // a walk evaluates at most budget + (largest node - 1) centroids after the budget check, and never more than the tree holds
+    uint32_t max_node = 1;
+    {
+        std::vector<uint32_t> cf(r->n_nodes + 1);
+        GPANN_HIP_TRY(hipMemcpy(cf.data(), r->node_cent_first, (r->n_nodes + 1) * 4, hipMemcpyDeviceToHost));
+        for (uint32_t u = 0; u < r->n_nodes; ++u) max_node = std::max(max_node, cf[u + 1] - cf[u]);
+    }
+    uint64_t rec_cap = std::min<uint64_t>(r->n_centroids, (uint64_t)std::max(budget, 0) + max_node);
+    rec_cap = std::max<uint64_t>(rec_cap, 1);
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (512ull << 20) / (rec_cap * 8)));
+    DeviceBuffer rec;
+    GPANN_TRY(rec.Reserve((size_t)batch * rec_cap * 8 + (size_t)batch * 4));
+    float* d_rec_dist = rec.as<float>();
+    int32_t* d_rec_shard = reinterpret_cast<int32_t*>(d_rec_dist + (size_t)batch * rec_cap);
+    uint32_t* d_rec_count = reinterpret_cast<uint32_t*>(d_rec_shard + (size_t)batch * rec_cap);
+    std::vector<float> h_dist((size_t)batch * rec_cap);
+    std::vector<int32_t> h_shard((size_t)batch * rec_cap);
+    std::vector<uint32_t> h_count(batch);
+    const size_t qstride = (flags & GPANN_QUERIES_ON_DEVICE) ? r->d : r->d;
+    float total_ms = 0.f;
+    gpann_status status = GPANN_OK;
+    for (uint32_t q0 = 0; q0 < nq && status == GPANN_OK; q0 += batch) {
+        const uint32_t m = std::min(batch, nq - q0);
+        status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap);
+        if (status != GPANN_OK) break;
+        hipError_t e = hipMemcpyAsync(out_min_dist + (size_t)q0 * S, r->ws_out.ptr, (size_t)m * S * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_count.data(), d_rec_count, (size_t)m * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_dist.data(), d_rec_dist, (size_t)m * rec_cap * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_shard.data(), d_rec_shard, (size_t)m * rec_cap * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            SetLastError("frequency query transfer failed: %s", hipGetErrorString(e));
+            status = GPANN_ERR_HIP;
+            break;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r->ev[0], r->ev[1]);
+        total_ms += ms;
+        std::vector<std::pair<float, uint32_t>> pairs;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t cnt = h_count[i];
+            pairs.resize(cnt);
+            for (uint32_t x = 0; x < cnt; ++x) pairs[x] = {h_dist[(size_t)i * rec_cap + x], (uint32_t)h_shard[(size_t)i * rec_cap + x]};
+            const uint32_t keep = std::min<uint32_t>(num_voting, cnt);
+            std::partial_sort(pairs.begin(), pairs.begin() + keep, pairs.end());   // = TopN(num_voting).Take() then Init()
+            for (uint32_t x = 0; x < keep; ++x) {
+                out_nn_dist[(size_t)(q0 + i) * num_voting + x] = pairs[x].first;
+                out_nn_shard[(size_t)(q0 + i) * num_voting + x] = pairs[x].second;
+            }
+            out_nn_count[q0 + i] = keep;
+        }
+    }
+    rec.Release();
+    if (elapsed_ms) *elapsed_ms = total_ms;
+    return status;
 }
 
 // DedupNeighbors (small_scale_queries.cpp:15-23) over per-slot result lists; host-side, libstdc++ sorts as the reference.

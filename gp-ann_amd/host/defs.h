@@ -1,0 +1,3 @@
+// defs.h - forwards to the host mirror (reference header of the same name: src/defs.h)
+#pragma once
+#include "gpann_host.h"

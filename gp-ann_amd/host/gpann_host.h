@@ -165,7 +165,9 @@ public:
         void Init() { std::sort(near_neighbors.begin(), near_neighbors.end()); }
         std::vector<int> Query(int num_shards, int num_voting_neighbors);
     };
-    FrequencyQueryData FrequencyQuery(float* Q, int budget, int num_voting_neighbors);   // :132-172 (host walk)
+    FrequencyQueryData FrequencyQuery(float* Q, int budget, int num_voting_neighbors);   // :132-172, GPU walk
+    // additive: all queries in one GPU batch
+    std::vector<FrequencyQueryData> FrequencyQueryBatch(PointSet& queries, int budget, int num_voting_neighbors);
 
     std::pair<PointSet, std::vector<int>> ExtractPoints();   // :174-201
 

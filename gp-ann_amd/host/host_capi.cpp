@@ -1,0 +1,87 @@
+// host_capi.cpp — a small extern "C" surface over the C++ host mirror so that Python (tests, bench.py) can drive the
+// host-side pieces that have no device counterpart: router training, k-means, the text/binary file formats.
+#include <cstring>
+
+#include "gpann_host.h"
+#include "host_util.h"
+
+namespace {
+Clusters FromCsr(const uint32_t* ids, const uint64_t* offsets, uint32_t S) {
+    Clusters c(S);
+    for (uint32_t b = 0; b < S; ++b) c[b].assign(ids + offsets[b], ids + offsets[b + 1]);
+    return c;
+}
+thread_local std::string g_err;
+}   // namespace
+
+extern "C" {
+
+const char* gpann_host_last_error() { return g_err.c_str(); }
+
+void gpann_host_configure(int mips, int device, int threads) {
+    gpann_host::SetMetricMIPS(mips != 0);
+    gpann_host::SetDevice(device);
+    gpann_host::SetNumThreads(threads);
+}
+
+// KMeansTreeRouter::Train on the host; returns an opaque router (the C++ object), or null on error
+void* gpann_host_router_train(const float* points, uint64_t n, uint32_t d, const uint32_t* ids, const uint64_t* offsets, uint32_t S,
+                              uint64_t num_centroids, uint64_t min_cluster_size, int64_t budget) {
+    try {
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        KMeansTreeRouterOptions o;
+        o.num_centroids = num_centroids;
+        o.min_cluster_size = min_cluster_size;
+        o.budget = budget;
+        auto* r = new KMeansTreeRouter();
+        r->Train(ps, FromCsr(ids, offsets, S), o);
+        return r;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+void gpann_host_router_free(void* r) { delete static_cast<KMeansTreeRouter*>(r); }
+
+void gpann_host_router_sizes(void* r, uint32_t* n_nodes, uint64_t* n_centroids) {
+    const auto& f = static_cast<KMeansTreeRouter*>(r)->flat();
+    *n_nodes = (uint32_t)f.node_shard.size();
+    *n_centroids = f.node_cent_first.empty() ? 0 : f.node_cent_first.back();
+}
+
+void gpann_host_router_export(void* r, int32_t* node_shard, uint32_t* node_cent_first, uint32_t* node_child_first, uint32_t* node_child_count,
+                              uint32_t* shard_root, float* centroids) {
+    const auto& f = static_cast<KMeansTreeRouter*>(r)->flat();
+    std::memcpy(node_shard, f.node_shard.data(), f.node_shard.size() * 4);
+    std::memcpy(node_cent_first, f.node_cent_first.data(), f.node_cent_first.size() * 4);
+    std::memcpy(node_child_first, f.node_child_first.data(), f.node_child_first.size() * 4);
+    std::memcpy(node_child_count, f.node_child_count.data(), f.node_child_count.size() * 4);
+    std::memcpy(shard_root, f.shard_root.data(), f.shard_root.size() * 4);
+    std::memcpy(centroids, f.centroids.data(), f.centroids.size() * 4);
+}
+
+// RandomSample(seed) + KMeans; returns the number of centroids left, -1 on error
+int64_t gpann_host_kmeans(const float* points, uint64_t n, uint32_t d, uint32_t k, int seed, int32_t* out_partition, float* out_centroids) {
+    try {
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        PointSet cent = RandomSample(ps, k, seed);
+        std::vector<int> part = KMeans(ps, cent);
+        for (uint64_t i = 0; i < n; ++i) out_partition[i] = part[i];
+        if (out_centroids) std::memcpy(out_centroids, cent.coordinates.data(), cent.coordinates.size() * 4);
+        return (int64_t)cent.n;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+float gpann_host_distance(const float* p, const float* q, uint32_t d) { return distance(const_cast<float*>(p), const_cast<float*>(q), d); }
+
+}   // extern "C"

@@ -1,0 +1,3 @@
+// kmeans.h - forwards to the host mirror (reference header of the same name: src/kmeans.h)
+#pragma once
+#include "gpann_host.h"

@@ -1,0 +1,3 @@
+// points_io.h - forwards to the host mirror (reference header of the same name: src/points_io.h)
+#pragma once
+#include "gpann_host.h"

@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -84,6 +84,8 @@ def lib():
                                       C.POINTER(C.c_void_p)]
     L.gpann_router_destroy.argtypes = [C.c_void_p]
     L.gpann_router_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
+    L.gpann_router_frequency_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, _f32p, _f32p, _u32p, _u32p,
+                                                     C.c_int, C.c_void_p, _f32p]
     L.gpann_merge_dedup.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, _u32p, _u32p]
     L.gpann_synth_rows_device.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                           C.c_void_p]
@@ -293,6 +295,24 @@ class Router:
         _check(lib().gpann_router_query_batch(self.h, qp, nq, budget, probes.ctypes.data_as(_i32p), md.ctypes.data_as(_f32p), flags,
                                               C.c_void_p(stream or 0), C.byref(ms)))
         return probes, md, ms.value
+
+
+def _router_frequency_query_batch(self, queries, budget, num_voting, stream=None):
+    """Batched FrequencyQuery: min_dist [nq,S], nn_dist / nn_shard [nq,V], nn_count [nq], ms."""
+    queries = _np(queries, np.float32)
+    nq = queries.shape[0]
+    md = np.empty((nq, self.S), np.float32)
+    nd = np.full((nq, num_voting), np.inf, np.float32)
+    ns = np.full((nq, num_voting), 0xFFFFFFFF, np.uint32)
+    nc = np.empty(nq, np.uint32)
+    ms = C.c_float(0)
+    _check(lib().gpann_router_frequency_query_batch(self.h, _vp(queries), nq, budget, num_voting, md.ctypes.data_as(_f32p),
+                                                    nd.ctypes.data_as(_f32p), ns.ctypes.data_as(_u32p), nc.ctypes.data_as(_u32p), 0,
+                                                    C.c_void_p(stream or 0), C.byref(ms)))
+    return md, nd, ns, nc, ms.value
+
+
+Router.frequency_query_batch = _router_frequency_query_batch
 
 
 def merge_dedup(dist, ids, nprobe_used, k):

@@ -1,0 +1,78 @@
+"""ctypes access to the extern "C" surface of libgpann_host.so (gp-ann_amd/host/host_capi.cpp): the host-side mirror of
+the reference's router training and k-means.  Loading it needs libgpann_hip.so next to it but no GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import LIB_PATH, clusters_to_csr
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_host.so")
+_f32p, _u32p, _i32p, _u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(HOST_LIB_PATH)
+        L.gpann_host_last_error.restype = C.c_char_p
+        L.gpann_host_configure.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.gpann_host_router_train.restype = C.c_void_p
+        L.gpann_host_router_train.argtypes = [_f32p, C.c_uint64, C.c_uint32, _u32p, _u64p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int64]
+        L.gpann_host_router_free.argtypes = [C.c_void_p]
+        L.gpann_host_router_sizes.argtypes = [C.c_void_p, _u32p, _u64p]
+        L.gpann_host_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
+        L.gpann_host_kmeans.restype = C.c_int64
+        L.gpann_host_kmeans.argtypes = [_f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _i32p, _f32p]
+        L.gpann_host_distance.restype = C.c_float
+        L.gpann_host_distance.argtypes = [_f32p, _f32p, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def configure(mips=False, device=0, threads=0):
+    lib().gpann_host_configure(int(mips), device, threads)
+
+
+def train_router(points, clusters, num_centroids=64, min_cluster_size=250, budget=50000, mips=False, threads=0):
+    """KMeansTreeRouter::Train on the host (reference src/kmeans_tree_router.cpp:9-78) -> flat tree dict."""
+    points = np.ascontiguousarray(points, np.float32)
+    ids, offs = clusters_to_csr(clusters)
+    configure(mips, 0, threads)
+    n, d = points.shape
+    S = len(clusters)
+    h = lib().gpann_host_router_train(points.ctypes.data_as(_f32p), n, d, ids.ctypes.data_as(_u32p), offs.ctypes.data_as(_u64p), S, num_centroids,
+                                      min_cluster_size, budget)
+    if not h:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    try:
+        nn, nc = C.c_uint32(), C.c_uint64()
+        lib().gpann_host_router_sizes(h, C.byref(nn), C.byref(nc))
+        f = dict(d=d, S=S, node_shard=np.empty(nn.value, np.int32), node_cent_first=np.empty(nn.value + 1, np.uint32),
+                 node_child_first=np.empty(nn.value, np.uint32), node_child_count=np.empty(nn.value, np.uint32),
+                 shard_root=np.empty(S, np.uint32), centroids=np.empty((nc.value, d), np.float32))
+        lib().gpann_host_router_export(h, f["node_shard"].ctypes.data_as(_i32p), f["node_cent_first"].ctypes.data_as(_u32p),
+                                       f["node_child_first"].ctypes.data_as(_u32p), f["node_child_count"].ctypes.data_as(_u32p),
+                                       f["shard_root"].ctypes.data_as(_u32p), f["centroids"].ctypes.data_as(_f32p))
+        return f
+    finally:
+        lib().gpann_host_router_free(h)
+
+
+def kmeans(points, k, seed, mips=False, threads=0):
+    points = np.ascontiguousarray(points, np.float32)
+    configure(mips, 0, threads)
+    part = np.empty(points.shape[0], np.int32)
+    cent = np.empty((k, points.shape[1]), np.float32)
+    kk = lib().gpann_host_kmeans(points.ctypes.data_as(_f32p), points.shape[0], points.shape[1], k, seed, part.ctypes.data_as(_i32p),
+                                 cent.ctypes.data_as(_f32p))
+    if kk < 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return part, cent[:kk]
+
+
+def distance(p, q, mips=False):
+    p, q = np.ascontiguousarray(p, np.float32), np.ascontiguousarray(q, np.float32)
+    configure(mips, 0, 0)
+    return np.float32(lib().gpann_host_distance(p.ctypes.data_as(_f32p), q.ctypes.data_as(_f32p), p.shape[0]))

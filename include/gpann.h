@@ -11,6 +11,7 @@
  *   gpann_shard_search_hits        <- RunInShardSearches(...) hit lists (exact scan instead of HNSW) src/shard_searches.cpp:11-104
  *   gpann_router_create            <- KMeansTreeRouter (trained tree, flattened as ExtractPoints)    src/kmeans_tree_router.cpp:174-201
  *   gpann_router_query_batch       <- KMeansTreeRouter::Query(float* Q, int budget)                 src/kmeans_tree_router.cpp:93-130
+ *   gpann_router_frequency_query_batch <- KMeansTreeRouter::FrequencyQuery                      src/kmeans_tree_router.cpp:132-172
  *   gpann_merge_dedup              <- DedupNeighbors(neighbors, k)                                  small_scale_queries.cpp:15-23
  *
  * Conventions: plain pointers and sizes, no C++/torch types; every function returns a gpann_status (0 = OK) and never
@@ -148,6 +149,13 @@ gpann_status gpann_router_destroy(gpann_router* r);
  */
 gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
                                       float* out_min_dist, int flags, void* stream, float* elapsed_ms);
+
+/* Batched KMeansTreeRouter::FrequencyQuery (kmeans_tree_router.cpp:132-172): the same walk, plus for every query the
+ * num_voting lexicographically smallest (distance, shard) pairs over all evaluated centroids, ascending (what
+ * FrequencyQueryData holds after Init()).  out_nn_* are host [nq][num_voting]; out_nn_count host [nq]. */
+gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t num_voting,
+                                                float* out_min_dist, float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count,
+                                                int flags, void* stream, float* elapsed_ms);
 
 /* ------------------------------------------------------------------------------------------------------- merge */
 /* DedupNeighbors over per-slot results: for each query, the first `nprobe_used` slots of in_* [nq][nprobe][k] are
