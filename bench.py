@@ -57,27 +57,17 @@ def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
     return cent, assign
 
 
-def build_router_tree(torch, pygpann, sample, sample_assign, S, num_centroids, seed, stream):
-    """A depth-1 KMeansTreeRouter (one root of <= num_centroids centroids per shard) trained on a device sample.
-    (The multi-level host trainer is gp-ann_amd/host; the bench only needs *a* valid tree for the fixed workload.)"""
-    d = sample.shape[1]
-    cents, node_shard, cent_first = [], [], [0]
-    for b in range(S):
-        rows = sample[sample_assign == b]
-        kk = int(min(num_centroids, max(1, rows.shape[0])))
-        if rows.shape[0] == 0:
-            c = torch.zeros((1, d), dtype=sample.dtype, device=sample.device)
-        else:
-            c, a = lloyd_gpu(torch, pygpann, rows.contiguous(), kk, 10, seed + b, stream)
-            used = torch.bincount(a.to(torch.int64), minlength=c.shape[0]) > 0
-            c = c[used] if used.any() else c[:1]
-        cents.append(c)
-        node_shard.append(b)
-        cent_first.append(cent_first[-1] + c.shape[0])
-    cen = torch.cat(cents).cpu().numpy()
-    return dict(d=d, S=S, node_shard=np.asarray(node_shard, np.int32), node_cent_first=np.asarray(cent_first, np.uint32),
-                node_child_first=np.zeros(S, np.uint32), node_child_count=np.zeros(S, np.uint32),
-                shard_root=np.arange(S, dtype=np.uint32), centroids=cen)
+def build_router_tree(torch, pygpann, sample, sample_assign, S, args):
+    """KMeansTreeRouter::Train (reference src/kmeans_tree_router.cpp:9-78) with the product's host trainer
+    (gp-ann_amd/host/router_host.cpp) on a sample of the cloud pulled to the host; options as routes.cpp:130-157
+    (64 centroids per node, min cluster size 350)."""
+    from pygpann import host
+    pts = sample.cpu().numpy()
+    a = sample_assign.cpu().numpy()
+    order = np.argsort(a, kind="stable")
+    bounds = np.searchsorted(a[order], np.arange(S + 1))
+    clusters = [order[bounds[b]:bounds[b + 1]].astype(np.uint32) for b in range(S)]
+    return host.train_router(pts, clusters, args.router_centroids, args.router_min_cluster, args.router_budget, mips=False, threads=0)
 
 
 def main():
@@ -93,12 +83,16 @@ def main():
     ap.add_argument("--target-recall", type=float, default=0.9)
     ap.add_argument("--search-budget", type=int, default=50000)
     ap.add_argument("--router-centroids", type=int, default=64)
+    ap.add_argument("--router-min-cluster", type=int, default=350)
+    ap.add_argument("--router-budget", type=int, default=100000, help="index size (centroids) of the k-means tree, routes.cpp:130")
+    ap.add_argument("--router-train-points", type=int, default=1_000_000, help="rows of the cloud the router is trained on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import pygpann
+    from pygpann import multigpu
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +116,8 @@ def main():
     sample = torch.empty((n_sample, d), dtype=torch.float32, device=dev)
     pygpann.synth_rows_device(sample.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, n_sample, d, stream)
     shard_cent, sample_assign = lloyd_gpu(torch, pygpann, sample, S, 20, 555, stream)
-    tree = build_router_tree(torch, pygpann, sample, sample_assign, S, args.router_centroids, 555, stream)
+    n_train = min(n_sample, args.router_train_points)
+    tree = build_router_tree(torch, pygpann, sample[:n_train], sample_assign[:n_train], S, args)
     del sample
     log(f"shard centroids + router tree ({tree['centroids'].shape[0]} centroids) ready in {time.time() - t_setup:.1f}s")
 
@@ -136,13 +131,7 @@ def main():
         pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
         pygpann.nearest_centroid_device(buf.data_ptr(), m, d, 0, shard_cent.data_ptr(), S, assign_all[r0:r0 + m].data_ptr(), stream)
     counts = torch.bincount(assign_all.to(torch.int64), minlength=S).cpu().numpy()
-    # LPT: biggest shard first onto the least loaded rank
-    owner = np.zeros(S, np.int64)
-    load = np.zeros(world, np.int64)
-    for b in np.argsort(-counts, kind="stable"):
-        r = int(np.argmin(load))
-        owner[b] = r
-        load[r] += counts[b]
+    owner, load = multigpu.lpt_owner(counts, world)
     mine = np.flatnonzero(owner == rank)
     log(f"shard sizes min/max {counts.min()}/{counts.max()}, rank loads {load.tolist()}")
     # local point set = rows of my shards, in global-id order; Clusters hold GLOBAL ids, local_rows maps them to local rows
@@ -191,36 +180,21 @@ def main():
     my_ids_host = my_ids.cpu().numpy().astype(np.uint32)
     del my_ids
 
-    owner32 = owner.astype(np.int32)
-
-    def local_probes(probes):
-        """probe lists with the shards of other ranks masked out (-1 = skip)"""
-        p = probes.copy()
-        p[owner32[np.clip(p, 0, S - 1)] != rank] = -1
-        return p
-
     out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, S, k), dtype=torch.float32, device=dev)
 
     def scan_slots(probes, nprobe, timed=False, aux=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
-        lp = local_probes(np.ascontiguousarray(probes[:, :nprobe]))
+        lp = multigpu.mask_probes(np.ascontiguousarray(probes[:, :nprobe]), owner, rank)
         oi = out_ids[:, :nprobe].contiguous() if nprobe != S else out_ids
         od = out_dist[:, :nprobe].contiguous() if nprobe != S else out_dist
         ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
         if world > 1:
-            gi = [torch.empty_like(oi) for _ in range(world)]
-            gd = [torch.empty_like(od) for _ in range(world)]
-            # translate to global ids before the exchange
+            # translate to global ids, then the exchange: all-gather of the fixed-shape slot arrays over RCCL
             ids_h = to_global(oi.cpu().numpy().view(np.uint32))
             oi.copy_(torch.from_numpy(ids_h.view(np.int32)))
-            dist.all_gather(gi, oi)
-            dist.all_gather(gd, od)
-            gd_h = torch.stack(gd).cpu().numpy()
-            gi_h = torch.stack(gi).cpu().numpy().view(np.uint32)
-            sel = owner32[np.clip(probes[:, :nprobe], 0, S - 1)]                       # [nq, nprobe] owning rank of each slot
-            dist_h = np.take_along_axis(gd_h, sel[None, :, :, None], axis=0)[0]
-            ids_h = np.take_along_axis(gi_h, sel[None, :, :, None], axis=0)[0]
+            gd_h, gi_h = multigpu.all_gather_slots(od, oi, dist, world)
+            dist_h, ids_h = multigpu.combine_slots(gd_h, gi_h, probes, owner)
         else:
             torch.cuda.current_stream().synchronize()
             dist_h = od.cpu().numpy()
@@ -292,7 +266,7 @@ def main():
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"NS: {n}x{d} f32 Gaussian mixture ({N_CENTERS} centres, sigma {SIGMA}), {nq} queries, {S} k-means shards, "
-                               f"k={k}, KMeansTreeRouter ({tree['centroids'].shape[0]} centroids, search budget {args.search_budget}) + exact "
+                               f"k={k}, KMeansTreeRouter ({tree['centroids'].shape[0]} centroids in {len(tree['node_shard'])} nodes, search budget {args.search_budget}) + exact "
                                f"shard scan, nprobe={nprobe}",
                    "n": n, "d": d, "queries": nq, "shards": S, "k": k, "nprobe": nprobe, "recall_at_k": recall,
                    "parallelism": f"shards over {world} GPU(s), LPT"},

@@ -1,0 +1,55 @@
+"""Shard-parallel execution over several GPUs (one process per GPU, torch.distributed; backend nccl = RCCL on ROCm).
+
+The path shards naturally: a shard lives on exactly one rank, every rank scans the (query, probe) tasks whose
+shard it owns, and the only exchange is an all-gather of the fixed-shape per-slot results followed by a host-side selection.
+These helpers are backend-agnostic (the CPU tests drive them over gloo)."""
+import numpy as np
+
+NO_ID = np.uint32(0xFFFFFFFF)
+
+
+def lpt_owner(shard_sizes, world):
+    """Longest-processing-time bin packing: biggest shard first onto the least loaded rank.  Returns (owner[S], load[world])."""
+    sizes = np.asarray(shard_sizes, np.int64)
+    owner = np.zeros(len(sizes), np.int32)
+    load = np.zeros(world, np.int64)
+    for b in np.argsort(-sizes, kind="stable"):
+        r = int(np.argmin(load))
+        owner[b] = r
+        load[r] += sizes[b]
+    return owner, load
+
+
+def mask_probes(probes, owner, rank):
+    """Probe lists with the shards of other ranks replaced by -1 (= skip in gpann_scan_buckets)."""
+    p = np.array(probes, np.int32, copy=True)
+    valid = p >= 0
+    theirs = np.zeros_like(valid)
+    theirs[valid] = owner[p[valid]] != rank
+    p[theirs] = -1
+    return p
+
+
+def combine_slots(gathered_dist, gathered_ids, probes, owner):
+    """gathered_*: [world][nq][nprobe][k] (every rank's slot arrays, +inf / NO_ID where it does not own the shard).
+    Picks each slot from the rank that owns its shard -> ([nq][nprobe][k] dist, ids)."""
+    gd = np.asarray(gathered_dist)
+    gi = np.asarray(gathered_ids)
+    p = np.asarray(probes)[:, :gd.shape[2]]
+    sel = np.where(p >= 0, owner[np.clip(p, 0, len(owner) - 1)], 0).astype(np.int64)
+    dist = np.take_along_axis(gd, sel[None, :, :, None], axis=0)[0]
+    ids = np.take_along_axis(gi, sel[None, :, :, None], axis=0)[0]
+    skipped = p < 0
+    dist[skipped] = np.inf
+    ids[skipped] = NO_ID
+    return dist, ids
+
+
+def all_gather_slots(dist_t, ids_t, torch_dist, world):
+    """all_gather of this rank's slot tensors (torch tensors on the backend's device); returns numpy [world, ...] arrays."""
+    import torch
+    gd = [torch.empty_like(dist_t) for _ in range(world)]
+    gi = [torch.empty_like(ids_t) for _ in range(world)]
+    torch_dist.all_gather(gd, dist_t)
+    torch_dist.all_gather(gi, ids_t)
+    return torch.stack(gd).cpu().numpy(), torch.stack(gi).cpu().numpy().view(np.uint32)

@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gpann.h declares, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gpann.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpann_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import pygpann
+    pygpann.build()
+    L = ctypes.CDLL(pygpann.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/gpann.h but not exported"
+    assert set(pygpann.EXPORTS) == set(names)
+
+
+def test_host_mirror_library_loads():
+    import pygpann
+    pygpann.build()
+    from pygpann import host
+    L = host.lib()
+    for n in ("gpann_host_router_train", "gpann_host_kmeans", "gpann_host_distance"):
+        assert hasattr(L, n)
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import pygpann
+    pygpann.build()
+    if pygpann.device_count() > 0:
+        pytest.skip("a GPU is present")
+    pts = np.zeros((4, 4), np.float32)
+    with pytest.raises(pygpann.GpannError) as e:
+        pygpann.Shards(pts, [np.arange(4, dtype=np.uint32)], 0, 0)
+    assert e.value.status == pygpann.ERR_NO_DEVICE
+    flat = dict(d=4, S=1, node_shard=np.zeros(1, np.int32), node_cent_first=np.array([0, 1], np.uint32), node_child_first=np.zeros(1, np.uint32),
+                node_child_count=np.zeros(1, np.uint32), shard_root=np.zeros(1, np.uint32), centroids=np.zeros((1, 4), np.float32))
+    with pytest.raises(pygpann.GpannError) as e:
+        pygpann.Router(flat, 0, 0)
+    assert e.value.status == pygpann.ERR_NO_DEVICE
+
+
+def test_merge_dedup_is_host_side(orc):
+    """gpann_merge_dedup (DedupNeighbors, small_scale_queries.cpp:15-23) needs no device"""
+    import pygpann
+    rng = np.random.default_rng(1)
+    nq, nprobe, k = 30, 4, 5
+    ids = rng.integers(0, 40, (nq, nprobe, k)).astype(np.uint32)
+    dist = (ids % 7).astype(np.float32)             # equal ids carry equal distances, as in the real path
+    ids[3, 2, 3:] = 0xFFFFFFFF
+    dist[3, 2, 3:] = np.inf
+    for used in (1, 3, 4):
+        md, mi, mc = pygpann.merge_dedup(dist, ids, used, k)
+        flat_d, flat_i, offs = [], [], [0]
+        for q in range(nq):
+            v = ids[q, :used].reshape(-1) != 0xFFFFFFFF
+            flat_d.extend(dist[q, :used].reshape(-1)[v])
+            flat_i.extend(ids[q, :used].reshape(-1)[v])
+            offs.append(len(flat_d))
+        od, oi, oc = orc.dedup_neighbors(np.asarray(flat_d, np.float32), np.asarray(flat_i, np.uint32), np.asarray(offs, np.uint64), k)
+        assert np.array_equal(mi, oi) and np.array_equal(md, od) and np.array_equal(mc, oc)
