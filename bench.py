@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--router-min-cluster", type=int, default=350)
     ap.add_argument("--router-budget", type=int, default=100000, help="index size (centroids) of the k-means tree, routes.cpp:130")
     ap.add_argument("--router-train-points", type=int, default=1_000_000, help="rows of the cloud the router is trained on")
+    ap.add_argument("--scan-mode", choices=["exact", "filter"], default=os.environ.get("GPANN_BENCH_SCAN_MODE", "filter"),
+                    help="exact: VALU scan of every row; filter: same exact results with the MFMA pre-filter (scan_filter.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -164,6 +166,7 @@ def main():
     clusters_local = [local_rows_by_shard[bounds[b]:bounds[b + 1]] for b in range(S)]
     torch.cuda.synchronize()
     shards = pygpann.Shards(local_points.data_ptr(), clusters_local, 0, local_rank, n=n_local, d=d)
+    shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
     del local_points
     torch.cuda.empty_cache()
     router = pygpann.Router(tree, 0, local_rank)
@@ -277,7 +280,8 @@ def main():
                           "traffic": None, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
                           "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY §8d) of rank 0 / HIP-event kernel time; "
                                   "each HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
-                          "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0}
+                          "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0,
+                          "scan_mode": args.scan_mode, "filtered": stats["filtered"], "filter_pairs": stats["filter_pairs"]}
     result["detail"] = {"recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "scan_kernel_ms": float(np.mean(scan_ms)),
                         "merge_kernel_ms": stats["merge_ms"], "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"],
                         "padded_pairs": stats["padded_pairs"], "setup_s": time.time() - t_setup}

@@ -114,6 +114,61 @@ __device__ __forceinline__ float ExactDistance(const float* __restrict__ p, cons
     }
 }
 
+// ---- 4x4 (query x point) register tile, the reference's exact op sequence per group of 4 dimensions ---------------
+template <int METRIC>
+__device__ __forceinline__ void AccumulateGroup(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (METRIC == GPANN_METRIC_L2) {
+                // src/dist.cpp:23-31: diffN = a[N] - b[N] (a = point, b = query); result += d0*d0 + d1*d1 + d2*d2 + d3*d3
+                float d0 = pv[j].x - qv[i].x;
+                float d1 = pv[j].y - qv[i].y;
+                float d2 = pv[j].z - qv[i].z;
+                float d3 = pv[j].w - qv[i].w;
+                float s = d0 * d0 + d1 * d1;
+                s = s + d2 * d2;
+                s = s + d3 * d3;
+                acc[i][j] = acc[i][j] + s;
+            } else {
+                // src/dist.cpp:44-46: result += q[i] * p[i], one dimension after the other
+                float r = acc[i][j];
+                r = r + qv[i].x * pv[j].x;
+                r = r + qv[i].y * pv[j].y;
+                r = r + qv[i].z * pv[j].z;
+                r = r + qv[i].w * pv[j].w;
+                acc[i][j] = r;
+            }
+        }
+    }
+}
+
+// the 0..3 trailing dimensions (src/dist.cpp:33-36): one at a time
+template <int METRIC>
+__device__ __forceinline__ float TailStep(float r, float pe, float qe) {
+    if (METRIC == GPANN_METRIC_L2) {
+        float d0 = pe - qe;
+        return r + d0 * d0;
+    }
+    return r + qe * pe;
+}
+
+template <int METRIC>
+__device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4], int tail) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = acc[i][j];
+            if (tail > 0) r = TailStep<METRIC>(r, pv[j].x, qv[i].x);
+            if (tail > 1) r = TailStep<METRIC>(r, pv[j].y, qv[i].y);
+            if (tail > 2) r = TailStep<METRIC>(r, pv[j].z, qv[i].z);
+            acc[i][j] = r;
+        }
+    }
+}
+
 // lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
 

@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <numeric>
+#include <string>
 #include <vector>
 
 struct gpann_router {
@@ -33,7 +35,7 @@ struct gpann_router {
     uint32_t* node_child_first = nullptr;
     uint32_t* node_child_count = nullptr;
     uint32_t* shard_root = nullptr;
-    gpann::DeviceBuffer ws_queries, ws_heap, ws_out;
+    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
@@ -99,23 +101,16 @@ __device__ __forceinline__ void AdjustHeap(float* key, uint32_t* node, int64_t h
     PushHeap(key, node, hole, top, vkey, vnode);
 }
 
-template <int METRIC>
-__device__ __forceinline__ float TailStep(float r, float pe, float qe) {
-    if (METRIC == GPANN_METRIC_L2) {
-        float d0 = pe - qe;
-        return r + d0 * d0;
-    }
-    return r + qe * pe;
-}
-
-template <int METRIC>
+// LDS_HEAP: the priority queue of every wave lives in LDS (a.heap_cap entries per wave, appended to the wave's LDS slice)
+// instead of the global workspace.  Same algorithm; lane 0's dependent heap accesses cost ~100 cycles instead of ~1000+.
+template <int METRIC, bool LDS_HEAP>
 __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
     extern __shared__ float4 rsmem4[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t d = a.d, ld = a.ld, S = a.S;
     // wave-private LDS: query row [ld] | centroid chunk tile [64][36] | node distances [64] | min_dist [S]
-    const size_t per_wave = (size_t)ld + 64 * kRStride + 64 + S;
+    const size_t per_wave = (size_t)ld + 64 * kRStride + 64 + S + (LDS_HEAP ? 2 * a.heap_cap : 0);
     float* sQ = reinterpret_cast<float*>(rsmem4) + (size_t)wave * ((per_wave + 3) & ~(size_t)3);
     float* sC = sQ + ld;
     float* sDist = sC + 64 * kRStride;
@@ -123,8 +118,15 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
 
     const uint32_t slot = blockIdx.x * kRWaves + wave;
     const uint32_t n_slots = gridDim.x * kRWaves;
-    float* hkey = a.heap_key + (size_t)slot * a.heap_cap;
-    uint32_t* hnode = a.heap_node + (size_t)slot * a.heap_cap;
+    float* hkey;
+    uint32_t* hnode;
+    if (LDS_HEAP) {
+        hkey = sMin + S;
+        hnode = reinterpret_cast<uint32_t*>(hkey + a.heap_cap);
+    } else {
+        hkey = a.heap_key + (size_t)slot * a.heap_cap;
+        hnode = a.heap_node + (size_t)slot * a.heap_cap;
+    }
     const uint32_t full_groups = d >> 2;
     const int tail = (int)(d & 3u);
     const uint32_t nchunks = (ld + kRDC - 1) / kRDC;
@@ -235,6 +237,188 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterWalkKernel(RouterArgs a) {
     }
 }
 
+// ---- dense evaluation + replay ------------------------------------------------------------------------------------------
+// When the search budget is of the order of the tree size, the walk visits most nodes anyway and re-fetching every
+// node's centroids per query (the kernel above) is bound by L2 traffic (nq x visited centroids x row bytes).  The dense
+// path evaluates D[q][c] for ALL tree centroids with the register-tiled exact kernel (each centroid row is fetched once
+// per 64 queries) and then REPLAYS the reference's walk on the precomputed distances: same priority queue, same budget
+// rule, same pushes — only distance() is a table lookup.  Bit-identical results; chosen by LaunchWalk().
+struct DenseArgs {
+    const float* centroids;   // [C][ld]
+    const float* queries;     // [nq][ld]
+    float* out;               // [nq][C]
+    uint32_t d, ld, nq, C;
+};
+
+template <int METRIC>
+__global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
+    extern __shared__ float4 dsm4[];
+    constexpr int kStride = kRDC + 4;
+    float* sQ = reinterpret_cast<float*>(dsm4);   // [64][36]
+    float* sP = sQ + 64 * kStride;                 // [64][36]
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    const uint32_t q0 = blockIdx.y * 64u, c0 = blockIdx.x * 64u;
+    const uint32_t d = a.d, ld = a.ld;
+    const uint32_t full_groups = d >> 2;
+    const int tail = (int)(d & 3u);
+    const uint32_t nchunks = (ld + kRDC - 1) / kRDC;
+    const int st_row0 = tid >> 3, st_row1 = (tid + 256) >> 3, st_c4 = tid & 7;
+    const float* qrow0 = a.queries + (size_t)min(q0 + st_row0, a.nq - 1) * ld;
+    const float* qrow1 = a.queries + (size_t)min(q0 + st_row1, a.nq - 1) * ld;
+    const float* prow0 = a.centroids + (size_t)min(c0 + st_row0, a.C - 1) * ld;
+    const float* prow1 = a.centroids + (size_t)min(c0 + st_row1, a.C - 1) * ld;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        const uint32_t c = ch * kRDC + 4u * st_c4;
+        const bool in = c < ld;
+        const float4 gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
+        const float4 gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
+        const float4 gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
+        const float4 gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+        __syncthreads();
+        *reinterpret_cast<float4*>(sQ + st_row0 * kStride + 4 * st_c4) = gq0;
+        *reinterpret_cast<float4*>(sQ + st_row1 * kStride + 4 * st_c4) = gq1;
+        *reinterpret_cast<float4*>(sP + st_row0 * kStride + 4 * st_c4) = gp0;
+        *reinterpret_cast<float4*>(sP + st_row1 * kStride + 4 * st_c4) = gp1;
+        __syncthreads();
+        const uint32_t g0 = ch * (kRDC / 4);
+        const float* q_base = sQ + ty * kStride;
+        const float* p_base = sP + tx * kStride;
+#pragma unroll 2
+        for (int g = 0; g < kRDC / 4; ++g) {
+            const uint32_t G = g0 + g;
+            if (G > full_groups || (G == full_groups && tail == 0)) break;
+            float4 qv[4], pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kStride + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kStride + 4 * g);
+            if (G < full_groups) AccumulateGroup<METRIC>(acc, qv, pv);
+            else AccumulateTail<METRIC>(acc, qv, pv, tail);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t q = q0 + ty + 16 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = c0 + tx + 16 * j;
+            float v = acc[i][j];
+            if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;
+            if (q < a.nq && c < a.C) a.out[(size_t)q * a.C + c] = v;
+        }
+    }
+}
+
+struct ReplayArgs {
+    const float* dense;       // [nq][C] exact distances
+    const int32_t* node_shard;
+    const uint32_t* node_cent_first;
+    const uint32_t* node_child_first;
+    const uint32_t* node_child_count;
+    const uint32_t* shard_root;
+    float* heap_key;          // global queue workspace (LDS_HEAP == false)
+    uint32_t* heap_node;
+    float* out_min_dist;      // [nq][S]
+    float* rec_dist;          // optional, see RouterArgs
+    int32_t* rec_shard;
+    uint32_t* rec_count;
+    uint64_t rec_cap;
+    uint64_t heap_cap;
+    uint32_t S, nq, C;
+    int32_t budget;
+};
+
+// kmeans_tree_router.cpp:93-130 with distance() replaced by the table: one wavefront per query.
+template <bool LDS_HEAP>
+__global__ void __launch_bounds__(64 * kRWaves) RouterReplayKernel(ReplayArgs a) {
+    extern __shared__ float4 rpsm4[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = a.S;
+    const size_t per_wave = ((size_t)64 + S + (LDS_HEAP ? 2 * a.heap_cap : 0) + 3) & ~(size_t)3;
+    float* sDist = reinterpret_cast<float*>(rpsm4) + (size_t)wave * per_wave;
+    float* sMin = sDist + 64;
+    const uint32_t slot = blockIdx.x * kRWaves + wave, n_slots = gridDim.x * kRWaves;
+    float* hkey;
+    uint32_t* hnode;
+    if (LDS_HEAP) {
+        hkey = sMin + S;
+        hnode = reinterpret_cast<uint32_t*>(hkey + a.heap_cap);
+    } else {
+        hkey = a.heap_key + (size_t)slot * a.heap_cap;
+        hnode = a.heap_node + (size_t)slot * a.heap_cap;
+    }
+    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        const float* D = a.dense + (size_t)q * a.C;
+        for (uint32_t b = lane; b < S; b += 64) sMin[b] = FLT_MAX;
+        int64_t size = 0;
+        if (lane == 0) {
+            for (uint32_t r = 0; r < S; ++r) {
+                PushHeap(hkey, hnode, size, 0, -FLT_MAX, a.shard_root[r]);
+                size++;
+            }
+        }
+        size = S;
+        __builtin_amdgcn_wave_barrier();
+        int32_t budget = a.budget;
+        uint32_t n_rec = 0;
+        while (size > 0 && budget > 0) {
+            uint32_t node = 0;
+            if (lane == 0) {
+                node = hnode[0];
+                if (size > 1) {
+                    float vk = hkey[size - 1];
+                    uint32_t vn = hnode[size - 1];
+                    hkey[size - 1] = hkey[0];
+                    hnode[size - 1] = hnode[0];
+                    AdjustHeap(hkey, hnode, 0, size - 1, vk, vn);
+                }
+            }
+            size--;
+            node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const uint32_t c_first = a.node_cent_first[node];
+            const uint32_t n = a.node_cent_first[node + 1] - c_first;
+            const uint32_t n_child = a.node_child_count[node];
+            const uint32_t child_first = a.node_child_first[node];
+            const int shard = a.node_shard[node];
+            budget -= (int32_t)n;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t m = min(64u, n - base);
+                float dist = FLT_MAX;
+                if ((uint32_t)lane < m) {
+                    dist = D[c_first + base + lane];
+                    if (a.rec_dist) {
+                        a.rec_dist[(size_t)q * a.rec_cap + n_rec + lane] = dist;
+                        a.rec_shard[(size_t)q * a.rec_cap + n_rec + lane] = shard;
+                    }
+                }
+                n_rec += m;
+                sDist[lane] = dist;
+                float mn = dist;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    if (mn < sMin[shard]) sMin[shard] = mn;
+                    for (uint32_t i = base; i < base + m && i < n_child; ++i)
+                        PushHeap(hkey, hnode, size + (int64_t)(i - base), 0, sDist[i - base], child_first + i);
+                }
+                if (n_child > base) size += (int64_t)(min(n_child, base + m) - base);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = sMin[b];
+        if (a.rec_count && lane == 0) a.rec_count[q] = n_rec;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace gpann
 
 using namespace gpann;
@@ -312,6 +496,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_queries.Release();
     r->ws_heap.Release();
     r->ws_out.Release();
+    r->ws_dense.Release();
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     delete r;
@@ -336,21 +521,81 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     uint64_t cap = r->n_nodes;
     if (budget > 0) cap = std::min<uint64_t>(cap, (uint64_t)S + (uint64_t)budget * std::max<uint32_t>(1, r->max_children));
     cap = std::max<uint64_t>(cap, S);
-    const size_t per_wave_lds = (((size_t)ld + 64 * kRStride + 64 + S) + 3) & ~(size_t)3;
+    hipDeviceProp_t prop;
+    GPANN_HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
+    const char* force = std::getenv("GPANN_ROUTER_MODE");   // "walk" | "dense" (default: by size)
+    const uint64_t C = r->n_centroids;
+    bool dense = budget > 0 && C <= 4ull * (uint64_t)budget && (uint64_t)nq * C * 4 <= (3ull << 30) && C < 0xFFFFFFFFull;
+    if (force && std::string(force) == "walk") dense = false;
+    if (force && std::string(force) == "dense" && (uint64_t)nq * C * 4 <= (16ull << 30)) dense = budget > 0;
+    GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
+    if (dense) {
+        GPANN_TRY(r->ws_dense.Reserve((size_t)nq * C * 4));
+        DenseArgs da;
+        da.centroids = r->centroids;
+        da.queries = r->ws_queries.as<float>();
+        da.out = r->ws_dense.as<float>();
+        da.d = r->d;
+        da.ld = ld;
+        da.nq = nq;
+        da.C = (uint32_t)C;
+        const dim3 dgrid((uint32_t)((C + 63) / 64), (nq + 63) / 64);
+        const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+        if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_L2>, dgrid, dim3(256), dlds, st, da);
+        else hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_MIPS>, dgrid, dim3(256), dlds, st, da);
+        GPANN_HIP_TRY(hipGetLastError());
+
+        const size_t base_floats = (size_t)64 + S;
+        const bool lds_heap = ((((base_floats + 2 * cap) + 3) & ~(size_t)3) * kRWaves * sizeof(float)) <= 40 * 1024;
+        const size_t per_wave_lds = ((base_floats + (lds_heap ? 2 * cap : 0)) + 3) & ~(size_t)3;
+        const size_t lds = per_wave_lds * kRWaves * sizeof(float);
+        uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+        uint32_t grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * blocks_per_cu);
+        while (!lds_heap && grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
+        const uint64_t slots = (uint64_t)grid * kRWaves;
+        GPANN_TRY(r->ws_heap.Reserve(lds_heap ? 256 : slots * cap * 8));
+        ReplayArgs ra;
+        ra.dense = r->ws_dense.as<float>();
+        ra.node_shard = r->node_shard;
+        ra.node_cent_first = r->node_cent_first;
+        ra.node_child_first = r->node_child_first;
+        ra.node_child_count = r->node_child_count;
+        ra.shard_root = r->shard_root;
+        ra.heap_key = r->ws_heap.as<float>();
+        ra.heap_node = reinterpret_cast<uint32_t*>(ra.heap_key + slots * cap);
+        ra.out_min_dist = r->ws_out.as<float>();
+        ra.rec_dist = rec_dist;
+        ra.rec_shard = rec_shard;
+        ra.rec_count = rec_count;
+        ra.rec_cap = rec_cap;
+        ra.heap_cap = cap;
+        ra.S = S;
+        ra.nq = nq;
+        ra.C = (uint32_t)C;
+        ra.budget = budget;
+        if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(grid), dim3(64 * kRWaves), lds, st, ra);
+        else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(grid), dim3(64 * kRWaves), lds, st, ra);
+        GPANN_HIP_TRY(hipGetLastError());
+        GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
+        return GPANN_OK;
+    }
+
+    // the queue goes to LDS when it leaves room for 4 workgroups per CU, otherwise to the global workspace
+    const size_t base_floats = (size_t)ld + 64 * kRStride + 64 + S;
+    const bool lds_heap = ((((base_floats + 2 * cap) + 3) & ~(size_t)3) * kRWaves * sizeof(float)) <= 40 * 1024;
+    const size_t per_wave_lds = ((base_floats + (lds_heap ? 2 * cap : 0)) + 3) & ~(size_t)3;
     const size_t lds = per_wave_lds * kRWaves * sizeof(float);
     if (lds > 160 * 1024) {
         SetLastError("router needs %zu bytes of LDS per workgroup (d = %u, S = %u): unsupported", lds, r->d, S);
         return GPANN_ERR_UNSUPPORTED;
     }
-    hipDeviceProp_t prop;
-    GPANN_HIP_TRY(hipGetDeviceProperties(&prop, r->device));
     uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
     uint32_t grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * blocks_per_cu);
     // keep the queue workspace bounded (<= 4 GiB)
-    while (grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
+    while (!lds_heap && grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
     const uint64_t slots = (uint64_t)grid * kRWaves;
-    GPANN_TRY(r->ws_heap.Reserve(slots * cap * 8));
-    GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
+    GPANN_TRY(r->ws_heap.Reserve(lds_heap ? 256 : slots * cap * 8));
 
     RouterArgs a;
     a.centroids = r->centroids;
@@ -373,11 +618,20 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     a.nq = nq;
     a.heap_cap = cap;
     a.budget = budget;
-    GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
-    if (r->metric == GPANN_METRIC_L2)
-        hipLaunchKernelGGL(RouterWalkKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64 * kRWaves), lds, st, a);
-    else
-        hipLaunchKernelGGL(RouterWalkKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64 * kRWaves), lds, st, a);
+    const dim3 g(grid), b(64 * kRWaves);
+    if (lds > 48 * 1024) {   // dynamic LDS beyond the default limit has to be requested per kernel
+        const void* fn = r->metric == GPANN_METRIC_L2
+                             ? (lds_heap ? (const void*)RouterWalkKernel<GPANN_METRIC_L2, true> : (const void*)RouterWalkKernel<GPANN_METRIC_L2, false>)
+                             : (lds_heap ? (const void*)RouterWalkKernel<GPANN_METRIC_MIPS, true> : (const void*)RouterWalkKernel<GPANN_METRIC_MIPS, false>);
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (r->metric == GPANN_METRIC_L2) {
+        if (lds_heap) hipLaunchKernelGGL((RouterWalkKernel<GPANN_METRIC_L2, true>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((RouterWalkKernel<GPANN_METRIC_L2, false>), g, b, lds, st, a);
+    } else {
+        if (lds_heap) hipLaunchKernelGGL((RouterWalkKernel<GPANN_METRIC_MIPS, true>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((RouterWalkKernel<GPANN_METRIC_MIPS, false>), g, b, lds, st, a);
+    }
     GPANN_HIP_TRY(hipGetLastError());
     GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
     return GPANN_OK;

@@ -18,8 +18,10 @@
 //   * a second kernel merges the per-segment lists of a task, maps rows to global ids through `permutation`
 //     (inverted_index.h:56-58) and writes the caller's [nq][nprobe][k] arrays.
 #include "shards.h"
+#include "scan_filter.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -57,60 +59,6 @@ __device__ __forceinline__ void ListInsert(float& ld_, uint32_t& lr_, float cd, 
     } else if (lane > pos) {
         ld_ = up_d;
         lr_ = up_r;
-    }
-}
-
-template <int METRIC>
-__device__ __forceinline__ void AccumulateGroup(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (METRIC == GPANN_METRIC_L2) {
-                // src/dist.cpp:23-31: diffN = a[N] - b[N] (a = point, b = query); result += d0*d0 + d1*d1 + d2*d2 + d3*d3
-                float d0 = pv[j].x - qv[i].x;
-                float d1 = pv[j].y - qv[i].y;
-                float d2 = pv[j].z - qv[i].z;
-                float d3 = pv[j].w - qv[i].w;
-                float s = d0 * d0 + d1 * d1;
-                s = s + d2 * d2;
-                s = s + d3 * d3;
-                acc[i][j] = acc[i][j] + s;
-            } else {
-                // src/dist.cpp:44-46: result += q[i] * p[i], one dimension after the other
-                float r = acc[i][j];
-                r = r + qv[i].x * pv[j].x;
-                r = r + qv[i].y * pv[j].y;
-                r = r + qv[i].z * pv[j].z;
-                r = r + qv[i].w * pv[j].w;
-                acc[i][j] = r;
-            }
-        }
-    }
-}
-
-// the 0..3 trailing dimensions (src/dist.cpp:33-36): one at a time
-template <int METRIC>
-__device__ __forceinline__ float TailStep(float r, float pe, float qe) {
-    if (METRIC == GPANN_METRIC_L2) {
-        float d0 = pe - qe;
-        return r + d0 * d0;
-    }
-    return r + qe * pe;
-}
-
-template <int METRIC>
-__device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4], int tail) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float r = acc[i][j];
-            if (tail > 0) r = TailStep<METRIC>(r, pv[j].x, qv[i].x);
-            if (tail > 1) r = TailStep<METRIC>(r, pv[j].y, qv[i].y);
-            if (tail > 2) r = TailStep<METRIC>(r, pv[j].z, qv[i].z);
-            acc[i][j] = r;
-        }
     }
 }
 
@@ -323,7 +271,7 @@ __global__ void __launch_bounds__(256) MergeListsKernel(MergeArgs a) {
         }
     }
     if (lane < (int)k) {
-        const size_t dst = (size_t)(MODE == 0 ? a.out_index[o] : o) * k + lane;
+        const size_t dst = (size_t)(MODE == 0 && a.out_index ? a.out_index[o] : o) * k + lane;
         if (a.out_dist) a.out_dist[dst] = ld_;
         if (a.out_rows) a.out_rows[dst] = lr_;
         if (a.out_ids) a.out_ids[dst] = lr_ == kNoId ? kNoId : a.permutation[lr_];
@@ -363,12 +311,11 @@ static uint32_t EnvU32(const char* name, uint32_t dflt) {
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-// Group the (query, slot) pairs by shard and cut every shard into row segments so that the launch has enough
-// workgroups to fill 256 CUs several times over while each unit still amortises its list warm-up.
-static gpann_status BuildPlan(const gpann_shards* s, uint32_t nq, const int32_t* probes, uint32_t probe_stride, uint32_t nprobe,
-                              ScanPlan& plan) {
+// Group the caller's (query, slot) pairs by shard (counting sort): the TASKS of this call.
+static gpann_status BuildTasks(const gpann_shards* s, uint32_t nq, const int32_t* probes, uint32_t probe_stride, uint32_t nprobe, ScanPlan& plan) {
     const uint32_t S = s->S;
-    std::vector<uint32_t> count(S + 1, 0);
+    std::vector<uint32_t>& count = plan.shard_task_begin;
+    count.assign(S + 1, 0);
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t j = 0; j < nprobe; ++j) {
             int32_t b = probes[(size_t)q * probe_stride + j];
@@ -380,8 +327,7 @@ static gpann_status BuildPlan(const gpann_shards* s, uint32_t nq, const int32_t*
     const uint32_t T = count[S];
     plan.task_query.resize(T);
     plan.task_out.resize(T);
-    plan.task_part.resize(T);
-    plan.task_nseg.resize(T);
+    plan.task_shard.resize(T);
     std::vector<uint32_t> cursor(count.begin(), count.end() - 1);
     for (uint32_t q = 0; q < nq; ++q)
         for (uint32_t j = 0; j < nprobe; ++j) {
@@ -390,27 +336,34 @@ static gpann_status BuildPlan(const gpann_shards* s, uint32_t nq, const int32_t*
             uint32_t t = cursor[b]++;
             plan.task_query[t] = q;
             plan.task_out[t] = q * nprobe + j;
+            plan.task_shard[t] = (uint32_t)b;
         }
+    plan.pairs = 0;
+    for (uint32_t b = 0; b < S; ++b) plan.pairs += (uint64_t)(count[b + 1] - count[b]) * (uint64_t)(s->offsets[b + 1] - s->offsets[b]);
+    return GPANN_OK;
+}
 
-    // total tile work, to size segments
+// Units of the exact kernel for the row range [lo[b], hi[b]) of every shard: (<= 64 tasks) x (one row segment).  Segments
+// are sized so that the launch has enough workgroups to fill 256 CUs several times over while each unit still amortises
+// the warm-up of its top-k lists.
+static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vector<int64_t>& lo, const std::vector<int64_t>& hi) {
+    const std::vector<uint32_t>& count = plan.shard_task_begin;
+    const uint32_t T = count[S];
+    plan.task_part.assign(T, 0);
+    plan.task_nseg.assign(T, 0);
+    plan.units.clear();
     uint64_t tile_rows = 0;
-    for (uint32_t b = 0; b < S; ++b) {
-        uint32_t tb = count[b + 1] - count[b];
-        uint64_t nb = (uint64_t)(s->offsets[b + 1] - s->offsets[b]);
-        tile_rows += (uint64_t)((tb + kQT - 1) / kQT) * nb;
-        plan.pairs += (uint64_t)tb * nb;
-    }
+    for (uint32_t b = 0; b < S; ++b) tile_rows += (uint64_t)((count[b + 1] - count[b] + kQT - 1) / kQT) * (uint64_t)std::max<int64_t>(0, hi[b] - lo[b]);
     const uint32_t target_units = EnvU32("GPANN_SCAN_TARGET_UNITS", 8192);
     const uint32_t min_seg_rows = EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 2048);
     uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
     seg_rows = (seg_rows + kPT - 1) / kPT * kPT;
-
     uint64_t lists = 0;
     for (uint32_t b = 0; b < S; ++b) {
         const uint32_t tb = count[b + 1] - count[b];
         if (tb == 0) continue;
-        const int64_t r0 = s->offsets[b], r1 = s->offsets[b + 1];
-        const uint64_t nb = (uint64_t)(r1 - r0);
+        const int64_t r0 = lo[b], r1 = hi[b];
+        const uint64_t nb = (uint64_t)std::max<int64_t>(0, r1 - r0);
         const uint32_t nseg = nb == 0 ? 0 : (uint32_t)((nb + seg_rows - 1) / seg_rows);
         for (uint32_t t = count[b]; t < count[b + 1]; ++t) {
             plan.task_part[t] = (uint32_t)lists;
@@ -420,20 +373,17 @@ static gpann_status BuildPlan(const gpann_shards* s, uint32_t nq, const int32_t*
         GPANN_REQUIRE(lists < 0xFFFFFFFFull, "too many partial lists");
         if (nseg == 0) continue;
         // equal segments (multiples of the tile height) rather than seg_rows + remainder
-        uint64_t per = ((nb + nseg - 1) / nseg + kPT - 1) / kPT * kPT;
+        const uint64_t per = ((nb + nseg - 1) / nseg + kPT - 1) / kPT * kPT;
         const uint32_t ntiles_q = (tb + kQT - 1) / kQT;
         for (uint32_t qt = 0; qt < ntiles_q; ++qt) {
             // balanced query tiles: e.g. 65 tasks -> 33 + 32 instead of 64 + 1
-            uint32_t tbeg = count[b] + (uint32_t)((uint64_t)tb * qt / ntiles_q);
-            uint32_t tend = count[b] + (uint32_t)((uint64_t)tb * (qt + 1) / ntiles_q);
+            const uint32_t tbeg = count[b] + (uint32_t)((uint64_t)tb * qt / ntiles_q);
+            const uint32_t tend = count[b] + (uint32_t)((uint64_t)tb * (qt + 1) / ntiles_q);
             for (uint32_t sg = 0; sg < nseg; ++sg) {
                 ScanUnit u;
                 u.row_begin = r0 + (int64_t)(sg * per);
                 u.row_end = std::min<int64_t>(r1, u.row_begin + (int64_t)per);
-                if (u.row_begin >= u.row_end) {
-                    // cannot happen for sg < nseg with per >= nb/nseg, but keep lists well-defined
-                    u.row_begin = u.row_end = r1;
-                }
+                if (u.row_begin >= u.row_end) u.row_begin = u.row_end = r1;
                 u.task_begin = tbeg;
                 u.task_count = tend - tbeg;
                 u.seg = sg;
@@ -465,51 +415,30 @@ struct DeviceLists {   // per-(query, slot) result lists on the device: [nq*npro
     uint32_t* rows = nullptr;
 };
 
-// Runs plan + scan + merge; results land in device arrays (caller-provided or workspace).
-static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
-                                 uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
-    ScanPlan& plan = s->plan;
-    plan.Clear();
-    GPANN_TRY(BuildPlan(s, nq, probes, probe_stride, nprobe, plan));
+struct TaskArrays {   // device copies of the shard-sorted task arrays
+    uint32_t *query, *out, *part, *nseg, *shard;
+};
+
+// One exact stage: ScanTileKernel over plan.units, then MergeListsKernel into `m` (destination chosen by the caller).
+static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags, hipStream_t st,
+                                  MergeArgs m) {
     const uint32_t T = (uint32_t)plan.task_query.size();
-    const size_t n_out = (size_t)nq * nprobe;
-
-    const float* d_queries = nullptr;
-    GPANN_TRY(StageQueries(s, queries, nq, (flags & GPANN_QUERIES_ON_DEVICE) != 0, st, &d_queries));
-
-    // task arrays: query | out | part | nseg
-    GPANN_TRY(s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 4 * sizeof(uint32_t), 256)));
-    uint32_t* d_task_query = s->ws_tasks.as<uint32_t>();
-    uint32_t* d_task_out = d_task_query + T;
-    uint32_t* d_task_part = d_task_out + T;
-    uint32_t* d_task_nseg = d_task_part + T;
     GPANN_TRY(s->ws_units.Reserve(std::max<size_t>(plan.units.size() * sizeof(ScanUnit), 256)));
     GPANN_TRY(s->ws_partials.Reserve(std::max<size_t>(plan.n_lists * k * 8, 256)));
     float* d_part_dist = s->ws_partials.as<float>();
     uint32_t* d_part_row = reinterpret_cast<uint32_t*>(d_part_dist + plan.n_lists * k);
     if (T) {
-        GPANN_HIP_TRY(hipMemcpyAsync(d_task_query, plan.task_query.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(d_task_out, plan.task_out.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(d_task_part, plan.task_part.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(d_task_nseg, plan.task_nseg.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.part, plan.task_part.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.nseg, plan.task_nseg.data(), T * 4, hipMemcpyHostToDevice, st));
     }
-    // (the plan's host arrays live in the handle until the next scan call, so the async uploads above stay valid)
-
-    {   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID)
-        size_t n = n_out * k;
-        int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-        if (n) hipLaunchKernelGGL(FillKernel, dim3(grid), dim3(256), 0, st, out.dist, out.ids, out.rows, n);
-    }
-
-    GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
     if (!plan.units.empty()) {
+        GPANN_HIP_TRY(hipMemcpyAsync(s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice, st));
         ScanArgs a;
         a.points = s->points;
         a.queries = d_queries;
         a.units = s->ws_units.as<ScanUnit>();
-        a.task_query = d_task_query;
-        a.task_part = d_task_part;
+        a.task_query = ta.query;
+        a.task_part = ta.part;
         a.part_dist = d_part_dist;
         a.part_row = d_part_row;
         a.d = s->d;
@@ -529,30 +458,253 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     }
     GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
     if (T) {
-        MergeArgs m{};
         m.in_dist = d_part_dist;
         m.in_row = d_part_row;
-        m.first_list = d_task_part;
-        m.n_lists = d_task_nseg;
-        m.out_index = d_task_out;
-        m.permutation = s->permutation;
-        m.out_dist = out.dist;
-        m.out_ids = out.ids;
-        m.out_rows = out.rows;
+        m.first_list = ta.part;
+        m.n_lists = ta.nseg;
         m.n_out = T;
         m.k = k;
         m.lists_per_out = 0;
         hipLaunchKernelGGL(MergeListsKernel<0>, dim3((T + 3) / 4), dim3(256), 0, st, m);
         GPANN_HIP_TRY(hipGetLastError());
     }
+    return GPANN_OK;
+}
+
+// The MFMA-filtered pipeline (scan_filter.h).  On return *overflow tells whether a candidate bucket overflowed, in which
+// case the outputs are not written and the caller runs the plain exact scan instead.
+static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
+                                    hipStream_t st, DeviceLists out, bool* overflow) {
+    *overflow = false;
+    const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
+    if (T == 0) return GPANN_OK;
+    const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
+    const int64_t m1 = std::max<int64_t>(m0, (int64_t)EnvU32("GPANN_FILTER_MID_ROWS", 131072) / kPT * kPT);
+    // candidate bucket per task: as large as ~1.5 GB of workspace allows, within [1024, 4096] (expected fill: a few hundred)
+    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (1536ull << 20) / (4ull * T))));
+
+    // per-task exact lists (dist | row), thresholds, candidate buckets, overflow word
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256));
+    float* list_dist = s->ws_lists.as<float>();
+    uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
+    float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
+    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T);
+    GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
+    uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
+    uint32_t* cand_row = cand_cnt + T;
+    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
+
+    // ---- stage 0: exact scan of the first m0 rows of every shard -> lists
+    std::vector<int64_t> lo(S), hi(S);
+    for (uint32_t b = 0; b < S; ++b) {
+        lo[b] = s->offsets[b];
+        hi[b] = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + m0);
+    }
+    plan.padded_pairs = 0;
+    GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
+    {
+        MergeArgs m{};
+        m.out_index = nullptr;   // identity: list t
+        m.permutation = s->permutation;
+        m.out_dist = list_dist;
+        m.out_rows = list_row;
+        m.out_ids = nullptr;
+        GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
+    }
+
+    // ---- filter passes over [m0, m1) and [m1, end)
+    const int64_t bounds[3] = {m0, m1, std::numeric_limits<int64_t>::max()};
+    const uint32_t target_units = EnvU32("GPANN_FILTER_TARGET_UNITS", 2048);
+    for (int pass = 0; pass < 2; ++pass) {
+        // units: (<= 256 tasks of a shard) x (row segment of the pass range)
+        std::vector<FilterUnit>& funits = plan.filter_units;
+        funits.clear();
+        uint64_t block_rows = 0;
+        for (uint32_t b = 0; b < S; ++b) {
+            const uint32_t tb = plan.shard_task_begin[b + 1] - plan.shard_task_begin[b];
+            const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
+            const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
+                                                                                       : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
+            if (tb && r1 > r0) block_rows += (uint64_t)((tb + kFQB - 1) / kFQB) * (uint64_t)(r1 - r0);
+        }
+        if (block_rows == 0) continue;
+        uint64_t seg_rows = std::max<uint64_t>(4096, (block_rows + target_units - 1) / target_units);
+        seg_rows = (seg_rows + kFPT - 1) / kFPT * kFPT;
+        for (uint32_t b = 0; b < S; ++b) {
+            const uint32_t t0 = plan.shard_task_begin[b], tb = plan.shard_task_begin[b + 1] - t0;
+            const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
+            const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
+                                                                                       : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
+            if (tb == 0 || r1 <= r0) continue;
+            const uint32_t nqb = (tb + kFQB - 1) / kFQB;
+            const uint64_t nb = (uint64_t)(r1 - r0);
+            const uint32_t nseg = (uint32_t)((nb + seg_rows - 1) / seg_rows);
+            const uint64_t per = ((nb + nseg - 1) / nseg + kFPT - 1) / kFPT * kFPT;
+            for (uint32_t qb = 0; qb < nqb; ++qb) {
+                const uint32_t tbeg = t0 + (uint32_t)((uint64_t)tb * qb / nqb), tend = t0 + (uint32_t)((uint64_t)tb * (qb + 1) / nqb);
+                for (uint32_t sg = 0; sg < nseg; ++sg) {
+                    FilterUnit u;
+                    u.row_begin = r0 + (int64_t)(sg * per);
+                    u.row_end = std::min<int64_t>(r1, u.row_begin + (int64_t)per);
+                    if (u.row_begin >= u.row_end) continue;
+                    u.task_begin = tbeg;
+                    u.task_count = tend - tbeg;
+                    funits.push_back(u);
+                    plan.filter_pairs += (uint64_t)kFQB * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
+                }
+            }
+        }
+        if (funits.empty()) continue;
+        GPANN_TRY((pass == 0 ? s->ws_funits0 : s->ws_funits1).Reserve(funits.size() * sizeof(FilterUnit)));
+        FilterUnit* d_funits = (pass == 0 ? s->ws_funits0 : s->ws_funits1).as<FilterUnit>();
+        // the two passes use separate device arrays, but plan.filter_units is rebuilt: upload synchronously w.r.t. the host
+        GPANN_HIP_TRY(hipMemcpyAsync(d_funits, funits.data(), funits.size() * sizeof(FilterUnit), hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+
+        ThresholdArgs th;
+        th.list_dist = list_dist;
+        th.queries = d_queries;
+        th.task_query = ta.query;
+        th.task_shard = ta.shard;
+        th.shard_rmax = s->d_shard_rmax;
+        th.task_U = task_U;
+        th.tasks = T;
+        th.k = k;
+        th.d = s->d;
+        th.ld = s->ld;
+        FilterArgs fa;
+        fa.points = s->points;
+        fa.queries = d_queries;
+        fa.neg_half_norm = s->neg_half_norm;
+        fa.units = d_funits;
+        fa.task_query = ta.query;
+        fa.task_U = task_U;
+        fa.cand_cnt = cand_cnt;
+        fa.cand_row = cand_row;
+        fa.cand_cap = cap;
+        fa.d = s->d;
+        fa.ld = s->ld;
+        RescoreArgs ra;
+        ra.points = s->points;
+        ra.queries = d_queries;
+        ra.task_query = ta.query;
+        ra.cand_cnt = cand_cnt;
+        ra.cand_row = cand_row;
+        ra.list_dist = list_dist;
+        ra.list_row = list_row;
+        ra.task_shard = ta.shard;
+        ra.shard_offsets = s->d_offsets;
+        ra.range_lo = bounds[pass];
+        ra.range_hi = bounds[pass + 1];
+        ra.tasks = T;
+        ra.k = k;
+        ra.d = s->d;
+        ra.ld = s->ld;
+        ra.cand_cap = cap;
+        GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
+        const size_t flds = (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
+        const size_t rlds = (size_t)4 * s->ld * sizeof(float);
+        if (s->metric == GPANN_METRIC_L2) {
+            hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+        } else {
+            hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+        }
+        GPANN_HIP_TRY(hipGetLastError());
+        // a handful of overflowed buckets (tail of the candidate-count distribution) are re-scanned exactly inside
+        // RescoreKernel; wide-spread overflow (masses of equal distances) sends the whole call to the plain exact scan
+        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow);
+        uint32_t h_overflow = 0;
+        GPANN_HIP_TRY(hipMemcpyAsync(&h_overflow, d_overflow, 4, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+        if (h_overflow > std::max<uint32_t>(8, T / 1000)) {
+            *overflow = true;
+            return GPANN_OK;
+        }
+        if (h_overflow) GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
+        if (s->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        GPANN_HIP_TRY(hipGetLastError());
+        plan.filter_launches++;
+    }
+    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+    const size_t n = (size_t)T * k;
+    hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k, out.dist,
+                       out.ids, out.rows);
+    GPANN_HIP_TRY(hipGetLastError());
+    return GPANN_OK;
+}
+
+static bool FilterWanted(const gpann_shards* s, uint32_t k) {
+    if (!s->filter_ok || s->d > 16u * kFKS || k > GPANN_MAX_K) return false;
+    const char* mode = std::getenv("GPANN_SCAN_MODE");
+    if (mode && *mode) return std::string(mode) == "filter";
+    return s->scan_mode == 1;
+}
+
+// Runs tasks + scan + merge; results land in device arrays (caller-provided or workspace).
+static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
+                                 uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
+    ScanPlan& plan = s->plan;
+    plan.Clear();
+    GPANN_TRY(BuildTasks(s, nq, probes, probe_stride, nprobe, plan));
+    const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
+    const size_t n_out = (size_t)nq * nprobe;
+
+    const float* d_queries = nullptr;
+    GPANN_TRY(StageQueries(s, queries, nq, (flags & GPANN_QUERIES_ON_DEVICE) != 0, st, &d_queries));
+
+    // task arrays: query | out | part | nseg | shard
+    GPANN_TRY(s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256)));
+    TaskArrays ta;
+    ta.query = s->ws_tasks.as<uint32_t>();
+    ta.out = ta.query + T;
+    ta.part = ta.out + T;
+    ta.nseg = ta.part + T;
+    ta.shard = ta.nseg + T;
+    if (T) {
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, plan.task_query.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, plan.task_out.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.shard, plan.task_shard.data(), T * 4, hipMemcpyHostToDevice, st));
+    }
+    // (the plan's host arrays live in the handle until the next scan call, so the async uploads stay valid)
+
+    {   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID)
+        size_t n = n_out * k;
+        int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+        if (n) hipLaunchKernelGGL(FillKernel, dim3(grid), dim3(256), 0, st, out.dist, out.ids, out.rows, n);
+    }
+
+    GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
+    bool done = false;
+    s->stats = gpann_scan_stats{};
+    if (FilterWanted(s, k)) {
+        bool overflow = false;
+        GPANN_TRY(RunFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
+        done = !overflow;
+        s->stats.filtered = done ? 1 : 0;
+    }
+    if (!done) {
+        std::vector<int64_t> lo(s->offsets.begin(), s->offsets.end() - 1), hi(s->offsets.begin() + 1, s->offsets.end());
+        plan.padded_pairs = 0;
+        GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
+        MergeArgs m{};
+        m.out_index = ta.out;
+        m.permutation = s->permutation;
+        m.out_dist = out.dist;
+        m.out_ids = out.ids;
+        m.out_rows = out.rows;
+        GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
+    }
     GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
 
-    s->stats = gpann_scan_stats{};
     s->stats.pairs = plan.pairs;
     s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)T * k * 8ull;
     s->stats.tasks = T;
-    s->stats.units = plan.units.size();
+    s->stats.units = plan.units.size() + plan.filter_units.size();
     s->stats.padded_pairs = plan.padded_pairs;
+    s->stats.filter_pairs = plan.filter_pairs;
     return GPANN_OK;
 }
 

@@ -7,7 +7,7 @@
 
 namespace gpann {
 
-// One scan workgroup's job: <= 64 tasks of one shard x one contiguous row segment (see scan.hip).
+// One exact-scan workgroup's job: <= 64 tasks of one shard x one contiguous row segment (see scan.hip).
 struct ScanUnit {
     int64_t row_begin;
     int64_t row_end;
@@ -17,19 +17,31 @@ struct ScanUnit {
     uint32_t pad;
 };
 
+// One filter workgroup's job: <= 256 tasks of one shard x one row segment (see scan_filter.h).
+struct FilterUnit {
+    int64_t row_begin, row_end;
+    uint32_t task_begin, task_count;
+};
+
 // Host-side launch plan of one scan call; kept alive in the handle until the next call because its arrays are the
 // sources of asynchronous uploads.
 struct ScanPlan {
-    std::vector<uint32_t> task_query, task_out, task_part, task_nseg;
+    std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
-    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0;
+    std::vector<FilterUnit> filter_units;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0;
+    uint32_t filter_launches = 0;
     void Clear() {
         task_query.clear();
         task_out.clear();
         task_part.clear();
         task_nseg.clear();
+        task_shard.clear();
+        shard_task_begin.clear();
         units.clear();
-        n_lists = pairs = padded_pairs = 0;
+        filter_units.clear();
+        n_lists = pairs = padded_pairs = filter_pairs = 0;
+        filter_launches = 0;
     }
 };
 
@@ -47,8 +59,14 @@ struct gpann_shards {
     int64_t* d_offsets = nullptr;    // [S+1]        device copy
     std::vector<int64_t> offsets;    // [S+1]        host copy
 
+    // MFMA pre-filter support (scan_filter.h): -|p|^2/2 per row, max |p| per shard, and whether the data is fit for it
+    float* neg_half_norm = nullptr;  // [rows]
+    double* d_shard_rmax = nullptr;  // [S]
+    bool filter_ok = false;
+    int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
+
     // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc;
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_funits0, ws_funits1;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;

@@ -4,6 +4,7 @@
 // into one shard-contiguous row-major array so that a shard is one coalesced HBM stream; offsets[S+1] and
 // permutation[row] -> global id are kept exactly as the reference keeps them.
 #include "shards.h"
+#include "scan_filter.h"
 
 #include <algorithm>
 #include <thread>
@@ -170,8 +171,33 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
             }
         }
     }
+    // support data of the MFMA pre-filter: row norms, per-shard max norm, sanity of the values
+    if (rows) {
+        unsigned long long* d_max_bits = nullptr;
+        uint32_t* d_bad = nullptr;
+        TRY_OR_FAIL(hipMalloc(&s->neg_half_norm, rows * sizeof(float)));
+        TRY_OR_FAIL(hipMalloc(&s->d_shard_rmax, S * sizeof(double)));
+        TRY_OR_FAIL(hipMalloc(&d_bad, 4));
+        d_max_bits = reinterpret_cast<unsigned long long*>(s->d_shard_rmax);   // non-negative doubles order like their bit patterns
+        TRY_OR_FAIL(hipMemset(d_max_bits, 0, S * sizeof(double)));
+        TRY_OR_FAIL(hipMemset(d_bad, 0, 4));
+        const int grid = (int)std::min<uint64_t>((rows + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(RowNormKernel, dim3(grid), dim3(256), 0, 0, s->points, rows, d, s->ld, s->d_offsets, S, s->neg_half_norm, d_max_bits, d_bad);
+        TRY_OR_FAIL(hipGetLastError());
+        uint32_t bad = 0;
+        TRY_OR_FAIL(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_bad);
+        s->filter_ok = bad == 0;
+    }
 #undef TRY_OR_FAIL
     *out = s;
+    return GPANN_OK;
+}
+
+gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    GPANN_REQUIRE(mode == 0 || mode == 1, "scan mode must be 0 (exact) or 1 (filter)");
+    s->scan_mode = mode;
     return GPANN_OK;
 }
 
@@ -181,6 +207,12 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->points) (void)hipFree(s->points);
     if (s->permutation) (void)hipFree(s->permutation);
     if (s->d_offsets) (void)hipFree(s->d_offsets);
+    if (s->neg_half_norm) (void)hipFree(s->neg_half_norm);
+    if (s->d_shard_rmax) (void)hipFree(s->d_shard_rmax);
+    s->ws_lists.Release();
+    s->ws_cand.Release();
+    s->ws_funits0.Release();
+    s->ws_funits1.Release();
     s->ws_queries.Release();
     s->ws_tasks.Release();
     s->ws_units.Release();

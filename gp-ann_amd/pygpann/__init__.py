@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -41,7 +41,8 @@ class GpannError(RuntimeError):
 
 class ScanStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("tasks", C.c_uint64), ("units", C.c_uint64),
-                ("padded_pairs", C.c_uint64), ("scan_ms", C.c_float), ("merge_ms", C.c_float)]
+                ("padded_pairs", C.c_uint64), ("filter_pairs", C.c_uint64), ("filtered", C.c_uint32), ("reserved", C.c_uint32),
+                ("scan_ms", C.c_float), ("merge_ms", C.c_float)]
 
 
 def build(force=False):
@@ -80,6 +81,7 @@ def lib():
     L.gpann_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, _f32p]
     L.gpann_scan_last_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats)]
+    L.gpann_shards_set_scan_mode.argtypes = [C.c_void_p, C.c_int]
     L.gpann_router_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, C.c_int,
                                       C.POINTER(C.c_void_p)]
     L.gpann_router_destroy.argtypes = [C.c_void_p]
@@ -158,6 +160,10 @@ class Shards:
             self.close()
         except Exception:
             pass
+
+    def set_scan_mode(self, mode):
+        """0 = exact VALU scan, 1 = exact scan with the MFMA pre-filter (same results)"""
+        _check(lib().gpann_shards_set_scan_mode(self.h, int(mode)))
 
     def export(self):
         offsets = np.empty(self.S + 1, np.int64)

@@ -124,11 +124,20 @@ typedef struct gpann_scan_stats {
     uint64_t algorithmic_bytes;  /* pairs * d * 4  +  tasks * k * 8    */
     uint64_t tasks;              /* (query, probe slot) pairs with a valid shard */
     uint64_t units;              /* workgroups launched by the scan kernel */
-    uint64_t padded_pairs;       /* distance evaluations actually executed (tile padding included) */
+    uint64_t padded_pairs;       /* exact (VALU) distance evaluations actually executed (tile padding included) */
+    uint64_t filter_pairs;       /* (query, row) pairs evaluated by the MFMA pre-filter (0 in exact mode) */
+    uint32_t filtered;           /* 1 if the MFMA-filtered pipeline produced the result, 0 if the plain exact scan did */
+    uint32_t reserved;
     float scan_ms;               /* scan kernel, HIP events */
     float merge_ms;              /* merge kernel(s), HIP events */
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
+
+/* Scan mode of a store: 0 = exact VALU scan of every row (default); 1 = the same exact results with a matrix-core
+ * pre-filter (bf16x3 MFMA bound + exact re-scoring of the candidates, gp-ann_amd/csrc/scan_filter.h).  Both modes return
+ * bit-identical ids and distances; mode 1 silently uses the plain scan where the filter does not apply (d > 128, non-finite
+ * data, candidate overflow).  The environment variable GPANN_SCAN_MODE=exact|filter overrides the handle setting. */
+gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode);
 
 /* ------------------------------------------------------------------------------------------------------ router */
 /* Flattened KMeansTreeRouter.  Nodes are numbered per shard in BFS order (the order of ExtractPoints); the centroids of

@@ -1,0 +1,121 @@
+"""GPU parity of the MFMA-filtered scan mode (gp-ann_amd/csrc/scan_filter.h): same bit-exact ids / distances as the plain exact
+scan and the CPU oracle — the filter only chooses which rows receive the canonical evaluation."""
+import numpy as np
+import pytest
+
+from conftest import make_mixture, random_clusters
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(orc, gp, pts, clusters, queries, probes, nprobe, k, metric, expect_filtered=True):
+    shards = gp.Shards(pts, clusters, metric, 0)
+    shards.set_scan_mode(1)
+    ids, dist, rows, _ = shards.scan_buckets(queries, k, probes, nprobe, want_rows=True)
+    st = shards.stats()
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, nprobe, metric, nthreads=4)
+    assert np.array_equal(ids, wi)
+    assert np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+    if expect_filtered is not None:
+        assert st["filtered"] == (1 if expect_filtered else 0), st
+    shards.set_scan_mode(0)
+    ids0, dist0, _ = shards.scan_buckets(queries, k, probes, nprobe)
+    assert np.array_equal(ids0, ids) and np.array_equal(dist0.view(np.uint32), dist.view(np.uint32))
+    shards.close()
+    return st
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [128, 96, 100, 30, 7])
+def test_filtered_scan_matches_oracle(orc, gp, metric, d):
+    rng = np.random.default_rng(d * 3 + metric)
+    n, S, nq, k = 40000, 3, 300, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S, overlap=0.15)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    st = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    assert st["filter_pairs"] > 0
+
+
+def test_filtered_scan_two_passes_and_many_tasks(orc, gp):
+    """a shard longer than the mid boundary (131072 rows) and more than 256 tasks per shard"""
+    rng = np.random.default_rng(17)
+    n, d, nq, k = 200000, 32, 600, 10
+    pts = make_mixture(orc, n, d, n_centers=40)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=40)
+    probes = np.zeros((nq, 1), np.int32)
+    _check(orc, gp, pts, clusters, queries, probes, 1, k, 0)
+
+
+@pytest.mark.parametrize("k", [1, 7, 64])
+def test_filtered_scan_k_values(orc, gp, k):
+    rng = np.random.default_rng(k)
+    n, d, S, nq = 30000, 64, 2, 130
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    _check(orc, gp, pts, clusters, queries, probes, S, k, 0)
+
+
+def test_filtered_scan_far_queries_and_scaled_data(orc, gp):
+    """large norms / tiny gaps: the error bound has to hold when |p|, |q| >> distance"""
+    rng = np.random.default_rng(23)
+    n, d, nq, k = 30000, 48, 100, 10
+    base = make_mixture(orc, n, d, n_centers=8, sigma=0.01)
+    pts = (base * np.float32(37.0) + np.float32(900.0)).astype(np.float32)       # |p| ~ 6000, neighbours within ~1
+    queries = pts[rng.integers(0, n, nq)] + rng.standard_normal((nq, d)).astype(np.float32) * np.float32(0.05)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
+
+
+def test_filtered_scan_duplicates_overflow_falls_back(orc, gp):
+    """tens of thousands of identical rows tie with the k-th distance: every one is a candidate, buckets overflow, the call
+    falls back to the plain exact scan and still returns the reference's answer (ties broken by row)"""
+    rng = np.random.default_rng(29)
+    n, d, nq, k = 30000, 16, 90, 10
+    pts = make_mixture(orc, n, d, n_centers=4)
+    pts[2000:] = pts[2000]
+    clusters = [np.arange(n, dtype=np.uint32)]
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=4)
+    queries[:40] = pts[2000]          # for these every duplicate ties at distance 0: 40 buckets overflow -> whole-call fallback
+    probes = np.zeros((nq, 1), np.int32)
+    st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
+    assert st["filtered"] == 0
+    queries[1:40] = queries[41:80][:39] if nq >= 80 else queries[40:41]   # only one flooding query: re-scanned inside the rescoring kernel
+    st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
+    assert st["filtered"] == 1
+
+
+def test_filtered_ground_truth_and_merged(orc, gp):
+    rng = np.random.default_rng(31)
+    n, d, S, nq, k = 50000, 40, 4, 150, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S, overlap=0.2)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(1)
+    ivf = orc.ivf_build(pts, clusters)
+    ids, dist, _ = shards.scan_merged(queries, k, probes, 3)
+    for q in range(0, nq, 7):
+        wd, wi = orc.ivf_query(ivf, queries[q], k, probes[q], 3, 0)
+        assert np.array_equal(ids[q], wi) and np.array_equal(dist[q].view(np.uint32), wd.view(np.uint32))
+    assert shards.stats()["filtered"] == 1
+
+
+def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, monkeypatch):
+    """a tiny candidate cap forces a few buckets to overflow: those tasks are re-scanned exactly by the rescoring kernel"""
+    rng = np.random.default_rng(37)
+    n, d, nq, k = 30000, 24, 3000, 10
+    pts = make_mixture(orc, n, d, n_centers=16)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
+    probes = np.zeros((nq, 1), np.int32)
+    monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "200")     # expected fill ~ k * 26000 / 4096 = 63 + tail
+    _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
