@@ -484,15 +484,16 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
     const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (1536ull << 20) / (4ull * T))));
 
     // per-task exact lists (dist | row), thresholds, candidate buckets, overflow word
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256));
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
     float* list_dist = s->ws_lists.as<float>();
     uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
     float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
-    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T);
+    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T + ((T & 1) ? 1 : 0));   // [0] overflow count, [2..3] candidate total (u64)
+    unsigned long long* d_cand_total = reinterpret_cast<unsigned long long*>(d_overflow + 2);
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
-    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
+    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 16, st));
 
     // ---- stage 0: exact scan of the first m0 rows of every shard -> lists
     std::vector<int64_t> lo(S), hi(S);
@@ -514,7 +515,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
 
     // ---- filter passes over [m0, m1) and [m1, end)
     const int64_t bounds[3] = {m0, m1, std::numeric_limits<int64_t>::max()};
-    const uint32_t target_units = EnvU32("GPANN_FILTER_TARGET_UNITS", 2048);
+    const uint32_t target_units = EnvU32("GPANN_FILTER_TARGET_UNITS", 8192);
     for (int pass = 0; pass < 2; ++pass) {
         // units: (<= 256 tasks of a shard) x (row segment of the pass range)
         std::vector<FilterUnit>& funits = plan.filter_units;
@@ -550,7 +551,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
                     u.task_begin = tbeg;
                     u.task_count = tend - tbeg;
                     funits.push_back(u);
-                    plan.filter_pairs += (uint64_t)kFQB * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
+                    plan.filter_pairs += (uint64_t)((u.task_count + 31) / 32 * 32) * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
                 }
             }
         }
@@ -584,6 +585,10 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         fa.cand_cap = cap;
         fa.d = s->d;
         fa.ld = s->ld;
+        fa.plane_hi = s->plane_hi;
+        fa.plane_lo = s->plane_lo;
+        fa.debug = EnvU32("GPANN_FILTER_DEBUG", 0);
+        const bool dma = s->plane_hi != nullptr && s->plane_lo != nullptr;
         RescoreArgs ra;
         ra.points = s->points;
         ra.queries = d_queries;
@@ -602,22 +607,34 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         ra.ld = s->ld;
         ra.cand_cap = cap;
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-        const size_t flds = (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
+        const size_t flds = dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
         const size_t rlds = (size_t)4 * s->ld * sizeof(float);
         if (s->metric == GPANN_METRIC_L2) {
             hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            if (dma) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL(FilterKernelDma<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            } else {
+                hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            }
         } else {
             hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            if (dma) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL(FilterKernelDma<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            } else {
+                hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            }
         }
         GPANN_HIP_TRY(hipGetLastError());
         // a handful of overflowed buckets (tail of the candidate-count distribution) are re-scanned exactly inside
         // RescoreKernel; wide-spread overflow (masses of equal distances) sends the whole call to the plain exact scan
-        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow);
-        uint32_t h_overflow = 0;
-        GPANN_HIP_TRY(hipMemcpyAsync(&h_overflow, d_overflow, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
+        uint32_t h_words[4] = {0, 0, 0, 0};
+        GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t h_overflow = h_words[0];
+        plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
         if (h_overflow > std::max<uint32_t>(8, T / 1000)) {
             *overflow = true;
             return GPANN_OK;
@@ -705,6 +722,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.units = plan.units.size() + plan.filter_units.size();
     s->stats.padded_pairs = plan.padded_pairs;
     s->stats.filter_pairs = plan.filter_pairs;
+    s->stats.filter_candidates = plan.filter_candidates;
     return GPANN_OK;
 }
 

@@ -45,6 +45,9 @@ struct FilterArgs {
     uint32_t* cand_row;           // [tasks][cand_cap]
     uint32_t cand_cap;
     uint32_t d, ld;
+    const char* plane_hi;         // optional: pre-split bf16 planes [rows + 64][136] (FilterKernelDma)
+    const char* plane_lo;
+    uint32_t debug;               // experiments only: 1 = skip MFMA phase, 2 = skip DMA after the first tile, 4 = skip epilogue
 };
 
 // two floats -> packed bf16 hi pair and bf16 lo pair (round to nearest even; x - float(hi) is exact in binary32)
@@ -193,6 +196,187 @@ __global__ void __launch_bounds__(256, 2) FilterKernel(FilterArgs a) {
     }
 }
 
+// ---- the same filter fed by LDS-DMA ---------------------------------------------------------------------------------------
+// With the bf16 hi/lo planes of the points precomputed in HBM in exactly the padded LDS image ([row][136] bf16, 272 B per
+// row), a 64-row tile of a plane is 17 contiguous KiB and is moved HBM -> LDS by 17 global_load_lds_dwordx4 wave-instructions
+// with no VGPRs and no VALU work.  Two LDS buffers: the DMA of tile i+1 is in flight during the MFMA phase of tile i; the
+// one barrier per tile (preceded by the compiler's vmcnt(0)) publishes it.
+constexpr int kFPlaneBytes = kFPlane * 2;            // 17408
+constexpr int kFBufBytes = 2 * kFPlaneBytes;         // hi + lo
+constexpr int kFRowBytes = kFRowStride * 2;          // 272
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).
+// Issued through inline asm on purpose: for the builtin hipcc cannot tell which LDS bytes the DMA writes and waits
+// vmcnt(0) in front of the next LDS read, which would serialise the DMA with the MFMA phase it is meant to hide under.
+// The kernel waits for its DMAs itself (DmaWaitAll) right before the barrier that publishes them.
+__device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "m0");
+}
+__device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int METRIC>
+__global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
+    extern __shared__ uint4 fsm4[];
+    char* lds = reinterpret_cast<char*>(fsm4);
+
+    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
+    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t d = a.d, ld = a.ld;
+    const int ksteps = (int)((d + 15) / 16);
+
+    // query tiles of 32 this wave really has (the unit's task count is rarely a multiple of 256): 0, 1 or 2.  A wave
+    // without tasks still takes part in the DMA and the barriers but issues no MFMA.
+    const int nqt = (int)min(2u, (task_count > 64u * wave ? task_count - 64u * wave + 31u : 0u) / 32u);
+    Frag qh[2][kFKS], ql[2][kFKS];
+    float U[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t tl = 64u * wave + 32u * t + c;
+        const uint32_t task = task_begin + min(tl, task_count - 1);
+        U[t] = tl < task_count ? a.task_U[task] : INFINITY;
+        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
+#pragma unroll
+        for (int ks = 0; ks < kFKS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (ks < ksteps) {
+                const uint32_t k0 = 16u * ks + 8u * h;
+                if (k0 < ld) {
+                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+                }
+                if (k0 + 4 < ld) {
+                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
+                    v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], qh[t][ks].u[j], ql[t][ks].u[j]);
+        }
+    }
+
+    // 34 chunks of 1 KiB per tile (17 per plane); wave w moves chunks w, w + 4, ...
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    auto issue = [&](int buf, int64_t row0) {
+        for (int j = wave; j < 34; j += 4) {
+            const int plane = j >= 17, chunk = j - 17 * plane;
+            const char* src = (plane ? a.plane_lo : a.plane_hi) + (size_t)row0 * kFRowBytes + chunk * 1024 + lane * 16;
+            const uint32_t dst = lds_base + buf * kFBufBytes + plane * kFPlaneBytes + chunk * 1024;
+            DmaToLds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)dst));
+        }
+    };
+    issue(0, row_begin);
+    DmaWaitAll();
+    __syncthreads();
+
+    int buf = 0;
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += kFPT, buf ^= 1) {
+        // no ordinary global load may sit in this loop: beside an LDS-DMA in flight hipcc would wait vmcnt(0) for it before
+        // the first LDS read and serialise DMA and MFMA (the row norms therefore travel inside the hi plane's row padding)
+        if (row0 + kFPT < row_end && !(a.debug & 2)) issue(buf ^ 1, row0 + kFPT);
+        const __bf16* sHi = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes);
+        const __bf16* sLo = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes + kFPlaneBytes);
+        const char* sN = lds + buf * kFBufBytes + 2 * 128;   // -|p|^2/2 of row r: float at byte r * 272 + 256 of the hi plane
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (METRIC == GPANN_METRIC_L2) {
+                    const char* n0 = sN + (32 * pt + 8 * g + 4 * h) * kFRowBytes;
+                    nv.x = *reinterpret_cast<const float*>(n0);
+                    nv.y = *reinterpret_cast<const float*>(n0 + kFRowBytes);
+                    nv.z = *reinterpret_cast<const float*>(n0 + 2 * kFRowBytes);
+                    nv.w = *reinterpret_cast<const float*>(n0 + 3 * kFRowBytes);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    acc[pt][qt][4 * g + 0] = nv.x;
+                    acc[pt][qt][4 * g + 1] = nv.y;
+                    acc[pt][qt][4 * g + 2] = nv.z;
+                    acc[pt][qt][4 * g + 3] = nv.w;
+                }
+            }
+#pragma unroll
+        for (int ks = 0; ks < kFKS; ++ks) {
+            if (ks < ksteps && nqt > 0 && !(a.debug & 1)) {
+                Frag ah[2], al[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int off = (32 * pt + c) * kFRowStride + 16 * ks + 8 * h;
+                    ah[pt].q = *reinterpret_cast<const uint4*>(sHi + off);
+                    al[pt].q = *reinterpret_cast<const uint4*>(sLo + off);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    if (qt < nqt) {
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, ql[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+
+        bool any = false;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) any |= acc[pt][qt][r] >= U[qt];
+        if (__any(any) && !(a.debug & 4)) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[pt][qt][r] >= U[qt]) {
+                            const int64_t row = row0 + 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const uint32_t tl = 64u * wave + 32u * qt + c;
+                            if (row < row_end && tl < task_count) {
+                                const uint32_t task = task_begin + tl;
+                                const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
+                                if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
+                            }
+                        }
+                    }
+        }
+        DmaWaitAll();      // this wave's share of the next tile has landed ...
+        __syncthreads();   // ... and so has everyone else's; all waves are done reading `buf`
+    }
+}
+
+// f32 rows -> the two bf16 planes in the padded LDS image ([row][136], pad = 0); one thread per pair of elements
+static __global__ void __launch_bounds__(256) SplitPlanesKernel(const float* points, const float* neg_half_norm, uint64_t rows, uint32_t ld, char* plane_hi,
+                                                                char* plane_lo) {
+    const uint64_t pairs_per_row = kFRowStride / 2;   // 68
+    const uint64_t total = rows * pairs_per_row;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / pairs_per_row;
+        const uint32_t c = (uint32_t)(i % pairs_per_row) * 2;
+        float x0 = 0.f, x1 = 0.f;
+        if (c < ld) {
+            x0 = points[r * ld + c];
+            x1 = points[r * ld + c + 1];   // ld is even (multiple of 4)
+        }
+        uint32_t hi, lo;
+        SplitBf16(x0, x1, hi, lo);
+        if (c == 128) hi = __float_as_uint(neg_half_norm[r]);   // the row's -|p|^2/2 rides in the first 4 pad bytes of the hi plane
+        *reinterpret_cast<uint32_t*>(plane_hi + r * kFRowBytes + c * 2) = hi;
+        *reinterpret_cast<uint32_t*>(plane_lo + r * kFRowBytes + c * 2) = lo;
+    }
+}
+
 // ---- thresholds ------------------------------------------------------------------------------------------------------
 // For task t with exact k-th distance tau (its list's last entry; +inf while the list is not full):  U[t] such that every
 // row whose CANONICAL binary32 distance E satisfies E <= tau has acc >= U.  All in double, rounded towards -inf.
@@ -267,9 +451,16 @@ struct RescoreArgs {
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
-static __global__ void OverflowCountKernel(const uint32_t* cand_cnt, uint32_t tasks, uint32_t cap, uint32_t* out) {
+static __global__ void OverflowCountKernel(const uint32_t* cand_cnt, uint32_t tasks, uint32_t cap, uint32_t* out, unsigned long long* total) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < tasks && cand_cnt[t] > cap) atomicAdd(out, 1u);
+    if (t >= tasks) return;
+    const uint32_t c = cand_cnt[t];
+    if (c > cap) atomicAdd(out, 1u);
+    // wave-level sum, one atomic per wavefront
+    unsigned long long v = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(total, v);
 }
 
 __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd, uint32_t cr, uint32_t k, int lane) {

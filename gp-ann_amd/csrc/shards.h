@@ -29,7 +29,7 @@ struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
     std::vector<FilterUnit> filter_units;
-    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0;
     uint32_t filter_launches = 0;
     void Clear() {
         task_query.clear();
@@ -40,7 +40,7 @@ struct ScanPlan {
         shard_task_begin.clear();
         units.clear();
         filter_units.clear();
-        n_lists = pairs = padded_pairs = filter_pairs = 0;
+        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = 0;
         filter_launches = 0;
     }
 };
@@ -62,6 +62,8 @@ struct gpann_shards {
     // MFMA pre-filter support (scan_filter.h): -|p|^2/2 per row, max |p| per shard, and whether the data is fit for it
     float* neg_half_norm = nullptr;  // [rows]
     double* d_shard_rmax = nullptr;  // [S]
+    char* plane_hi = nullptr;        // optional [rows + 64][136] bf16: the points pre-split for FilterKernelDma
+    char* plane_lo = nullptr;
     bool filter_ok = false;
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 

@@ -7,6 +7,7 @@
 #include "scan_filter.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -188,6 +189,25 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         TRY_OR_FAIL(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_bad);
         s->filter_ok = bad == 0;
+        // pre-split bf16 planes for the DMA-fed filter (about 2.1x the bytes of the rows once more); optional: without them
+        // (allocation failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly
+        const char* want = std::getenv("GPANN_FILTER_PLANES");
+        if (s->filter_ok && d <= 128 && !(want && want[0] == '0')) {
+            const size_t plane_bytes = (rows + 64) * (size_t)kFRowBytes;
+            if (hipMalloc(&s->plane_hi, plane_bytes) == hipSuccess && hipMalloc(&s->plane_lo, plane_bytes) == hipSuccess) {
+                TRY_OR_FAIL(hipMemsetAsync(s->plane_hi + rows * (size_t)kFRowBytes, 0, 64 * (size_t)kFRowBytes, 0));
+                TRY_OR_FAIL(hipMemsetAsync(s->plane_lo + rows * (size_t)kFRowBytes, 0, 64 * (size_t)kFRowBytes, 0));
+                const uint64_t total = rows * (kFRowStride / 2);
+                const int g2 = (int)std::min<uint64_t>((total + 255) / 256, 256 * 64);
+                hipLaunchKernelGGL(SplitPlanesKernel, dim3(g2), dim3(256), 0, 0, s->points, s->neg_half_norm, rows, s->ld, s->plane_hi, s->plane_lo);
+                TRY_OR_FAIL(hipGetLastError());
+                TRY_OR_FAIL(hipDeviceSynchronize());
+            } else {
+                (void)hipGetLastError();
+                if (s->plane_hi) (void)hipFree(s->plane_hi);
+                s->plane_hi = s->plane_lo = nullptr;
+            }
+        }
     }
 #undef TRY_OR_FAIL
     *out = s;
@@ -209,6 +229,8 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->d_offsets) (void)hipFree(s->d_offsets);
     if (s->neg_half_norm) (void)hipFree(s->neg_half_norm);
     if (s->d_shard_rmax) (void)hipFree(s->d_shard_rmax);
+    if (s->plane_hi) (void)hipFree(s->plane_hi);
+    if (s->plane_lo) (void)hipFree(s->plane_lo);
     s->ws_lists.Release();
     s->ws_cand.Release();
     s->ws_funits0.Release();

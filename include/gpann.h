@@ -126,6 +126,7 @@ typedef struct gpann_scan_stats {
     uint64_t units;              /* workgroups launched by the scan kernel */
     uint64_t padded_pairs;       /* exact (VALU) distance evaluations actually executed (tile padding included) */
     uint64_t filter_pairs;       /* (query, row) pairs evaluated by the MFMA pre-filter (0 in exact mode) */
+    uint64_t filter_candidates;  /* rows that passed the pre-filter and were re-scored exactly (all passes) */
     uint32_t filtered;           /* 1 if the MFMA-filtered pipeline produced the result, 0 if the plain exact scan did */
     uint32_t reserved;
     float scan_ms;               /* scan kernel, HIP events */
