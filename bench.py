@@ -29,6 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 POINT_SEED, QUERY_SEED, CENTER_SEED = 555, 556, 7
 N_CENTERS, SIGMA = 1024, 0.35
 
@@ -89,6 +90,7 @@ def main():
     ap.add_argument("--scan-mode", choices=["exact", "filter"], default=os.environ.get("GPANN_BENCH_SCAN_MODE", "filter"),
                     help="exact: VALU scan of every row; filter: same exact results with the MFMA pre-filter (scan_filter.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
 
     import torch
@@ -231,10 +233,19 @@ def main():
     log(f"recall curve {recall_curve} -> nprobe {nprobe}")
 
     # ---------------------------------------------------------------- the timed hot path
+    trace = os.environ.get("GPANN_BENCH_TRACE") == "1"
+
     def step():
+        t_a = time.perf_counter()
         pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+        t_b = time.perf_counter()
         sd, si, s_ms = scan_slots(pr, nprobe, timed=True)
+        t_c = time.perf_counter()
         md, mi, _ = pygpann.merge_dedup(sd, si, nprobe, k)
+        t_d = time.perf_counter()
+        if trace:
+            log(f"step: route {1e3 * (t_b - t_a):.2f} ms (kernels {r_ms:.2f}), scan+gather {1e3 * (t_c - t_b):.2f} ms (kernels {s_ms:.2f}), "
+                f"merge {1e3 * (t_d - t_c):.2f} ms")
         return md, mi, r_ms, s_ms
 
     def barrier():
@@ -244,13 +255,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    scan_ms, router_ms, algo_bytes, stats = [], [], [], None
+    scan_ms, router_ms, algo_bytes, filter_ms, stats = [], [], [], [], None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         md, mi, r_ms, s_ms = step()
         st = shards.stats()
         scan_ms.append(st["scan_ms"])
+        filter_ms.append(st["filter_ms"])
         router_ms.append(r_ms)
         algo_bytes.append(st["algorithmic_bytes"])
         stats = st
@@ -275,16 +287,49 @@ def main():
                    "parallelism": f"shards over {world} GPU(s), LPT"},
     }
     avg_scan_s = float(np.mean(scan_ms)) / 1000.0
-    achieved = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
-    result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                          "traffic": None, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
-                          "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY §8d) of rank 0 / HIP-event kernel time; "
-                                  "each HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
-                          "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0,
-                          "scan_mode": args.scan_mode, "filtered": stats["filtered"], "filter_pairs": stats["filter_pairs"]}
-    result["detail"] = {"recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "scan_kernel_ms": float(np.mean(scan_ms)),
-                        "merge_kernel_ms": stats["merge_ms"], "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"],
-                        "padded_pairs": stats["padded_pairs"], "setup_s": time.time() - t_setup}
+    hbm_alg = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
+    filtered = bool(stats["filtered"])
+    # per step: the filter kernel is launched twice (two row ranges), the exact kernel once
+    traffic = lookup_traffic(n, d, S, nprobe, "FilterKernelDma<0, 0>" if filtered else "ScanTileKernel<0, 0>", 2 if filtered else 1)
+    if filtered:
+        # dominant kernel: FilterKernelDma — bf16x3 matrix-core bound on (query, row) pairs: 3 MFMA products x 2 flop per dimension
+        f_s = float(np.mean(filter_ms)) / 1000.0
+        flops = stats["filter_pairs"] * d * 6.0
+        achieved = flops / f_s / 1e12 if f_s > 0 else 0.0
+        result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gpann::FilterKernelDma", "kernel_ms": 1000.0 * f_s,
+                              "note": "the exact scan in filter mode: v_mfma_f32_32x32x16_bf16 on bf16 hi/lo planes (3 products) bounds every "
+                                      "(query,row) distance, only candidates get the exact VALU evaluation; flops = filter_pairs x d x 6 per launch "
+                                      "(both filter launches of a step), time = HIP events around them",
+                              "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
+                              "hbm_algorithmic_GBps": hbm_alg, "hbm_algorithmic_frac": hbm_alg / HBM_PEAK_GBPS}
+    else:
+        result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
+                              "traffic": traffic, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
+                              "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY 8d) of rank 0 / HIP-event kernel time; each "
+                                      "HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
+                              "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0}
+    result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)),
+                        "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
+                        "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
+                        "setup_s": time.time() - t_setup}
+
+    # the same steps with the plain exact (VALU) scan, for reference: identical results, no matrix cores
+    if args.scan_mode == "filter" and not args.no_exact_compare:
+        shards.set_scan_mode(0)
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        md0, mi0, _, _ = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        st0 = shards.stats()
+        same = bool(np.array_equal(mi0, mi) and np.array_equal(md0.view(np.uint32), md.view(np.uint32)))
+        result["detail"]["exact_mode"] = {"qps": nq / dt, "ms_per_step": 1000.0 * dt, "scan_kernel_ms": st0["scan_ms"],
+                                          "valu_lane_ops_per_s": st0["padded_pairs"] * d * 3 / (st0["scan_ms"] / 1000.0),
+                                          "hbm_algorithmic_GBps": st0["algorithmic_bytes"] / (st0["scan_ms"] / 1000.0) / 1e9,
+                                          "results_identical_to_filter_mode": same}
+        shards.set_scan_mode(1)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -296,6 +341,25 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
+        try:
+            j = json.load(open(path))
+            w = j["workload"]
+            if (w["n"], w["d"], w["shards"], w["nprobe"]) != (n, d, S, nprobe):
+                continue
+            for name, v in j["kernels"].items():
+                if kernel in name:
+                    best = float(v["hbm_bytes_per_launch"]) * launches_per_step
+        except Exception:
+            continue
+    return best
 
 
 def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts):

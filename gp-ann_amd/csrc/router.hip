@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct gpann_router {
@@ -29,6 +30,8 @@ struct gpann_router {
     uint32_t d = 0, ld = 0, S = 0, n_nodes = 0;
     uint64_t n_centroids = 0;
     uint32_t max_children = 0;
+    uint32_t max_node = 1;   // largest node (centroids)
+    int num_cus = 256;       // cached hipDeviceProp_t::multiProcessorCount
     float* centroids = nullptr;          // [n_centroids][ld]
     int32_t* node_shard = nullptr;
     uint32_t* node_cent_first = nullptr; // [n_nodes+1]
@@ -482,6 +485,12 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
     TRY_OR_FAIL(hipMemcpy(r->node_child_count, node_child_count, n_nodes * 4, hipMemcpyHostToDevice));
     TRY_OR_FAIL(hipMemcpy(r->shard_root, shard_root, S * 4, hipMemcpyHostToDevice));
     for (auto& e : r->ev) TRY_OR_FAIL(hipEventCreate(&e));
+    {
+        hipDeviceProp_t prop;
+        TRY_OR_FAIL(hipGetDeviceProperties(&prop, device));
+        r->num_cus = prop.multiProcessorCount;
+        for (uint32_t u = 0; u < n_nodes; ++u) r->max_node = std::max(r->max_node, node_cent_first[u + 1] - node_cent_first[u]);
+    }
 #undef TRY_OR_FAIL
     *out = r;
     return GPANN_OK;
@@ -521,8 +530,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     uint64_t cap = r->n_nodes;
     if (budget > 0) cap = std::min<uint64_t>(cap, (uint64_t)S + (uint64_t)budget * std::max<uint32_t>(1, r->max_children));
     cap = std::max<uint64_t>(cap, S);
-    hipDeviceProp_t prop;
-    GPANN_HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    struct { int multiProcessorCount; } prop{r->num_cus};
     GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
     const char* force = std::getenv("GPANN_ROUTER_MODE");   // "walk" | "dense" (default: by size)
     const uint64_t C = r->n_centroids;
@@ -661,13 +669,25 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
 
     if (out_probes) {
-        // kmeans_tree_router.cpp:125-127 — the reference's own call, on the GPU-computed min_dist
-        std::vector<int> probes(S);
-        for (uint32_t q = 0; q < nq; ++q) {
-            const float* min_dist = md + (size_t)q * S;
-            std::iota(probes.begin(), probes.end(), 0);
-            std::sort(probes.begin(), probes.end(), [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
-            std::copy(probes.begin(), probes.end(), out_probes + (size_t)q * S);
+        // kmeans_tree_router.cpp:125-127 — the reference's own call, on the GPU-computed min_dist; queries are independent,
+        // so the batch is spread over a few host threads
+        auto sort_range = [&](uint32_t q0, uint32_t q1) {
+            std::vector<int> probes(S);
+            for (uint32_t q = q0; q < q1; ++q) {
+                const float* min_dist = md + (size_t)q * S;
+                std::iota(probes.begin(), probes.end(), 0);
+                std::sort(probes.begin(), probes.end(), [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
+                std::copy(probes.begin(), probes.end(), out_probes + (size_t)q * S);
+            }
+        };
+        const uint32_t threads = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ((uint64_t)nq * S) / 32768));
+        if (threads <= 1) {
+            sort_range(0, nq);
+        } else {
+            std::vector<std::thread> pool;
+            for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(sort_range, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads));
+            sort_range(0, nq / threads);
+            for (auto& th : pool) th.join();
         }
     }
     return GPANN_OK;
@@ -688,12 +708,7 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t S = r->S;
     // a walk evaluates at most budget + (largest node - 1) centroids after the budget check, and never more than the tree holds
-    uint32_t max_node = 1;
-    {
-        std::vector<uint32_t> cf(r->n_nodes + 1);
-        GPANN_HIP_TRY(hipMemcpy(cf.data(), r->node_cent_first, (r->n_nodes + 1) * 4, hipMemcpyDeviceToHost));
-        for (uint32_t u = 0; u < r->n_nodes; ++u) max_node = std::max(max_node, cf[u + 1] - cf[u]);
-    }
+    const uint32_t max_node = r->max_node;
     uint64_t rec_cap = std::min<uint64_t>(r->n_centroids, (uint64_t)std::max(budget, 0) + max_node);
     rec_cap = std::max<uint64_t>(rec_cap, 1);
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (512ull << 20) / (rec_cap * 8)));

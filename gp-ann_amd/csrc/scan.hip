@@ -476,6 +476,7 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
 static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
                                     hipStream_t st, DeviceLists out, bool* overflow) {
     *overflow = false;
+    s->filter_passes_timed = 0;
     const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
     if (T == 0) return GPANN_OK;
     const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
@@ -589,6 +590,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         fa.plane_lo = s->plane_lo;
         fa.debug = EnvU32("GPANN_FILTER_DEBUG", 0);
         const bool dma = s->plane_hi != nullptr && s->plane_lo != nullptr;
+        const bool aux = (flags & GPANN_AUX_PASS) != 0;
         RescoreArgs ra;
         ra.points = s->points;
         ra.queries = d_queries;
@@ -609,24 +611,33 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         const size_t flds = dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
         const size_t rlds = (size_t)4 * s->ld * sizeof(float);
+        GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         if (s->metric == GPANN_METRIC_L2) {
             hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            if (dma) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL(FilterKernelDma<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            if (dma && aux) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_L2, 1>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            } else if (dma) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_L2, 0>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
             } else {
                 hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
             }
         } else {
             hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            if (dma) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL(FilterKernelDma<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            if (dma && aux) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_MIPS, 1>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
+            } else if (dma) {
+                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_MIPS, 0>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
             } else {
                 hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
             }
         }
         GPANN_HIP_TRY(hipGetLastError());
+        GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
+        s->filter_passes_timed++;
         // a handful of overflowed buckets (tail of the candidate-count distribution) are re-scanned exactly inside
         // RescoreKernel; wide-spread overflow (masses of equal distances) sends the whole call to the plain exact scan
         hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
@@ -696,6 +707,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
     bool done = false;
     s->stats = gpann_scan_stats{};
+    s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
         GPANN_TRY(RunFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
@@ -733,6 +745,14 @@ static gpann_status FinishTiming(gpann_shards* s, float* elapsed_ms) {
     GPANN_HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
     s->stats.scan_ms = a;
     s->stats.merge_ms = b;
+    s->stats.filter_ms = 0.f;
+    if (s->stats.filtered) {
+        for (int p = 0; p < s->filter_passes_timed; ++p) {
+            float f = 0.f;
+            GPANN_HIP_TRY(hipEventElapsedTime(&f, s->ev_filter[2 * p], s->ev_filter[2 * p + 1]));
+            s->stats.filter_ms += f;
+        }
+    }
     if (elapsed_ms) *elapsed_ms = a + b;
     return GPANN_OK;
 }

@@ -214,7 +214,8 @@ __device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) 
 }
 __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int METRIC>
+// TAG: profiling label as for ScanTileKernel (1 = auxiliary pass such as ground truth)
+template <int METRIC, int TAG>
 __global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
     extern __shared__ uint4 fsm4[];
     char* lds = reinterpret_cast<char*>(fsm4);

@@ -70,6 +70,8 @@ struct gpann_shards {
     // per-call workspace, grown on demand and reused
     gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_funits0, ws_funits1;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_filter[4] = {nullptr, nullptr, nullptr, nullptr};   // begin/end of the filter kernel of pass 0 and pass 1
+    int filter_passes_timed = 0;
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;
 };

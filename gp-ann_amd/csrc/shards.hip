@@ -121,6 +121,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     TRY_OR_FAIL(hipMemcpy(s->d_offsets, s->offsets.data(), (S + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     if (rows) TRY_OR_FAIL(hipMemcpy(s->permutation, ids_concat, rows * sizeof(uint32_t), hipMemcpyHostToDevice));
     for (auto& e : s->ev) TRY_OR_FAIL(hipEventCreate(&e));
+    for (auto& e : s->ev_filter) TRY_OR_FAIL(hipEventCreate(&e));
 
     if (rows) {
         if (flags & GPANN_POINTS_ON_DEVICE) {
@@ -242,6 +243,8 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     s->ws_out.Release();
     s->ws_misc.Release();
     for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->ev_filter)
         if (e) (void)hipEventDestroy(e);
     delete s;
     return GPANN_OK;

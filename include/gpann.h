@@ -129,8 +129,10 @@ typedef struct gpann_scan_stats {
     uint64_t filter_candidates;  /* rows that passed the pre-filter and were re-scored exactly (all passes) */
     uint32_t filtered;           /* 1 if the MFMA-filtered pipeline produced the result, 0 if the plain exact scan did */
     uint32_t reserved;
-    float scan_ms;               /* scan kernel, HIP events */
+    float scan_ms;               /* scan kernels (exact mode: ScanTileKernel; filter mode: every kernel of the pipeline), HIP events */
     float merge_ms;              /* merge kernel(s), HIP events */
+    float filter_ms;             /* of scan_ms: the MFMA filter kernels (threshold + filter launches of all passes) */
+    float reserved2;
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 

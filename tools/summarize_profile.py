@@ -80,7 +80,8 @@ if traffic:
         fb = 2 * 1024 * (sum(fv) / len(fv)) if fv else 0
         wb = 1024 * (sum(wv) / len(wv)) if wv else 0
         lines.append(f"| `{name}` | {len(fv)} | {', '.join(f'{x:.0f}' for x in fv[:6])} | {', '.join(f'{x:.0f}' for x in wv[:6])} | {fb + wb:.4g} |")
-        tj[name] = {"fetch_kib": fv, "write_kib": wv, "hbm_bytes_per_launch": fb + wb}
+        tj[name] = {"fetch_kib": fv, "write_kib": wv, "hbm_bytes_per_launch": fb + wb, "launches": len(fv),
+                    "hbm_bytes_all_launches": 2 * 1024 * sum(fv) + 1024 * sum(wv)}
     lines.append("")
     json.dump({"workload": bench["config"], "kernels": tj}, open(f"{outdir}/{tag}_pmc_traffic.json", "w"), indent=1)
 
