@@ -16,6 +16,7 @@ the 8 TB/s HBM peak), `cpu_baseline` (the CPU oracle timed on this box's host co
 workload) and `detail`.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -37,6 +38,19 @@ N_CENTERS, SIGMA = 1024, 0.35
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """the host mirror prints progress to std::cout like the reference does; keep bench's stdout to the one JSON line"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
@@ -68,7 +82,8 @@ def build_router_tree(torch, pygpann, sample, sample_assign, S, args):
     order = np.argsort(a, kind="stable")
     bounds = np.searchsorted(a[order], np.arange(S + 1))
     clusters = [order[bounds[b]:bounds[b + 1]].astype(np.uint32) for b in range(S)]
-    return host.train_router(pts, clusters, args.router_centroids, args.router_min_cluster, args.router_budget, mips=False, threads=0)
+    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
+    return host.train_router(pts, clusters, args.router_centroids, args.router_min_cluster, args.router_budget, mips=False, threads=threads)
 
 
 def main():
@@ -76,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("GPANN_BENCH_N", 100_000_000)))
+    ap.add_argument("--points", dest="n", type=int, default=int(os.environ.get("GPANN_BENCH_N", 100_000_000)))
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--shards", type=int, default=40)
@@ -89,6 +104,8 @@ def main():
     ap.add_argument("--router-train-points", type=int, default=1_000_000, help="rows of the cloud the router is trained on")
     ap.add_argument("--scan-mode", choices=["exact", "filter"], default=os.environ.get("GPANN_BENCH_SCAN_MODE", "filter"),
                     help="exact: VALU scan of every row; filter: same exact results with the MFMA pre-filter (scan_filter.h)")
+    ap.add_argument("--backend", default=os.environ.get("GPANN_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI) or gloo (debugging: exchanges go through host tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
@@ -105,10 +122,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # GPANN_BENCH_FORCE_DEVICE: debugging aid — run every rank on one GPU (only sensible with --backend gloo and a small --n)
+    if "GPANN_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["GPANN_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     stream = torch.cuda.current_stream().cuda_stream
     n, d, nq, S, k = args.n, args.d, args.nq, args.shards, args.k
 
@@ -120,8 +143,19 @@ def main():
     sample = torch.empty((n_sample, d), dtype=torch.float32, device=dev)
     pygpann.synth_rows_device(sample.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, n_sample, d, stream)
     shard_cent, sample_assign = lloyd_gpu(torch, pygpann, sample, S, 20, 555, stream)
+    if world > 1:
+        # the device k-means sums with float atomics, so its centroids differ in the last bits from run to run: every rank
+        # must cut the cloud with rank 0's centroids or rows would be owned by two ranks / by none
+        if args.backend == "nccl":
+            dist.broadcast(shard_cent, src=0)
+        else:
+            c = shard_cent.cpu()
+            dist.broadcast(c, src=0)
+            shard_cent.copy_(c)
+        pygpann.nearest_centroid_device(sample.data_ptr(), n_sample, d, 0, shard_cent.data_ptr(), S, sample_assign.data_ptr(), stream)
     n_train = min(n_sample, args.router_train_points)
-    tree = build_router_tree(torch, pygpann, sample[:n_train], sample_assign[:n_train], S, args)
+    with stdout_to_stderr():
+        tree = build_router_tree(torch, pygpann, sample[:n_train], sample_assign[:n_train], S, args)
     del sample
     log(f"shard centroids + router tree ({tree['centroids'].shape[0]} centroids) ready in {time.time() - t_setup:.1f}s")
 
@@ -198,13 +232,38 @@ def main():
             # translate to global ids, then the exchange: all-gather of the fixed-shape slot arrays over RCCL
             ids_h = to_global(oi.cpu().numpy().view(np.uint32))
             oi.copy_(torch.from_numpy(ids_h.view(np.int32)))
-            gd_h, gi_h = multigpu.all_gather_slots(od, oi, dist, world)
+            if args.backend == "nccl":
+                gd_h, gi_h = multigpu.all_gather_slots(od, oi, dist, world)
+            else:
+                gd_h, gi_h = multigpu.all_gather_slots(od.cpu(), oi.cpu(), dist, world)
             dist_h, ids_h = multigpu.combine_slots(gd_h, gi_h, probes, owner)
         else:
             torch.cuda.current_stream().synchronize()
             dist_h = od.cpu().numpy()
             ids_h = to_global(oi.cpu().numpy().view(np.uint32))
         return dist_h, ids_h, ms
+
+    chunk_q = (nq + world - 1) // world
+
+    def route():
+        """KMeansTreeRouter::Query for the whole batch.  N > 1: the router is replicated, every rank routes its slice of the
+        queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered."""
+        if world == 1:
+            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+            return pr, r_ms
+        lo = min(nq, rank * chunk_q)
+        hi = min(nq, lo + chunk_q)
+        mine = np.full((chunk_q, S), -1, np.int32)
+        r_ms = 0.0
+        if hi > lo:
+            pr, _, r_ms = router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo)
+            mine[:hi - lo] = pr
+        t = torch.from_numpy(mine)
+        if args.backend == "nccl":
+            t = t.to(dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return torch.cat(parts).cpu().numpy()[:nq], r_ms
 
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
@@ -216,7 +275,7 @@ def main():
 
     # nprobe sweep on the host: the ground-truth pass already produced the exact top-k of EVERY (query, shard), so the
     # result of probing the first j shards of a route is a gather + DedupNeighbors (small_scale_queries.cpp:149-157)
-    probes, _, _ = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+    probes, _ = route()
     nprobe, recall_curve = None, []
     routed_d = np.take_along_axis(gt_slot_d, probes[:, :, None].astype(np.int64), axis=1)
     routed_i = np.take_along_axis(gt_slot_i, probes[:, :, None].astype(np.int64), axis=1)
@@ -234,10 +293,9 @@ def main():
 
     # ---------------------------------------------------------------- the timed hot path
     trace = os.environ.get("GPANN_BENCH_TRACE") == "1"
-
     def step():
         t_a = time.perf_counter()
-        pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+        pr, r_ms = route()
         t_b = time.perf_counter()
         sd, si, s_ms = scan_slots(pr, nprobe, timed=True)
         t_c = time.perf_counter()
@@ -269,7 +327,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
