@@ -458,7 +458,20 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts):
     offsets = np.arange(len(qidx) + 1, dtype=np.uint64) * (nprobe * k)
     orc.dedup_neighbors(od.reshape(-1), oi.reshape(-1), offsets, k)                      # merge
     dt = time.perf_counter() - t0
-    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+    # the same sample with the flags upstream ships (-O3 -march=native -ffast-math, CMakeLists.txt:15): not the parity oracle
+    # (results may differ in the last bits), reported so the strict flags do not flatter the GPU
+    fast = None
+    try:
+        orc_fast = pyoracle.Oracle("refflags")
+        ftree = orc_fast.kmtr_from_flat(tree, 0)
+        t1 = time.perf_counter()
+        ftree.query_batch(q_host, args.search_budget, nthreads=cores)
+        fd, fi, _ = orc_fast.ivf_query_bucket_batch(ivf, q_host, k, pr, nprobe, 0, nthreads=cores)
+        orc_fast.dedup_neighbors(fd.reshape(-1), fi.reshape(-1), offsets, k)
+        fast = len(qidx) / (time.perf_counter() - t1)
+    except Exception:
+        pass
+    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port", "value_reference_flags": fast,
             "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
                       f"{pairs:.3g} (query,row) pairs in {dt:.1f}s on {cores} threads; strict build (-O2, no fast-math/FMA/AVX)",
             "seconds": dt}

@@ -19,12 +19,15 @@ bool g_mips = false;
 #endif
 int g_device = 0;
 int g_threads = 0;
+bool g_filtered = true;
 }   // namespace
 void SetMetricMIPS(bool mips) { g_mips = mips; }
 bool MetricIsMIPS() { return g_mips; }
 void SetDevice(int device) { g_device = device; }
 int Device() { return g_device; }
 void SetNumThreads(int n) { g_threads = n; }
+void SetFilteredScan(bool on) { g_filtered = on; }
+bool FilteredScan() { return g_filtered; }
 int NumThreads() {
     if (g_threads > 0) return g_threads;
     unsigned hw = std::thread::hardware_concurrency();

@@ -116,6 +116,10 @@ void SetDevice(int device);   // HIP device used by subsequently constructed obj
 int Device();
 void SetNumThreads(int n);    // host worker threads for training / IO (default: hardware concurrency)
 int NumThreads();
+// Scan mode of subsequently constructed InvertedIndex / RunInShardSearches stores: true (default) = exact results through the
+// matrix-core pre-filter (csrc/scan_filter.h), false = plain exact VALU scan.  Both return identical neighbours.
+void SetFilteredScan(bool on);
+bool FilteredScan();
 }   // namespace gpann_host
 
 // --------------------------------------------------------------------------------------------- src/points_io.h:5-11

@@ -60,6 +60,7 @@ InvertedIndex::InvertedIndex(PointSet& points, const Clusters& clusters) {
     Check(gpann_shards_create(points.coordinates.data(), points.n, (uint32_t)points.d, mips_ ? GPANN_METRIC_MIPS : GPANN_METRIC_L2, csr.ids.data(),
                               csr.offsets.data(), (uint32_t)clusters.size(), gpann_host::Device(), 0, &shards_),
           "gpann_shards_create");
+    Check(gpann_shards_set_scan_mode(shards_, gpann_host::FilteredScan() ? 1 : 0), "gpann_shards_set_scan_mode");
 }
 
 InvertedIndex::~InvertedIndex() {
@@ -253,6 +254,7 @@ std::vector<ShardSearch> RunInShardSearches(PointSet& points, PointSet& queries,
     Check(gpann_shards_create(points.coordinates.data(), points.n, (uint32_t)points.d, MetricNow(), csr.ids.data(), csr.offsets.data(),
                               (uint32_t)clusters.size(), gpann_host::Device(), 0, &shards),
           "gpann_shards_create");
+    Check(gpann_shards_set_scan_mode(shards, gpann_host::FilteredScan() ? 1 : 0), "gpann_shards_set_scan_mode");
     const uint32_t nq = (uint32_t)queries.n, k = (uint32_t)num_neighbors, S = (uint32_t)num_shards;
     std::vector<uint32_t> hit_ids((size_t)S * nq * k), hit_count((size_t)S * nq);
     gpann_status st = gpann_shard_search_hits(shards, queries.coordinates.data(), nq, k, distance_to_kth_neighbor.data(), hit_ids.data(),
