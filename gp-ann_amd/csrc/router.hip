@@ -38,7 +38,9 @@ struct gpann_router {
     uint32_t* node_child_first = nullptr;
     uint32_t* node_child_count = nullptr;
     uint32_t* shard_root = nullptr;
-    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense;
+    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo;
+    uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
+    bool leaves_only = false;                                   // every non-root node is a leaf
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
@@ -336,7 +338,190 @@ struct ReplayArgs {
     uint64_t heap_cap;
     uint32_t S, nq, C;
     int32_t budget;
+    uint32_t* redo;           // [nq] RouterSortedReplayKernel: 1 = needs the real priority queue; RouterReplayKernel with only_redo:
+                              // process only those
+    uint32_t only_redo;
+    uint32_t root_total;      // sum of the root node sizes
+    uint32_t sort_n;          // power of two >= number of root children (frontier capacity of the sorted replay)
+    uint32_t n_nodes;
 };
+
+__device__ __forceinline__ uint32_t OrderedBits(float f) {   // unsigned order == float order
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float FromOrderedBits(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+
+// ---- sorted replay: trees whose root children are all leaves ------------------------------------------------------------------
+// After the S roots have been opened (always first: their keys are lowest()), nothing is pushed any more, so the walk pops the
+// root children in ascending key order until the budget is used up: no queue is needed.  One wavefront per query:
+//   roots (coalesced reads of D, min per shard, children keys into LDS) -> bitonic sort of the <= 2048 keys in LDS ->
+//   prefix sum of node sizes against the budget (:112-115: a node is popped iff the budget BEFORE it is > 0) ->
+//   one lane per popped node takes the minimum of its D entries into min_dist[shard] (LDS atomic min on order-preserving bits).
+// libstdc++'s tie order among equal keys only matters if an equal key straddles the cut-off; such queries (and budgets too
+// small to open every root) are marked in `redo` and done by RouterReplayKernel with the real heap.
+__global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayArgs a) {
+    extern __shared__ float4 rpsm4[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = a.S, N = a.sort_n, n_nodes = a.n_nodes;
+    // workgroup-shared node tables (the walk's only other global reads would be dependent metadata loads per node)
+    uint32_t* sCf = reinterpret_cast<uint32_t*>(rpsm4);            // [n_nodes + 1] first centroid of a node
+    uint16_t* sShard = reinterpret_cast<uint16_t*>(sCf + n_nodes + 1);   // [n_nodes]
+    const size_t table_words = ((size_t)(n_nodes + 1) + (n_nodes + 1) / 2 + 3) & ~(size_t)3;
+    const size_t per_wave = ((size_t)2 * N + S + 3) & ~(size_t)3;
+    float* fkey = reinterpret_cast<float*>(rpsm4) + table_words + (size_t)wave * per_wave;
+    uint32_t* fnode = reinterpret_cast<uint32_t*>(fkey + N);
+    uint32_t* sMinOrd = fnode + N;
+    for (uint32_t u = threadIdx.x; u <= n_nodes; u += blockDim.x) sCf[u] = a.node_cent_first[u];
+    for (uint32_t u = threadIdx.x; u < n_nodes; u += blockDim.x) sShard[u] = (uint16_t)a.node_shard[u];
+    __syncthreads();
+    // lane r keeps root r (S <= 64 on this path)
+    uint32_t my_root = 0, my_nchild = 0, my_child_first = 0;
+    if ((uint32_t)lane < S) {
+        my_root = a.shard_root[lane];
+        my_nchild = a.node_child_count[my_root];
+        my_child_first = a.node_child_first[my_root];
+    }
+    const uint32_t slot = blockIdx.x * kRWaves + wave, n_slots = gridDim.x * kRWaves;
+    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        if (lane == 0) a.redo[q] = 0;
+        const float* D = a.dense + (size_t)q * a.C;
+        for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t size = 0, n_rec = 0;
+        for (uint32_t r = 0; r < S; ++r) {
+            const uint32_t node = (uint32_t)__shfl((int)my_root, r);
+            const uint32_t n_child = (uint32_t)__shfl((int)my_nchild, r);
+            const uint32_t child_first = (uint32_t)__shfl((int)my_child_first, r);
+            const uint32_t c_first = sCf[node];
+            const uint32_t n = sCf[node + 1] - c_first;
+            const int shard = sShard[node];
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t m = min(64u, n - base);
+                float dist = FLT_MAX;
+                if ((uint32_t)lane < m) {
+                    dist = D[c_first + base + lane];
+                    if (a.rec_dist) {
+                        a.rec_dist[(size_t)q * a.rec_cap + n_rec + lane] = dist;
+                        a.rec_shard[(size_t)q * a.rec_cap + n_rec + lane] = shard;
+                    }
+                    if (base + lane < n_child) {
+                        fkey[size + lane] = dist;
+                        fnode[size + lane] = child_first + base + lane;
+                    }
+                }
+                n_rec += m;
+                if (n_child > base) size += min(n_child, base + m) - base;
+                float mn = dist;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                if (lane == 0) atomicMin(&sMinOrd[shard], OrderedBits(mn));
+            }
+        }
+        for (uint32_t i = size + lane; i < N; i += 64) {
+            fkey[i] = INFINITY;
+            fnode[i] = kNoId;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
+        bool redo = false;
+        if (budget_left > 0 && size > 0) {
+            // bitonic sort ascending by (key, node)
+            for (uint32_t k2 = 2; k2 <= N; k2 <<= 1) {
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = lane; t < N / 2; t += 64) {
+                        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
+                        const uint32_t p = i | j;
+                        const bool up = (i & k2) == 0;
+                        const float ki = fkey[i], kp = fkey[p];
+                        const uint32_t ni = fnode[i], np_ = fnode[p];
+                        const bool gt = ki > kp || (ki == kp && ni > np_);
+                        if (gt == up) {
+                            fkey[i] = kp;
+                            fkey[p] = ki;
+                            fnode[i] = np_;
+                            fnode[p] = ni;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // how many nodes are popped: node i iff budget_left - (sizes of nodes 0..i-1) > 0
+            int64_t used = 0;
+            uint32_t cut = 0;
+            bool open_end = true;
+            for (uint32_t base = 0; base < size && open_end; base += 64) {
+                const uint32_t i = base + lane;
+                uint32_t ni = 0;
+                if (i < size) {
+                    const uint32_t node = fnode[i];
+                    ni = sCf[node + 1] - sCf[node];
+                }
+                uint32_t incl = ni;   // inclusive scan over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const bool popped = i < size && budget_left - (used + (int64_t)(incl - ni)) > 0;
+                const unsigned long long pm = __ballot(popped);
+                cut += (uint32_t)__popcll(pm);
+                used += (int64_t)__shfl((int)incl, 63);
+                open_end = pm == ~0ull;
+            }
+            // equal keys across the cut-off: the reference's queue layout decides which of them is popped
+            if (cut > 0 && cut < size && fkey[cut - 1] == fkey[cut]) redo = true;
+            if (!redo) {
+                // minima of the popped nodes: 8 lanes per node, 4 independent loads in flight per lane
+                const int grp = lane >> 3, sub = lane & 7;
+                for (uint32_t i0 = 0; i0 < cut; i0 += 8) {
+                    const uint32_t i = i0 + grp;
+                    float mn = FLT_MAX;
+                    int shard = 0;
+                    if (i < cut) {
+                        const uint32_t node = fnode[i];
+                        const uint32_t c_first = sCf[node];
+                        const uint32_t n = sCf[node + 1] - c_first;
+                        shard = sShard[node];
+                        const float* row = D + c_first;
+                        for (uint32_t e = sub; e < n; e += 32) {
+                            const float v0 = row[e];
+                            const float v1 = e + 8 < n ? row[e + 8] : FLT_MAX;
+                            const float v2 = e + 16 < n ? row[e + 16] : FLT_MAX;
+                            const float v3 = e + 24 < n ? row[e + 24] : FLT_MAX;
+                            mn = fminf(mn, fminf(fminf(v0, v1), fminf(v2, v3)));
+                        }
+                    }
+                    mn = fminf(mn, __shfl_xor(mn, 1));
+                    mn = fminf(mn, __shfl_xor(mn, 2));
+                    mn = fminf(mn, __shfl_xor(mn, 4));
+                    if (i < cut && sub == 0) atomicMin(&sMinOrd[shard], OrderedBits(mn));
+                }
+                if (a.rec_dist) {   // FrequencyQuery: every evaluated (distance, shard) pair; the order is irrelevant
+                    for (uint32_t i = 0; i < cut; ++i) {
+                        const uint32_t node = fnode[i];
+                        const uint32_t c_first = sCf[node];
+                        const uint32_t n = sCf[node + 1] - c_first;
+                        const int shard = sShard[node];
+                        for (uint32_t e = lane; e < n; e += 64) {
+                            a.rec_dist[(size_t)q * a.rec_cap + n_rec + e] = D[c_first + e];
+                            a.rec_shard[(size_t)q * a.rec_cap + n_rec + e] = shard;
+                        }
+                        n_rec += n;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (redo) {
+            if (lane == 0) a.redo[q] = 1;
+        } else {
+            for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
+            if (a.rec_count && lane == 0) a.rec_count[q] = n_rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // kmeans_tree_router.cpp:93-130 with distance() replaced by the table: one wavefront per query.
 template <bool LDS_HEAP>
@@ -358,6 +543,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterReplayKernel(ReplayArgs a)
         hnode = a.heap_node + (size_t)slot * a.heap_cap;
     }
     for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        if (a.only_redo && a.redo[q] == 0) continue;
         const float* D = a.dense + (size_t)q * a.C;
         for (uint32_t b = lane; b < S; b += 64) sMin[b] = FLT_MAX;
         int64_t size = 0;
@@ -490,6 +676,19 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         TRY_OR_FAIL(hipGetDeviceProperties(&prop, device));
         r->num_cus = prop.multiProcessorCount;
         for (uint32_t u = 0; u < n_nodes; ++u) r->max_node = std::max(r->max_node, node_cent_first[u + 1] - node_cent_first[u]);
+        std::vector<uint8_t> is_root(n_nodes, 0);
+        r->root_min = 0xFFFFFFFFu;
+        for (uint32_t b = 0; b < S; ++b) {
+            const uint32_t u = shard_root[b];
+            const uint32_t sz = node_cent_first[u + 1] - node_cent_first[u];
+            is_root[u] = 1;
+            r->root_total += sz;
+            r->root_min = std::min(r->root_min, sz);
+            r->root_children += node_child_count[u];
+        }
+        r->leaves_only = true;
+        for (uint32_t u = 0; u < n_nodes; ++u)
+            if (!is_root[u] && node_child_count[u] != 0) r->leaves_only = false;
     }
 #undef TRY_OR_FAIL
     *out = r;
@@ -506,6 +705,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_heap.Release();
     r->ws_out.Release();
     r->ws_dense.Release();
+    r->ws_redo.Release();
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     delete r;
@@ -582,8 +782,40 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         ra.nq = nq;
         ra.C = (uint32_t)C;
         ra.budget = budget;
-        if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(grid), dim3(64 * kRWaves), lds, st, ra);
-        else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(grid), dim3(64 * kRWaves), lds, st, ra);
+        // trees whose root children are all leaves: sorted replay (no queue); it marks the rare query that needs the real
+        // heap (equal keys across the cut-off) and RouterReplayKernel then does only those
+        ra.only_redo = 0;
+        ra.redo = nullptr;
+        ra.root_total = r->root_total;
+        ra.sort_n = 1;
+        while (ra.sort_n < std::max<uint32_t>(r->root_children, 64)) ra.sort_n <<= 1;
+        const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" disables the sorted replay
+        ra.n_nodes = r->n_nodes;
+        const bool sorted_ok = r->leaves_only && ra.sort_n <= 2048 && r->n_nodes <= 4096 && S <= 64 &&
+                               (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min && !(rmode && std::string(rmode) == "heap");
+        if (sorted_ok) {
+            GPANN_TRY(r->ws_redo.Reserve((size_t)nq * 4));
+            ra.redo = r->ws_redo.as<uint32_t>();
+            const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
+            const size_t s_lds = (table_words + ((((size_t)2 * ra.sort_n + S) + 3) & ~(size_t)3) * kRWaves) * sizeof(float);
+            const uint32_t s_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / s_lds));
+            const uint32_t s_grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * s_bpc);
+            if (s_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterSortedReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_lds));
+            hipLaunchKernelGGL(RouterSortedReplayKernel, dim3(s_grid), dim3(64 * kRWaves), s_lds, st, ra);
+            ra.only_redo = 1;
+            if (std::getenv("GPANN_ROUTER_DEBUG")) {
+                std::vector<uint32_t> h(nq);
+                GPANN_HIP_TRY(hipMemcpyAsync(h.data(), ra.redo, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+                GPANN_HIP_TRY(hipStreamSynchronize(st));
+                uint32_t c = 0;
+                for (uint32_t v : h) c += v != 0;
+                fprintf(stderr, "[gpann router] sorted replay: %u of %u queries need the heap (sort_n %u, root children %u)\n", c, nq, ra.sort_n, r->root_children);
+            }
+        }
+        // (after a sorted replay the heap kernel only visits the marked queries: a small grid is enough to find them)
+        const uint32_t hgrid = sorted_ok ? std::min<uint32_t>(grid, 64) : grid;
+        if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+        else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
         GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
         return GPANN_OK;
