@@ -341,6 +341,7 @@ struct ReplayArgs {
     uint32_t* redo;           // [nq] RouterSortedReplayKernel: 1 = needs the real priority queue; RouterReplayKernel with only_redo:
                               // process only those
     uint32_t only_redo;
+    uint32_t* redo_count;     // number of queries RouterSortedReplayKernel marked
     uint32_t root_total;      // sum of the root node sizes
     uint32_t sort_n;          // power of two >= number of root children (frontier capacity of the sorted replay)
     uint32_t n_nodes;
@@ -369,9 +370,9 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
     uint16_t* sShard = reinterpret_cast<uint16_t*>(sCf + n_nodes + 1);   // [n_nodes]
     const size_t table_words = ((size_t)(n_nodes + 1) + (n_nodes + 1) / 2 + 3) & ~(size_t)3;
     const size_t per_wave = ((size_t)2 * N + S + 3) & ~(size_t)3;
-    float* fkey = reinterpret_cast<float*>(rpsm4) + table_words + (size_t)wave * per_wave;
-    uint32_t* fnode = reinterpret_cast<uint32_t*>(fkey + N);
-    uint32_t* sMinOrd = fnode + N;
+    // frontier entry = (order-preserving key bits << 32) | node: one 64-bit compare sorts by (key, node)
+    unsigned long long* fent = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(rpsm4) + table_words + (size_t)wave * per_wave);
+    uint32_t* sMinOrd = reinterpret_cast<uint32_t*>(fent + N);
     for (uint32_t u = threadIdx.x; u <= n_nodes; u += blockDim.x) sCf[u] = a.node_cent_first[u];
     for (uint32_t u = threadIdx.x; u < n_nodes; u += blockDim.x) sShard[u] = (uint16_t)a.node_shard[u];
     __syncthreads();
@@ -405,10 +406,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                         a.rec_dist[(size_t)q * a.rec_cap + n_rec + lane] = dist;
                         a.rec_shard[(size_t)q * a.rec_cap + n_rec + lane] = shard;
                     }
-                    if (base + lane < n_child) {
-                        fkey[size + lane] = dist;
-                        fnode[size + lane] = child_first + base + lane;
-                    }
+                    if (base + lane < n_child) fent[size + lane] = ((unsigned long long)OrderedBits(dist) << 32) | (child_first + base + lane);
                 }
                 n_rec += m;
                 if (n_child > base) size += min(n_child, base + m) - base;
@@ -418,10 +416,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                 if (lane == 0) atomicMin(&sMinOrd[shard], OrderedBits(mn));
             }
         }
-        for (uint32_t i = size + lane; i < N; i += 64) {
-            fkey[i] = INFINITY;
-            fnode[i] = kNoId;
-        }
+        for (uint32_t i = size + lane; i < N; i += 64) fent[i] = ~0ull;
         __builtin_amdgcn_wave_barrier();
         const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
         bool redo = false;
@@ -433,14 +428,10 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                         const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
                         const uint32_t p = i | j;
                         const bool up = (i & k2) == 0;
-                        const float ki = fkey[i], kp = fkey[p];
-                        const uint32_t ni = fnode[i], np_ = fnode[p];
-                        const bool gt = ki > kp || (ki == kp && ni > np_);
-                        if (gt == up) {
-                            fkey[i] = kp;
-                            fkey[p] = ki;
-                            fnode[i] = np_;
-                            fnode[p] = ni;
+                        const unsigned long long ei = fent[i], ep = fent[p];
+                        if ((ei > ep) == up) {
+                            fent[i] = ep;
+                            fent[p] = ei;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -454,7 +445,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                 const uint32_t i = base + lane;
                 uint32_t ni = 0;
                 if (i < size) {
-                    const uint32_t node = fnode[i];
+                    const uint32_t node = (uint32_t)fent[i];
                     ni = sCf[node + 1] - sCf[node];
                 }
                 uint32_t incl = ni;   // inclusive scan over the lanes
@@ -470,7 +461,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                 open_end = pm == ~0ull;
             }
             // equal keys across the cut-off: the reference's queue layout decides which of them is popped
-            if (cut > 0 && cut < size && fkey[cut - 1] == fkey[cut]) redo = true;
+            if (cut > 0 && cut < size && (uint32_t)(fent[cut - 1] >> 32) == (uint32_t)(fent[cut] >> 32)) redo = true;
             if (!redo) {
                 // minima of the popped nodes: 8 lanes per node, 4 independent loads in flight per lane
                 const int grp = lane >> 3, sub = lane & 7;
@@ -479,7 +470,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                     float mn = FLT_MAX;
                     int shard = 0;
                     if (i < cut) {
-                        const uint32_t node = fnode[i];
+                        const uint32_t node = (uint32_t)fent[i];
                         const uint32_t c_first = sCf[node];
                         const uint32_t n = sCf[node + 1] - c_first;
                         shard = sShard[node];
@@ -499,7 +490,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
                 }
                 if (a.rec_dist) {   // FrequencyQuery: every evaluated (distance, shard) pair; the order is irrelevant
                     for (uint32_t i = 0; i < cut; ++i) {
-                        const uint32_t node = fnode[i];
+                        const uint32_t node = (uint32_t)fent[i];
                         const uint32_t c_first = sCf[node];
                         const uint32_t n = sCf[node + 1] - c_first;
                         const int shard = sShard[node];
@@ -514,7 +505,10 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
         }
         __builtin_amdgcn_wave_barrier();
         if (redo) {
-            if (lane == 0) a.redo[q] = 1;
+            if (lane == 0) {
+                a.redo[q] = 1;
+                atomicAdd(a.redo_count, 1u);
+            }
         } else {
             for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
             if (a.rec_count && lane == 0) a.rec_count[q] = n_rec;
@@ -786,6 +780,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         // heap (equal keys across the cut-off) and RouterReplayKernel then does only those
         ra.only_redo = 0;
         ra.redo = nullptr;
+        ra.redo_count = nullptr;
         ra.root_total = r->root_total;
         ra.sort_n = 1;
         while (ra.sort_n < std::max<uint32_t>(r->root_children, 64)) ra.sort_n <<= 1;
@@ -794,8 +789,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const bool sorted_ok = r->leaves_only && ra.sort_n <= 2048 && r->n_nodes <= 4096 && S <= 64 &&
                                (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min && !(rmode && std::string(rmode) == "heap");
         if (sorted_ok) {
-            GPANN_TRY(r->ws_redo.Reserve((size_t)nq * 4));
+            GPANN_TRY(r->ws_redo.Reserve((size_t)nq * 4 + 16));
             ra.redo = r->ws_redo.as<uint32_t>();
+            ra.redo_count = ra.redo + nq;
+            GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 4, st));
             const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
             const size_t s_lds = (table_words + ((((size_t)2 * ra.sort_n + S) + 3) & ~(size_t)3) * kRWaves) * sizeof(float);
             const uint32_t s_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / s_lds));
@@ -803,20 +800,23 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             if (s_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterSortedReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_lds));
             hipLaunchKernelGGL(RouterSortedReplayKernel, dim3(s_grid), dim3(64 * kRWaves), s_lds, st, ra);
             ra.only_redo = 1;
-            if (std::getenv("GPANN_ROUTER_DEBUG")) {
-                std::vector<uint32_t> h(nq);
-                GPANN_HIP_TRY(hipMemcpyAsync(h.data(), ra.redo, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-                GPANN_HIP_TRY(hipStreamSynchronize(st));
-                uint32_t c = 0;
-                for (uint32_t v : h) c += v != 0;
-                fprintf(stderr, "[gpann router] sorted replay: %u of %u queries need the heap (sort_n %u, root children %u)\n", c, nq, ra.sort_n, r->root_children);
-            }
         }
-        // (after a sorted replay the heap kernel only visits the marked queries: a small grid is enough to find them)
-        const uint32_t hgrid = sorted_ok ? std::min<uint32_t>(grid, 64) : grid;
-        if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
-        else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
-        GPANN_HIP_TRY(hipGetLastError());
+        // after a sorted replay the heap kernel is needed only for the marked queries — usually none
+        bool need_heap = true;
+        uint32_t hgrid = grid;
+        if (sorted_ok) {
+            uint32_t marked = 0;
+            GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipStreamSynchronize(st));
+            need_heap = marked != 0;
+            if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] sorted replay: %u of %u queries go to the heap kernel\n", marked, nq);
+            hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
+        }
+        if (need_heap) {
+            if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+            else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+            GPANN_HIP_TRY(hipGetLastError());
+        }
         GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
         return GPANN_OK;
     }
@@ -996,23 +996,35 @@ gpann_status gpann_merge_dedup(const float* in_dist, const uint32_t* in_ids, uin
                                float* out_dist, uint32_t* out_ids, uint32_t* out_count) {
     GPANN_REQUIRE(nq == 0 || (in_dist && in_ids && out_dist && out_ids), "null argument");
     GPANN_REQUIRE(nprobe_used <= nprobe, "nprobe_used > nprobe");
-    std::vector<std::pair<float, uint32_t>> n;
-    for (uint32_t q = 0; q < nq; ++q) {
-        n.clear();
-        for (uint32_t j = 0; j < nprobe_used; ++j)
+    // queries are independent: a few host threads for large batches (the per-query work is the reference's four calls)
+    auto merge_range = [&](uint32_t q0, uint32_t q1) {
+        std::vector<std::pair<float, uint32_t>> n;
+        for (uint32_t q = q0; q < q1; ++q) {
+            n.clear();
+            for (uint32_t j = 0; j < nprobe_used; ++j)
+                for (uint32_t x = 0; x < k; ++x) {
+                    const size_t idx = ((size_t)q * nprobe + j) * k + x;
+                    if (in_ids[idx] != GPANN_NO_ID) n.emplace_back(in_dist[idx], in_ids[idx]);
+                }
+            std::sort(n.begin(), n.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
+            n.erase(std::unique(n.begin(), n.end()), n.end());
+            std::sort(n.begin(), n.end());
+            n.resize(std::min<size_t>(n.size(), k));
             for (uint32_t x = 0; x < k; ++x) {
-                const size_t idx = ((size_t)q * nprobe + j) * k + x;
-                if (in_ids[idx] != GPANN_NO_ID) n.emplace_back(in_dist[idx], in_ids[idx]);
+                out_dist[(size_t)q * k + x] = x < n.size() ? n[x].first : std::numeric_limits<float>::infinity();
+                out_ids[(size_t)q * k + x] = x < n.size() ? n[x].second : GPANN_NO_ID;
             }
-        std::sort(n.begin(), n.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
-        n.erase(std::unique(n.begin(), n.end()), n.end());
-        std::sort(n.begin(), n.end());
-        n.resize(std::min<size_t>(n.size(), k));
-        for (uint32_t x = 0; x < k; ++x) {
-            out_dist[(size_t)q * k + x] = x < n.size() ? n[x].first : std::numeric_limits<float>::infinity();
-            out_ids[(size_t)q * k + x] = x < n.size() ? n[x].second : GPANN_NO_ID;
+            if (out_count) out_count[q] = (uint32_t)n.size();
         }
-        if (out_count) out_count[q] = (uint32_t)n.size();
+    };
+    const uint32_t threads = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ((uint64_t)nq * nprobe_used * k) / 16384));
+    if (threads <= 1) {
+        merge_range(0, nq);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(merge_range, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads));
+        merge_range(0, nq / threads);
+        for (auto& th : pool) th.join();
     }
     return GPANN_OK;
 }

@@ -119,3 +119,16 @@ def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, mo
     probes = np.zeros((nq, 1), np.int32)
     monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "200")     # expected fill ~ k * 26000 / 4096 = 63 + tail
     _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
+
+
+def test_filter_without_precomputed_planes(orc, gp, monkeypatch):
+    """GPANN_FILTER_PLANES=0: no bf16 planes in HBM, the filter kernel splits the rows on the fly (FilterKernel)"""
+    rng = np.random.default_rng(41)
+    n, d, S, nq, k = 30000, 100, 2, 140, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    monkeypatch.setenv("GPANN_FILTER_PLANES", "0")
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, S, k, metric)
