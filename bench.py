@@ -72,20 +72,6 @@ def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
     return cent, assign
 
 
-def build_router_tree(torch, pygpann, sample, sample_assign, S, args):
-    """KMeansTreeRouter::Train (reference src/kmeans_tree_router.cpp:9-78) with the product's host trainer
-    (gp-ann_amd/host/router_host.cpp) on a sample of the cloud pulled to the host; options as routes.cpp:130-157
-    (64 centroids per node, min cluster size 350)."""
-    from pygpann import host
-    pts = sample.cpu().numpy()
-    a = sample_assign.cpu().numpy()
-    order = np.argsort(a, kind="stable")
-    bounds = np.searchsorted(a[order], np.arange(S + 1))
-    clusters = [order[bounds[b]:bounds[b + 1]].astype(np.uint32) for b in range(S)]
-    threads = max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
-    return host.train_router(pts, clusters, args.router_centroids, args.router_min_cluster, args.router_budget, mips=False, threads=threads)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,8 +86,9 @@ def main():
     ap.add_argument("--search-budget", type=int, default=50000)
     ap.add_argument("--router-centroids", type=int, default=64)
     ap.add_argument("--router-min-cluster", type=int, default=350)
-    ap.add_argument("--router-budget", type=int, default=100000, help="index size (centroids) of the k-means tree, routes.cpp:130")
-    ap.add_argument("--router-train-points", type=int, default=1_000_000, help="rows of the cloud the router is trained on")
+    ap.add_argument("--router-budget", type=str, default="20000,100000",
+                    help="index sizes (centroids) of the k-means tree to try, the reference's grid (routes.cpp:130-157); the configuration "
+                         "with the best QPS at the target recall is the one timed, as in the reference's Pareto evaluation")
     ap.add_argument("--scan-mode", choices=["exact", "filter"], default=os.environ.get("GPANN_BENCH_SCAN_MODE", "filter"),
                     help="exact: VALU scan of every row; filter: same exact results with the MFMA pre-filter (scan_filter.h)")
     ap.add_argument("--backend", default=os.environ.get("GPANN_BENCH_BACKEND", "nccl"),
@@ -153,11 +140,8 @@ def main():
             dist.broadcast(c, src=0)
             shard_cent.copy_(c)
         pygpann.nearest_centroid_device(sample.data_ptr(), n_sample, d, 0, shard_cent.data_ptr(), S, sample_assign.data_ptr(), stream)
-    n_train = min(n_sample, args.router_train_points)
-    with stdout_to_stderr():
-        tree = build_router_tree(torch, pygpann, sample[:n_train], sample_assign[:n_train], S, args)
-    del sample
-    log(f"shard centroids + router tree ({tree['centroids'].shape[0]} centroids) ready in {time.time() - t_setup:.1f}s")
+    del sample, sample_assign
+    log(f"shard centroids ready in {time.time() - t_setup:.1f}s")
 
     # shard assignment of all rows, chunked; every rank keeps only the rows of the shards it owns
     chunk = 4_000_000
@@ -205,7 +189,22 @@ def main():
     shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
     del local_points
     torch.cuda.empty_cache()
-    router = pygpann.Router(tree, 0, local_rank)
+    def train_router(index_budget):
+        """KMeansTreeRouter::Train (reference src/kmeans_tree_router.cpp:9-78; options as routes.cpp:130-157) on the GPU over ALL rows
+        of the shards this rank holds; with several ranks every rank trains the subtrees of its own shards and the parts are merged"""
+        t_train = time.time()
+        rt = pygpann.Router.train(shards, n, args.router_centroids, args.router_min_cluster, index_budget)
+        if world > 1:
+            part = rt.export()
+            parts = [None] * world
+            dist.all_gather_object(parts, part)
+            rt.close()
+            rt = pygpann.Router(multigpu.merge_trees(parts, owner), 0, local_rank)
+        train_s = time.time() - t_train
+        tr = rt.export()
+        log(f"router (index budget {index_budget}) trained on the GPU in {train_s:.2f}s: {len(tr['node_shard'])} nodes, {tr['centroids'].shape[0]} centroids")
+        return rt, tr, train_s
+
     log(f"rank {rank}: {n_local} rows in {len(mine)} shards resident; setup {time.time() - t_setup:.1f}s")
 
     def to_global(ids_local):
@@ -273,23 +272,19 @@ def main():
     kth = gt_d[:, k - 1].copy()
     log(f"ground truth over {n} points in {time.time() - t0:.1f}s")
 
-    # nprobe sweep on the host: the ground-truth pass already produced the exact top-k of EVERY (query, shard), so the
-    # result of probing the first j shards of a route is a gather + DedupNeighbors (small_scale_queries.cpp:149-157)
-    probes, _ = route()
-    nprobe, recall_curve = None, []
-    routed_d = np.take_along_axis(gt_slot_d, probes[:, :, None].astype(np.int64), axis=1)
-    routed_i = np.take_along_axis(gt_slot_i, probes[:, :, None].astype(np.int64), axis=1)
-    for np_try in range(1, S + 1):
-        md, mi, _ = pygpann.merge_dedup(routed_d, routed_i, np_try, k)
-        rec = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
-        recall_curve.append(round(rec, 6))
-        if rec >= args.target_recall:
-            nprobe = np_try
-            break
-    if nprobe is None:
-        nprobe = S
-    del routed_d, routed_i, gt_slot_d, gt_slot_i
-    log(f"recall curve {recall_curve} -> nprobe {nprobe}")
+    def find_nprobe(probes):
+        """nprobe sweep on the host: the ground-truth pass already produced the exact top-k of EVERY (query, shard), so the
+        result of probing the first j shards of a route is a gather + DedupNeighbors (small_scale_queries.cpp:149-157)"""
+        curve = []
+        routed_d = np.take_along_axis(gt_slot_d, probes[:, :, None].astype(np.int64), axis=1)
+        routed_i = np.take_along_axis(gt_slot_i, probes[:, :, None].astype(np.int64), axis=1)
+        for np_try in range(1, S + 1):
+            md, mi, _ = pygpann.merge_dedup(routed_d, routed_i, np_try, k)
+            rec = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
+            curve.append(round(rec, 6))
+            if rec >= args.target_recall:
+                return np_try, curve
+        return S, curve
 
     # ---------------------------------------------------------------- the timed hot path
     trace = os.environ.get("GPANN_BENCH_TRACE") == "1"
@@ -310,6 +305,30 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- router configurations (the reference's grid), best one is timed
+    candidates = []
+    for index_budget in [int(x) for x in str(args.router_budget).split(",") if x]:
+        router, tree, router_train_s = train_router(index_budget)
+        probes, _ = route()
+        nprobe, recall_curve = find_nprobe(probes)
+        log(f"index budget {index_budget}: recall curve {recall_curve} -> nprobe {nprobe}")
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        barrier()
+        trial = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=dev if (world > 1 and args.backend == "nccl") else "cpu")
+        if world > 1:
+            dist.all_reduce(trial, op=dist.ReduceOp.MAX)
+        candidates.append(dict(index_budget=index_budget, router=router, tree=tree, train_s=router_train_s, nprobe=nprobe, recall_curve=recall_curve,
+                               trial_ms=1000.0 * float(trial.item())))
+        log(f"index budget {index_budget}: {candidates[-1]['trial_ms']:.2f} ms per step")
+    del gt_slot_d, gt_slot_i
+    best = min(candidates, key=lambda c: c["trial_ms"])
+    router, tree, router_train_s, nprobe, recall_curve = best["router"], best["tree"], best["train_s"], best["nprobe"], best["recall_curve"]
+    log(f"timed configuration: index budget {best['index_budget']}, nprobe {nprobe}")
 
     for _ in range(args.warmup):
         step()
@@ -370,7 +389,10 @@ def main():
     result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)),
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
-                        "setup_s": time.time() - t_setup}
+                        "router_train_s": router_train_s, "router_index_budget": best["index_budget"],
+                        "router_configs": [{kk: c[kk] for kk in ("index_budget", "nprobe", "trial_ms", "train_s", "recall_curve")} | {"centroids": int(c["tree"]["centroids"].shape[0]), "nodes": int(len(c["tree"]["node_shard"]))} for c in candidates],
+                        "router_nodes": int(len(tree["node_shard"])),
+                        "router_centroids": int(tree["centroids"].shape[0]), "setup_s": time.time() - t_setup}
 
     # the same steps with the plain exact (VALU) scan, for reference: identical results, no matrix cores
     if args.scan_mode == "filter" and not args.no_exact_compare:

@@ -38,7 +38,10 @@ struct gpann_router {
     uint32_t* node_child_first = nullptr;
     uint32_t* node_child_count = nullptr;
     uint32_t* shard_root = nullptr;
-    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo;
+    uint32_t* path_cent = nullptr;       // [n_nodes][kPathMax] centroids whose distances are the keys on the path root -> node (threshold replay)
+    uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
+    uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
+    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
     bool leaves_only = false;                                   // every non-root node is a leaf
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -517,6 +520,246 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
     }
 }
 
+// ---- threshold replay: any tree -------------------------------------------------------------------------------------------
+// The walk pops the queue's minimum, and a node enters the queue when its parent is popped.  Let key(u) be the distance that
+// is u's queue key and  pi(u) = max of the keys on the path from u's root child down to u  (roots: lowest()).  A node v
+// cannot be popped while a node u with pi(u) < pi(v) is still waiting: when the ancestor of v that carries the key pi(v) was
+// popped, the first unpopped node on u's path was in the queue with a smaller key.  So nodes leave the queue in order of
+// pi, and the walk — pop while budget > 0 (:112-115) — visits exactly
+//     the roots,  every node with pi < x*,  and part of the group pi == x*
+// where x* is the pi value at which the node sizes, accumulated in pi order, reach the budget left after the roots.  None of
+// this needs a queue: per query, one wavefront
+//   1. computes pi(u) for every node from the dense distance row (independent loads along a precomputed path table),
+//   2. finds x* with a 4-pass byte-wise radix select over (pi bits, node size) histograms in LDS,
+//   3. walks the group pi == x*: its bottleneck node w (key(w) == x*) and, budget permitting, w's descendants with smaller
+//      keys, best-first from a small frontier list in LDS (typically a handful of nodes),
+//   4. takes per-shard minima over the centroids of all visited nodes (one coalesced pass over the distance row).
+// Equal keys make the order libstdc++'s business only if they sit in the cut-off group (two bottlenecks, or equal minima in
+// the group's frontier); those queries are marked in `redo` and replayed by RouterReplayKernel with the real heap.
+constexpr int kPathMax = 6;
+constexpr uint32_t kFrontCap = 512;
+constexpr uint32_t kNoCent = 0xFFFFFFFFu;
+
+struct ThresholdTree {
+    const uint32_t* path_cent;   // [n_nodes][kPathMax]
+    const uint32_t* cent_node;   // [C]
+    uint32_t* pi;                // [slots][n_nodes] scratch
+};
+
+__global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(ReplayArgs a, ThresholdTree t) {
+    extern __shared__ uint32_t thsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = a.S, n_nodes = a.n_nodes, C = a.C;
+    const size_t per_wave = ((size_t)256 + S + 2 * kFrontCap + 3) & ~(size_t)3;
+    uint32_t* hist = thsm + (size_t)wave * per_wave;
+    uint32_t* sMinOrd = hist + 256;
+    uint32_t* fkey = sMinOrd + S;
+    uint32_t* fnode = fkey + kFrontCap;
+    const uint32_t slot = blockIdx.x * kRWaves + wave, n_slots = gridDim.x * kRWaves;
+    uint32_t* pi = t.pi + (size_t)slot * n_nodes;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        const float* D = a.dense + (size_t)q * C;
+        for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
+
+        // ---- 1. pi (order-preserving bits; 0 = root, later also "visited")
+        for (uint32_t u = lane; u < n_nodes; u += 64) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < kPathMax; ++j) {
+                const uint32_t c = t.path_cent[(size_t)u * kPathMax + j];
+                if (c != kNoCent) m = max(m, OrderedBits(D[c]));
+            }
+            pi[u] = m;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 2. x*: the smallest pi value at which the accumulated sizes reach the budget left after the roots
+        const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
+        bool all = false, redo = false;
+        uint32_t xs = 1;          // visited <=> pi < xs; 1 = roots only
+        uint32_t w_lt = 0;        // sum of the sizes with pi < xs
+        if (budget_left > 0) {
+            const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
+            uint32_t prefix = 0, prefix_mask = 0;
+            for (int pass = 0; pass < 4 && !all; ++pass) {
+                const int shift = 24 - 8 * pass;
+                for (int b = lane; b < 256; b += 64) hist[b] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t u = lane; u < n_nodes; u += 64) {
+                    const uint32_t p = pi[u];
+                    if (p != 0 && (p & prefix_mask) == prefix) atomicAdd(&hist[(p >> shift) & 255u], a.node_cent_first[u + 1] - a.node_cent_first[u]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // lane l owns bins 4l .. 4l+3
+                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const uint32_t mine = h0 + h1 + h2 + h3;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const uint32_t before = w_lt + incl - mine;
+                const unsigned long long hit = __ballot(before + mine >= need);
+                if (hit == 0) {
+                    all = true;   // (only possible in pass 0) the whole tree is visited
+                } else {
+                    const int l = __builtin_ctzll(hit);
+                    uint32_t bin = 0, excl = 0;
+                    if (lane == l) {
+                        uint32_t c = before;
+                        if (c + h0 >= need) { bin = 0; excl = c; }
+                        else if ((c += h0) + h1 >= need) { bin = 1; excl = c; }
+                        else if ((c += h1) + h2 >= need) { bin = 2; excl = c; }
+                        else { c += h2; bin = 3; excl = c; }
+                    }
+                    bin = (uint32_t)__shfl((int)bin, l) + 4u * (uint32_t)l;
+                    w_lt = (uint32_t)__shfl((int)excl, l);
+                    prefix |= bin << shift;
+                    prefix_mask |= 255u << shift;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!all) {
+                xs = prefix;
+                // ---- 3. the cut-off group
+                int64_t budget_in = (int64_t)need - (int64_t)w_lt;   // > 0
+                uint32_t n_bottle = 0, w = 0;
+                for (uint32_t u = lane; u < n_nodes; u += 64) {
+                    if (pi[u] == xs && OrderedBits(D[t.path_cent[(size_t)u * kPathMax]]) == xs) {
+                        ++n_bottle;
+                        w = u;
+                    }
+                }
+                const unsigned long long have = __ballot(n_bottle != 0);
+                uint32_t total_bottle = n_bottle;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) total_bottle += __shfl_xor(total_bottle, o);
+                if (total_bottle != 1) {
+                    redo = true;
+                } else {
+                    w = (uint32_t)__shfl((int)w, __builtin_ctzll(have));
+                    uint32_t fcount = 0;
+                    uint32_t node = w;
+                    while (true) {
+                        // visit `node`
+                        if (lane == 0) pi[node] = 0;
+                        const uint32_t c_first = a.node_cent_first[node];
+                        budget_in -= (int64_t)(a.node_cent_first[node + 1] - c_first);
+                        if (budget_in <= 0) break;
+                        // its children with smaller keys join the group's frontier
+                        const uint32_t n_child = a.node_child_count[node], child_first = a.node_child_first[node];
+                        for (uint32_t base = 0; base < n_child && !redo; base += 64) {
+                            const uint32_t i = base + lane;
+                            uint32_t key = 0xFFFFFFFFu;
+                            if (i < n_child) key = OrderedBits(D[c_first + i]);
+                            const bool in = i < n_child && key < xs;
+                            const unsigned long long m = __ballot(in);
+                            const uint32_t add = (uint32_t)__popcll(m);
+                            if (fcount + add > kFrontCap) {
+                                redo = true;
+                            } else {
+                                if (in) {
+                                    const uint32_t at = fcount + (uint32_t)__popcll(m & lanes_below);
+                                    fkey[at] = key;
+                                    fnode[at] = child_first + i;
+                                }
+                                fcount += add;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (redo || fcount == 0) break;
+                        // next: the frontier's minimum
+                        uint32_t best = 0xFFFFFFFFu, best_at = 0;
+                        for (uint32_t i = lane; i < fcount; i += 64) {
+                            const uint32_t k = fkey[i];
+                            if (k < best) {
+                                best = k;
+                                best_at = i;
+                            }
+                        }
+                        uint32_t mn = best;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                        uint32_t n_min = 0;
+                        for (uint32_t i = lane; i < fcount; i += 64) n_min += fkey[i] == mn ? 1u : 0u;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) n_min += __shfl_xor(n_min, o);
+                        if (n_min != 1) {   // equal keys inside the cut-off group
+                            redo = true;
+                            break;
+                        }
+                        const int owner = __builtin_ctzll(__ballot(best == mn));
+                        best_at = (uint32_t)__shfl((int)best_at, owner);
+                        node = fnode[best_at];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) {
+                            fkey[best_at] = fkey[fcount - 1];
+                            fnode[best_at] = fnode[fcount - 1];
+                        }
+                        --fcount;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+
+        if (redo) {
+            if (lane == 0) {
+                a.redo[q] = 1;
+                atomicAdd(a.redo_count, 1u);
+            }
+        } else {
+            // ---- 4. minima over the centroids of the visited nodes
+            uint32_t n_rec = 0;
+            for (uint32_t base = 0; base < C; base += 64) {
+                const uint32_t c = base + lane;
+                bool take = false;
+                uint32_t shard = 0;
+                float dist = FLT_MAX;
+                if (c < C) {
+                    const uint32_t u = t.cent_node[c];
+                    take = all || pi[u] < xs;
+                    if (take) {
+                        shard = (uint32_t)a.node_shard[u];
+                        dist = D[c];
+                    }
+                }
+                const unsigned long long tm = __ballot(take);
+                if (tm == 0) continue;
+                const uint32_t shard0 = (uint32_t)__shfl((int)shard, __builtin_ctzll(tm));
+                if (__ballot(take && shard != shard0) == 0) {   // the usual case: one shard for the whole wavefront
+                    float mn = dist;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                    if (lane == 0) atomicMin(&sMinOrd[shard0], OrderedBits(mn));
+                } else if (take) {
+                    atomicMin(&sMinOrd[shard], OrderedBits(dist));
+                }
+                if (a.rec_dist) {   // FrequencyQuery: every evaluated (distance, shard) pair; the order is irrelevant
+                    if (take) {
+                        const uint64_t at = (uint64_t)n_rec + (uint32_t)__popcll(tm & lanes_below);
+                        if (at < a.rec_cap) {
+                            a.rec_dist[(size_t)q * a.rec_cap + at] = dist;
+                            a.rec_shard[(size_t)q * a.rec_cap + at] = (int32_t)shard;
+                        }
+                    }
+                    n_rec += (uint32_t)__popcll(tm);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
+            if (lane == 0) a.redo[q] = 0;
+            if (a.rec_count && lane == 0) a.rec_count[q] = n_rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // kmeans_tree_router.cpp:93-130 with distance() replaced by the table: one wavefront per query.
 template <bool LDS_HEAP>
 __global__ void __launch_bounds__(64 * kRWaves) RouterReplayKernel(ReplayArgs a) {
@@ -683,9 +926,58 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         r->leaves_only = true;
         for (uint32_t u = 0; u < n_nodes; ++u)
             if (!is_root[u] && node_child_count[u] != 0) r->leaves_only = false;
+
+        // threshold replay tables: the key centroids along every node's path, and the node of every centroid
+        std::vector<uint32_t> parent(n_nodes, kNoCent), key_cent(n_nodes, kNoCent), depth(n_nodes, 0);
+        for (uint32_t u = 0; u < n_nodes; ++u)
+            for (uint32_t i = 0; i < node_child_count[u]; ++i) {
+                parent[node_child_first[u] + i] = u;
+                key_cent[node_child_first[u] + i] = node_cent_first[u] + i;
+            }
+        std::vector<uint32_t> path((size_t)n_nodes * kPathMax, kNoCent), cent_node(std::max<size_t>(nc, 1), 0);
+        for (uint32_t u = 0; u < n_nodes; ++u) {
+            uint32_t v = u, len = 0;
+            while (parent[v] != kNoCent && len <= n_nodes) {   // (len bound: malformed input must not hang)
+                if (len < (uint32_t)kPathMax) path[(size_t)u * kPathMax + len] = key_cent[v];
+                v = parent[v];
+                ++len;
+            }
+            depth[u] = len;
+            r->max_depth = std::max(r->max_depth, len);
+            for (uint32_t c = node_cent_first[u]; c < node_cent_first[u + 1]; ++c) cent_node[c] = u;
+        }
+        TRY_OR_FAIL(hipMalloc(&r->path_cent, path.size() * 4));
+        TRY_OR_FAIL(hipMalloc(&r->cent_node, cent_node.size() * 4));
+        TRY_OR_FAIL(hipMemcpy(r->path_cent, path.data(), path.size() * 4, hipMemcpyHostToDevice));
+        TRY_OR_FAIL(hipMemcpy(r->cent_node, cent_node.data(), cent_node.size() * 4, hipMemcpyHostToDevice));
     }
 #undef TRY_OR_FAIL
     *out = r;
+    return GPANN_OK;
+}
+
+gpann_status gpann_router_info(const gpann_router* r, uint32_t* d, int* metric, uint32_t* S, uint32_t* n_nodes, uint64_t* n_centroids) {
+    GPANN_REQUIRE(r != nullptr, "router is null");
+    if (d) *d = r->d;
+    if (metric) *metric = r->metric;
+    if (S) *S = r->S;
+    if (n_nodes) *n_nodes = r->n_nodes;
+    if (n_centroids) *n_centroids = r->n_centroids;
+    return GPANN_OK;
+}
+
+gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uint32_t* node_cent_first, uint32_t* node_child_first,
+                                 uint32_t* node_child_count, uint32_t* shard_root, float* centroids) {
+    GPANN_REQUIRE(r != nullptr, "router is null");
+    GPANN_TRY(EnsureDevice(r->device));
+    const size_t n = r->n_nodes;
+    if (node_shard) GPANN_HIP_TRY(hipMemcpy(node_shard, r->node_shard, n * 4, hipMemcpyDeviceToHost));
+    if (node_cent_first) GPANN_HIP_TRY(hipMemcpy(node_cent_first, r->node_cent_first, (n + 1) * 4, hipMemcpyDeviceToHost));
+    if (node_child_first) GPANN_HIP_TRY(hipMemcpy(node_child_first, r->node_child_first, n * 4, hipMemcpyDeviceToHost));
+    if (node_child_count) GPANN_HIP_TRY(hipMemcpy(node_child_count, r->node_child_count, n * 4, hipMemcpyDeviceToHost));
+    if (shard_root) GPANN_HIP_TRY(hipMemcpy(shard_root, r->shard_root, (size_t)r->S * 4, hipMemcpyDeviceToHost));
+    if (centroids && r->n_centroids)
+        GPANN_HIP_TRY(hipMemcpy2D(centroids, (size_t)r->d * 4, r->centroids, (size_t)r->ld * 4, (size_t)r->d * 4, r->n_centroids, hipMemcpyDeviceToHost));
     return GPANN_OK;
 }
 
@@ -693,13 +985,14 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
     r->ws_out.Release();
     r->ws_dense.Release();
     r->ws_redo.Release();
+    r->ws_pi.Release();
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     delete r;
@@ -728,94 +1021,124 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
     const char* force = std::getenv("GPANN_ROUTER_MODE");   // "walk" | "dense" (default: by size)
     const uint64_t C = r->n_centroids;
-    bool dense = budget > 0 && C <= 4ull * (uint64_t)budget && (uint64_t)nq * C * 4 <= (3ull << 30) && C < 0xFFFFFFFFull;
+    // dense + replay: all distances of a block of queries at once (exact, tiled), then the queue logic on the table
+    const uint64_t dense_cap = 6ull << 30;   // bytes of distance table per block of queries
+    bool dense = budget > 0 && C <= 4ull * (uint64_t)budget && C < 0xFFFFFFFFull && C * 4 * 64 <= dense_cap;
     if (force && std::string(force) == "walk") dense = false;
-    if (force && std::string(force) == "dense" && (uint64_t)nq * C * 4 <= (16ull << 30)) dense = budget > 0;
+    if (force && std::string(force) == "dense" && C * 4 * 64 <= dense_cap) dense = budget > 0;
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
     if (dense) {
-        GPANN_TRY(r->ws_dense.Reserve((size_t)nq * C * 4));
-        DenseArgs da;
-        da.centroids = r->centroids;
-        da.queries = r->ws_queries.as<float>();
-        da.out = r->ws_dense.as<float>();
-        da.d = r->d;
-        da.ld = ld;
-        da.nq = nq;
-        da.C = (uint32_t)C;
-        const dim3 dgrid((uint32_t)((C + 63) / 64), (nq + 63) / 64);
-        const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
-        if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_L2>, dgrid, dim3(256), dlds, st, da);
-        else hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_MIPS>, dgrid, dim3(256), dlds, st, da);
-        GPANN_HIP_TRY(hipGetLastError());
-
-        const size_t base_floats = (size_t)64 + S;
-        const bool lds_heap = ((((base_floats + 2 * cap) + 3) & ~(size_t)3) * kRWaves * sizeof(float)) <= 40 * 1024;
-        const size_t per_wave_lds = ((base_floats + (lds_heap ? 2 * cap : 0)) + 3) & ~(size_t)3;
-        const size_t lds = per_wave_lds * kRWaves * sizeof(float);
-        uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
-        uint32_t grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * blocks_per_cu);
-        while (!lds_heap && grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
-        const uint64_t slots = (uint64_t)grid * kRWaves;
-        GPANN_TRY(r->ws_heap.Reserve(lds_heap ? 256 : slots * cap * 8));
-        ReplayArgs ra;
-        ra.dense = r->ws_dense.as<float>();
-        ra.node_shard = r->node_shard;
-        ra.node_cent_first = r->node_cent_first;
-        ra.node_child_first = r->node_child_first;
-        ra.node_child_count = r->node_child_count;
-        ra.shard_root = r->shard_root;
-        ra.heap_key = r->ws_heap.as<float>();
-        ra.heap_node = reinterpret_cast<uint32_t*>(ra.heap_key + slots * cap);
-        ra.out_min_dist = r->ws_out.as<float>();
-        ra.rec_dist = rec_dist;
-        ra.rec_shard = rec_shard;
-        ra.rec_count = rec_count;
-        ra.rec_cap = rec_cap;
-        ra.heap_cap = cap;
-        ra.S = S;
-        ra.nq = nq;
-        ra.C = (uint32_t)C;
-        ra.budget = budget;
-        // trees whose root children are all leaves: sorted replay (no queue); it marks the rare query that needs the real
-        // heap (equal keys across the cut-off) and RouterReplayKernel then does only those
-        ra.only_redo = 0;
-        ra.redo = nullptr;
-        ra.redo_count = nullptr;
-        ra.root_total = r->root_total;
-        ra.sort_n = 1;
-        while (ra.sort_n < std::max<uint32_t>(r->root_children, 64)) ra.sort_n <<= 1;
-        const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" disables the sorted replay
-        ra.n_nodes = r->n_nodes;
-        const bool sorted_ok = r->leaves_only && ra.sort_n <= 2048 && r->n_nodes <= 4096 && S <= 64 &&
-                               (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min && !(rmode && std::string(rmode) == "heap");
-        if (sorted_ok) {
-            GPANN_TRY(r->ws_redo.Reserve((size_t)nq * 4 + 16));
-            ra.redo = r->ws_redo.as<uint32_t>();
-            ra.redo_count = ra.redo + nq;
-            GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 4, st));
-            const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
-            const size_t s_lds = (table_words + ((((size_t)2 * ra.sort_n + S) + 3) & ~(size_t)3) * kRWaves) * sizeof(float);
-            const uint32_t s_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / s_lds));
-            const uint32_t s_grid = std::min<uint32_t>((nq + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * s_bpc);
-            if (s_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterSortedReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_lds));
-            hipLaunchKernelGGL(RouterSortedReplayKernel, dim3(s_grid), dim3(64 * kRWaves), s_lds, st, ra);
-            ra.only_redo = 1;
-        }
-        // after a sorted replay the heap kernel is needed only for the marked queries — usually none
-        bool need_heap = true;
-        uint32_t hgrid = grid;
-        if (sorted_ok) {
-            uint32_t marked = 0;
-            GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
-            GPANN_HIP_TRY(hipStreamSynchronize(st));
-            need_heap = marked != 0;
-            if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] sorted replay: %u of %u queries go to the heap kernel\n", marked, nq);
-            hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
-        }
-        if (need_heap) {
-            if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
-            else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+        const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (C * 4) / 64 * 64));
+        GPANN_TRY(r->ws_dense.Reserve((size_t)q_block * C * 4));
+        const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
+        const bool force_heap = rmode && std::string(rmode) == "heap";
+        const bool all_roots_open = (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min;
+        uint32_t sort_n = 1;
+        while (sort_n < std::max<uint32_t>(r->root_children, 64)) sort_n <<= 1;
+        // trees whose root children are all leaves: sorted replay; any other tree: threshold replay.  Both mark the rare query
+        // that needs the real heap (equal keys in the cut-off group) and RouterReplayKernel then does only those.
+        const bool sorted_ok = r->leaves_only && sort_n <= 2048 && r->n_nodes <= 4096 && S <= 64 && all_roots_open && !force_heap &&
+                               !(rmode && std::string(rmode) == "threshold");
+        const size_t t_lds = ((((size_t)256 + S + 2 * kFrontCap) + 3) & ~(size_t)3) * kRWaves * sizeof(uint32_t);
+        const bool threshold_ok = !sorted_ok && !force_heap && all_roots_open && r->max_depth <= (uint32_t)kPathMax && t_lds <= 64 * 1024 &&
+                                  budget < 0x7FFFFFFF;
+        for (uint32_t q0 = 0; q0 < nq; q0 += q_block) {
+            const uint32_t nb = std::min(q_block, nq - q0);
+            DenseArgs da;
+            da.centroids = r->centroids;
+            da.queries = r->ws_queries.as<float>() + (size_t)q0 * ld;
+            da.out = r->ws_dense.as<float>();
+            da.d = r->d;
+            da.ld = ld;
+            da.nq = nb;
+            da.C = (uint32_t)C;
+            const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
+            const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+            if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_L2>, dgrid, dim3(256), dlds, st, da);
+            else hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_MIPS>, dgrid, dim3(256), dlds, st, da);
             GPANN_HIP_TRY(hipGetLastError());
+
+            const size_t base_floats = (size_t)64 + S;
+            const bool lds_heap = ((((base_floats + 2 * cap) + 3) & ~(size_t)3) * kRWaves * sizeof(float)) <= 40 * 1024;
+            const size_t per_wave_lds = ((base_floats + (lds_heap ? 2 * cap : 0)) + 3) & ~(size_t)3;
+            const size_t lds = per_wave_lds * kRWaves * sizeof(float);
+            uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+            uint32_t grid = std::min<uint32_t>((nb + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * blocks_per_cu);
+            while (!lds_heap && grid > 1 && (uint64_t)grid * kRWaves * cap * 8 > (4ull << 30)) grid /= 2;
+            const uint64_t slots = (uint64_t)grid * kRWaves;
+            GPANN_TRY(r->ws_heap.Reserve(lds_heap ? 256 : slots * cap * 8));
+            ReplayArgs ra;
+            ra.dense = r->ws_dense.as<float>();
+            ra.node_shard = r->node_shard;
+            ra.node_cent_first = r->node_cent_first;
+            ra.node_child_first = r->node_child_first;
+            ra.node_child_count = r->node_child_count;
+            ra.shard_root = r->shard_root;
+            ra.heap_key = r->ws_heap.as<float>();
+            ra.heap_node = reinterpret_cast<uint32_t*>(ra.heap_key + slots * cap);
+            ra.out_min_dist = r->ws_out.as<float>() + (size_t)q0 * S;
+            ra.rec_dist = rec_dist ? rec_dist + (size_t)q0 * rec_cap : nullptr;
+            ra.rec_shard = rec_shard ? rec_shard + (size_t)q0 * rec_cap : nullptr;
+            ra.rec_count = rec_count ? rec_count + q0 : nullptr;
+            ra.rec_cap = rec_cap;
+            ra.heap_cap = cap;
+            ra.S = S;
+            ra.nq = nb;
+            ra.C = (uint32_t)C;
+            ra.budget = budget;
+            ra.only_redo = 0;
+            ra.redo = nullptr;
+            ra.redo_count = nullptr;
+            ra.root_total = r->root_total;
+            ra.sort_n = sort_n;
+            ra.n_nodes = r->n_nodes;
+            if (sorted_ok || threshold_ok) {
+                GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 16));
+                ra.redo = r->ws_redo.as<uint32_t>();
+                ra.redo_count = ra.redo + nb;
+                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 4, st));
+            }
+            if (sorted_ok) {
+                const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
+                const size_t s_lds = (table_words + ((((size_t)2 * ra.sort_n + S) + 3) & ~(size_t)3) * kRWaves) * sizeof(float);
+                const uint32_t s_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / s_lds));
+                const uint32_t s_grid = std::min<uint32_t>((nb + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * s_bpc);
+                if (s_lds > 48 * 1024)
+                    GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterSortedReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s_lds));
+                hipLaunchKernelGGL(RouterSortedReplayKernel, dim3(s_grid), dim3(64 * kRWaves), s_lds, st, ra);
+                GPANN_HIP_TRY(hipGetLastError());
+                ra.only_redo = 1;
+            } else if (threshold_ok) {
+                const uint32_t t_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / t_lds));
+                const uint32_t t_grid = std::min<uint32_t>((nb + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * t_bpc);
+                GPANN_TRY(r->ws_pi.Reserve((size_t)t_grid * kRWaves * r->n_nodes * 4));
+                ThresholdTree tt;
+                tt.path_cent = r->path_cent;
+                tt.cent_node = r->cent_node;
+                tt.pi = r->ws_pi.as<uint32_t>();
+                if (t_lds > 48 * 1024)
+                    GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterThresholdReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t_lds));
+                hipLaunchKernelGGL(RouterThresholdReplayKernel, dim3(t_grid), dim3(64 * kRWaves), t_lds, st, ra, tt);
+                GPANN_HIP_TRY(hipGetLastError());
+                ra.only_redo = 1;
+            }
+            // after a sorted / threshold replay the heap kernel is needed only for the marked queries — usually none
+            bool need_heap = true;
+            uint32_t hgrid = grid;
+            if (ra.only_redo) {
+                uint32_t marked = 0;
+                GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
+                GPANN_HIP_TRY(hipStreamSynchronize(st));
+                need_heap = marked != 0;
+                if (std::getenv("GPANN_ROUTER_DEBUG"))
+                    fprintf(stderr, "[gpann router] %s replay: %u of %u queries go to the heap kernel\n", sorted_ok ? "sorted" : "threshold", marked, nb);
+                hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
+            }
+            if (need_heap) {
+                if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+                else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
+                GPANN_HIP_TRY(hipGetLastError());
+            }
         }
         GPANN_HIP_TRY(hipEventRecord(r->ev[1], st));
         return GPANN_OK;

@@ -20,7 +20,10 @@ bool g_mips = false;
 int g_device = 0;
 int g_threads = 0;
 bool g_filtered = true;
+bool g_device_training = true;
 }   // namespace
+void SetDeviceTraining(bool on) { g_device_training = on; }
+bool DeviceTraining() { return g_device_training; }
 void SetMetricMIPS(bool mips) { g_mips = mips; }
 bool MetricIsMIPS() { return g_mips; }
 void SetDevice(int device) { g_device = device; }

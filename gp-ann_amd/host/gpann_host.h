@@ -120,6 +120,10 @@ int NumThreads();
 // matrix-core pre-filter (csrc/scan_filter.h), false = plain exact VALU scan.  Both return identical neighbours.
 void SetFilteredScan(bool on);
 bool FilteredScan();
+// KMeansTreeRouter::Train runs on the GPU (gpann_router_train, csrc/kmeans.hip) by default; false selects the host trainer
+// (router_host.cpp).  Both build the same tree, bit for bit.
+void SetDeviceTraining(bool on);
+bool DeviceTraining();
 }   // namespace gpann_host
 
 // --------------------------------------------------------------------------------------------- src/points_io.h:5-11
@@ -156,7 +160,10 @@ public:
     KMeansTreeRouter(KMeansTreeRouter&& other) noexcept;
     KMeansTreeRouter& operator=(KMeansTreeRouter&& other) noexcept;
 
-    void Train(PointSet& points, const Clusters& clusters, KMeansTreeRouterOptions options);   // host, kmeans_tree_router.cpp:9-78
+    void Train(PointSet& points, const Clusters& clusters, KMeansTreeRouterOptions options);   // kmeans_tree_router.cpp:9-78 (GPU)
+    // additive: train over the rows an InvertedIndex already holds in HBM (built from the same clusters); num_points = PointSet::n
+    void Train(struct InvertedIndex& index, size_t num_points, KMeansTreeRouterOptions options);
+    void TrainOnHost(PointSet& points, const Clusters& clusters, KMeansTreeRouterOptions options);   // the same tree, built by host threads
 
     std::vector<int> Query(float* Q, int budget);   // :93-130, one query = a GPU batch of one
 
@@ -188,6 +195,7 @@ public:
 
 private:
     void EnsureOnDevice();
+    void TrainOnDevice(gpann_shards* store, size_t num_points, KMeansTreeRouterOptions options);
     Flat tree_;
     gpann_router* device_router_ = nullptr;
 };

@@ -37,7 +37,7 @@ void* gpann_host_router_train(const float* points, uint64_t n, uint32_t d, const
         o.min_cluster_size = min_cluster_size;
         o.budget = budget;
         auto* r = new KMeansTreeRouter();
-        r->Train(ps, FromCsr(ids, offsets, S), o);
+        r->TrainOnHost(ps, FromCsr(ids, offsets, S), o);
         return r;
     } catch (const std::exception& e) {
         g_err = e.what();

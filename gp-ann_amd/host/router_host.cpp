@@ -1,6 +1,7 @@
 // router_host.cpp — host mirror of k-means (reference src/kmeans.cpp:12-50,72-149,207-244) and of KMeansTreeRouter
-// (src/kmeans_tree_router.{h,cpp}).  Training stays on the host as in the reference; Query / QueryBatch /
-// FrequencyQuery run on the GPU through libgpann_hip.so.
+// (src/kmeans_tree_router.{h,cpp}).  Train() runs on the GPU (gpann_router_train) unless gpann_host::SetDeviceTraining(false);
+// TrainOnHost() below is the host-thread trainer that builds the same tree.  Query / QueryBatch / FrequencyQuery run on the GPU
+// through libgpann_hip.so.
 //
 // The trainer is written against row-index views instead of copying a PointSet per tree node, and emits the flat BFS
 // layout directly, but every arithmetic step, every std:: call whose result depends on libstdc++ (std::sample with
@@ -245,6 +246,64 @@ void KMeansTreeRouter::LoadFlat(Flat tree) {
 
 // kmeans_tree_router.cpp:9-33
 void KMeansTreeRouter::Train(PointSet& points, const Clusters& clusters, KMeansTreeRouterOptions options) {
+    if (!gpann_host::DeviceTraining()) {
+        TrainOnHost(points, clusters, options);
+        return;
+    }
+    // a temporary shard store (the gather InvertedIndex would do): shard b = clusters[b] in order, which is all the trainer reads
+    std::vector<uint64_t> offsets(clusters.size() + 1, 0);
+    for (size_t b = 0; b < clusters.size(); ++b) offsets[b + 1] = offsets[b] + clusters[b].size();
+    std::vector<uint32_t> ids;
+    ids.reserve(offsets.back());
+    for (const auto& c : clusters) ids.insert(ids.end(), c.begin(), c.end());
+    gpann_shards* store = nullptr;
+    gpann_host::Check(gpann_shards_create(points.coordinates.data(), points.n, (uint32_t)points.d,
+                                          gpann_host::MetricIsMIPS() ? GPANN_METRIC_MIPS : GPANN_METRIC_L2, ids.data(), offsets.data(),
+                                          (uint32_t)clusters.size(), gpann_host::Device(), 0, &store),
+                      "gpann_shards_create");
+    try {
+        TrainOnDevice(store, points.n, options);
+    } catch (...) {
+        gpann_shards_destroy(store);
+        throw;
+    }
+    gpann_shards_destroy(store);
+}
+
+void KMeansTreeRouter::Train(InvertedIndex& index, size_t num_points, KMeansTreeRouterOptions options) {
+    TrainOnDevice(index.device_handle(), num_points, options);
+}
+
+void KMeansTreeRouter::TrainOnDevice(gpann_shards* store, size_t num_points, KMeansTreeRouterOptions options) {
+    std::cout << "Train. budget = " << options.budget << " (GPU)" << std::endl;
+    gpann_router* trained = nullptr;
+    gpann_host::Check(gpann_router_train(store, num_points, (uint32_t)options.num_centroids, (uint32_t)options.min_cluster_size, options.budget, &trained),
+                      "gpann_router_train");
+    Flat flat;
+    uint32_t n_nodes = 0;
+    uint64_t n_cent = 0;
+    int metric = 0;
+    gpann_status st = gpann_router_info(trained, &flat.d, &metric, &flat.S, &n_nodes, &n_cent);
+    if (st == GPANN_OK) {
+        flat.mips = metric == GPANN_METRIC_MIPS;
+        flat.node_shard.resize(n_nodes);
+        flat.node_cent_first.resize(n_nodes + 1);
+        flat.node_child_first.resize(n_nodes);
+        flat.node_child_count.resize(n_nodes);
+        flat.shard_root.resize(flat.S);
+        flat.centroids.resize(n_cent * flat.d);
+        st = gpann_router_export(trained, flat.node_shard.data(), flat.node_cent_first.data(), flat.node_child_first.data(),
+                                 flat.node_child_count.data(), flat.shard_root.data(), flat.centroids.data());
+    }
+    if (st != GPANN_OK) {
+        gpann_router_destroy(trained);
+        gpann_host::Check(st, "gpann_router_export");
+    }
+    LoadFlat(std::move(flat));
+    device_router_ = trained;   // already resident: Query needs no upload
+}
+
+void KMeansTreeRouter::TrainOnHost(PointSet& points, const Clusters& clusters, KMeansTreeRouterOptions options) {
     const int S = (int)clusters.size();
     const bool mips = gpann_host::MetricIsMIPS();
     std::cout << "Train. num-shards = " << S << " dim = " << points.d << " budget = " << options.budget << std::endl;

@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_router_info", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -85,6 +85,9 @@ def lib():
     L.gpann_router_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, C.c_int,
                                       C.POINTER(C.c_void_p)]
     L.gpann_router_destroy.argtypes = [C.c_void_p]
+    L.gpann_router_train.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]
+    L.gpann_router_info.argtypes = [C.c_void_p, _u32p, C.POINTER(C.c_int), _u32p, _u32p, _u64p]
+    L.gpann_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
     L.gpann_router_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
     L.gpann_router_frequency_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, _f32p, _f32p, _u32p, _u32p,
                                                      C.c_int, C.c_void_p, _f32p]
@@ -273,6 +276,31 @@ class Router:
         _check(lib().gpann_router_create(self.d, metric, self.S, len(ns), ns.ctypes.data_as(_i32p), cf.ctypes.data_as(_u32p),
                                          chf.ctypes.data_as(_u32p), chc.ctypes.data_as(_u32p), sr.ctypes.data_as(_u32p),
                                          cen.ctypes.data_as(_f32p), device, C.byref(self.h)))
+
+    @classmethod
+    def train(cls, shards, n_points, num_centroids=64, min_cluster_size=250, budget=50000):
+        """KMeansTreeRouter::Train on the GPU over the rows of a shard store (gpann_router_train)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        _check(lib().gpann_router_train(shards.h, C.c_uint64(int(n_points)), C.c_uint32(int(num_centroids)), C.c_uint32(int(min_cluster_size)),
+                                        C.c_int64(int(budget)), C.byref(self.h)))
+        d, S = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().gpann_router_info(self.h, C.byref(d), None, C.byref(S), None, None))
+        self.S, self.d = S.value, d.value
+        return self
+
+    def export(self):
+        """The flattened tree as the dict Router(flat) takes."""
+        d, S, n_nodes, metric, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_uint64(0)
+        _check(lib().gpann_router_info(self.h, C.byref(d), C.byref(metric), C.byref(S), C.byref(n_nodes), C.byref(nc)))
+        n = n_nodes.value
+        flat = dict(S=S.value, d=d.value, metric=metric.value, node_shard=np.empty(n, np.int32), node_cent_first=np.empty(n + 1, np.uint32),
+                    node_child_first=np.empty(n, np.uint32), node_child_count=np.empty(n, np.uint32), shard_root=np.empty(S.value, np.uint32),
+                    centroids=np.empty((nc.value, d.value), np.float32))
+        _check(lib().gpann_router_export(self.h, flat["node_shard"].ctypes.data_as(_i32p), flat["node_cent_first"].ctypes.data_as(_u32p),
+                                         flat["node_child_first"].ctypes.data_as(_u32p), flat["node_child_count"].ctypes.data_as(_u32p),
+                                         flat["shard_root"].ctypes.data_as(_u32p), flat["centroids"].ctypes.data_as(_f32p)))
+        return flat
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

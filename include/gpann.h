@@ -10,6 +10,7 @@
  *   gpann_ground_truth             <- ComputeGroundTruth(points, queries, k)                        src/recall.h:25-39
  *   gpann_shard_search_hits        <- RunInShardSearches(...) hit lists (exact scan instead of HNSW) src/shard_searches.cpp:11-104
  *   gpann_router_create            <- KMeansTreeRouter (trained tree, flattened as ExtractPoints)    src/kmeans_tree_router.cpp:174-201
+ *   gpann_router_train             <- KMeansTreeRouter::Train / TrainRecursive + KMeans             src/kmeans_tree_router.cpp:9-91, src/kmeans.cpp:12-244
  *   gpann_router_query_batch       <- KMeansTreeRouter::Query(float* Q, int budget)                 src/kmeans_tree_router.cpp:93-130
  *   gpann_router_frequency_query_batch <- KMeansTreeRouter::FrequencyQuery                      src/kmeans_tree_router.cpp:132-172
  *   gpann_merge_dedup              <- DedupNeighbors(neighbors, k)                                  small_scale_queries.cpp:15-23
@@ -42,7 +43,8 @@ typedef enum gpann_status {
     GPANN_ERR_NO_DEVICE = 2,   /* no usable HIP device */
     GPANN_ERR_HIP = 3,         /* a HIP runtime call failed; see gpann_last_error() */
     GPANN_ERR_OOM = 4,         /* device or host allocation failed */
-    GPANN_ERR_UNSUPPORTED = 5
+    GPANN_ERR_UNSUPPORTED = 5,
+    GPANN_ERR_INTERNAL = 6     /* an internal consistency check failed; see gpann_last_error() */
 } gpann_status;
 
 enum {
@@ -151,6 +153,24 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
                                  const uint32_t* node_cent_first, const uint32_t* node_child_first, const uint32_t* node_child_count,
                                  const uint32_t* shard_root, const float* centroids, int device, gpann_router** out);
 gpann_status gpann_router_destroy(gpann_router* r);
+
+/* KMeansTreeRouter::Train (src/kmeans_tree_router.cpp:9-91) on the GPU, over the rows of a shard store: shard b of the
+ * store is Clusters[b] in the reference's call, in the same order.  All k-means problems of one tree level run as one
+ * batch of launches (gp-ann_amd/csrc/kmeans.hip); sampling (std::sample / std::mt19937, seeds 555*b and seed+i), the 20
+ * Lloyd rounds, the sequential point-order centroid sums, empty-cluster removal, std::partition by min_cluster_size and
+ * the budget rules are the reference's, so the tree is the one the reference builds (bit-identical while every node has
+ * at most max(5e6, 200*centroids*d) points; beyond that the reference's own sums are unordered atomics and this build
+ * takes its block partials in block order).
+ * An empty shard gets a root without centroids (additive; lets a rank that stores only its own shards train their subtrees).
+ *   n_points          PointSet::n of the reference's call (the denominator of the per-shard budget share, :28)
+ *   num_centroids, min_cluster_size, budget     KMeansTreeRouterOptions (kmeans_tree_router.h:6-11) */
+gpann_status gpann_router_train(gpann_shards* shards, uint64_t n_points, uint32_t num_centroids, uint32_t min_cluster_size, int64_t budget,
+                                gpann_router** out);
+
+/* Size and contents of a router's flattened tree (the arrays gpann_router_create takes; host outputs, any may be NULL). */
+gpann_status gpann_router_info(const gpann_router* r, uint32_t* d, int* metric, uint32_t* S, uint32_t* n_nodes, uint64_t* n_centroids);
+gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uint32_t* node_cent_first, uint32_t* node_child_first,
+                                 uint32_t* node_child_count, uint32_t* shard_root, float* centroids);
 
 /* Batched KMeansTreeRouter::Query.  The best-first walk (all distance evaluations, the priority queue and the budget
  * rule) runs on the GPU; the final order is std::sort over min_dist on the host, the very call the reference makes

@@ -103,3 +103,50 @@ def test_end_to_end_route_scan_merge_recall(orc, gp):
         assert rec >= prev - 1e-12
         prev = rec
     assert abs(prev - 1.0) < 1e-6        # all shards probed: exact
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_router_deep_tree_threshold_replay(orc, gp, metric, monkeypatch):
+    """multi-level trees with budgets that stop the walk in the middle of the tree: the queue-free threshold replay (dense
+    distances -> path maxima -> radix select of the cut-off key -> cut-off group) must visit exactly the nodes the
+    reference's priority queue pops"""
+    pts, clusters, tree = _tree(orc, 30000, 16, 6, metric, 6, 12, 4000, seed=3)
+    f = tree.flat()
+    C = int(f["node_cent_first"][-1])
+    depth_nodes = int((f["node_child_count"] > 0).sum())
+    assert depth_nodes > 6 + 10 and C > 1500          # inner nodes below the roots
+    queries = make_mixture(orc, 300, 16, seed=556, n_centers=24)
+    router = gp.Router(f, metric, 0)
+    for mode in ("", "heap"):                          # default (threshold replay) and the real queue on the same table
+        monkeypatch.setenv("GPANN_ROUTER_REPLAY", mode)
+        for budget in (C // 4 + 1, C // 3, C // 2, (3 * C) // 4, C - 1, C, C + 50):
+            probes, md, _ = router.query_batch(queries, budget)
+            wp, wm = tree.query_batch(queries, budget, nthreads=8)
+            assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), (mode, budget)
+            assert np.array_equal(probes, wp), (mode, budget)
+    monkeypatch.delenv("GPANN_ROUTER_REPLAY")
+    # FrequencyQuery over the same walk
+    budget = C // 2
+    md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, 50)
+    for q in range(0, len(queries), 7):
+        wmd, wnd, wns = tree.frequency_query(queries[q], budget, 50)
+        assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32))
+        assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns)
+
+
+def test_router_deep_tree_with_duplicates(orc, gp):
+    """equal keys everywhere (50 distinct points): the threshold replay must hand every ambiguous query to the real queue"""
+    n, d, S = 12000, 8, 4
+    rng = np.random.default_rng(8)
+    base = make_mixture(orc, 50, d, n_centers=4)
+    pts = base[rng.integers(0, 50, size=n)] + (rng.integers(0, 3, size=(n, 1)) * np.float32(0.25)).astype(np.float32)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=5, min_cluster_size=10, budget=3000, metric=0, nthreads=4)
+    f = tree.flat()
+    C = int(f["node_cent_first"][-1])
+    queries = base[rng.integers(0, 50, size=150)]
+    router = gp.Router(f, 0, 0)
+    for budget in (C // 3, C // 2, C - 3):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget, nthreads=4)
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp), budget
