@@ -379,6 +379,8 @@ def main():
                                       "(query,row) distance, only candidates get the exact VALU evaluation; flops = filter_pairs x d x 6 per launch "
                                       "(both filter launches of a step), time = HIP events around them",
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
+                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": stats["filter_rows"] * 544,
+                              "filter_plane_GBps": stats["filter_rows"] * 544 / f_s / 1e9 if f_s > 0 else 0.0,
                               "hbm_algorithmic_GBps": hbm_alg, "hbm_algorithmic_frac": hbm_alg / HBM_PEAK_GBPS}
     else:
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,

@@ -471,6 +471,49 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
     return GPANN_OK;
 }
 
+// Splits the tb tasks of a shard into filter groups.  In units of (32-task query tile x 32-row point tile) products per
+// 64-row tile a group costs its slowest wave: 4 for a full group (mode 0, <= 8 query tiles), 2 when the 4 waves split the rows
+// of <= 4 query tiles (mode 1), 1 for <= 2 query tiles (mode 2).
+struct FilterGroup {
+    uint32_t task_off, task_count, mode;
+};
+static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, bool roles) {
+    std::vector<FilterGroup> out;
+    uint32_t off = 0;
+    auto emit = [&](uint32_t tiles, uint32_t mode) {
+        const uint32_t cnt = std::min(tb - off, tiles * 32u);
+        out.push_back({off, cnt, mode});
+        off += cnt;
+    };
+    if (!roles) {
+        // groups of <= 256 tasks, sized in whole 32-task query tiles (only a shard's last group can end on a partly used tile)
+        const uint32_t nqb = (tb + kFQB - 1) / kFQB;
+        const uint32_t tiles = (tb + 31) / 32;
+        uint32_t done = 0;
+        for (uint32_t qb = 0; qb < nqb; ++qb) {
+            const uint32_t p0 = (uint32_t)((uint64_t)tiles * qb / nqb), p1 = (uint32_t)((uint64_t)tiles * (qb + 1) / nqb);
+            const uint32_t cnt = std::min(tb - done, (p1 - p0) * 32u);
+            out.push_back({done, cnt, 0});
+            done += cnt;
+        }
+        return out;
+    }
+    uint32_t q = (tb + 31) / 32;
+    while (q >= 8) {
+        emit(8, 0);
+        q -= 8;
+    }
+    if (q == 7) emit(7, 0);
+    else {
+        if (q >= 3) {
+            emit(std::min(q, 4u), 1);
+            q -= std::min(q, 4u);
+        }
+        if (q > 0) emit(q, 2);
+    }
+    return out;
+}
+
 // The MFMA-filtered pipeline (scan_filter.h).  On return *overflow tells whether a candidate bucket overflowed, in which
 // case the outputs are not written and the caller runs the plain exact scan instead.
 static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
@@ -517,6 +560,8 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
     // ---- filter passes over [m0, m1) and [m1, end)
     const int64_t bounds[3] = {m0, m1, std::numeric_limits<int64_t>::max()};
     const uint32_t target_units = EnvU32("GPANN_FILTER_TARGET_UNITS", 8192);
+    // wave roles (FilterUnit::mode) exist in FilterKernelDma only; GPANN_FILTER_ROLES=0 plans plain 256-task groups
+    const bool dma_roles = s->plane_hi != nullptr && s->plane_lo != nullptr && s->frag_planes == nullptr && EnvU32("GPANN_FILTER_ROLES", 1) != 0;
     for (int pass = 0; pass < 2; ++pass) {
         // units: (<= 256 tasks of a shard) x (row segment of the pass range)
         std::vector<FilterUnit>& funits = plan.filter_units;
@@ -527,7 +572,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
             const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
             const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
                                                                                        : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
-            if (tb && r1 > r0) block_rows += (uint64_t)((tb + kFQB - 1) / kFQB) * (uint64_t)(r1 - r0);
+            if (tb && r1 > r0) block_rows += (uint64_t)PlanFilterGroups(tb, dma_roles).size() * (uint64_t)(r1 - r0);
         }
         if (block_rows == 0) continue;
         uint64_t seg_rows = std::max<uint64_t>(4096, (block_rows + target_units - 1) / target_units);
@@ -538,21 +583,29 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
             const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
                                                                                        : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
             if (tb == 0 || r1 <= r0) continue;
-            const uint32_t nqb = (tb + kFQB - 1) / kFQB;
+            const std::vector<FilterGroup> groups = PlanFilterGroups(tb, dma_roles);
+            const uint32_t nqb = (uint32_t)groups.size();
             const uint64_t nb = (uint64_t)(r1 - r0);
             const uint32_t nseg = (uint32_t)((nb + seg_rows - 1) / seg_rows);
             const uint64_t per = ((nb + nseg - 1) / nseg + kFPT - 1) / kFPT * kFPT;
+            // launch order: 8 consecutive segments of one group, then the same 8 segments of the next group, ...: workgroups are
+            // dealt round-robin to the 8 XCDs, so the groups that stream the same rows land on the same XCD back to back and the
+            // second one finds the rows in that XCD's L2
+            const uint32_t xcds = EnvU32("GPANN_FILTER_XCD_STRIDE", 8);
+            for (uint32_t sg0 = 0; sg0 < nseg; sg0 += xcds)
             for (uint32_t qb = 0; qb < nqb; ++qb) {
-                const uint32_t tbeg = t0 + (uint32_t)((uint64_t)tb * qb / nqb), tend = t0 + (uint32_t)((uint64_t)tb * (qb + 1) / nqb);
-                for (uint32_t sg = 0; sg < nseg; ++sg) {
+                for (uint32_t sg = sg0; sg < std::min(nseg, sg0 + xcds); ++sg) {
                     FilterUnit u;
                     u.row_begin = r0 + (int64_t)(sg * per);
                     u.row_end = std::min<int64_t>(r1, u.row_begin + (int64_t)per);
                     if (u.row_begin >= u.row_end) continue;
-                    u.task_begin = tbeg;
-                    u.task_count = tend - tbeg;
+                    u.task_begin = t0 + groups[qb].task_off;
+                    u.task_count = groups[qb].task_count;
+                    u.mode = groups[qb].mode;
+                    u.pad = 0;
                     funits.push_back(u);
                     plan.filter_pairs += (uint64_t)((u.task_count + 31) / 32 * 32) * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
+                    plan.filter_rows += (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
                 }
             }
         }
@@ -588,6 +641,8 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         fa.ld = s->ld;
         fa.plane_hi = s->plane_hi;
         fa.plane_lo = s->plane_lo;
+        fa.frag_planes = s->frag_planes;
+        fa.row_limit = (int64_t)s->rows;
         fa.debug = EnvU32("GPANN_FILTER_DEBUG", 0);
         const bool dma = s->plane_hi != nullptr && s->plane_lo != nullptr;
         const bool aux = (flags & GPANN_AUX_PASS) != 0;
@@ -609,31 +664,40 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         ra.ld = s->ld;
         ra.cand_cap = cap;
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-        const size_t flds = dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
+        const size_t flds = (dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float)) + EnvU32("GPANN_FILTER_LDS_PAD", 0);   // (pad: occupancy experiments)
         const size_t rlds = (size_t)4 * s->ld * sizeof(float);
         GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
-        if (s->metric == GPANN_METRIC_L2) {
-            hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            if (dma && aux) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_L2, 1>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            } else if (dma) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_L2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_L2, 0>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            } else {
-                hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            }
+        if (s->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+        else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+        if (s->frag_planes) {
+            const void* fn = nullptr;
+            const bool l2 = s->metric == GPANN_METRIC_L2, ks4 = s->d <= 64;
+#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelReg<M, TAG_, KS_>
+            if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
+                             : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
+            else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
+                          : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
+#undef GPANN_PICK
+            const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+            GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            void* kargs[] = {&fa};
+            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)funits.size()), dim3(512), kargs, glds, st));
+        } else if (dma) {
+            const void* fn = nullptr;
+            const bool l2 = s->metric == GPANN_METRIC_L2, ks4 = s->d <= 64;
+#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelDma<M, TAG_, KS_>
+            if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
+                             : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
+            else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
+                          : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
+#undef GPANN_PICK
+            GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+            void* kargs[] = {&fa};
+            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)funits.size()), dim3(256), kargs, flds, st));
+        } else if (s->metric == GPANN_METRIC_L2) {
+            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
         } else {
-            hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            if (dma && aux) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_MIPS, 1>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            } else if (dma) {
-                GPANN_HIP_TRY(hipFuncSetAttribute((const void*)FilterKernelDma<GPANN_METRIC_MIPS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((FilterKernelDma<GPANN_METRIC_MIPS, 0>), dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            } else {
-                hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-            }
+            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
         }
         GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
@@ -734,6 +798,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.units = plan.units.size() + plan.filter_units.size();
     s->stats.padded_pairs = plan.padded_pairs;
     s->stats.filter_pairs = plan.filter_pairs;
+    s->stats.filter_rows = plan.filter_rows;
     s->stats.filter_candidates = plan.filter_candidates;
     return GPANN_OK;
 }

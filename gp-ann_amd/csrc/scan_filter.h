@@ -21,6 +21,8 @@
 
 #include "shards.h"
 
+#include <type_traits>
+
 namespace gpann {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,6 +49,8 @@ struct FilterArgs {
     uint32_t d, ld;
     const char* plane_hi;         // optional: pre-split bf16 planes [rows + 64][136] (FilterKernelDma)
     const char* plane_lo;
+    const char* frag_planes;      // optional: pre-split bf16 planes in MFMA fragment order (FilterKernelReg), see kGTileBytes
+    int64_t row_limit;            // rows of the store (frag_planes and neg_half_norm are readable 64 rows beyond it)
     uint32_t debug;               // experiments only: 1 = skip MFMA phase, 2 = skip DMA after the first tile, 4 = skip epilogue
 };
 
@@ -214,53 +218,16 @@ __device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) 
 }
 __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// TAG: profiling label as for ScanTileKernel (1 = auxiliary pass such as ground truth)
-template <int METRIC, int TAG>
-__global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
-    extern __shared__ uint4 fsm4[];
-    char* lds = reinterpret_cast<char*>(fsm4);
-
-    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
-    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// The tile loop of FilterKernelDma for a wave that owns NPT (1 or 2) of the two 32-row point tiles of every 64-row tile,
+// starting at point tile pt0, and NQT (0..2) query tiles whose fragments are qh/ql.  Everything in the MFMA phase is
+// compile-time shaped (KS k-steps, no branches) so that the A fragments of k-step ks+1 are read from LDS while the matrix
+// core works on k-step ks; a wave with NQT = 0 only moves its share of the tiles and keeps the barriers.
+template <int METRIC, int NPT, int NQT, int KS>
+__device__ __forceinline__ void FilterTileLoop(const FilterArgs& a, char* lds, uint32_t lds_base, int64_t row_begin, int64_t row_end, uint32_t task_begin,
+                                               uint32_t task_count, uint32_t qbase, int pt0, const Frag (&qh)[2][KS], const Frag (&ql)[2][KS],
+                                               const float (&U)[2], int wave, int lane) {
     const int c = lane & 31, h = lane >> 5;
-    const uint32_t d = a.d, ld = a.ld;
-    const int ksteps = (int)((d + 15) / 16);
-
-    // query tiles of 32 this wave really has (the unit's task count is rarely a multiple of 256): 0, 1 or 2.  A wave
-    // without tasks still takes part in the DMA and the barriers but issues no MFMA.
-    const int nqt = (int)min(2u, (task_count > 64u * wave ? task_count - 64u * wave + 31u : 0u) / 32u);
-    Frag qh[2][kFKS], ql[2][kFKS];
-    float U[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t tl = 64u * wave + 32u * t + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        U[t] = tl < task_count ? a.task_U[task] : INFINITY;
-        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
-#pragma unroll
-        for (int ks = 0; ks < kFKS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (ks < ksteps) {
-                const uint32_t k0 = 16u * ks + 8u * h;
-                if (k0 < ld) {
-                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                }
-                if (k0 + 4 < ld) {
-                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
-                    v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], qh[t][ks].u[j], ql[t][ks].u[j]);
-        }
-    }
-
     // 34 chunks of 1 KiB per tile (17 per plane); wave w moves chunks w, w + 4, ...
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
     auto issue = [&](int buf, int64_t row0) {
         for (int j = wave; j < 34; j += 4) {
             const int plane = j >= 17, chunk = j - 17 * plane;
@@ -277,83 +244,354 @@ __global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
     for (int64_t row0 = row_begin; row0 < row_end; row0 += kFPT, buf ^= 1) {
         // no ordinary global load may sit in this loop: beside an LDS-DMA in flight hipcc would wait vmcnt(0) for it before
         // the first LDS read and serialise DMA and MFMA (the row norms therefore travel inside the hi plane's row padding)
-        if (row0 + kFPT < row_end && !(a.debug & 2)) issue(buf ^ 1, row0 + kFPT);
-        const __bf16* sHi = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes);
-        const __bf16* sLo = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes + kFPlaneBytes);
-        const char* sN = lds + buf * kFBufBytes + 2 * 128;   // -|p|^2/2 of row r: float at byte r * 272 + 256 of the hi plane
+        const bool late = (a.debug & 8) != 0;
+        if (row0 + kFPT < row_end && !(a.debug & 2) && !late) issue(buf ^ 1, row0 + kFPT);   // (debug bits: timing experiments only)
+        if (NQT > 0 && !(a.debug & 1)) {
+            const __bf16* sHi = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes) + (32 * pt0 + c) * kFRowStride + 8 * h;
+            const __bf16* sLo = sHi + kFPlane;
+            const char* sN = lds + buf * kFBufBytes + 2 * 128;   // -|p|^2/2 of row r: float at byte r * 272 + 256 of the hi plane
 
-        f32x16 acc[2][2];
+            f32x16 acc[NPT][NQT > 0 ? NQT : 1];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (METRIC == GPANN_METRIC_L2) {
-                    const char* n0 = sN + (32 * pt + 8 * g + 4 * h) * kFRowBytes;
-                    nv.x = *reinterpret_cast<const float*>(n0);
-                    nv.y = *reinterpret_cast<const float*>(n0 + kFRowBytes);
-                    nv.z = *reinterpret_cast<const float*>(n0 + 2 * kFRowBytes);
-                    nv.w = *reinterpret_cast<const float*>(n0 + 3 * kFRowBytes);
-                }
+                for (int g = 0; g < 4; ++g) {
+                    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (METRIC == GPANN_METRIC_L2) {
+                        const char* n0 = sN + (32 * (pt0 + pt) + 8 * g + 4 * h) * kFRowBytes;
+                        nv.x = *reinterpret_cast<const float*>(n0);
+                        nv.y = *reinterpret_cast<const float*>(n0 + kFRowBytes);
+                        nv.z = *reinterpret_cast<const float*>(n0 + 2 * kFRowBytes);
+                        nv.w = *reinterpret_cast<const float*>(n0 + 3 * kFRowBytes);
+                    }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    acc[pt][qt][4 * g + 0] = nv.x;
-                    acc[pt][qt][4 * g + 1] = nv.y;
-                    acc[pt][qt][4 * g + 2] = nv.z;
-                    acc[pt][qt][4 * g + 3] = nv.w;
-                }
-            }
-#pragma unroll
-        for (int ks = 0; ks < kFKS; ++ks) {
-            if (ks < ksteps && nqt > 0 && !(a.debug & 1)) {
-                Frag ah[2], al[2];
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const int off = (32 * pt + c) * kFRowStride + 16 * ks + 8 * h;
-                    ah[pt].q = *reinterpret_cast<const uint4*>(sHi + off);
-                    al[pt].q = *reinterpret_cast<const uint4*>(sLo + off);
-                }
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    if (qt < nqt) {
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) {
-                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, ql[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                            acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                        }
+                    for (int qt = 0; qt < NQT; ++qt) {
+                        acc[pt][qt][4 * g + 0] = nv.x;
+                        acc[pt][qt][4 * g + 1] = nv.y;
+                        acc[pt][qt][4 * g + 2] = nv.z;
+                        acc[pt][qt][4 * g + 3] = nv.w;
                     }
                 }
+            Frag ah[2][NPT], al[2][NPT];   // double buffered over the k-steps
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                ah[0][pt].q = *reinterpret_cast<const uint4*>(sHi + 32 * pt * kFRowStride);
+                al[0][pt].q = *reinterpret_cast<const uint4*>(sLo + 32 * pt * kFRowStride);
             }
-        }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        ah[(ks + 1) & 1][pt].q = *reinterpret_cast<const uint4*>(sHi + 32 * pt * kFRowStride + 16 * (ks + 1));
+                        al[(ks + 1) & 1][pt].q = *reinterpret_cast<const uint4*>(sLo + 32 * pt * kFRowStride + 16 * (ks + 1));
+                    }
+                }
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1][pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1][pt].v, ql[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks & 1][pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
+                    }
+            }
 
-        bool any = false;
+            // candidates: acc >= U.  First the maximum of each accumulator block against U (U = +inf for absent tasks)
+            bool any = false;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < NQT; ++qt) {
+                    float m = acc[pt][qt][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) any |= acc[pt][qt][r] >= U[qt];
-        if (__any(any) && !(a.debug & 4)) {
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[pt][qt][r]);
+                    any |= m >= U[qt];
+                }
+            if (__any(any) && !(a.debug & 4)) {
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+                for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                    for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[pt][qt][r] >= U[qt]) {
-                            const int64_t row = row0 + 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const uint32_t tl = 64u * wave + 32u * qt + c;
-                            if (row < row_end && tl < task_count) {
-                                const uint32_t task = task_begin + tl;
-                                const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                                if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
+                        for (int r = 0; r < 16; ++r) {
+                            if (acc[pt][qt][r] >= U[qt]) {
+                                const int64_t row = row0 + 32 * (pt0 + pt) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const uint32_t tl = qbase + 32u * qt + c;
+                                if (row < row_end && tl < task_count) {
+                                    const uint32_t task = task_begin + tl;
+                                    const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
+                                    if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
+                                }
                             }
                         }
-                    }
+            }
         }
+        if (row0 + kFPT < row_end && !(a.debug & 2) && late) issue(buf ^ 1, row0 + kFPT);
         DmaWaitAll();      // this wave's share of the next tile has landed ...
         __syncthreads();   // ... and so has everyone else's; all waves are done reading `buf`
+    }
+}
+
+// TAG: profiling label as for ScanTileKernel (1 = auxiliary pass such as ground truth).  KS: k-steps of 16 dimensions
+// (4: d <= 64, 8: d <= 128; dimensions beyond d are zero in the planes and in the query fragments).
+template <int METRIC, int TAG, int KS>
+__global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
+    extern __shared__ uint4 fsm4[];
+    char* lds = reinterpret_cast<char*>(fsm4);
+
+    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
+    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t ld = a.ld;
+
+    // Wave roles.  A wave owns up to 2 query tiles of 32 tasks (their bf16 fragments live in registers) and 1 or 2 of the two
+    // 32-row point tiles; the time of a 64-row tile is the largest (query tiles x point tiles) product among the 4 waves.
+    // Units with few tasks split the ROWS between waves instead of leaving waves idle (mode, see FilterUnit).
+    const uint32_t mode = a.units[blockIdx.x].mode;
+    const uint32_t qbase = mode == 0 ? 64u * wave : (mode == 1 ? 64u * (wave & 1) : 32u * (wave & 1));
+    const int nqt = (int)min(mode == 2 ? 1u : 2u, (task_count > qbase ? task_count - qbase + 31u : 0u) / 32u);
+    Frag qh[2][KS], ql[2][KS];
+    float U[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t tl = qbase + 32u * t + c;
+        const uint32_t task = task_begin + min(tl, task_count - 1);
+        U[t] = (tl < task_count && t < nqt) ? a.task_U[task] : INFINITY;
+        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            const uint32_t k0 = 16u * ks + 8u * h;
+            if (k0 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            }
+            if (k0 + 4 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
+                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], qh[t][ks].u[j], ql[t][ks].u[j]);
+        }
+    }
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+#define GPANN_FILTER_LOOP(NPT, NQT, PT0) \
+    FilterTileLoop<METRIC, NPT, NQT, KS>(a, lds, lds_base, row_begin, row_end, task_begin, task_count, qbase, PT0, qh, ql, U, wave, lane)
+    if (nqt == 0) GPANN_FILTER_LOOP(1, 0, 0);
+    else if (mode == 0) {
+        if (nqt == 2) GPANN_FILTER_LOOP(2, 2, 0);
+        else GPANN_FILTER_LOOP(2, 1, 0);
+    } else {
+        if (nqt == 2) GPANN_FILTER_LOOP(1, 2, wave >> 1);
+        else GPANN_FILTER_LOOP(1, 1, wave >> 1);
+    }
+#undef GPANN_FILTER_LOOP
+}
+
+// ---- the filter with the QUERIES stationary in LDS and the points streamed through registers --------------------------------
+// FilterKernelDma stages point tiles in LDS for 256 tasks and keeps the query fragments in registers; every tile costs a
+// workgroup barrier, and an LDS-DMA fill landing in LDS and the ds_read/MFMA stream slow each other down (measured: filter time
+// = fill-only time + compute-only time, no overlap).  FilterKernelReg turns the roles around:
+//   * the bf16 hi/lo fragments of the unit's <= 256 tasks are built ONCE into LDS (128 KiB, in MFMA B-operand order: a
+//     ds_read_b128 with lane-linear addresses, conflict free) and stay there for the unit's whole row segment;
+//   * the points are pre-split in HBM in MFMA A-operand order — per 32-row tile and k-step one contiguous KiB per plane
+//     (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7) — so a wavefront loads a tile's fragments with 16 perfectly
+//     coalesced global_load_dwordx4 straight into the registers the MFMA reads.  No LDS traffic for the points, no barrier in
+//     the loop: the 8 wavefronts of a workgroup take tiles round robin and run independently, each prefetching its next tile
+//     into a second register set while the matrix core works on the current one;
+//   * every wavefront meets ALL tasks of the unit, so units with few tasks keep all 8 wavefronts busy;
+//   * candidates of a tile are collected as bit masks and written after the tile's MFMA phase, when the prefetch has landed
+//     (the atomic's vmcnt wait would otherwise stall on the loads issued before it).
+constexpr int kGTileRows = 32;
+constexpr int kGTileBytes = kFKS * 2 * 1024;   // [ks][plane hi|lo][lane][16 B]: 16 KiB per 32 rows (512 B per row)
+constexpr int kGTasks = 256;                   // tasks per unit: 8 query tiles of 32
+
+template <int METRIC, int TAG, int KS>
+__global__ void __launch_bounds__(512, 1) FilterKernelReg(FilterArgs a) {
+    extern __shared__ uint4 gsm4[];
+    char* lds = reinterpret_cast<char*>(gsm4);   // [8 query tiles][KS][2 planes][1 KiB]
+
+    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
+    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t ld = a.ld;
+    const int nqt = (int)((task_count + 31u) / 32u);
+
+    // ---- the query image: wavefront w builds query tile w (zeros for absent tasks)
+    {
+        const uint32_t tl = 32u * wave + c;
+        const uint32_t task = task_begin + min(tl, task_count - 1);
+        const bool real = tl < task_count;
+        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            const uint32_t k0 = 16u * ks + 8u * h;
+            if (real && k0 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            }
+            if (real && k0 + 4 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
+                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+            }
+            Frag fh, fl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
+            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 0) * 1024 + lane * 16) = fh.q;
+            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 1) * 1024 + lane * 16) = fl.q;
+        }
+    }
+    float U[8];
+#pragma unroll
+    for (int qt = 0; qt < 8; ++qt) {
+        const uint32_t tl = 32u * qt + c;
+        U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
+    }
+    __syncthreads();
+
+    const int64_t t_begin = row_begin >> 5, t_end = (row_end + 31) >> 5;
+    const char* lane_planes = a.frag_planes + lane * 16;
+    const char* lane_lds = lds + lane * 16;
+
+    // the tile's 32 row norms travel as one float per lane and are spread to the accumulator layout through 128 B of
+    // wave-private LDS (16 registers per buffered tile otherwise)
+    float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
+
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
+        const char* base = lane_planes + (size_t)T * kGTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Ah[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 0) * 1024);
+            Al[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 1) * 1024);
+        }
+        if (METRIC == GPANN_METRIC_L2) nrm = a.neg_half_norm[T * kGTileRows + c];
+    };
+
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, int64_t T) {
+        if (METRIC == GPANN_METRIC_L2) {
+            if (h == 0) wave_norms[c] = nrm;
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
+        // one pass of the k-loop for query tiles 2 qp and (PAIR) 2 qp + 1: two independent accumulator chains
+        auto pass = [&](auto pair_tag, int qp) {
+            constexpr bool PAIR = decltype(pair_tag)::value;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc0[4 * g + 0] = n.x; acc0[4 * g + 1] = n.y; acc0[4 * g + 2] = n.z; acc0[4 * g + 3] = n.w;
+                if (PAIR) {
+                    acc1[4 * g + 0] = n.x; acc1[4 * g + 1] = n.y; acc1[4 * g + 2] = n.z; acc1[4 * g + 3] = n.w;
+                }
+            }
+            const char* q0 = lane_lds + (2 * qp * KS) * 2048;
+            const char* q1 = lane_lds + ((2 * qp + 1) * KS) * 2048;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag bh0, bl0, bh1, bl1;
+                bh0.q = *reinterpret_cast<const uint4*>(q0 + ks * 2048);
+                bl0.q = *reinterpret_cast<const uint4*>(q0 + ks * 2048 + 1024);
+                if (PAIR) {
+                    bh1.q = *reinterpret_cast<const uint4*>(q1 + ks * 2048);
+                    bl1.q = *reinterpret_cast<const uint4*>(q1 + ks * 2048 + 1024);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
+            }
+            float m0 = acc0[0], m1 = PAIR ? acc1[0] : -INFINITY;
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                m0 = fmaxf(m0, acc0[r]);
+                if (PAIR) m1 = fmaxf(m1, acc1[r]);
+            }
+            if (__any(m0 >= U[2 * qp] || m1 >= U[2 * qp + 1])) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    bits |= acc0[r] >= U[2 * qp] ? 1u << r : 0u;
+                    if (PAIR) bits |= acc1[r] >= U[2 * qp + 1] ? 0x10000u << r : 0u;
+                }
+                cmask[qp] = bits;
+            }
+        };
+#pragma unroll
+        for (int qp = 0; qp < 4; ++qp) {
+            if (2 * qp + 1 < nqt) pass(std::true_type{}, qp);
+            else if (2 * qp < nqt) pass(std::false_type{}, qp);
+        }
+        if (__any((cmask[0] | cmask[1] | cmask[2] | cmask[3]) != 0u)) {
+#pragma unroll
+            for (int qp = 0; qp < 4; ++qp) {
+                uint32_t bits = cmask[qp];
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int r = b & 15;
+                    const int64_t row = T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
+                    if (row >= row_begin && row < row_end && tl < task_count) {
+                        const uint32_t task = task_begin + tl;
+                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
+                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
+                    }
+                }
+            }
+        }
+    };
+
+    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];
+    float n0 = 0.f, n1 = 0.f;
+    int64_t T = t_begin + wave;
+    if (T < t_end) load_tile(A0h, A0l, n0, T);
+    while (T < t_end) {
+        if (T + 8 < t_end) load_tile(A1h, A1l, n1, T + 8);
+        compute_tile(A0h, A0l, n0, T);
+        T += 8;
+        if (T >= t_end) break;
+        if (T + 8 < t_end) load_tile(A0h, A0l, n0, T + 8);
+        compute_tile(A1h, A1l, n1, T);
+        T += 8;
+    }
+}
+
+// f32 rows -> bf16 hi/lo planes in MFMA A-operand order (kGTileBytes per 32 rows); one thread per (row, 8 dimensions)
+static __global__ void __launch_bounds__(256) SplitFragPlanesKernel(const float* points, uint64_t rows, uint32_t ld, char* planes) {
+    const uint64_t total = rows * 16;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i >> 4;
+        const uint32_t g8 = (uint32_t)(i & 15);   // dims 8 g8 .. 8 g8 + 7
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (8 * g8 < ld) {
+            const float4 x = *reinterpret_cast<const float4*>(points + r * ld + 8 * g8);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        }
+        if (8 * g8 + 4 < ld) {
+            const float4 x = *reinterpret_cast<const float4*>(points + r * ld + 8 * g8 + 4);
+            v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+        }
+        Frag fh, fl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
+        const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
+        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + (ks * 2) * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(base) = fh.q;
+        *reinterpret_cast<uint4*>(base + 1024) = fl.q;
     }
 }
 

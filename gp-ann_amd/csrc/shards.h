@@ -21,6 +21,9 @@ struct ScanUnit {
 struct FilterUnit {
     int64_t row_begin, row_end;
     uint32_t task_begin, task_count;
+    uint32_t mode;   // how the 4 wavefronts share (tasks x 64-row tile): 0 = 64 tasks each, all rows (<= 256 tasks);
+                     // 1 = 64 tasks x half the rows (<= 128 tasks); 2 = 32 tasks x half the rows (<= 64 tasks)
+    uint32_t pad;
 };
 
 // Host-side launch plan of one scan call; kept alive in the handle until the next call because its arrays are the
@@ -29,7 +32,7 @@ struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
     std::vector<FilterUnit> filter_units;
-    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0;
     uint32_t filter_launches = 0;
     void Clear() {
         task_query.clear();
@@ -40,7 +43,7 @@ struct ScanPlan {
         shard_task_begin.clear();
         units.clear();
         filter_units.clear();
-        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = 0;
+        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = 0;
         filter_launches = 0;
     }
 };
@@ -64,6 +67,7 @@ struct gpann_shards {
     double* d_shard_rmax = nullptr;  // [S]
     char* plane_hi = nullptr;        // optional [rows + 64][136] bf16: the points pre-split for FilterKernelDma
     char* plane_lo = nullptr;
+    char* frag_planes = nullptr;     // optional: bf16 hi/lo planes in MFMA fragment order, 16 KiB per 32 rows (FilterKernelReg)
     bool filter_ok = false;
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 

@@ -177,7 +177,8 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     if (rows) {
         unsigned long long* d_max_bits = nullptr;
         uint32_t* d_bad = nullptr;
-        TRY_OR_FAIL(hipMalloc(&s->neg_half_norm, rows * sizeof(float)));
+        TRY_OR_FAIL(hipMalloc(&s->neg_half_norm, (rows + 64) * sizeof(float)));   // FilterKernelReg reads whole 32-row tiles
+        TRY_OR_FAIL(hipMemset(s->neg_half_norm + rows, 0, 64 * sizeof(float)));
         TRY_OR_FAIL(hipMalloc(&s->d_shard_rmax, S * sizeof(double)));
         TRY_OR_FAIL(hipMalloc(&d_bad, 4));
         d_max_bits = reinterpret_cast<unsigned long long*>(s->d_shard_rmax);   // non-negative doubles order like their bit patterns
@@ -190,10 +191,26 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         TRY_OR_FAIL(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_bad);
         s->filter_ok = bad == 0;
-        // pre-split bf16 planes for the DMA-fed filter (about 2.1x the bytes of the rows once more); optional: without them
-        // (allocation failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly
+        // pre-split bf16 planes for the filter (about as many bytes as the rows once more); optional: without them (allocation
+        // failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly.  Default layout: MFMA fragment order for
+        // FilterKernelReg; GPANN_FILTER_PLANES=dma builds the row-major padded planes of FilterKernelDma instead.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
-        if (s->filter_ok && d <= 128 && !(want && want[0] == '0')) {
+        const bool want_none = want && want[0] == '0', want_dma = want && std::string(want) == "dma";
+        if (s->filter_ok && d <= 128 && !want_none && !want_dma) {
+            const uint64_t tiles = (rows + kGTileRows - 1) / kGTileRows + 2;
+            if (hipMalloc(&s->frag_planes, tiles * (size_t)kGTileBytes) == hipSuccess) {
+                const uint64_t first_partial = rows / kGTileRows;
+                TRY_OR_FAIL(hipMemsetAsync(s->frag_planes + first_partial * (size_t)kGTileBytes, 0, (tiles - first_partial) * (size_t)kGTileBytes, 0));
+                const int g2 = (int)std::min<uint64_t>((rows * 16 + 255) / 256, 256 * 64);
+                hipLaunchKernelGGL(SplitFragPlanesKernel, dim3(g2), dim3(256), 0, 0, s->points, rows, s->ld, s->frag_planes);
+                TRY_OR_FAIL(hipGetLastError());
+                TRY_OR_FAIL(hipDeviceSynchronize());
+            } else {
+                (void)hipGetLastError();
+                s->frag_planes = nullptr;
+            }
+        }
+        if (s->filter_ok && d <= 128 && want_dma) {
             const size_t plane_bytes = (rows + 64) * (size_t)kFRowBytes;
             if (hipMalloc(&s->plane_hi, plane_bytes) == hipSuccess && hipMalloc(&s->plane_lo, plane_bytes) == hipSuccess) {
                 TRY_OR_FAIL(hipMemsetAsync(s->plane_hi + rows * (size_t)kFRowBytes, 0, 64 * (size_t)kFRowBytes, 0));
@@ -232,6 +249,7 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->d_shard_rmax) (void)hipFree(s->d_shard_rmax);
     if (s->plane_hi) (void)hipFree(s->plane_hi);
     if (s->plane_lo) (void)hipFree(s->plane_lo);
+    if (s->frag_planes) (void)hipFree(s->frag_planes);
     s->ws_lists.Release();
     s->ws_cand.Release();
     s->ws_funits0.Release();

@@ -135,6 +135,7 @@ typedef struct gpann_scan_stats {
     float merge_ms;              /* merge kernel(s), HIP events */
     float filter_ms;             /* of scan_ms: the MFMA filter kernels (threshold + filter launches of all passes) */
     float reserved2;
+    uint64_t filter_rows;        /* rows streamed by the filter kernels: sum over their workgroups of the row segment (all passes) */
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 
