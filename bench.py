@@ -367,20 +367,21 @@ def main():
     hbm_alg = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
     filtered = bool(stats["filtered"])
     # per step: the filter kernel is launched twice (two row ranges), the exact kernel once
-    traffic = lookup_traffic(n, d, S, nprobe, "FilterKernelDma<0, 0>" if filtered else "ScanTileKernel<0, 0>", 2 if filtered else 1)
+    traffic = lookup_traffic(n, d, S, nprobe, "FilterKernelReg<0, 0" if filtered else "ScanTileKernel<0, 0>", 2 if filtered else 1)
     if filtered:
         # dominant kernel: FilterKernelDma — bf16x3 matrix-core bound on (query, row) pairs: 3 MFMA products x 2 flop per dimension
         f_s = float(np.mean(filter_ms)) / 1000.0
         flops = stats["filter_pairs"] * d * 6.0
         achieved = flops / f_s / 1e12 if f_s > 0 else 0.0
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gpann::FilterKernelDma", "kernel_ms": 1000.0 * f_s,
+                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gpann::FilterKernelReg", "kernel_ms": 1000.0 * f_s,
                               "note": "the exact scan in filter mode: v_mfma_f32_32x32x16_bf16 on bf16 hi/lo planes (3 products) bounds every "
                                       "(query,row) distance, only candidates get the exact VALU evaluation; flops = filter_pairs x d x 6 per launch "
-                                      "(both filter launches of a step), time = HIP events around them",
+                                      "(both filter launches of a step; pairs = tasks padded to 32 x rows padded to 64 per workgroup), time = HIP "
+                                      "events around them",
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
-                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": stats["filter_rows"] * 544,
-                              "filter_plane_GBps": stats["filter_rows"] * 544 / f_s / 1e9 if f_s > 0 else 0.0,
+                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": stats["filter_rows"] * 512,
+                              "filter_plane_GBps": stats["filter_rows"] * 512 / f_s / 1e9 if f_s > 0 else 0.0,
                               "hbm_algorithmic_GBps": hbm_alg, "hbm_algorithmic_frac": hbm_alg / HBM_PEAK_GBPS}
     else:
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,

@@ -14,7 +14,8 @@
 //   OffsetsKernel    per problem: exclusive prefix of the cluster sizes = start of every cluster's member slab
 //   ScatterKernel    per chunk: STABLE counting sort of the rows by cluster — members of a cluster stay in ascending position
 //   SumKernel        per cluster: the reference's sequential float sum over its members IN POINT ORDER (batches of rows staged
-//                    through LDS by the whole workgroup, one column per thread doing the adds in order); beyond the
+//                    HBM -> registers -> LDS by the whole workgroup, the next batch in flight while one column per thread does the
+//                    adds of the current one in order); beyond the
 //                    reference's block size (kmeans.cpp:153) block partials are added in block order — one of the orders its
 //                    atomics can produce
 //   NormalizeKernel  per problem: divide / rescale, drop empty clusters (compacting the centroid slab)
@@ -42,7 +43,7 @@ constexpr int kKDC = 32;                // dims per staged chunk
 constexpr int kKStride = kKDC + 4;
 constexpr int kKThreads = 256;
 constexpr uint32_t kChunkRows = 2048;   // rows per counting chunk (one wavefront, 32 steps)
-constexpr uint32_t kSumFloats = 16384;  // floats of rows staged per SumKernel batch (64 KB of LDS)
+constexpr uint32_t kSumFloats = 8192;   // floats of rows staged per SumKernel batch (32 KB of LDS; one register stage of 8 float4 per thread)
 constexpr uint32_t kSumMaxRows = 256;
 constexpr uint32_t kMaxTrainDim = 1023; // SumKernel: 4 columns per thread, one more column for the IP norm sums
 
@@ -300,6 +301,9 @@ __global__ void __launch_bounds__(64) ScatterKernel(LloydArgs a) {
 
 // ---------------------------------------------------------------------------------------------------- SumKernel
 // One workgroup per slot.  Column `col` of the cluster's sum is accumulated by one thread, strictly in member order.
+// Batches of member rows travel HBM -> registers -> LDS: the loads of batch b+1 are in flight while batch b is summed.
+constexpr int kSumRegs = 8;   // float4 per thread and batch: 256 threads x 8 x 4 floats = kSumFloats
+
 template <int METRIC>
 __global__ void __launch_bounds__(kKThreads) SumKernel(LloydArgs a) {
     extern __shared__ float4 s_sum4[];
@@ -330,28 +334,70 @@ __global__ void __launch_bounds__(kKThreads) SumKernel(LloydArgs a) {
     const uint32_t ncols = METRIC == GPANN_METRIC_MIPS ? d + 1 : d;   // column d = norm_sums (kmeans.cpp:95)
     float part[4] = {0.f, 0.f, 0.f, 0.f}, total[4] = {0.f, 0.f, 0.f, 0.f};
 
+    // register stage of one batch: kSumRegs float4 of the rows, and (thread t < rows) the row's position / norm
+    float4 stage[kSumRegs];
+#pragma unroll
+    for (int r = 0; r < kSumRegs; ++r) stage[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t st_pos = 0;
+    float st_sn = 1.f;
+#define GPANN_SUM_FETCH(B0)                                                                                        \
+    do {                                                                                                           \
+        const uint32_t nr_ = min(batch_rows, size - (B0));                                                          \
+        _Pragma("unroll") for (int r = 0; r < kSumRegs; ++r) {                                                     \
+            const uint32_t f = (uint32_t)tid + 256u * r;                                                           \
+            const uint32_t row = f / ld4, c4 = f - row * ld4;                                                      \
+            if (row < nr_) {                                                                                       \
+                const uint32_t srow = a.members_row[base + (B0) + row];                                            \
+                stage[r] = *reinterpret_cast<const float4*>(a.X + (size_t)srow * ld + 4u * c4);                    \
+            }                                                                                                      \
+        }                                                                                                          \
+        if ((uint32_t)tid < nr_) {                                                                                 \
+            if (multi) st_pos = a.members_pos[base + (B0) + tid];                                                  \
+            if (METRIC == GPANN_METRIC_MIPS) st_sn = a.sqrt_norm[a.members_row[base + (B0) + tid]];                \
+        }                                                                                                          \
+    } while (0)
+    if (size) GPANN_SUM_FETCH(0u);
+
     for (uint32_t b0 = 0; b0 < size; b0 += batch_rows) {
         const uint32_t nr = min(batch_rows, size - b0);
-        __syncthreads();
-        // stage nr member rows: 4096 float4 slots, 16 per thread
-#pragma unroll 4
-        for (int r = 0; r < 16; ++r) {
+        __syncthreads();   // the previous batch has been summed
+#pragma unroll
+        for (int r = 0; r < kSumRegs; ++r) {
             const uint32_t f = (uint32_t)tid + 256u * r;
             const uint32_t row = f / ld4, c4 = f - row * ld4;
-            if (row < nr) {
-                const uint32_t srow = a.members_row[base + b0 + row];
-                reinterpret_cast<float4*>(sX)[row * ld4 + c4] = *reinterpret_cast<const float4*>(a.X + (size_t)srow * ld + 4u * c4);
-            }
+            if (row < nr) reinterpret_cast<float4*>(sX)[row * ld4 + c4] = stage[r];
         }
         if ((uint32_t)tid < nr) {
-            if (multi) sPos[tid] = a.members_pos[base + b0 + tid];
+            if (multi) sPos[tid] = st_pos;
             if (METRIC == GPANN_METRIC_MIPS) {
-                const float sn = a.sqrt_norm[a.members_row[base + b0 + tid]];
-                sMul[tid] = (1.0f / sn);     // kmeans.cpp:96
-                sSq[tid] = (sn * sn);        // kmeans.cpp:95
+                sMul[tid] = 1.0f / st_sn;     // kmeans.cpp:96
+                sSq[tid] = st_sn * st_sn;     // kmeans.cpp:95
             }
         }
         __syncthreads();
+        if (b0 + batch_rows < size) GPANN_SUM_FETCH(b0 + batch_rows);   // lands while this batch is summed
+
+        if (!multi && ncols <= (uint32_t)kKThreads) {
+            // the common shape: one column per thread, no slice boundaries
+            if ((uint32_t)tid < ncols) {
+                float p = part[0];
+                const float* col = sX + tid;
+                if (METRIC == GPANN_METRIC_MIPS) {
+                    if ((uint32_t)tid < d) {
+#pragma unroll 8
+                        for (uint32_t r = 0; r < nr; ++r) p = p + col[r * ld] * sMul[r];
+                    } else {
+#pragma unroll 8
+                        for (uint32_t r = 0; r < nr; ++r) p = p + sSq[r];
+                    }
+                } else {
+#pragma unroll 8
+                    for (uint32_t r = 0; r < nr; ++r) p = p + col[r * ld];
+                }
+                part[0] = p;
+            }
+            continue;
+        }
         for (uint32_t r = 0; r < nr; ++r) {
             if (multi) {
                 const uint32_t pos = sPos[r];
@@ -393,6 +439,8 @@ __global__ void __launch_bounds__(kKThreads) SumKernel(LloydArgs a) {
         else if (METRIC == GPANN_METRIC_MIPS && col == d) a.cnorm[slot] = result;
     }
 }
+
+#undef GPANN_SUM_FETCH
 
 // ---------------------------------------------------------------------------------------------------- NormalizeKernel
 // One workgroup per problem: kmeans.cpp:72-86 / :104-115, then RemoveEmptyClusters (:29-50) as a compaction of the slab.

@@ -544,6 +544,7 @@ struct ThresholdTree {
     const uint32_t* path_cent;   // [n_nodes][kPathMax]
     const uint32_t* cent_node;   // [C]
     uint32_t* pi;                // [slots][n_nodes] scratch
+    uint32_t visit_all;          // the budget exceeds the tree: every node is visited, steps 1-3 are skipped
 };
 
 __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(ReplayArgs a, ThresholdTree t) {
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
         for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
 
         // ---- 1. pi (order-preserving bits; 0 = root, later also "visited")
-        for (uint32_t u = lane; u < n_nodes; u += 64) {
+        for (uint32_t u = lane; u < n_nodes && !t.visit_all; u += 64) {
             uint32_t m = 0;
 #pragma unroll
             for (int j = 0; j < kPathMax; ++j) {
@@ -577,10 +578,10 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
 
         // ---- 2. x*: the smallest pi value at which the accumulated sizes reach the budget left after the roots
         const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
-        bool all = false, redo = false;
+        bool all = t.visit_all != 0, redo = false;
         uint32_t xs = 1;          // visited <=> pi < xs; 1 = roots only
         uint32_t w_lt = 0;        // sum of the sizes with pi < xs
-        if (budget_left > 0) {
+        if (budget_left > 0 && !all) {
             const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
             uint32_t prefix = 0, prefix_mask = 0;
             for (int pass = 0; pass < 4 && !all; ++pass) {
@@ -1116,6 +1117,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 tt.path_cent = r->path_cent;
                 tt.cent_node = r->cent_node;
                 tt.pi = r->ws_pi.as<uint32_t>();
+                tt.visit_all = (uint64_t)budget > C ? 1u : 0u;   // then budget_left exceeds the sizes of all non-root nodes together
                 if (t_lds > 48 * 1024)
                     GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterThresholdReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t_lds));
                 hipLaunchKernelGGL(RouterThresholdReplayKernel, dim3(t_grid), dim3(64 * kRWaves), t_lds, st, ra, tt);
