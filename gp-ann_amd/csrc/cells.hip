@@ -1,0 +1,244 @@
+// cells.hip — sub-clusters ("cells") of every shard for the MFMA pre-filter of the exact scan (gfx950).
+//
+// The reference's QueryBucket streams EVERY row of a probed shard (src/inverted_index.h:64-68).  The result only depends on
+// the rows within the k-th distance, so whole groups of rows can be skipped when a bound proves them farther than that.
+// At store build every shard is cut into cells by a few Lloyd rounds of the batched k-means engine (kmeans.hip, L2 geometry
+// whatever the metric) and the filter's bf16 planes are written cell by cell; per cell the store keeps centre c and radius
+// r = max |p - c|.  For a task (query q, current k-th distance tau) every row p of the cell has
+//     L2:   |q - p| >= |q - c| - r                      MIPS:   q.p <= q.c + |q| r
+// so the cell is skipped when that bound already exceeds tau (scan_cells.h makes the comparison safe against the rounding of
+// the canonical binary32 distance).  Exactness is untouched: skipped rows cannot enter the top-k, all other rows go through
+// the same filter + exact re-scoring as before.
+#include "kmeans.h"
+#include "scan_filter.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace gpann {
+
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+
+// plane_perm / plane_norm of one cell: members in slab order, then padding up to the tile boundary.  One workgroup per cell.
+__global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members, const uint64_t* cell_member_begin, const uint32_t* cell_size,
+                                                        const uint64_t* cell_tile_begin, const float* neg_half_norm, uint32_t* plane_perm,
+                                                        float* plane_norm) {
+    const uint32_t cell = blockIdx.x;
+    const uint64_t src = cell_member_begin[cell], dst = cell_tile_begin[cell] * kGTileRows;
+    const uint32_t size = cell_size[cell];
+    const uint32_t padded = (uint32_t)((cell_tile_begin[cell + 1] - cell_tile_begin[cell]) * kGTileRows);
+    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
+        const uint32_t row = i < size ? members[src + i] : kNoRow;
+        plane_perm[dst + i] = row;
+        plane_norm[dst + i] = row != kNoRow ? neg_half_norm[row] : -INFINITY;
+    }
+}
+
+// bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
+__global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
+                                                                 char* planes) {
+    const uint64_t total = plane_rows * 16;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i >> 4;
+        const uint32_t g8 = (uint32_t)(i & 15);
+        const uint32_t row = plane_perm[r];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (row != kNoRow && 8 * g8 < ld) {
+            const float4 x = *reinterpret_cast<const float4*>(points + (size_t)row * ld + 8 * g8);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        }
+        if (row != kNoRow && 8 * g8 + 4 < ld) {
+            const float4 x = *reinterpret_cast<const float4*>(points + (size_t)row * ld + 8 * g8 + 4);
+            v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+        }
+        Frag fh, fl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
+        const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
+        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + (ks * 2) * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(base) = fh.q;
+        *reinterpret_cast<uint4*>(base + 1024) = fl.q;
+    }
+}
+
+// radius of every cell: max over its rows of |p - c| (double accumulation), rounded up.  One workgroup per cell.
+__global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, const uint32_t* plane_perm, const uint64_t* cell_tile_begin,
+                                                        const float* center, uint32_t d, uint32_t ld, float* radius) {
+    __shared__ double s_max[256];
+    const uint32_t cell = blockIdx.x;
+    const uint64_t begin = cell_tile_begin[cell] * kGTileRows, end = cell_tile_begin[cell + 1] * kGTileRows;
+    const float* c = center + (size_t)cell * ld;
+    double mx = 0.0;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t row = plane_perm[i];
+        if (row == kNoRow) continue;
+        const float* p = points + (size_t)row * ld;
+        double acc = 0.0;
+        for (uint32_t x = 0; x < d; ++x) {
+            const double df = (double)p[x] - (double)c[x];
+            acc += df * df;
+        }
+        mx = fmax(mx, acc);
+    }
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double r = sqrt(s_max[0]) * (1.0 + 1e-6);
+        float rf = (float)r;
+        if ((double)rf < r) rf = nextafterf(rf, INFINITY);
+        radius[cell] = rf;
+    }
+}
+
+void ReleaseCells(gpann_shards* s) {
+    auto& c = s->cells;
+    for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
+                    (void*)c.plane_norm})
+        if (p) (void)hipFree(p);
+    c = gpann_shards::Cells{};
+}
+
+// Builds s->cells and s->frag_planes (cell order).  On any failure the store is left without cells and without planes
+// (the caller then builds the plain row-order planes); returns GPANN_OK unless the device itself failed.
+gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
+    const uint32_t S = s->S, ld = s->ld;
+    auto give_up = [&](const char* why) {
+        (void)why;
+        (void)hipGetLastError();
+        ReleaseCells(s);
+        if (s->frag_planes) (void)hipFree(s->frag_planes);
+        s->frag_planes = nullptr;
+        return GPANN_OK;
+    };
+    LloydSession session;
+    if (session.Begin(s, GPANN_METRIC_L2) != GPANN_OK) return give_up("session");
+
+    // one problem per non-empty shard: K_b cells, initial centres at evenly spaced rows
+    std::vector<LloydTask> level;
+    std::vector<uint32_t> pick, shard_of;
+    for (uint32_t b = 0; b < S; ++b) {
+        const uint64_t n = (uint64_t)(s->offsets[b + 1] - s->offsets[b]);
+        if (n == 0) continue;
+        const uint32_t K = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(1, (n + target_rows / 2) / target_rows));
+        level.push_back({(uint64_t)s->offsets[b], (uint32_t)n, K});
+        for (uint32_t x = 0; x < K; ++x) pick.push_back((uint32_t)((uint64_t)x * n / K));
+        shard_of.push_back(b);
+    }
+    LloydResult res;
+    const int rounds = 4;
+    if (session.RunLevel(level, pick, rounds, res) != GPANN_OK) return give_up("lloyd");
+
+    // surviving cells, shard by shard, in slot order; tiles
+    auto& C = s->cells;
+    C.shard_cell_begin.assign(S + 1, 0);
+    C.cell_tile_begin.assign(1, 0);
+    std::vector<uint64_t> member_begin;
+    std::vector<uint32_t> cell_size;
+    std::vector<float> centers;
+    {
+        size_t p = 0;
+        for (uint32_t b = 0; b < S; ++b) {
+            C.shard_cell_begin[b] = (uint32_t)cell_size.size();
+            if (p < shard_of.size() && shard_of[p] == b) {
+                const uint32_t cb = res.cent_begin[p];
+                // surviving cells in slot order, then renumbered along a greedy nearest-neighbour chain over their centres: cells
+                // with neighbouring numbers are neighbours in space, so tasks sorted by nearest cell form spatially coherent
+                // 32-task query tiles (the unit the filter can skip by)
+                struct Surv {
+                    uint32_t slot, index;
+                };
+                std::vector<Surv> surv;
+                for (uint32_t j = 0; j < level[p].k0; ++j)
+                    if (res.csize[cb + j] != 0) surv.push_back({j, (uint32_t)surv.size()});
+                const uint32_t ns = (uint32_t)surv.size();
+                std::vector<uint32_t> chain;
+                std::vector<uint8_t> used(ns, 0);
+                uint32_t cur = 0;
+                for (uint32_t step = 0; step < ns; ++step) {
+                    used[cur] = 1;
+                    chain.push_back(cur);
+                    const float* cc = &res.cent[(size_t)(cb + surv[cur].index) * ld];
+                    double best = INFINITY;
+                    uint32_t nxt = cur;
+                    for (uint32_t o = 0; o < ns; ++o) {
+                        if (used[o]) continue;
+                        const float* oc = &res.cent[(size_t)(cb + surv[o].index) * ld];
+                        double acc = 0.0;
+                        for (uint32_t x = 0; x < s->d; ++x) acc += ((double)cc[x] - oc[x]) * ((double)cc[x] - oc[x]);
+                        if (acc < best) {
+                            best = acc;
+                            nxt = o;
+                        }
+                    }
+                    cur = nxt;
+                }
+                uint32_t survivor = 0;
+                for (uint32_t ci : chain) {
+                    const uint32_t j = surv[ci].slot;
+                    const uint32_t sz = res.csize[cb + j];
+                    member_begin.push_back(level[p].row_begin + res.coff[cb + j]);
+                    cell_size.push_back(sz);
+                    C.cell_tile_begin.push_back(C.cell_tile_begin.back() + (sz + kGTileRows - 1) / kGTileRows);
+                    const float* c = &res.cent[(size_t)(cb + surv[ci].index) * ld];
+                    centers.insert(centers.end(), c, c + ld);
+                    ++survivor;
+                }
+                C.kmax = std::max(C.kmax, survivor);
+                ++p;
+            }
+        }
+        C.shard_cell_begin[S] = (uint32_t)cell_size.size();
+    }
+    C.n_cells = (uint32_t)cell_size.size();
+    C.n_tiles = C.cell_tile_begin.back();
+    if (C.n_cells == 0) return give_up("no cells");
+    const uint64_t plane_rows = C.n_tiles * kGTileRows;
+
+    uint64_t* d_member_begin = nullptr;
+    uint32_t* d_cell_size = nullptr;
+    bool ok = hipMalloc(&C.d_shard_cell_begin, (S + 1) * 4) == hipSuccess && hipMalloc(&C.d_cell_tile_begin, (C.n_cells + 1) * 8) == hipSuccess &&
+              hipMalloc(&C.d_center, (size_t)C.n_cells * ld * 4) == hipSuccess && hipMalloc(&C.d_radius, (size_t)C.n_cells * 4) == hipSuccess &&
+              hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
+              hipMalloc(&C.plane_perm, plane_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (plane_rows + 64) * 4) == hipSuccess &&
+              hipMalloc(&s->frag_planes, (C.n_tiles + 2) * (size_t)kGTileBytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
+              hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess;
+    std::vector<float> cnorm(C.n_cells);
+    for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
+        double acc = 0.0;
+        for (uint32_t x = 0; x < s->d; ++x) acc += (double)centers[(size_t)cidx * ld + x] * (double)centers[(size_t)cidx * ld + x];
+        cnorm[cidx] = (float)(acc * (1.0 + 1e-6));
+    }
+    if (ok) {
+        ok = hipMemcpy(C.d_cnorm, cnorm.data(), (size_t)C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(C.d_shard_cell_begin, C.shard_cell_begin.data(), (S + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(C.d_cell_tile_begin, C.cell_tile_begin.data(), (C.n_cells + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(C.d_center, centers.data(), (size_t)C.n_cells * ld * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(d_member_begin, member_begin.data(), C.n_cells * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(d_cell_size, cell_size.data(), C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemset(C.plane_norm + plane_rows, 0, 64 * 4) == hipSuccess &&
+             hipMemset(s->frag_planes + C.n_tiles * (size_t)kGTileBytes, 0, 2 * (size_t)kGTileBytes) == hipSuccess;
+    }
+    if (ok) {
+        hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
+                           s->neg_half_norm, C.plane_perm, C.plane_norm);
+        const int g2 = (int)std::min<uint64_t>((plane_rows * 16 + 255) / 256, 256 * 64);
+        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes);
+        hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (d_member_begin) (void)hipFree(d_member_begin);
+    if (d_cell_size) (void)hipFree(d_cell_size);
+    if (!ok) return give_up("device");
+    return GPANN_OK;
+}
+
+}  // namespace gpann

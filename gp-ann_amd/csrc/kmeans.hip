@@ -27,6 +27,7 @@
 // sees, per level, the surviving centroids and cluster sizes, applies the reference's budget rules / std::partition /
 // std::sample (libstdc++ semantics matter, so these calls stay std::) and emits the next level's problem list.
 #include "shards.h"
+#include "kmeans.h"
 
 #include <algorithm>
 #include <atomic>
@@ -546,6 +547,168 @@ struct TrainNode {
     std::vector<uint32_t> children;   // node indices in the shard's list
 };
 
+// ---------------------------------------------------------------------------------------------------- LloydSession
+#define LLOYD_HIP(expr)                                                                               \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return _e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP;                         \
+        }                                                                                             \
+    } while (0)
+
+LloydSession::~LloydSession() { End(); }
+
+void LloydSession::End() {
+    for (DeviceBuffer* b : {&b_rows[0], &b_rows[1], &b_owner, &b_mpos, &b_sqrt, &b_probs, &b_tiles, &b_chunks, &b_ccnt, &b_cbase, &b_cent, &b_csum, &b_cnorm,
+                            &b_cnum, &b_csize, &b_coff, &b_slotprob, &b_pick})
+        b->Release();
+    store_ = nullptr;
+}
+
+gpann_status LloydSession::Begin(gpann_shards* s, int metric) {
+    End();
+    GPANN_REQUIRE(s->d <= kMaxTrainDim, "k-means supports d <= 1023");
+    GPANN_REQUIRE(s->rows < (1ull << 32), "k-means needs fewer than 2^32 rows");
+    GPANN_TRY(EnsureDevice(s->device));
+    store_ = s;
+    metric_ = metric;
+    cur_ = 0;
+    const uint64_t R = std::max<uint64_t>(s->rows, 1);
+    hipStream_t st = nullptr;
+    GPANN_TRY(b_rows[0].Reserve(R * 4));
+    GPANN_TRY(b_rows[1].Reserve(R * 4));
+    GPANN_TRY(b_owner.Reserve(R * 4));
+    GPANN_TRY(b_mpos.Reserve(R * 4));
+    hipLaunchKernelGGL(IotaKernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, b_rows[0].as<uint32_t>(), s->rows);
+    LLOYD_HIP(hipGetLastError());
+    if (metric == GPANN_METRIC_MIPS) {
+        GPANN_TRY(b_sqrt.Reserve(R * 4));
+        hipLaunchKernelGGL(SqrtNormKernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, s->points, s->rows, s->d, s->ld, b_sqrt.as<float>());
+        LLOYD_HIP(hipGetLastError());
+    }
+    return GPANN_OK;
+}
+
+const uint32_t* LloydSession::rows() const { return b_rows[cur_].as<uint32_t>(); }
+
+gpann_status LloydSession::RunLevel(const std::vector<LloydTask>& level, const std::vector<uint32_t>& pick, int rounds, LloydResult& out) {
+    gpann_shards* s = store_;
+    const uint32_t d = s->d, ld = s->ld;
+    const bool mips = metric_ == GPANN_METRIC_MIPS;
+    hipStream_t st = nullptr;
+    const uint32_t P = (uint32_t)level.size();
+    std::vector<LloydProblem> probs(P);
+    uint32_t n_slots = 0, kmax = 0, n_chunks = 0;
+    uint64_t n_tiles = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        probs[p].row_begin = level[p].row_begin;
+        probs[p].n = level[p].n;
+        probs[p].cent_begin = n_slots;
+        probs[p].k0 = level[p].k0;
+        probs[p].chunk_begin = n_chunks;
+        probs[p].n_chunks = (level[p].n + kChunkRows - 1) / kChunkRows;
+        probs[p].pad = 0;
+        n_slots += level[p].k0;
+        kmax = std::max(kmax, level[p].k0);
+        n_chunks += probs[p].n_chunks;
+        n_tiles += (level[p].n + kKP - 1) / kKP;
+    }
+    GPANN_REQUIRE(pick.size() == n_slots, "one initial row per centroid slot");
+    std::vector<uint32_t> slot_prob(n_slots);
+    std::vector<TileRef> tiles, chunks;
+    tiles.reserve(n_tiles);
+    chunks.reserve(n_chunks);
+    for (uint32_t p = 0; p < P; ++p) {
+        for (uint32_t x = 0; x < probs[p].k0; ++x) slot_prob[probs[p].cent_begin + x] = p;
+        for (uint32_t f = 0; f < probs[p].n; f += kKP) tiles.push_back({p, f});
+        for (uint32_t f = 0; f < probs[p].n; f += kChunkRows) chunks.push_back({p, f});
+    }
+    GPANN_TRY(b_probs.Reserve(std::max<size_t>(P, 1) * sizeof(LloydProblem)));
+    GPANN_TRY(b_tiles.Reserve(std::max<size_t>(tiles.size(), 1) * sizeof(TileRef)));
+    GPANN_TRY(b_chunks.Reserve(std::max<size_t>(chunks.size(), 1) * sizeof(TileRef)));
+    GPANN_TRY(b_ccnt.Reserve(std::max<size_t>((size_t)n_chunks * kmax, 1) * 4));
+    GPANN_TRY(b_cbase.Reserve(std::max<size_t>((size_t)n_chunks * kmax, 1) * 4));
+    GPANN_TRY(b_cent.Reserve(std::max<size_t>((size_t)n_slots * ld, 1) * 4));
+    GPANN_TRY(b_csum.Reserve(std::max<size_t>((size_t)n_slots * ld, 1) * 4));
+    GPANN_TRY(b_cnorm.Reserve(std::max<size_t>(n_slots, 1) * 4));
+    GPANN_TRY(b_cnum.Reserve(std::max<size_t>(P, 1) * 4));
+    GPANN_TRY(b_csize.Reserve(std::max<size_t>(n_slots, 1) * 4));
+    GPANN_TRY(b_coff.Reserve(std::max<size_t>(n_slots, 1) * 4));
+    GPANN_TRY(b_slotprob.Reserve(std::max<size_t>(n_slots, 1) * 4));
+    GPANN_TRY(b_pick.Reserve(std::max<size_t>(n_slots, 1) * 4));
+    out.cent_begin.resize(P);
+    out.cnum.resize(P);
+    for (uint32_t p = 0; p < P; ++p) {
+        out.cent_begin[p] = probs[p].cent_begin;
+        out.cnum[p] = probs[p].k0;
+    }
+    out.n_slots = n_slots;
+    out.ld = ld;
+    if (P == 0 || n_slots == 0) return GPANN_OK;
+    LLOYD_HIP(hipMemcpyAsync(b_probs.ptr, probs.data(), P * sizeof(LloydProblem), hipMemcpyHostToDevice, st));
+    LLOYD_HIP(hipMemcpyAsync(b_tiles.ptr, tiles.data(), tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, st));
+    LLOYD_HIP(hipMemcpyAsync(b_chunks.ptr, chunks.data(), chunks.size() * sizeof(TileRef), hipMemcpyHostToDevice, st));
+    LLOYD_HIP(hipMemcpyAsync(b_cnum.ptr, out.cnum.data(), P * 4, hipMemcpyHostToDevice, st));
+    LLOYD_HIP(hipMemcpyAsync(b_slotprob.ptr, slot_prob.data(), n_slots * 4, hipMemcpyHostToDevice, st));
+    LLOYD_HIP(hipMemcpyAsync(b_pick.ptr, pick.data(), n_slots * 4, hipMemcpyHostToDevice, st));
+
+    LloydArgs a{};
+    a.X = s->points;
+    a.sqrt_norm = b_sqrt.as<float>();
+    a.probs = b_probs.as<LloydProblem>();
+    a.rows = b_rows[cur_].as<uint32_t>();
+    a.cent = b_cent.as<float>();
+    a.csum = b_csum.as<float>();
+    a.cnorm = b_cnorm.as<float>();
+    a.cnum = b_cnum.as<uint32_t>();
+    a.csize = b_csize.as<uint32_t>();
+    a.coff = b_coff.as<uint32_t>();
+    a.slot_prob = b_slotprob.as<uint32_t>();
+    a.owner = b_owner.as<int32_t>();
+    a.members_row = b_rows[cur_ ^ 1].as<uint32_t>();
+    a.members_pos = b_mpos.as<uint32_t>();
+    a.tiles = b_tiles.as<TileRef>();
+    a.chunks = b_chunks.as<TileRef>();
+    a.chunk_cnt = b_ccnt.as<uint32_t>();
+    a.chunk_base = b_cbase.as<uint32_t>();
+    a.n_probs = P;
+    a.n_slots = n_slots;
+    a.kmax = kmax;
+    a.d = d;
+    a.ld = ld;
+
+    hipLaunchKernelGGL(GatherInitKernel, dim3(n_slots), dim3(64), 0, st, a, b_pick.as<uint32_t>());
+    LLOYD_HIP(hipGetLastError());
+    const size_t sum_lds = (size_t)kSumFloats * 4 + (size_t)kSumMaxRows * 12;
+    for (int round = 0; round < rounds; ++round) {
+        if (mips) hipLaunchKernelGGL(AssignKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)tiles.size()), dim3(kKThreads), 0, st, a);
+        else hipLaunchKernelGGL(AssignKernel<GPANN_METRIC_L2>, dim3((uint32_t)tiles.size()), dim3(kKThreads), 0, st, a);
+        hipLaunchKernelGGL(CountKernel, dim3(n_chunks), dim3(64), (size_t)kmax * 4, st, a);
+        hipLaunchKernelGGL(ChunkScanKernel, dim3((n_slots + 3) / 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(OffsetsKernel, dim3((P + 3) / 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(ScatterKernel, dim3(n_chunks), dim3(64), (size_t)kmax * 4, st, a);
+        if (mips) {
+            hipLaunchKernelGGL(SumKernel<GPANN_METRIC_MIPS>, dim3(n_slots), dim3(kKThreads), sum_lds, st, a);
+            hipLaunchKernelGGL(NormalizeKernel<GPANN_METRIC_MIPS>, dim3(P), dim3(kKThreads), (size_t)kmax * 8, st, a);
+        } else {
+            hipLaunchKernelGGL(SumKernel<GPANN_METRIC_L2>, dim3(n_slots), dim3(kKThreads), sum_lds, st, a);
+            hipLaunchKernelGGL(NormalizeKernel<GPANN_METRIC_L2>, dim3(P), dim3(kKThreads), (size_t)kmax * 8, st, a);
+        }
+        LLOYD_HIP(hipGetLastError());
+    }
+    out.csize.resize(n_slots);
+    out.coff.resize(n_slots);
+    out.cent.resize((size_t)n_slots * ld);
+    LLOYD_HIP(hipMemcpyAsync(out.cnum.data(), b_cnum.ptr, P * 4, hipMemcpyDeviceToHost, st));
+    LLOYD_HIP(hipMemcpyAsync(out.csize.data(), b_csize.ptr, n_slots * 4, hipMemcpyDeviceToHost, st));
+    LLOYD_HIP(hipMemcpyAsync(out.coff.data(), b_coff.ptr, n_slots * 4, hipMemcpyDeviceToHost, st));
+    LLOYD_HIP(hipMemcpyAsync(out.cent.data(), b_cent.ptr, (size_t)n_slots * ld * 4, hipMemcpyDeviceToHost, st));
+    LLOYD_HIP(hipStreamSynchronize(st));
+    cur_ ^= 1;   // this level's member slabs are the next level's rows
+    return GPANN_OK;
+}
+
 }  // namespace gpann
 
 using namespace gpann;
@@ -555,51 +718,10 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
     GPANN_REQUIRE(s != nullptr && out != nullptr, "null handle");
     *out = nullptr;
     GPANN_REQUIRE(n_points > 0, "n_points must be positive");
-    GPANN_REQUIRE(s->d <= kMaxTrainDim, "router training supports d <= 1023");
-    GPANN_REQUIRE(s->rows < (1ull << 32), "router training needs fewer than 2^32 rows");
     GPANN_REQUIRE(num_centroids >= 1 && num_centroids <= 4096, "num_centroids must be in [1, 4096]");
-    const uint32_t S = s->S, d = s->d, ld = s->ld;
-    GPANN_TRY(EnsureDevice(s->device));
-    const bool mips = s->metric == GPANN_METRIC_MIPS;
-    hipStream_t st = nullptr;
-    const uint64_t R = s->rows;
-
-    DeviceBuffer b_rows[2], b_owner, b_mpos, b_sqrt, b_probs, b_tiles, b_chunks, b_ccnt, b_cbase, b_cent, b_csum, b_cnorm, b_cnum, b_csize, b_coff,
-        b_slotprob, b_pick;
-    auto release = [&] {
-        for (DeviceBuffer* b : {&b_rows[0], &b_rows[1], &b_owner, &b_mpos, &b_sqrt, &b_probs, &b_tiles, &b_chunks, &b_ccnt, &b_cbase, &b_cent, &b_csum,
-                                &b_cnorm, &b_cnum, &b_csize, &b_coff, &b_slotprob, &b_pick})
-            b->Release();
-    };
-#define TRAIN_TRY(expr)                  \
-    do {                                 \
-        gpann_status _s = (expr);        \
-        if (_s != GPANN_OK) {            \
-            release();                   \
-            return _s;                   \
-        }                                \
-    } while (0)
-#define TRAIN_HIP(expr)                                                                               \
-    do {                                                                                              \
-        hipError_t _e = (expr);                                                                       \
-        if (_e != hipSuccess) {                                                                       \
-            SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
-            release();                                                                                \
-            return _e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP;                         \
-        }                                                                                             \
-    } while (0)
-
-    TRAIN_TRY(b_rows[0].Reserve(R * 4));
-    TRAIN_TRY(b_rows[1].Reserve(R * 4));
-    TRAIN_TRY(b_owner.Reserve(R * 4));
-    TRAIN_TRY(b_mpos.Reserve(R * 4));
-    hipLaunchKernelGGL(IotaKernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, b_rows[0].as<uint32_t>(), R);
-    TRAIN_HIP(hipGetLastError());
-    if (mips) {
-        TRAIN_TRY(b_sqrt.Reserve(R * 4));
-        hipLaunchKernelGGL(SqrtNormKernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, st, s->points, R, d, ld, b_sqrt.as<float>());
-        TRAIN_HIP(hipGetLastError());
-    }
+    const uint32_t S = s->S, d = s->d;
+    LloydSession session;
+    GPANN_TRY(session.Begin(s, s->metric));
 
     // kmeans_tree_router.cpp:9-33: one root problem per shard, budget share by shard size, seed 555 * b
     std::vector<std::vector<TrainNode>> nodes(S);
@@ -619,143 +741,48 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
         level.push_back(p);
     }
 
-    int cur = 0;
     while (!level.empty()) {
         const uint32_t P = (uint32_t)level.size();
-        // ---- host: problem table, initial samples, tile and chunk lists
-        std::vector<LloydProblem> probs(P);
-        uint32_t n_slots = 0, kmax = 0, n_chunks = 0;
-        uint64_t n_tiles = 0;
+        // ---- host: problem sizes and the initial samples
+        std::vector<LloydTask> tasks(P);
+        std::vector<uint32_t> slot_begin(P + 1, 0);
         for (uint32_t p = 0; p < P; ++p) {
             // kmeans_tree_router.cpp:36: std::max(2, std::min<int>(options.num_centroids, options.budget))
             const uint32_t k0 = (uint32_t)std::max(2, std::min<int>((int)num_centroids, (int)level[p].budget));
-            probs[p].row_begin = level[p].row_begin;
-            probs[p].n = level[p].n;
-            probs[p].cent_begin = n_slots;
-            probs[p].k0 = k0;
-            probs[p].chunk_begin = n_chunks;
-            probs[p].n_chunks = (level[p].n + kChunkRows - 1) / kChunkRows;
-            probs[p].pad = 0;
-            n_slots += k0;
-            kmax = std::max(kmax, k0);
-            n_chunks += probs[p].n_chunks;
-            n_tiles += (level[p].n + kKP - 1) / kKP;
+            tasks[p] = {level[p].row_begin, level[p].n, k0};
+            slot_begin[p + 1] = slot_begin[p] + k0;
         }
-        std::vector<uint32_t> pick(n_slots, 0), slot_prob(n_slots);
+        std::vector<uint32_t> pick(slot_begin[P], 0);
         ParallelForHost(P, [&](size_t p) {
             // kmeans.cpp:212-217; when the problem has fewer rows than samples the tail of `sample` stays 0
-            const uint32_t n = probs[p].n, k0 = probs[p].k0;
+            const uint32_t n = tasks[p].n, k0 = tasks[p].k0;
             std::vector<int> all(n);
             std::iota(all.begin(), all.end(), 0);
             std::mt19937 prng(level[p].seed);
             std::vector<int> sample(k0);
             std::sample(all.begin(), all.end(), sample.begin(), k0, prng);
-            for (uint32_t x = 0; x < k0; ++x) {
-                pick[probs[p].cent_begin + x] = (uint32_t)sample[x];
-                slot_prob[probs[p].cent_begin + x] = (uint32_t)p;
-            }
+            for (uint32_t x = 0; x < k0; ++x) pick[slot_begin[p] + x] = (uint32_t)sample[x];
         });
-        std::vector<TileRef> tiles;
-        tiles.reserve(n_tiles);
-        std::vector<TileRef> chunks;
-        chunks.reserve(n_chunks);
-        for (uint32_t p = 0; p < P; ++p) {
-            for (uint32_t f = 0; f < probs[p].n; f += kKP) tiles.push_back({p, f});
-            for (uint32_t f = 0; f < probs[p].n; f += kChunkRows) chunks.push_back({p, f});
-        }
-
-        TRAIN_TRY(b_probs.Reserve(P * sizeof(LloydProblem)));
-        TRAIN_TRY(b_tiles.Reserve(tiles.size() * sizeof(TileRef)));
-        TRAIN_TRY(b_chunks.Reserve(chunks.size() * sizeof(TileRef)));
-        TRAIN_TRY(b_ccnt.Reserve((size_t)n_chunks * kmax * 4));
-        TRAIN_TRY(b_cbase.Reserve((size_t)n_chunks * kmax * 4));
-        TRAIN_TRY(b_cent.Reserve((size_t)n_slots * ld * 4));
-        TRAIN_TRY(b_csum.Reserve((size_t)n_slots * ld * 4));
-        TRAIN_TRY(b_cnorm.Reserve((size_t)n_slots * 4));
-        TRAIN_TRY(b_cnum.Reserve((size_t)P * 4));
-        TRAIN_TRY(b_csize.Reserve((size_t)n_slots * 4));
-        TRAIN_TRY(b_coff.Reserve((size_t)n_slots * 4));
-        TRAIN_TRY(b_slotprob.Reserve((size_t)n_slots * 4));
-        TRAIN_TRY(b_pick.Reserve((size_t)n_slots * 4));
-        std::vector<uint32_t> cnum(P);
-        for (uint32_t p = 0; p < P; ++p) cnum[p] = probs[p].k0;
-        TRAIN_HIP(hipMemcpyAsync(b_probs.ptr, probs.data(), P * sizeof(LloydProblem), hipMemcpyHostToDevice, st));
-        TRAIN_HIP(hipMemcpyAsync(b_tiles.ptr, tiles.data(), tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, st));
-        TRAIN_HIP(hipMemcpyAsync(b_chunks.ptr, chunks.data(), chunks.size() * sizeof(TileRef), hipMemcpyHostToDevice, st));
-        TRAIN_HIP(hipMemcpyAsync(b_cnum.ptr, cnum.data(), P * 4, hipMemcpyHostToDevice, st));
-        TRAIN_HIP(hipMemcpyAsync(b_slotprob.ptr, slot_prob.data(), n_slots * 4, hipMemcpyHostToDevice, st));
-        TRAIN_HIP(hipMemcpyAsync(b_pick.ptr, pick.data(), n_slots * 4, hipMemcpyHostToDevice, st));
-
-        LloydArgs a{};
-        a.X = s->points;
-        a.sqrt_norm = b_sqrt.as<float>();
-        a.probs = b_probs.as<LloydProblem>();
-        a.rows = b_rows[cur].as<uint32_t>();
-        a.cent = b_cent.as<float>();
-        a.csum = b_csum.as<float>();
-        a.cnorm = b_cnorm.as<float>();
-        a.cnum = b_cnum.as<uint32_t>();
-        a.csize = b_csize.as<uint32_t>();
-        a.coff = b_coff.as<uint32_t>();
-        a.slot_prob = b_slotprob.as<uint32_t>();
-        a.owner = b_owner.as<int32_t>();
-        a.members_row = b_rows[cur ^ 1].as<uint32_t>();
-        a.members_pos = b_mpos.as<uint32_t>();
-        a.tiles = b_tiles.as<TileRef>();
-        a.chunks = b_chunks.as<TileRef>();
-        a.chunk_cnt = b_ccnt.as<uint32_t>();
-        a.chunk_base = b_cbase.as<uint32_t>();
-        a.n_probs = P;
-        a.n_slots = n_slots;
-        a.kmax = kmax;
-        a.d = d;
-        a.ld = ld;
-
-        hipLaunchKernelGGL(GatherInitKernel, dim3(n_slots), dim3(64), 0, st, a, b_pick.as<uint32_t>());
-        TRAIN_HIP(hipGetLastError());
-        const size_t sum_lds = (size_t)kSumFloats * 4 + (size_t)kSumMaxRows * 12;
-        for (int round = 0; round < 20; ++round) {   // kmeans.cpp:239-243
-            if (mips) hipLaunchKernelGGL(AssignKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)tiles.size()), dim3(kKThreads), 0, st, a);
-            else hipLaunchKernelGGL(AssignKernel<GPANN_METRIC_L2>, dim3((uint32_t)tiles.size()), dim3(kKThreads), 0, st, a);
-            hipLaunchKernelGGL(CountKernel, dim3(n_chunks), dim3(64), (size_t)kmax * 4, st, a);
-            hipLaunchKernelGGL(ChunkScanKernel, dim3((n_slots + 3) / 4), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(OffsetsKernel, dim3((P + 3) / 4), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(ScatterKernel, dim3(n_chunks), dim3(64), (size_t)kmax * 4, st, a);
-            if (mips) {
-                hipLaunchKernelGGL(SumKernel<GPANN_METRIC_MIPS>, dim3(n_slots), dim3(kKThreads), sum_lds, st, a);
-                hipLaunchKernelGGL(NormalizeKernel<GPANN_METRIC_MIPS>, dim3(P), dim3(kKThreads), (size_t)kmax * 8, st, a);
-            } else {
-                hipLaunchKernelGGL(SumKernel<GPANN_METRIC_L2>, dim3(n_slots), dim3(kKThreads), sum_lds, st, a);
-                hipLaunchKernelGGL(NormalizeKernel<GPANN_METRIC_L2>, dim3(P), dim3(kKThreads), (size_t)kmax * 8, st, a);
-            }
-            TRAIN_HIP(hipGetLastError());
-        }
+        LloydResult res;
+        GPANN_TRY(session.RunLevel(tasks, pick, 20, res));   // kmeans.cpp:239-243: 20 rounds
 
         // ---- host: what the reference does after KMeans returns (kmeans_tree_router.cpp:38-77)
-        std::vector<uint32_t> csize(n_slots), coff(n_slots);
-        std::vector<float> cent((size_t)n_slots * ld);
-        TRAIN_HIP(hipMemcpyAsync(cnum.data(), b_cnum.ptr, P * 4, hipMemcpyDeviceToHost, st));
-        TRAIN_HIP(hipMemcpyAsync(csize.data(), b_csize.ptr, n_slots * 4, hipMemcpyDeviceToHost, st));
-        TRAIN_HIP(hipMemcpyAsync(coff.data(), b_coff.ptr, n_slots * 4, hipMemcpyDeviceToHost, st));
-        TRAIN_HIP(hipMemcpyAsync(cent.data(), b_cent.ptr, (size_t)n_slots * ld * 4, hipMemcpyDeviceToHost, st));
-        TRAIN_HIP(hipStreamSynchronize(st));
-
+        const uint32_t ld = res.ld;
         std::vector<HostProblem> next;
         for (uint32_t p = 0; p < P; ++p) {
-            const uint32_t cb = probs[p].cent_begin, k0 = probs[p].k0;
+            const uint32_t cb = res.cent_begin[p], k0 = tasks[p].k0;
             // surviving clusters in slot order; the i-th survivor's centroid is row i of the compacted slab
             std::vector<std::pair<size_t, size_t>> size_and_id;
             std::vector<uint32_t> slab;   // survivor -> start of its member slab inside the problem
             for (uint32_t j = 0; j < k0; ++j)
-                if (csize[cb + j] != 0) {
-                    size_and_id.emplace_back((size_t)csize[cb + j], size_and_id.size());
-                    slab.push_back(coff[cb + j]);
+                if (res.csize[cb + j] != 0) {
+                    size_and_id.emplace_back((size_t)res.csize[cb + j], size_and_id.size());
+                    slab.push_back(res.coff[cb + j]);
                 }
-            const uint32_t c = cnum[p];
+            const uint32_t c = res.cnum[p];
             if (size_and_id.size() != c) {
                 SetLastError("router training: inconsistent cluster bookkeeping (problem %u: %zu clusters with members, %u centroids)", p,
                              size_and_id.size(), c);
-                release();
                 return GPANN_ERR_INTERNAL;
             }
             const size_t recursed =
@@ -765,7 +792,7 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
             const uint32_t me = level[p].node;
             shard_nodes[me].centroids.reserve((size_t)c * d);
             for (const auto& e : size_and_id) {
-                const float* row = &cent[(size_t)(cb + e.second) * ld];
+                const float* row = &res.cent[(size_t)(cb + e.second) * ld];
                 shard_nodes[me].centroids.insert(shard_nodes[me].centroids.end(), row, row + d);
             }
             int64_t left = level[p].budget - (int64_t)c;
@@ -775,7 +802,7 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
             for (size_t i = 0; i < recursed; ++i) {
                 HostProblem ch;
                 ch.shard = level[p].shard;
-                ch.row_begin = probs[p].row_begin + slab[size_and_id[i].second];
+                ch.row_begin = level[p].row_begin + slab[size_and_id[i].second];
                 ch.n = (uint32_t)size_and_id[i].first;
                 ch.budget = (int64_t)(double(size_and_id[i].first * (size_t)left) / double(total));
                 ch.seed = level[p].seed + (int)i;
@@ -786,9 +813,8 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
             }
         }
         level.swap(next);
-        cur ^= 1;   // this level's member slabs are the next level's rows
     }
-    release();
+    session.End();
 
     // flatten: per shard breadth first, the children of a node consecutive (ExtractPoints order, kmeans_tree_router.cpp:180-198)
     std::vector<int32_t> node_shard;
@@ -811,6 +837,4 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
     }
     return gpann_router_create(d, s->metric, S, (uint32_t)node_shard.size(), node_shard.data(), node_cent_first.data(), node_child_first.data(),
                                node_child_count.data(), shard_root.data(), centroids.data(), s->device, out);
-#undef TRAIN_TRY
-#undef TRAIN_HIP
 }

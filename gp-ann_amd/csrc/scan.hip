@@ -19,6 +19,7 @@
 //     (inverted_index.h:56-58) and writes the caller's [nq][nprobe][k] arrays.
 #include "shards.h"
 #include "scan_filter.h"
+#include "scan_cells.h"
 
 #include <algorithm>
 #include <climits>
@@ -663,6 +664,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         ra.d = s->d;
         ra.ld = s->ld;
         ra.cand_cap = cap;
+        ra.dedupe = 0;
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         const size_t flds = (dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float)) + EnvU32("GPANN_FILTER_LDS_PAD", 0);   // (pad: occupancy experiments)
         const size_t rlds = (size_t)4 * s->ld * sizeof(float);
@@ -728,6 +730,265 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
     return GPANN_OK;
 }
 
+// The MFMA-filtered pipeline over a store with cells (cells.hip, scan_cells.h):
+//   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
+//   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
+//   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
+static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
+                                        hipStream_t st, DeviceLists out, bool* overflow) {
+    *overflow = false;
+    s->filter_passes_timed = 0;
+    const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
+    if (T == 0) return GPANN_OK;
+    const auto& C = s->cells;
+    const uint32_t kmax = C.kmax;
+    const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
+    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (1536ull << 20) / (4ull * T))));
+    // Three filter passes keep the candidate buckets small whatever the geometry: rows inside a cell are in store order, i.e.
+    // a random sample of the cell, so after a pass over a fraction 1/f of the needed rows only about f * k rows of the rest can
+    // still beat the k-th distance.  Pass 0 = the head of each task's nearest cell (at most half a bucket of rows), pass 1 =
+    // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
+    const uint32_t head_tiles = std::max<uint32_t>(1, std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows);
+    int64_t max_rows = 1;
+    for (uint32_t b = 0; b < S; ++b) max_rows = std::max<int64_t>(max_rows, s->offsets[b + 1] - s->offsets[b]);
+    // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
+    const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap);
+    const uint32_t sample_div = EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto)));
+    const bool l2 = s->metric == GPANN_METRIC_L2, aux = (flags & GPANN_AUX_PASS) != 0, ks4 = s->d <= 64;
+
+    // ---- workspace
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
+    float* list_dist = s->ws_lists.as<float>();
+    uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
+    float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
+    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T + ((T & 1) ? 1 : 0));   // [0] overflow count, [2..3] candidate total (u64)
+    unsigned long long* d_cand_total = reinterpret_cast<unsigned long long*>(d_overflow + 2);
+    GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
+    uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
+    uint32_t* cand_row = cand_cnt + T;
+    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 16, st));
+
+    // groups of <= 256 tasks per shard; distance-table tiles of <= 64 tasks
+    std::vector<CellGroup> groups;
+    std::vector<uint32_t> task_group(T);
+    std::vector<CellTileRef> dtiles;
+    for (uint32_t b = 0; b < S; ++b) {
+        const uint32_t t0 = plan.shard_task_begin[b], tb = plan.shard_task_begin[b + 1] - t0;
+        if (tb == 0) continue;
+        for (const FilterGroup& g : PlanFilterGroups(tb, false)) {
+            for (uint32_t x = 0; x < g.task_count; ++x) task_group[t0 + g.task_off + x] = (uint32_t)groups.size();
+            groups.push_back({t0 + g.task_off, g.task_count, b, 0});
+        }
+        for (uint32_t f = 0; f < tb; f += 64) dtiles.push_back({b, t0 + f, std::min(64u, tb - f), 0});
+    }
+    const uint32_t G = (uint32_t)groups.size();
+    const size_t need_words = (size_t)G * kmax;
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 12 + dtiles.size() * sizeof(CellTileRef) + 256));
+    float* cell_dist = s->ws_celld.as<float>();
+    uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
+    float* d_qnorm = reinterpret_cast<float*>(d_nearest + T);
+    uint32_t* d_task_group = reinterpret_cast<uint32_t*>(d_qnorm + T);
+    CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
+    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64));
+    uint32_t* need_pass[3];
+    need_pass[0] = s->ws_need.as<uint32_t>();
+    need_pass[1] = need_pass[0] + need_words;
+    need_pass[2] = need_pass[1] + need_words;
+    uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
+    CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);
+    GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
+    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 16, st));
+    GPANN_HIP_TRY(hipMemcpyAsync(d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), hipMemcpyHostToDevice, st));
+    GPANN_HIP_TRY(hipMemcpyAsync(d_groups, groups.data(), (size_t)G * sizeof(CellGroup), hipMemcpyHostToDevice, st));
+    GPANN_HIP_TRY(hipMemcpyAsync(d_task_group, task_group.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+
+    CellDistArgs cd;
+    cd.queries = d_queries;
+    cd.task_query = ta.query;
+    cd.center = C.d_center;
+    cd.shard_cell_begin = C.d_shard_cell_begin;
+    cd.tiles = d_dtiles;
+    cd.out = cell_dist;
+    cd.kmax = kmax;
+    cd.d = s->d;
+    cd.ld = s->ld;
+    auto cell_table = [&](bool with_qnorm) -> gpann_status {
+        hipLaunchKernelGGL(CellDistKernel, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
+        hipLaunchKernelGGL(NearestCellKernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
+                           s->d, s->ld, d_nearest, with_qnorm ? d_qnorm : nullptr);
+        GPANN_HIP_TRY(hipGetLastError());
+        return GPANN_OK;
+    };
+
+    // ---- order the tasks of every shard by their nearest cell
+    GPANN_TRY(cell_table(false));
+    {
+        std::vector<uint32_t> nearest(T);
+        GPANN_HIP_TRY(hipMemcpyAsync(nearest.data(), d_nearest, (size_t)T * 4, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+        std::vector<uint32_t> order(T), tq(T), to(T);
+        for (uint32_t t = 0; t < T; ++t) order[t] = t;
+        for (uint32_t b = 0; b < S; ++b)
+            std::stable_sort(order.begin() + plan.shard_task_begin[b], order.begin() + plan.shard_task_begin[b + 1],
+                             [&](uint32_t x, uint32_t y) { return nearest[x] < nearest[y]; });
+        for (uint32_t t = 0; t < T; ++t) {
+            tq[t] = plan.task_query[order[t]];
+            to[t] = plan.task_out[order[t]];
+        }
+        plan.task_query.swap(tq);
+        plan.task_out.swap(to);
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, plan.task_query.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, plan.task_out.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+    }
+    GPANN_TRY(cell_table(true));
+
+    // ---- stage 0: exact scan of the first m0 rows of every shard -> lists
+    std::vector<int64_t> lo(S), hi(S);
+    for (uint32_t b = 0; b < S; ++b) {
+        lo[b] = s->offsets[b];
+        hi[b] = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + m0);
+    }
+    plan.padded_pairs = 0;
+    GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
+    {
+        MergeArgs m{};
+        m.out_index = nullptr;   // identity: list t
+        m.permutation = s->permutation;
+        m.out_dist = list_dist;
+        m.out_rows = list_row;
+        m.out_ids = nullptr;
+        GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
+    }
+
+    ThresholdArgs th;
+    th.list_dist = list_dist;
+    th.queries = d_queries;
+    th.task_query = ta.query;
+    th.task_shard = ta.shard;
+    th.shard_rmax = s->d_shard_rmax;
+    th.task_U = task_U;
+    th.tasks = T;
+    th.k = k;
+    th.d = s->d;
+    th.ld = s->ld;
+    NeedArgs na;
+    na.cell_dist = cell_dist;
+    na.task_shard = ta.shard;
+    na.task_group = d_task_group;
+    na.groups = d_groups;
+    na.shard_cell_begin = C.d_shard_cell_begin;
+    na.radius = C.d_radius;
+    na.cell_cnorm = C.d_cnorm;
+    na.shard_rmax = s->d_shard_rmax;
+    na.task_qnorm = d_qnorm;
+    na.list_dist = list_dist;
+    na.nearest = d_nearest;
+    na.tasks = T;
+    na.kmax = kmax;
+    na.k = k;
+    na.d = s->d;
+    CellFilterArgs fa;
+    fa.queries = d_queries;
+    fa.task_query = ta.query;
+    fa.task_U = task_U;
+    fa.cand_cnt = cand_cnt;
+    fa.cand_row = cand_row;
+    fa.cand_cap = cap;
+    fa.ld = s->ld;
+    fa.frag_planes = s->frag_planes;
+    fa.plane_norm = C.plane_norm;
+    fa.plane_perm = C.plane_perm;
+    fa.groups = d_groups;
+    fa.shard_cell_begin = C.d_shard_cell_begin;
+    fa.cell_tile_begin = C.d_cell_tile_begin;
+    fa.kmax = kmax;
+    fa.head_tiles = head_tiles;
+    fa.sample_div = sample_div;
+    fa.work = d_work;
+    RescoreArgs ra;
+    ra.points = s->points;
+    ra.queries = d_queries;
+    ra.task_query = ta.query;
+    ra.cand_cnt = cand_cnt;
+    ra.cand_row = cand_row;
+    ra.list_dist = list_dist;
+    ra.list_row = list_row;
+    ra.task_shard = ta.shard;
+    ra.shard_offsets = s->d_offsets;
+    ra.range_lo = 0;               // an overflowed bucket re-reads the whole shard (duplicates are dropped)
+    ra.range_hi = INT64_MAX;
+    ra.tasks = T;
+    ra.k = k;
+    ra.d = s->d;
+    ra.ld = s->ld;
+    ra.cand_cap = cap;
+    ra.dedupe = 1;
+    const void* fn = nullptr;
+#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelCells<M, TAG_, KS_>
+    if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
+                     : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
+    else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
+                  : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
+#undef GPANN_PICK
+    const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+    GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    const size_t rlds = (size_t)4 * s->ld * sizeof(float);
+    const uint64_t need_threads = (uint64_t)T * kmax;
+
+    for (int pass = 0; pass < 3; ++pass) {
+        GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
+        if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
+        if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+        else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+        na.head = pass == 0 ? 1u : 0u;
+        na.need = need_pass[pass];
+        if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
+        else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
+        if (pass == 1) hipLaunchKernelGGL(OrWordsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, need_pass[0], need_pass[1], done_head, need_words);
+        fa.need = na.need;
+        fa.pass = (uint32_t)pass;
+        fa.done0 = pass == 0 ? nullptr : (pass == 1 ? need_pass[0] : done_head);
+        fa.done1 = pass == 2 ? need_pass[1] : nullptr;
+        void* kargs[] = {&fa};
+        GPANN_HIP_TRY(hipLaunchKernel(fn, dim3(kmax, G), dim3(512), kargs, glds, st));
+        GPANN_HIP_TRY(hipGetLastError());
+        // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
+        if (pass == 0 || pass == 2) {
+            GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
+            s->filter_passes_timed++;
+        }
+        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
+        uint32_t h_words[4] = {0, 0, 0, 0};
+        unsigned long long h_work[2] = {0, 0};
+        GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 16, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+        plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
+        plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
+        plan.filter_rows = (uint64_t)h_work[1] * kGTileRows;
+        if (std::getenv("GPANN_CELLS_DEBUG"))
+            fprintf(stderr, "[gpann cells] pass %d: T=%u G=%u kmax=%u cap=%u  pairs so far %.3e (all rows x tasks %.3e)  row tiles so far %llu  candidates %llu  overflowed %u\n",
+                    pass, T, G, kmax, cap, (double)plan.filter_pairs, (double)plan.pairs, (unsigned long long)h_work[1],
+                    (unsigned long long)plan.filter_candidates, h_words[0]);
+        if (h_words[0] > std::max<uint32_t>(8, T / 1000)) {
+            *overflow = true;
+            return GPANN_OK;
+        }
+        if (h_words[0]) GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        GPANN_HIP_TRY(hipGetLastError());
+        plan.filter_launches++;
+    }
+    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+    const size_t n = (size_t)T * k;
+    hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k, out.dist,
+                       out.ids, out.rows);
+    GPANN_HIP_TRY(hipGetLastError());
+    return GPANN_OK;
+}
+
 static bool FilterWanted(const gpann_shards* s, uint32_t k) {
     if (!s->filter_ok || s->d > 16u * kFKS || k > GPANN_MAX_K) return false;
     const char* mode = std::getenv("GPANN_SCAN_MODE");
@@ -774,7 +1035,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
-        GPANN_TRY(RunFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
+        if (s->cells.n_cells) GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
+        else GPANN_TRY(RunFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
         done = !overflow;
         s->stats.filtered = done ? 1 : 0;
     }

@@ -1,0 +1,388 @@
+// scan_cells.h — cell pruning for the MFMA pre-filter (see cells.hip for what a cell is and why skipping is exact).
+//
+// Per scan call:
+//   CellDistKernel   |q - c|^2 of every task against every cell of its shard (the exact kernels' 4x4 register tile; plain fp32)
+//   NearestCellKernel the nearest cell of every task (tasks of a shard are then ordered by it so that the 32-task query tiles
+//                    of the filter are spatially coherent)
+//   NeedKernel       which (task group, cell) blocks must be filtered, as a bit per 32-task query tile:
+//                      head pass: the first tiles of each task's nearest cell (tightens the k-th distance cheaply)
+//                      main pass: every cell whose bounding ball reaches the task's current k-th distance
+//   FilterKernelCells FilterKernelReg over one (task group, cell) block per workgroup, running only the query tiles whose bit
+//                    is set; candidates are mapped from plane rows back to store rows
+#pragma once
+
+#include "scan_filter.h"
+
+namespace gpann {
+
+struct CellGroup {
+    uint32_t task_begin, task_count, shard, pad;
+};
+
+struct CellTileRef {
+    uint32_t shard, first, count, pad;   // <= 64 consecutive tasks of one shard
+};
+
+struct CellDistArgs {
+    const float* queries;               // [nq][ld]
+    const uint32_t* task_query;         // [tasks]
+    const float* center;                // [cells][ld]
+    const uint32_t* shard_cell_begin;   // [S+1]
+    const CellTileRef* tiles;
+    float* out;                         // [tasks][kmax]
+    uint32_t kmax, d, ld;
+};
+
+// 64 tasks x 64 cells per pass of the cell loop; squared L2 distance in plain fp32 (bounds carry their own slack)
+static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) {
+    constexpr int kStride = 36;
+    __shared__ float sC[64 * kStride];
+    __shared__ float sQ[64 * kStride];
+    const uint32_t shard = a.tiles[blockIdx.x].shard, first = a.tiles[blockIdx.x].first, count = a.tiles[blockIdx.x].count;
+    const uint32_t cell0 = a.shard_cell_begin[shard], K = a.shard_cell_begin[shard + 1] - cell0;
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;   // cells ty + 16 i, tasks tx + 16 j
+    const uint32_t ld = a.ld;
+    const uint32_t nchunks = (ld + 31) / 32;
+    const int st_row0 = tid >> 3, st_row1 = (tid + 256) >> 3, st_c4 = tid & 7;
+    const float* qrow0 = a.queries + (size_t)a.task_query[first + min((uint32_t)st_row0, count - 1)] * ld;
+    const float* qrow1 = a.queries + (size_t)a.task_query[first + min((uint32_t)st_row1, count - 1)] * ld;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t ct = 0; ct < K; ct += 64) {
+        const float* crow0 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row0, K - 1)) * ld;
+        const float* crow1 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row1, K - 1)) * ld;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (uint32_t ch = 0; ch < nchunks; ++ch) {
+            const uint32_t col = ch * 32 + 4u * st_c4;
+            const bool in = col < ld;
+            const float4 gc0 = in ? *reinterpret_cast<const float4*>(crow0 + col) : zero4;
+            const float4 gc1 = in ? *reinterpret_cast<const float4*>(crow1 + col) : zero4;
+            const float4 gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + col) : zero4;
+            const float4 gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + col) : zero4;
+            __syncthreads();
+            *reinterpret_cast<float4*>(sC + st_row0 * kStride + 4 * st_c4) = gc0;
+            *reinterpret_cast<float4*>(sC + st_row1 * kStride + 4 * st_c4) = gc1;
+            *reinterpret_cast<float4*>(sQ + st_row0 * kStride + 4 * st_c4) = gq0;
+            *reinterpret_cast<float4*>(sQ + st_row1 * kStride + 4 * st_c4) = gq1;
+            __syncthreads();
+#pragma unroll 2
+            for (int g = 0; g < 8; ++g) {
+                float4 cv[4], qv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[i] = *reinterpret_cast<const float4*>(sC + (ty + 16 * i) * kStride + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(sQ + (tx + 16 * j) * kStride + 4 * g);
+                AccumulateGroup<GPANN_METRIC_L2>(acc, cv, qv);   // pad columns are zero on both sides
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cell = ct + ty + 16 * i, tl = tx + 16 * j;
+                if (cell < K && tl < count) a.out[(size_t)(first + tl) * a.kmax + cell] = acc[i][j];
+            }
+    }
+}
+
+// nearest cell (smallest |q - c|^2, first minimum) and |q|^2 of every task
+static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t* task_shard, const uint32_t* shard_cell_begin, const float* queries,
+                                         const uint32_t* task_query, uint32_t tasks, uint32_t kmax, uint32_t d, uint32_t ld, uint32_t* nearest,
+                                         float* task_qnorm) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tasks) return;
+    const uint32_t b = task_shard[t];
+    const uint32_t K = shard_cell_begin[b + 1] - shard_cell_begin[b];
+    uint32_t best = 0;
+    float bd = INFINITY;
+    for (uint32_t j = 0; j < K; ++j) {
+        const float v = cell_dist[(size_t)t * kmax + j];
+        if (v < bd) {
+            bd = v;
+            best = j;
+        }
+    }
+    nearest[t] = best;
+    if (task_qnorm) {
+        const float* q = queries + (size_t)task_query[t] * ld;
+        double nq = 0.0;
+        for (uint32_t i = 0; i < d; ++i) nq += (double)q[i] * (double)q[i];
+        task_qnorm[t] = (float)(nq * (1.0 + 1e-6));
+    }
+}
+
+struct NeedArgs {
+    const float* cell_dist;             // [tasks][kmax]
+    const uint32_t* task_shard;
+    const uint32_t* task_group;         // [tasks]
+    const CellGroup* groups;
+    const uint32_t* shard_cell_begin;
+    const float* radius;                // [cells]
+    const float* cell_cnorm;            // [cells] |c|^2 (MIPS)
+    const double* shard_rmax;           // [S]
+    const float* task_qnorm;            // [tasks] |q|^2, rounded up
+    const float* list_dist;             // [tasks][k]
+    const uint32_t* nearest;            // [tasks]
+    uint32_t* need;                     // [groups][kmax] bit per query tile
+    uint32_t tasks, kmax, k, d;
+    uint32_t head;                      // 1: only the nearest cell of each task
+};
+
+// One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
+//   L2   canonical E <= tau  =>  D <= tau (1 + 2 g1), g1 = (d + 32) 2^-23 (ThresholdKernel);  D >= (|q - c| - r)^2.
+//        |q - c|^2 comes from a plain fp32 sum of d squares: relative error <= (d + 2) 2^-24, covered by the factor (1 - s).
+//   MIPS E = fl(1 - fl(q.p)) <= tau  =>  q.p >= 1 - tau - e1 (ThresholdKernel);  q.p <= q.c + |q| r, and
+//        q.c = (|q|^2 + |c|^2 - |q - c|^2) / 2 from the same table, absolute error <= s (|q|^2 + |c|^2 + |q - c|^2).
+template <int METRIC>
+static __global__ void NeedKernel(NeedArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)a.tasks * a.kmax) return;
+    const uint32_t t = (uint32_t)(i / a.kmax), j = (uint32_t)(i % a.kmax);
+    const uint32_t b = a.task_shard[t];
+    const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
+    if (j >= K) return;
+    bool need;
+    if (a.head) {
+        need = a.nearest[t] == j;
+    } else {
+        const double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
+        if (!(tau < (double)INFINITY)) {
+            need = true;
+        } else {
+            const double dd = (double)a.d;
+            const double s = (dd + 64.0) * 0x1p-22;
+            const double D = (double)a.cell_dist[(size_t)t * a.kmax + j];
+            const double r = (double)a.radius[cell0 + j];
+            if (METRIC == GPANN_METRIC_L2) {
+                const double g1 = (dd + 32.0) * 0x1p-23;
+                const double lb = sqrt(fmax(D, 0.0)) * (1.0 - s) - r;
+                need = !(lb > 0.0 && lb * lb > tau * (1.0 + 2.0 * g1) * (1.0 + s) + 1e-30);
+            } else {
+                const double nq = (double)a.task_qnorm[t], nc = (double)a.cell_cnorm[cell0 + j];
+                const double R = a.shard_rmax[b];
+                const double qn = sqrt(nq);
+                const double dot_ub = 0.5 * (nq + nc - D) + s * (nq + nc + fabs(D));
+                const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
+                need = dot_ub + qn * r * (1.0 + s) >= 1.0 - tau - e1 - s;
+            }
+        }
+    }
+    if (need) {
+        const uint32_t g = a.task_group[t];
+        atomicOr(&a.need[(size_t)g * a.kmax + j], 1u << ((t - a.groups[g].task_begin) >> 5));
+    }
+}
+
+static __global__ void OrWordsKernel(const uint32_t* x, const uint32_t* y, uint32_t* out, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] | y[i];
+}
+
+struct CellFilterArgs {
+    const float* queries;
+    const uint32_t* task_query;
+    const float* task_U;
+    uint32_t* cand_cnt;
+    uint32_t* cand_row;
+    uint32_t cand_cap, ld;
+    const char* frag_planes;
+    const float* plane_norm;
+    const uint32_t* plane_perm;
+    const CellGroup* groups;
+    const uint32_t* shard_cell_begin;
+    const uint64_t* cell_tile_begin;
+    const uint32_t* need;        // [groups][kmax] query tiles to run in this pass
+    // A cell's tiles form three segments: head [0, head_tiles), sample [head_tiles, max(head_tiles, tiles / sample_div)), rest.
+    // Pass p (0 head, 1 sample, 2 rest) covers segments 0..p; done0 / done1 are the query tiles that already ran on segment 0 / 1.
+    const uint32_t* done0;
+    const uint32_t* done1;
+    uint32_t kmax, head_tiles, sample_div, pass;
+    unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
+};
+
+template <int METRIC, int TAG, int KS>
+__global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
+    extern __shared__ uint4 csm4[];
+    char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
+
+    const uint32_t g = blockIdx.y, j = blockIdx.x;
+    const uint32_t shard = a.groups[g].shard;
+    const uint32_t cell0 = a.shard_cell_begin[shard];
+    if (j >= a.shard_cell_begin[shard + 1] - cell0) return;
+    const uint32_t mask = a.need[(size_t)g * a.kmax + j];
+    if (mask == 0) return;
+    const uint32_t d0 = a.done0 ? a.done0[(size_t)g * a.kmax + j] : 0u;
+    const uint32_t d1 = a.done1 ? a.done1[(size_t)g * a.kmax + j] : 0u;
+    const int64_t t_begin = (int64_t)a.cell_tile_begin[cell0 + j];
+    const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
+    const int64_t t_a = min(t_cell_end, t_begin + (int64_t)a.head_tiles);                                      // end of the head segment
+    const int64_t t_b = min(t_cell_end, max(t_a, t_begin + (t_cell_end - t_begin + a.sample_div - 1) / a.sample_div));   // end of the sample
+    const int64_t t_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
+    // anything to do?  (segment 2 exists only in pass 2 and has no `done` mask)
+    if (!(((mask & ~d0) && t_a > t_begin) || ((mask & ~d1) && t_b > t_a && a.pass >= 1) || (a.pass == 2 && t_cell_end > t_b))) return;
+    const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t ld = a.ld;
+
+    // ---- the query image: wavefront w builds query tile w if any pass of this workgroup uses it
+    if (mask >> wave & 1u) {
+        const uint32_t tl = 32u * wave + c;
+        const uint32_t task = task_begin + min(tl, task_count - 1);
+        const bool real = tl < task_count;
+        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) v[x] = 0.f;
+            const uint32_t k0 = 16u * ks + 8u * h;
+            if (real && k0 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            }
+            if (real && k0 + 4 < ld) {
+                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
+                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+            }
+            Frag fh, fl;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) SplitBf16(v[2 * x], v[2 * x + 1], fh.u[x], fl.u[x]);
+            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 0) * 1024 + lane * 16) = fh.q;
+            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 1) * 1024 + lane * 16) = fl.q;
+        }
+    }
+    float U[8];
+#pragma unroll
+    for (int qt = 0; qt < 8; ++qt) {
+        const uint32_t tl = 32u * qt + c;
+        U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
+    }
+    __syncthreads();
+
+    const char* lane_planes = a.frag_planes + lane * 16;
+    const char* lane_lds = lds + lane * 16;
+    float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
+
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
+        const char* base = lane_planes + (size_t)T * kGTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Ah[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 0) * 1024);
+            Al[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 1) * 1024);
+        }
+        if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[T * kGTileRows + c];
+    };
+
+    unsigned long long my_products = 0, my_tiles = 0;
+
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, int64_t T) {
+        const uint32_t act = T < t_a ? mask & ~d0 : (T < t_b ? mask & ~d1 : mask);   // query tiles to run on this row tile
+        if (act == 0) return;
+        if (METRIC == GPANN_METRIC_L2) {
+            if (h == 0) wave_norms[c] = nrm;
+            __builtin_amdgcn_wave_barrier();
+        }
+        my_products += (unsigned long long)__builtin_popcount(act);
+        my_tiles += 1;
+        uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
+        // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
+        auto pass = [&](auto pair_tag, int q0, int qp, int shift) {
+            constexpr bool PAIR = decltype(pair_tag)::value;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc0[4 * gg + 0] = n.x; acc0[4 * gg + 1] = n.y; acc0[4 * gg + 2] = n.z; acc0[4 * gg + 3] = n.w;
+                if (PAIR) {
+                    acc1[4 * gg + 0] = n.x; acc1[4 * gg + 1] = n.y; acc1[4 * gg + 2] = n.z; acc1[4 * gg + 3] = n.w;
+                }
+            }
+            const char* p0 = lane_lds + (q0 * KS) * 2048;
+            const char* p1 = lane_lds + ((q0 + 1) * KS) * 2048;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag bh0, bl0, bh1, bl1;
+                bh0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048);
+                bl0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048 + 1024);
+                if (PAIR) {
+                    bh1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048);
+                    bl1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048 + 1024);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
+            }
+            const float u0 = (q0 & 1) ? U[2 * qp + 1] : U[2 * qp];
+            const float u1 = U[2 * qp + 1];
+            float m0 = acc0[0], m1 = PAIR ? acc1[0] : -INFINITY;
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                m0 = fmaxf(m0, acc0[r]);
+                if (PAIR) m1 = fmaxf(m1, acc1[r]);
+            }
+            if (__any(m0 >= u0 || (PAIR && m1 >= u1))) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    bits |= acc0[r] >= u0 ? 1u << (r + shift) : 0u;
+                    if (PAIR) bits |= acc1[r] >= u1 ? 0x10000u << r : 0u;
+                }
+                cmask[qp] = bits;
+            }
+        };
+#pragma unroll
+        for (int qp = 0; qp < 4; ++qp) {
+            const uint32_t two = act >> (2 * qp) & 3u;
+            if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
+            else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
+            else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
+        }
+        if (__any((cmask[0] | cmask[1] | cmask[2] | cmask[3]) != 0u)) {
+#pragma unroll
+            for (int qp = 0; qp < 4; ++qp) {
+                uint32_t bits = cmask[qp];
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int r = b & 15;
+                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
+                    const uint32_t row = a.plane_perm[T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    if (row != 0xFFFFFFFFu && tl < task_count) {
+                        const uint32_t task = task_begin + tl;
+                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
+                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = row;
+                    }
+                }
+            }
+        }
+    };
+
+    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];
+    float n0 = 0.f, n1 = 0.f;
+    int64_t T = t_begin + wave;
+    if (T < t_end) load_tile(A0h, A0l, n0, T);
+    while (T < t_end) {
+        if (T + 8 < t_end) load_tile(A1h, A1l, n1, T + 8);
+        compute_tile(A0h, A0l, n0, T);
+        T += 8;
+        if (T >= t_end) break;
+        if (T + 8 < t_end) load_tile(A0h, A0l, n0, T + 8);
+        compute_tile(A1h, A1l, n1, T);
+        T += 8;
+    }
+    if (a.work && lane == 0 && my_tiles) {
+        atomicAdd(&a.work[0], my_products);
+        atomicAdd(&a.work[1], my_tiles);
+    }
+}
+
+}  // namespace gpann

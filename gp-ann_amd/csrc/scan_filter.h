@@ -687,6 +687,7 @@ struct RescoreArgs {
     const int64_t* shard_offsets; // ... and the pass's row range inside it, [offset + range_lo, min(end, offset + range_hi))
     int64_t range_lo, range_hi;
     uint32_t tasks, k, d, ld, cand_cap;
+    uint32_t dedupe;              // 1: skip candidates already in the list (cell passes)
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
@@ -762,6 +763,13 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
             const int l = __builtin_ctzll(mask);
             const float cd = __shfl(e, l);
             const uint32_t cr = __shfl(row, l);
+            // a row may be offered twice (cell passes overlap a stage-0 row; an overflowed bucket re-reads its range): a row that is
+            // in the list stays once, one that was pushed out cannot pass the k-th entry again
+            if (a.dedupe && __ballot(lane < (int)k && lr_ == cr) != 0ull) {
+                pass = pass && lane != l;
+                mask = __ballot(pass);
+                continue;
+            }
             ListInsertF(ld_, lr_, cd, cr, k, lane);
             td = __shfl(ld_, k - 1);
             tr = __shfl(lr_, k - 1);

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <vector>
+#include <cstdint>
 
 #include "common.h"
 
@@ -68,14 +69,36 @@ struct gpann_shards {
     char* plane_hi = nullptr;        // optional [rows + 64][136] bf16: the points pre-split for FilterKernelDma
     char* plane_lo = nullptr;
     char* frag_planes = nullptr;     // optional: bf16 hi/lo planes in MFMA fragment order, 16 KiB per 32 rows (FilterKernelReg)
+
+    // Cells (cells.hip): with them the planes hold the rows of every shard GROUPED BY CELL (a k-means sub-cluster of the shard,
+    // padded to whole 32-row tiles); a cell's bounding ball lets the filter skip it for all tasks it cannot serve.
+    struct Cells {
+        uint32_t n_cells = 0, kmax = 0;            // all cells of the store (numbered shard by shard); most cells in one shard
+        uint64_t n_tiles = 0;                      // 32-row tiles of the planes
+        std::vector<uint32_t> shard_cell_begin;    // [S+1] host
+        std::vector<uint64_t> cell_tile_begin;     // [n_cells+1] host
+        uint32_t* d_shard_cell_begin = nullptr;    // [S+1]
+        uint64_t* d_cell_tile_begin = nullptr;     // [n_cells+1]
+        float* d_center = nullptr;                 // [n_cells][ld]
+        float* d_radius = nullptr;                 // [n_cells] max |p - center| over the cell's rows, rounded up
+        float* d_cnorm = nullptr;                  // [n_cells] |center|^2
+        uint32_t* plane_perm = nullptr;            // [n_tiles*32] plane row -> store row, 0xFFFFFFFF for padding
+        float* plane_norm = nullptr;               // [n_tiles*32 + 64] -|p|^2/2 in plane order (-inf for padding)
+    } cells;
     bool filter_ok = false;
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
     // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_funits0, ws_funits1;
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_funits0, ws_funits1, ws_celld, ws_need;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_filter[4] = {nullptr, nullptr, nullptr, nullptr};   // begin/end of the filter kernel of pass 0 and pass 1
     int filter_passes_timed = 0;
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;
 };
+
+namespace gpann {
+// cells.hip
+gpann_status BuildCells(gpann_shards* s, uint32_t target_rows);
+void ReleaseCells(gpann_shards* s);
+}  // namespace gpann

@@ -196,7 +196,17 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         // FilterKernelReg; GPANN_FILTER_PLANES=dma builds the row-major padded planes of FilterKernelDma instead.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
         const bool want_none = want && want[0] == '0', want_dma = want && std::string(want) == "dma";
-        if (s->filter_ok && d <= 128 && !want_none && !want_dma) {
+        // cells (cells.hip): rows grouped by sub-cluster so that the filter can skip what a bound excludes.  Default for stores of
+        // a million rows and more; GPANN_FILTER_CELLS=0|1 forces, GPANN_CELL_ROWS sets the target cell size.
+        const char* wc = std::getenv("GPANN_FILTER_CELLS");
+        const char* cr = std::getenv("GPANN_CELL_ROWS");
+        const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 16384u;
+        const bool want_cells = wc ? wc[0] == '1' : rows >= (1u << 20);
+        if (s->filter_ok && d <= 128 && !want_none && !want_dma && want_cells) {
+            gpann_status cst = BuildCells(s, cell_rows);
+            if (cst != GPANN_OK) return fail(cst);
+        }
+        if (s->filter_ok && d <= 128 && !want_none && !want_dma && !s->frag_planes) {
             const uint64_t tiles = (rows + kGTileRows - 1) / kGTileRows + 2;
             if (hipMalloc(&s->frag_planes, tiles * (size_t)kGTileBytes) == hipSuccess) {
                 const uint64_t first_partial = rows / kGTileRows;
@@ -250,10 +260,13 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->plane_hi) (void)hipFree(s->plane_hi);
     if (s->plane_lo) (void)hipFree(s->plane_lo);
     if (s->frag_planes) (void)hipFree(s->frag_planes);
+    ReleaseCells(s);
     s->ws_lists.Release();
     s->ws_cand.Release();
     s->ws_funits0.Release();
     s->ws_funits1.Release();
+    s->ws_celld.Release();
+    s->ws_need.Release();
     s->ws_queries.Release();
     s->ws_tasks.Release();
     s->ws_units.Release();

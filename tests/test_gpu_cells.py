@@ -1,0 +1,115 @@
+"""GPU parity of the cell-pruned filtered scan (gp-ann_amd/csrc/cells.hip, scan_cells.h): shards cut into k-means cells whose
+bounding balls let the filter skip rows; ids / distances must stay bit-identical to the CPU oracle and to the plain exact scan."""
+import numpy as np
+import pytest
+
+from conftest import make_mixture, random_clusters
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _cells_on(monkeypatch):
+    monkeypatch.setenv("GPANN_FILTER_CELLS", "1")     # stores of any size get cells
+    monkeypatch.setenv("GPANN_CELL_ROWS", "1500")
+
+
+def _check(orc, gp, pts, clusters, queries, probes, nprobe, k, metric, expect_filtered=True):
+    shards = gp.Shards(pts, clusters, metric, 0)
+    shards.set_scan_mode(1)
+    ids, dist, rows, _ = shards.scan_buckets(queries, k, probes, nprobe, want_rows=True)
+    st = shards.stats()
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, nprobe, metric, nthreads=4)
+    assert np.array_equal(ids, wi)
+    assert np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+    if expect_filtered is not None:
+        assert st["filtered"] == (1 if expect_filtered else 0), st
+    shards.set_scan_mode(0)
+    ids0, dist0, _ = shards.scan_buckets(queries, k, probes, nprobe)
+    assert np.array_equal(ids0, ids) and np.array_equal(dist0.view(np.uint32), dist.view(np.uint32))
+    shards.close()
+    return st
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [128, 96, 30, 7])
+def test_cells_match_oracle(orc, gp, metric, d):
+    rng = np.random.default_rng(d * 5 + metric)
+    n, S, nq, k = 40000, 3, 300, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S, overlap=0.15)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    st = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    assert st["filter_pairs"] > 0
+
+
+def test_cells_prune_clustered_data(orc, gp):
+    """well separated mixture: most (task, cell) blocks are skipped, the answer is still exact"""
+    rng = np.random.default_rng(3)
+    n, d, nq, k = 200000, 32, 700, 10
+    pts = make_mixture(orc, n, d, n_centers=40, sigma=0.2)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=40, sigma=0.2)
+    probes = np.zeros((nq, 1), np.int32)
+    st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0)
+    assert st["filter_pairs"] < 0.5 * nq * n, st          # pruning happened
+
+
+@pytest.mark.parametrize("k", [1, 7, 64])
+def test_cells_k_values(orc, gp, k):
+    rng = np.random.default_rng(k)
+    n, d, S, nq = 30000, 64, 2, 130
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    _check(orc, gp, pts, clusters, queries, probes, S, k, 0)
+
+
+def test_cells_uniform_data_no_pruning_possible(orc, gp):
+    """one Gaussian blob: no cell can be excluded, everything is filtered, results exact"""
+    rng = np.random.default_rng(8)
+    n, d, nq, k = 60000, 48, 200, 10
+    pts = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    clusters = [np.arange(n, dtype=np.uint32)]
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, 1, k, metric)
+
+
+def test_cells_far_queries_and_scaled_data(orc, gp):
+    rng = np.random.default_rng(23)
+    n, d, nq, k = 30000, 48, 100, 10
+    base = make_mixture(orc, n, d, n_centers=8, sigma=0.01)
+    pts = (base * np.float32(37.0) + np.float32(900.0)).astype(np.float32)
+    queries = pts[rng.integers(0, n, nq)] + rng.standard_normal((nq, d)).astype(np.float32) * np.float32(0.05)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
+
+
+def test_cells_duplicates_and_small_shards(orc, gp):
+    """duplicate rows (ties broken by row), a shard smaller than k, an empty shard, skipped probes"""
+    rng = np.random.default_rng(31)
+    d, k = 16, 10
+    base = make_mixture(orc, 300, d, n_centers=6)
+    pts = base[rng.integers(0, 300, size=20000)]
+    clusters = [np.arange(0, 12000, dtype=np.uint32), np.arange(12000, 19995, dtype=np.uint32), np.arange(19995, 20000, dtype=np.uint32),
+                np.zeros(0, np.uint32)]
+    queries = base[rng.integers(0, 300, size=90)] + np.float32(0.001)
+    probes = np.stack([rng.permutation(4) for _ in range(90)]).astype(np.int32)
+    probes[::7, 1] = -1
+    _check(orc, gp, pts, clusters, queries, probes, 3, k, 0, expect_filtered=None)
+
+
+def test_cells_ground_truth(orc, gp):
+    n, d, nq, k = 50000, 24, 150, 10
+    pts = make_mixture(orc, n, d, n_centers=16)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
+    ids, dist, _ = gp.ground_truth(pts, queries, k, 0)
+    wd, wi = orc.ground_truth(pts, queries, k, 0, nthreads=4)
+    assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
