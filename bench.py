@@ -64,7 +64,9 @@ def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
     for _ in range(rounds):
         pygpann.nearest_centroid_device(sample.data_ptr(), n, d, 0, cent.data_ptr(), cent.shape[0], assign.data_ptr(), stream)
         a64 = assign.to(torch.int64)
-        sums = torch.zeros_like(cent).index_add_(0, a64, sample)
+        # float64 accumulation: the scatter-add's atomic order then changes the float32 centroids (hence the shards and every
+        # number of the run) only with negligible probability — runs are repeatable
+        sums = torch.zeros(cent.shape, dtype=torch.float64, device=cent.device).index_add_(0, a64, sample.double()).to(sample.dtype)
         cnt = torch.bincount(a64, minlength=cent.shape[0]).clamp_(min=1).to(sample.dtype)
         keep = torch.bincount(a64, minlength=cent.shape[0]) > 0
         cent = torch.where(keep[:, None], sums / cnt[:, None], cent).contiguous()

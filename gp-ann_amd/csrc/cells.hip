@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + (ks * 2) * 1024 + lane * 16;
+        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
         *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + 1024) = fl.q;
+        *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
     }
 }
 

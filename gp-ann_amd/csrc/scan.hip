@@ -628,6 +628,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         th.k = k;
         th.d = s->d;
         th.ld = s->ld;
+        th.hi_only = 0;
         FilterArgs fa;
         fa.points = s->points;
         fa.queries = d_queries;
@@ -783,7 +784,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 12 + dtiles.size() * sizeof(CellTileRef) + 256));
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     float* cell_dist = s->ws_celld.as<float>();
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
     float* d_qnorm = reinterpret_cast<float*>(d_nearest + T);
@@ -796,9 +797,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
     CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor
+    uint32_t* d_next_item = reinterpret_cast<uint32_t*>(d_work + 2);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
-    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 16, st));
+    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 24, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), hipMemcpyHostToDevice, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_groups, groups.data(), (size_t)G * sizeof(CellGroup), hipMemcpyHostToDevice, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_task_group, task_group.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
@@ -821,25 +823,18 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         return GPANN_OK;
     };
 
-    // ---- order the tasks of every shard by their nearest cell
+    // ---- order the tasks of every shard by their nearest cell (on the device; the host copies of task_query / task_out are
+    //      not consulted again in this call)
     GPANN_TRY(cell_table(false));
     {
-        std::vector<uint32_t> nearest(T);
-        GPANN_HIP_TRY(hipMemcpyAsync(nearest.data(), d_nearest, (size_t)T * 4, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipStreamSynchronize(st));
-        std::vector<uint32_t> order(T), tq(T), to(T);
-        for (uint32_t t = 0; t < T; ++t) order[t] = t;
-        for (uint32_t b = 0; b < S; ++b)
-            std::stable_sort(order.begin() + plan.shard_task_begin[b], order.begin() + plan.shard_task_begin[b + 1],
-                             [&](uint32_t x, uint32_t y) { return nearest[x] < nearest[y]; });
-        for (uint32_t t = 0; t < T; ++t) {
-            tq[t] = plan.task_query[order[t]];
-            to[t] = plan.task_out[order[t]];
-        }
-        plan.task_query.swap(tq);
-        plan.task_out.swap(to);
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, plan.task_query.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, plan.task_out.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+        uint32_t* tmp_q = reinterpret_cast<uint32_t*>(d_dtiles + dtiles.size());
+        uint32_t* tmp_o = tmp_q + T;
+        uint32_t* d_stb = tmp_o + T;
+        GPANN_HIP_TRY(hipMemcpyAsync(d_stb, plan.shard_task_begin.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(TaskReorderKernel, dim3(S), dim3(256), (size_t)(kmax + 1) * 4, st, d_stb, d_nearest, C.d_shard_cell_begin, ta.query, ta.out, tmp_q, tmp_o);
+        GPANN_HIP_TRY(hipGetLastError());
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, tmp_q, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, tmp_o, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
     }
     GPANN_TRY(cell_table(true));
 
@@ -872,6 +867,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     th.k = k;
     th.d = s->d;
     th.ld = s->ld;
+    th.hi_only = 0;
     NeedArgs na;
     na.cell_dist = cell_dist;
     na.task_shard = ta.shard;
@@ -906,6 +902,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.head_tiles = head_tiles;
     fa.sample_div = sample_div;
     fa.work = d_work;
+    fa.next_item = d_next_item;
+    fa.n_groups = G;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -924,21 +922,34 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.ld = s->ld;
     ra.cand_cap = cap;
     ra.dedupe = 1;
-    const void* fn = nullptr;
-#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelCells<M, TAG_, KS_>
-    if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
-                     : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
-    else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
-                  : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
+    const void *fn = nullptr, *fn_hi = nullptr;
+#define GPANN_PICK(M, TAG_, KS_, HI_) (const void*)FilterKernelCells<M, TAG_, KS_, HI_>
+#define GPANN_PICK2(HI_)                                                                                                   \
+    (l2 ? (aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4, HI_) : GPANN_PICK(GPANN_METRIC_L2, 1, 8, HI_))                     \
+               : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_L2, 0, 8, HI_)))                    \
+        : (aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8, HI_))                 \
+               : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8, HI_))))
+    fn = GPANN_PICK2(false);
+    fn_hi = GPANN_PICK2(true);
+#undef GPANN_PICK2
 #undef GPANN_PICK
+    // GPANN_FILTER_HI_ONLY=1: the last (largest) pass reads only the hi plane of the points (half the bytes, looser bound); measured
+    // no faster on MI355X once the planes are plane-major, so off by default
+    const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 0) != 0;
     const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)4 * s->ld * sizeof(float);
     const uint64_t need_threads = (uint64_t)T * kmax;
+    int n_cus = 256;
+    (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
 
-    for (int pass = 0; pass < 3; ++pass) {
+    const int first_pass = EnvU32("GPANN_FILTER_SKIP_HEAD", 0) ? 1 : 0;   // (experiment: without the head pass)
+    for (int pass = first_pass; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
+        const bool hi_pass = hi_last && pass == 2;
+        th.hi_only = hi_pass ? 1u : 0u;
         if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
         else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
         na.head = pass == 0 ? 1u : 0u;
@@ -951,7 +962,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done0 = pass == 0 ? nullptr : (pass == 1 ? need_pass[0] : done_head);
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
-        GPANN_HIP_TRY(hipLaunchKernel(fn, dim3(kmax, G), dim3(512), kargs, glds, st));
+        GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 4, st));
+        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, (uint64_t)G * kmax)), dim3(512), kargs, glds, st));
         GPANN_HIP_TRY(hipGetLastError());
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
         if (pass == 0 || pass == 2) {

@@ -115,6 +115,28 @@ static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t*
     }
 }
 
+// Tasks of one shard -> grouped by nearest cell (counting sort; the order inside a cell does not matter).  One workgroup per shard.
+static __global__ void __launch_bounds__(256) TaskReorderKernel(const uint32_t* shard_task_begin, const uint32_t* nearest, const uint32_t* shard_cell_begin,
+                                                                const uint32_t* in_query, const uint32_t* in_out, uint32_t* out_query, uint32_t* out_out) {
+    extern __shared__ uint32_t s_cnt[];   // [K + 1]
+    const uint32_t b = blockIdx.x;
+    const uint32_t t0 = shard_task_begin[b], t1 = shard_task_begin[b + 1];
+    const uint32_t K = shard_cell_begin[b + 1] - shard_cell_begin[b];
+    if (t1 == t0) return;
+    for (uint32_t j = threadIdx.x; j <= K; j += blockDim.x) s_cnt[j] = 0;
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) atomicAdd(&s_cnt[min(nearest[t], K - 1) + 1], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (uint32_t j = 0; j < K; ++j) s_cnt[j + 1] += s_cnt[j];   // s_cnt[j] = first position of cell j
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const uint32_t pos = t0 + atomicAdd(&s_cnt[min(nearest[t], K - 1)], 1u);
+        out_query[pos] = in_query[t];
+        out_out[pos] = in_out[t];
+    }
+}
+
 struct NeedArgs {
     const float* cell_dist;             // [tasks][kmax]
     const uint32_t* task_shard;
@@ -202,19 +224,38 @@ struct CellFilterArgs {
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
     unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
+    uint32_t* next_item;         // work-stealing cursor over the (group, cell) index space (zeroed before the launch)
+    uint32_t n_groups;
 };
 
-template <int METRIC, int TAG, int KS>
+// HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
+// threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
+template <int METRIC, int TAG, int KS, bool HI_ONLY>
 __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     extern __shared__ uint4 csm4[];
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
 
-    const uint32_t g = blockIdx.y, j = blockIdx.x;
+    // persistent workgroups: one per CU, each claims (group, cell) blocks with work from a shared cursor
+    __shared__ uint32_t s_item;
+    const uint32_t n_items = a.n_groups * a.kmax;
+    uint32_t my_products = 0, my_tiles = 0;
+    for (;;) {
+    __syncthreads();   // everyone is done with the previous block's query image (and has read s_item)
+    if (threadIdx.x == 0) {
+        uint32_t it;
+        do {
+            it = atomicAdd(a.next_item, 1u);
+        } while (it < n_items && a.need[it] == 0);
+        s_item = it;
+    }
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= n_items) break;
+    const uint32_t g = item / a.kmax, j = item - g * a.kmax;
     const uint32_t shard = a.groups[g].shard;
     const uint32_t cell0 = a.shard_cell_begin[shard];
-    if (j >= a.shard_cell_begin[shard + 1] - cell0) return;
+    if (j >= a.shard_cell_begin[shard + 1] - cell0) continue;
     const uint32_t mask = a.need[(size_t)g * a.kmax + j];
-    if (mask == 0) return;
     const uint32_t d0 = a.done0 ? a.done0[(size_t)g * a.kmax + j] : 0u;
     const uint32_t d1 = a.done1 ? a.done1[(size_t)g * a.kmax + j] : 0u;
     const int64_t t_begin = (int64_t)a.cell_tile_begin[cell0 + j];
@@ -223,7 +264,7 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     const int64_t t_b = min(t_cell_end, max(t_a, t_begin + (t_cell_end - t_begin + a.sample_div - 1) / a.sample_div));   // end of the sample
     const int64_t t_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
     // anything to do?  (segment 2 exists only in pass 2 and has no `done` mask)
-    if (!(((mask & ~d0) && t_a > t_begin) || ((mask & ~d1) && t_b > t_a && a.pass >= 1) || (a.pass == 2 && t_cell_end > t_b))) return;
+    if (!(((mask & ~d0) && t_a > t_begin) || ((mask & ~d1) && t_b > t_a && a.pass >= 1) || (a.pass == 2 && t_cell_end > t_b))) continue;
     const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,13 +314,11 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         const char* base = lane_planes + (size_t)T * kGTileBytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            Ah[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 0) * 1024);
-            Al[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 1) * 1024);
+            Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
+            if (!HI_ONLY) Al[ks].q = *reinterpret_cast<const uint4*>(base + kGPlaneBytes + ks * 1024);
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[T * kGTileRows + c];
     };
-
-    unsigned long long my_products = 0, my_tiles = 0;
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, int64_t T) {
         const uint32_t act = T < t_a ? mask & ~d0 : (T < t_b ? mask & ~d1 : mask);   // query tiles to run on this row tile
@@ -288,7 +327,7 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
             if (h == 0) wave_norms[c] = nrm;
             __builtin_amdgcn_wave_barrier();
         }
-        my_products += (unsigned long long)__builtin_popcount(act);
+        my_products += (uint32_t)__builtin_popcount(act);
         my_tiles += 1;
         uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
         // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
@@ -318,8 +357,10 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
                 if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
                 if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
+                if (!HI_ONLY) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
+                    if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
+                }
             }
             const float u0 = (q0 & 1) ? U[2 * qp + 1] : U[2 * qp];
             const float u1 = U[2 * qp + 1];
@@ -366,7 +407,7 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         }
     };
 
-    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];
+    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];   // (the lo sets stay untouched, hence unallocated, when HI_ONLY)
     float n0 = 0.f, n1 = 0.f;
     int64_t T = t_begin + wave;
     if (T < t_end) load_tile(A0h, A0l, n0, T);
@@ -379,9 +420,10 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         compute_tile(A1h, A1l, n1, T);
         T += 8;
     }
-    if (a.work && lane == 0 && my_tiles) {
-        atomicAdd(&a.work[0], my_products);
-        atomicAdd(&a.work[1], my_tiles);
+    }   // next block
+    if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
+        atomicAdd(&a.work[0], (unsigned long long)my_products);
+        atomicAdd(&a.work[1], (unsigned long long)my_tiles);
     }
 }
 

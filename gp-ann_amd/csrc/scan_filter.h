@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
 //   * the bf16 hi/lo fragments of the unit's <= 256 tasks are built ONCE into LDS (128 KiB, in MFMA B-operand order: a
 //     ds_read_b128 with lane-linear addresses, conflict free) and stay there for the unit's whole row segment;
 //   * the points are pre-split in HBM in MFMA A-operand order — per 32-row tile and k-step one contiguous KiB per plane
-//     (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7) — so a wavefront loads a tile's fragments with 16 perfectly
+//     (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7; the hi plane of a tile is 8 contiguous KiB, then the lo plane) — so a wavefront loads a tile's fragments with 16 perfectly
 //     coalesced global_load_dwordx4 straight into the registers the MFMA reads.  No LDS traffic for the points, no barrier in
 //     the loop: the 8 wavefronts of a workgroup take tiles round robin and run independently, each prefetching its next tile
 //     into a second register set while the matrix core works on the current one;
@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
 //   * candidates of a tile are collected as bit masks and written after the tile's MFMA phase, when the prefetch has landed
 //     (the atomic's vmcnt wait would otherwise stall on the loads issued before it).
 constexpr int kGTileRows = 32;
-constexpr int kGTileBytes = kFKS * 2 * 1024;   // [ks][plane hi|lo][lane][16 B]: 16 KiB per 32 rows (512 B per row)
+constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane][16 B]
+constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
 constexpr int kGTasks = 256;                   // tasks per unit: 8 query tiles of 32
 
 template <int METRIC, int TAG, int KS>
@@ -470,8 +471,8 @@ __global__ void __launch_bounds__(512, 1) FilterKernelReg(FilterArgs a) {
         const char* base = lane_planes + (size_t)T * kGTileBytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            Ah[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 0) * 1024);
-            Al[ks].q = *reinterpret_cast<const uint4*>(base + (ks * 2 + 1) * 1024);
+            Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
+            Al[ks].q = *reinterpret_cast<const uint4*>(base + kGPlaneBytes + ks * 1024);
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.neg_half_norm[T * kGTileRows + c];
     };
@@ -589,9 +590,9 @@ static __global__ void __launch_bounds__(256) SplitFragPlanesKernel(const float*
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + (ks * 2) * 1024 + lane * 16;
+        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
         *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + 1024) = fl.q;
+        *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
     }
 }
 
@@ -641,6 +642,7 @@ struct ThresholdArgs {
     const double* shard_rmax;     // [S]
     float* task_U;
     uint32_t tasks, k, d, ld;
+    uint32_t hi_only;             // the filter pass reads only the hi plane of the points: the dropped q.p_lo term joins the error bound
 };
 
 template <int METRIC>
@@ -662,11 +664,14 @@ __global__ void ThresholdKernel(ThresholdArgs a) {
     if (METRIC == GPANN_METRIC_L2) {
         const double g1 = (dd + 32.0) * 0x1p-23;
         const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20;
-        const double e2 = c2 * (R + qn) * (R + qn) + 1e-30;
+        // hi plane only: |(q_h + q_l).(p_l + r_p) + r_q.p| <= (2^-9 * 1.01 + 2^-17) |q||p| of the dot product is missing, twice that in D
+        const double e_hi = a.hi_only ? 2.0 * 1.02 * 0x1p-9 * qn * R : 0.0;
+        const double e2 = c2 * (R + qn) * (R + qn) + e_hi + 1e-30;
         U = -(tau * (1.0 + 2.0 * g1) - nq * (1.0 - 0x1p-40) + e2) * 0.5;
     } else {
         const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
-        const double e2 = (4.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24) * qn * R + 1e-30;
+        const double e_hi = a.hi_only ? 1.02 * 0x1p-9 * qn * R : 0.0;
+        const double e2 = (4.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24) * qn * R + e_hi + 1e-30;
         U = 1.0 - tau - e1 - e2;
     }
     float Uf = (float)U;

@@ -113,3 +113,16 @@ def test_cells_ground_truth(orc, gp):
     ids, dist, _ = gp.ground_truth(pts, queries, k, 0)
     wd, wi = orc.ground_truth(pts, queries, k, 0, nthreads=4)
     assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+
+
+def test_cells_hi_plane_only_last_pass(orc, gp, monkeypatch):
+    """GPANN_FILTER_HI_ONLY=1: the last pass multiplies only the hi plane of the points; its threshold carries the dropped term"""
+    monkeypatch.setenv("GPANN_FILTER_HI_ONLY", "1")
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 120000, 64, 400, 10
+    pts = make_mixture(orc, n, d, n_centers=30)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=30)
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, 1, k, metric)
