@@ -369,22 +369,29 @@ def main():
     hbm_alg = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
     filtered = bool(stats["filtered"])
     # per step: the filter kernel is launched twice (two row ranges), the exact kernel once
-    traffic = lookup_traffic(n, d, S, nprobe, "FilterKernelReg<0, 0" if filtered else "ScanTileKernel<0, 0>", 2 if filtered else 1)
+    # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once
+    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"false>": 2, "true>": 1}) if filtered
+               else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
-        # dominant kernel: FilterKernelDma — bf16x3 matrix-core bound on (query, row) pairs: 3 MFMA products x 2 flop per dimension
+        # dominant kernel: FilterKernelCells (the three launches of a step).  Since the cells let it skip what a bound excludes and
+        # the last launch streams only the hi plane, it is bound by HBM (it reads the needed planes once), not by the matrix cores.
         f_s = float(np.mean(filter_ms)) / 1000.0
-        flops = stats["filter_pairs"] * d * 6.0
-        achieved = flops / f_s / 1e12 if f_s > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gpann::FilterKernelReg", "kernel_ms": 1000.0 * f_s,
-                              "note": "the exact scan in filter mode: v_mfma_f32_32x32x16_bf16 on bf16 hi/lo planes (3 products) bounds every "
-                                      "(query,row) distance, only candidates get the exact VALU evaluation; flops = filter_pairs x d x 6 per launch "
-                                      "(both filter launches of a step; pairs = tasks padded to 32 x rows padded to 64 per workgroup), time = HIP "
-                                      "events around them",
+        flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only last pass runs 2 of the 3 products)
+        tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
+        plane_bytes = stats["filter_rows"] * 256.0   # row tiles streamed x 32 rows x 256 B (hi plane; the small first passes read 512 B)
+        result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
+                              "traffic": traffic, "kernel": "gpann::FilterKernelCells" if n_local >= (1 << 20) else "gpann::FilterKernelReg",
+                              "kernel_ms": 1000.0 * f_s,
+                              "note": "achieved = algorithmic bytes of the reference's scan (rows x d x 4 per (query, probed shard), SURVEY 8d) / "
+                                      "HIP-event time of all scan kernels; frac > 1 because the exact answer needs far fewer bytes: cells whose "
+                                      "bounding ball cannot reach a task's k-th distance are skipped, the rest is bounded by bf16 MFMA products on "
+                                      "pre-split planes and only candidates get the canonical VALU evaluation.  The kernel itself streams the needed "
+                                      "planes once: kernel_hbm_* = those bytes / its own time (traffic = the PMC figure for the same launches)",
+                              "kernel_hbm_GBps": plane_bytes / f_s / 1e9 if f_s > 0 else 0.0,
+                              "kernel_hbm_frac": plane_bytes / f_s / 1e9 / HBM_PEAK_GBPS if f_s > 0 else 0.0,
+                              "kernel_mfma_TFLOPs": tflops, "kernel_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
-                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": stats["filter_rows"] * 512,
-                              "filter_plane_GBps": stats["filter_rows"] * 512 / f_s / 1e9 if f_s > 0 else 0.0,
-                              "hbm_algorithmic_GBps": hbm_alg, "hbm_algorithmic_frac": hbm_alg / HBM_PEAK_GBPS}
+                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": plane_bytes}
     else:
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
                               "traffic": traffic, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
@@ -429,8 +436,9 @@ def main():
 
 
 def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
-    the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None."""
+    """HBM bytes per STEP of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None.  `launches_per_step` maps a kernel
+    name fragment to its launches per step (the cells filter runs as two full-precision launches and one hi-plane launch)."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
@@ -439,9 +447,14 @@ def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
             w = j["workload"]
             if (w["n"], w["d"], w["shards"], w["nprobe"]) != (n, d, S, nprobe):
                 continue
+            total, found = 0.0, False
             for name, v in j["kernels"].items():
-                if kernel in name:
-                    best = float(v["hbm_bytes_per_launch"]) * launches_per_step
+                for frag, per_step in launches_per_step.items():
+                    if kernel in name and frag in name:
+                        total += float(v["hbm_bytes_per_launch"]) * per_step
+                        found = True
+            if found:
+                best = total
         except Exception:
             continue
     return best

@@ -200,7 +200,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         // a million rows and more; GPANN_FILTER_CELLS=0|1 forces, GPANN_CELL_ROWS sets the target cell size.
         const char* wc = std::getenv("GPANN_FILTER_CELLS");
         const char* cr = std::getenv("GPANN_CELL_ROWS");
-        const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 16384u;
+        const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
         const bool want_cells = wc ? wc[0] == '1' : rows >= (1u << 20);
         if (s->filter_ok && d <= 128 && !want_none && !want_dma && want_cells) {
             gpann_status cst = BuildCells(s, cell_rows);

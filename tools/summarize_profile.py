@@ -89,7 +89,7 @@ f = one(f"{src}/sq/**/*_counter_collection.csv")
 if f:
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if "gpann::ScanTileKernel" in r["Kernel_Name"] or "gpann::RouterWalk" in r["Kernel_Name"]:
+        if any(x in r["Kernel_Name"] for x in ("gpann::ScanTileKernel", "gpann::RouterWalk", "gpann::FilterKernel", "gpann::DenseDist")):
             vals[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines += ["## SQ counters (last launch of each kernel)", ""]
     for name, cs in vals.items():
