@@ -75,6 +75,11 @@ def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
 
 
 def main():
+    # stdout carries exactly ONE line, the result: everything any library prints there meanwhile (gloo's connection notes, the
+    # host trainer's progress lines, ...) goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -430,7 +435,8 @@ def main():
         except Exception as e:   # the baseline must never take the headline number down with it
             result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

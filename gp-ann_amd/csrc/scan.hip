@@ -936,7 +936,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #undef GPANN_PICK
     // the last (by far the largest) pass reads only the hi plane of the points: half the HBM bytes and two of the three products for
     // a slightly looser bound (10.1 -> 6.1 ms on the NS workload, 40% more candidates); GPANN_FILTER_HI_ONLY=0 keeps all three
-    const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0;
+    const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048;   // (small buckets of huge task counts cannot take the extra candidates)
     const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
