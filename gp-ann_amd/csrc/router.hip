@@ -40,6 +40,7 @@ struct gpann_router {
     uint32_t* shard_root = nullptr;
     uint32_t* path_cent = nullptr;       // [n_nodes][kPathMax] centroids whose distances are the keys on the path root -> node (threshold replay)
     uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
+    uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
@@ -256,9 +257,20 @@ struct DenseArgs {
     const float* queries;     // [nq][ld]
     float* out;               // [nq][C]
     uint32_t d, ld, nq, C;
+    // MIN_ONLY: instead of the table, the minimum over every shard's centroids as order-preserving bits
+    const uint32_t* cent_shard;   // [C]
+    uint32_t* out_min_bits;       // [nq][S], initialised to OrderedBits(FLT_MAX)
+    uint32_t S;
 };
 
-template <int METRIC>
+__device__ __forceinline__ uint32_t OrderedBitsD(float f) {   // unsigned order == float order
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// MIN_ONLY is the whole walk when the search budget exceeds the tree (kmeans_tree_router.cpp:112-123 then visits every node):
+// min_dist[shard] = min over all of the shard's centroids, taken in the tile's epilogue — no table, no replay.
+template <int METRIC, bool MIN_ONLY>
 __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
     extern __shared__ float4 dsm4[];
     constexpr int kStride = kRDC + 4;
@@ -311,6 +323,41 @@ __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
             else AccumulateTail<METRIC>(acc, qv, pv, tail);
         }
     }
+    if (MIN_ONLY) {
+        const uint32_t shard_first = a.cent_shard[c0], shard_last = a.cent_shard[min(c0 + 63u, a.C - 1)];
+        if (shard_first == shard_last) {   // (centroids are numbered shard by shard) the usual case: one shard per tile
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q = q0 + ty + 16 * i;
+                float m = INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[i][j];
+                    if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;
+                    if (c0 + tx + 16 * j < a.C) m = fminf(m, v);
+                }
+                // the 16 threads of a query are 16 consecutive lanes
+                m = fminf(m, __shfl_xor(m, 8));
+                m = fminf(m, __shfl_xor(m, 4));
+                m = fminf(m, __shfl_xor(m, 2));
+                m = fminf(m, __shfl_xor(m, 1));
+                if (tx == 0 && q < a.nq) atomicMin(&a.out_min_bits[(size_t)q * a.S + shard_first], OrderedBitsD(m));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q = q0 + ty + 16 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = c0 + tx + 16 * j;
+                    float v = acc[i][j];
+                    if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;
+                    if (q < a.nq && c < a.C) atomicMin(&a.out_min_bits[(size_t)q * a.S + a.cent_shard[c]], OrderedBitsD(v));
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t q = q0 + ty + 16 * i;
@@ -321,6 +368,19 @@ __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
             if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;
             if (q < a.nq && c < a.C) a.out[(size_t)q * a.C + c] = v;
         }
+    }
+}
+
+// min_dist workspace <-> order-preserving bits (DenseDistKernel<.., true>)
+__global__ void FillMinBitsKernel(uint32_t* out, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0xFF7FFFFFu;   // OrderedBits(FLT_MAX)
+}
+__global__ void MinBitsToFloatKernel(uint32_t* io, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t o = io[i];
+        io[i] = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
     }
 }
 
@@ -948,6 +1008,10 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             for (uint32_t c = node_cent_first[u]; c < node_cent_first[u + 1]; ++c) cent_node[c] = u;
         }
         TRY_OR_FAIL(hipMalloc(&r->path_cent, path.size() * 4));
+        std::vector<uint32_t> cent_shard(cent_node.size(), 0);
+        for (size_t c = 0; c < nc; ++c) cent_shard[c] = (uint32_t)node_shard[cent_node[c]];
+        TRY_OR_FAIL(hipMalloc(&r->cent_shard, cent_shard.size() * 4));
+        TRY_OR_FAIL(hipMemcpy(r->cent_shard, cent_shard.data(), cent_shard.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_FAIL(hipMalloc(&r->cent_node, cent_node.size() * 4));
         TRY_OR_FAIL(hipMemcpy(r->path_cent, path.data(), path.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_FAIL(hipMemcpy(r->cent_node, cent_node.data(), cent_node.size() * 4, hipMemcpyHostToDevice));
@@ -986,7 +1050,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -1030,7 +1094,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
     if (dense) {
         const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (C * 4) / 64 * 64));
-        GPANN_TRY(r->ws_dense.Reserve((size_t)q_block * C * 4));
+        GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * C * 4, 256)));
         const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
         const bool force_heap = rmode && std::string(rmode) == "heap";
         const bool all_roots_open = (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min;
@@ -1043,6 +1107,8 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const size_t t_lds = ((((size_t)256 + S + 2 * kFrontCap) + 3) & ~(size_t)3) * kRWaves * sizeof(uint32_t);
         const bool threshold_ok = !sorted_ok && !force_heap && all_roots_open && r->max_depth <= (uint32_t)kPathMax && t_lds <= 64 * 1024 &&
                                   budget < 0x7FFFFFFF;
+        // every node is visited iff the budget left after the roots exceeds all non-root sizes together, i.e. budget > C
+        const bool min_only = all_roots_open && (uint64_t)budget > C && rec_dist == nullptr && !force_heap;
         for (uint32_t q0 = 0; q0 < nq; q0 += q_block) {
             const uint32_t nb = std::min(q_block, nq - q0);
             DenseArgs da;
@@ -1055,8 +1121,21 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             da.C = (uint32_t)C;
             const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
             const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
-            if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_L2>, dgrid, dim3(256), dlds, st, da);
-            else hipLaunchKernelGGL(DenseDistKernel<GPANN_METRIC_MIPS>, dgrid, dim3(256), dlds, st, da);
+            da.cent_shard = r->cent_shard;
+            da.out_min_bits = reinterpret_cast<uint32_t*>(r->ws_out.as<float>() + (size_t)q0 * S);
+            da.S = S;
+            if (min_only) {
+                // the budget exceeds the tree and nobody asked for the evaluated distances: the per-shard minima are the whole answer
+                const size_t nb_s = (size_t)nb * S;
+                hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+                if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, da);
+                else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, true>), dgrid, dim3(256), dlds, st, da);
+                hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+                GPANN_HIP_TRY(hipGetLastError());
+                continue;
+            }
+            if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, false>), dgrid, dim3(256), dlds, st, da);
+            else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, false>), dgrid, dim3(256), dlds, st, da);
             GPANN_HIP_TRY(hipGetLastError());
 
             const size_t base_floats = (size_t)64 + S;
