@@ -473,45 +473,21 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
     return GPANN_OK;
 }
 
-// Splits the tb tasks of a shard into filter groups.  In units of (32-task query tile x 32-row point tile) products per
-// 64-row tile a group costs its slowest wave: 4 for a full group (mode 0, <= 8 query tiles), 2 when the 4 waves split the rows
-// of <= 4 query tiles (mode 1), 1 for <= 2 query tiles (mode 2).
+// Splits the tb tasks of a shard into filter groups of <= 256 tasks, sized in whole 32-task query tiles (only a shard's last
+// group can end on a partly used tile).
 struct FilterGroup {
-    uint32_t task_off, task_count, mode;
+    uint32_t task_off, task_count;
 };
-static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, bool roles) {
+static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb) {
     std::vector<FilterGroup> out;
-    uint32_t off = 0;
-    auto emit = [&](uint32_t tiles, uint32_t mode) {
-        const uint32_t cnt = std::min(tb - off, tiles * 32u);
-        out.push_back({off, cnt, mode});
-        off += cnt;
-    };
-    if (!roles) {
-        // groups of <= 256 tasks, sized in whole 32-task query tiles (only a shard's last group can end on a partly used tile)
-        const uint32_t nqb = (tb + kFQB - 1) / kFQB;
-        const uint32_t tiles = (tb + 31) / 32;
-        uint32_t done = 0;
-        for (uint32_t qb = 0; qb < nqb; ++qb) {
-            const uint32_t p0 = (uint32_t)((uint64_t)tiles * qb / nqb), p1 = (uint32_t)((uint64_t)tiles * (qb + 1) / nqb);
-            const uint32_t cnt = std::min(tb - done, (p1 - p0) * 32u);
-            out.push_back({done, cnt, 0});
-            done += cnt;
-        }
-        return out;
-    }
-    uint32_t q = (tb + 31) / 32;
-    while (q >= 8) {
-        emit(8, 0);
-        q -= 8;
-    }
-    if (q == 7) emit(7, 0);
-    else {
-        if (q >= 3) {
-            emit(std::min(q, 4u), 1);
-            q -= std::min(q, 4u);
-        }
-        if (q > 0) emit(q, 2);
+    const uint32_t nqb = (tb + kFQB - 1) / kFQB;
+    const uint32_t tiles = (tb + 31) / 32;
+    uint32_t done = 0;
+    for (uint32_t qb = 0; qb < nqb; ++qb) {
+        const uint32_t p0 = (uint32_t)((uint64_t)tiles * qb / nqb), p1 = (uint32_t)((uint64_t)tiles * (qb + 1) / nqb);
+        const uint32_t cnt = std::min(tb - done, (p1 - p0) * 32u);
+        out.push_back({done, cnt});
+        done += cnt;
     }
     return out;
 }
@@ -562,8 +538,6 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
     // ---- filter passes over [m0, m1) and [m1, end)
     const int64_t bounds[3] = {m0, m1, std::numeric_limits<int64_t>::max()};
     const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_TARGET_UNITS", 8192));
-    // wave roles (FilterUnit::mode) exist in FilterKernelDma only; GPANN_FILTER_ROLES=0 plans plain 256-task groups
-    const bool dma_roles = s->plane_hi != nullptr && s->plane_lo != nullptr && s->frag_planes == nullptr && EnvU32("GPANN_FILTER_ROLES", 1) != 0;
     for (int pass = 0; pass < 2; ++pass) {
         // units: (<= 256 tasks of a shard) x (row segment of the pass range)
         std::vector<FilterUnit>& funits = plan.filter_units;
@@ -574,7 +548,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
             const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
             const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
                                                                                        : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
-            if (tb && r1 > r0) block_rows += (uint64_t)PlanFilterGroups(tb, dma_roles).size() * (uint64_t)(r1 - r0);
+            if (tb && r1 > r0) block_rows += (uint64_t)PlanFilterGroups(tb).size() * (uint64_t)(r1 - r0);
         }
         if (block_rows == 0) continue;
         uint64_t seg_rows = std::max<uint64_t>(4096, (block_rows + target_units - 1) / target_units);
@@ -585,7 +559,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
             const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
                                                                                        : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
             if (tb == 0 || r1 <= r0) continue;
-            const std::vector<FilterGroup> groups = PlanFilterGroups(tb, dma_roles);
+            const std::vector<FilterGroup> groups = PlanFilterGroups(tb);
             const uint32_t nqb = (uint32_t)groups.size();
             const uint64_t nb = (uint64_t)(r1 - r0);
             const uint32_t nseg = (uint32_t)((nb + seg_rows - 1) / seg_rows);
@@ -603,8 +577,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
                     if (u.row_begin >= u.row_end) continue;
                     u.task_begin = t0 + groups[qb].task_off;
                     u.task_count = groups[qb].task_count;
-                    u.mode = groups[qb].mode;
-                    u.pad = 0;
+                    u.pad[0] = u.pad[1] = 0;
                     funits.push_back(u);
                     plan.filter_pairs += (uint64_t)((u.task_count + 31) / 32 * 32) * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
                     plan.filter_rows += (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
@@ -642,12 +615,8 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         fa.cand_cap = cap;
         fa.d = s->d;
         fa.ld = s->ld;
-        fa.plane_hi = s->plane_hi;
-        fa.plane_lo = s->plane_lo;
         fa.frag_planes = s->frag_planes;
         fa.row_limit = (int64_t)s->rows;
-        fa.debug = EnvU32("GPANN_FILTER_DEBUG", 0);
-        const bool dma = s->plane_hi != nullptr && s->plane_lo != nullptr;
         const bool aux = (flags & GPANN_AUX_PASS) != 0;
         RescoreArgs ra;
         ra.points = s->points;
@@ -668,7 +637,7 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
         ra.cand_cap = cap;
         ra.dedupe = 0;
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-        const size_t flds = (dma ? (size_t)2 * kFBufBytes : (size_t)2 * kFPlane * 2 + kFPT * sizeof(float)) + EnvU32("GPANN_FILTER_LDS_PAD", 0);   // (pad: occupancy experiments)
+        const size_t flds = (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
         const size_t rlds = (size_t)4 * s->ld * sizeof(float);
         GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         if (s->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
@@ -686,18 +655,6 @@ static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskA
             GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             void* kargs[] = {&fa};
             GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)funits.size()), dim3(512), kargs, glds, st));
-        } else if (dma) {
-            const void* fn = nullptr;
-            const bool l2 = s->metric == GPANN_METRIC_L2, ks4 = s->d <= 64;
-#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelDma<M, TAG_, KS_>
-            if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
-                             : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
-            else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
-                          : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
-#undef GPANN_PICK
-            GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-            void* kargs[] = {&fa};
-            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)funits.size()), dim3(256), kargs, flds, st));
         } else if (s->metric == GPANN_METRIC_L2) {
             hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
         } else {
@@ -777,7 +734,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (uint32_t b = 0; b < S; ++b) {
         const uint32_t t0 = plan.shard_task_begin[b], tb = plan.shard_task_begin[b + 1] - t0;
         if (tb == 0) continue;
-        for (const FilterGroup& g : PlanFilterGroups(tb, false)) {
+        for (const FilterGroup& g : PlanFilterGroups(tb)) {
             for (uint32_t x = 0; x < g.task_count; ++x) task_group[t0 + g.task_off + x] = (uint32_t)groups.size();
             groups.push_back({t0 + g.task_off, g.task_count, b, 0});
         }
@@ -949,7 +906,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (int pass = first_pass; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
-        const bool hi_pass = hi_last && pass == 2;
+        const bool hi_pass = hi_last && pass >= (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 2);
         th.hi_only = hi_pass ? 1u : 0u;
         if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
         else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);

@@ -47,11 +47,8 @@ struct FilterArgs {
     uint32_t* cand_row;           // [tasks][cand_cap]
     uint32_t cand_cap;
     uint32_t d, ld;
-    const char* plane_hi;         // optional: pre-split bf16 planes [rows + 64][136] (FilterKernelDma)
-    const char* plane_lo;
     const char* frag_planes;      // optional: pre-split bf16 planes in MFMA fragment order (FilterKernelReg), see kGTileBytes
     int64_t row_limit;            // rows of the store (frag_planes and neg_half_norm are readable 64 rows beyond it)
-    uint32_t debug;               // experiments only: 1 = skip MFMA phase, 2 = skip DMA after the first tile, 4 = skip epilogue
 };
 
 // two floats -> packed bf16 hi pair and bf16 lo pair (round to nearest even; x - float(hi) is exact in binary32)
@@ -200,203 +197,11 @@ __global__ void __launch_bounds__(256, 2) FilterKernel(FilterArgs a) {
     }
 }
 
-// ---- the same filter fed by LDS-DMA ---------------------------------------------------------------------------------------
-// With the bf16 hi/lo planes of the points precomputed in HBM in exactly the padded LDS image ([row][136] bf16, 272 B per
-// row), a 64-row tile of a plane is 17 contiguous KiB and is moved HBM -> LDS by 17 global_load_lds_dwordx4 wave-instructions
-// with no VGPRs and no VALU work.  Two LDS buffers: the DMA of tile i+1 is in flight during the MFMA phase of tile i; the
-// one barrier per tile (preceded by the compiler's vmcnt(0)) publishes it.
-constexpr int kFPlaneBytes = kFPlane * 2;            // 17408
-constexpr int kFBufBytes = 2 * kFPlaneBytes;         // hi + lo
-constexpr int kFRowBytes = kFRowStride * 2;          // 272
-
-// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).
-// Issued through inline asm on purpose: for the builtin hipcc cannot tell which LDS bytes the DMA writes and waits
-// vmcnt(0) in front of the next LDS read, which would serialise the DMA with the MFMA phase it is meant to hide under.
-// The kernel waits for its DMAs itself (DmaWaitAll) right before the barrier that publishes them.
-__device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "m0");
-}
-__device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// The tile loop of FilterKernelDma for a wave that owns NPT (1 or 2) of the two 32-row point tiles of every 64-row tile,
-// starting at point tile pt0, and NQT (0..2) query tiles whose fragments are qh/ql.  Everything in the MFMA phase is
-// compile-time shaped (KS k-steps, no branches) so that the A fragments of k-step ks+1 are read from LDS while the matrix
-// core works on k-step ks; a wave with NQT = 0 only moves its share of the tiles and keeps the barriers.
-template <int METRIC, int NPT, int NQT, int KS>
-__device__ __forceinline__ void FilterTileLoop(const FilterArgs& a, char* lds, uint32_t lds_base, int64_t row_begin, int64_t row_end, uint32_t task_begin,
-                                               uint32_t task_count, uint32_t qbase, int pt0, const Frag (&qh)[2][KS], const Frag (&ql)[2][KS],
-                                               const float (&U)[2], int wave, int lane) {
-    const int c = lane & 31, h = lane >> 5;
-    // 34 chunks of 1 KiB per tile (17 per plane); wave w moves chunks w, w + 4, ...
-    auto issue = [&](int buf, int64_t row0) {
-        for (int j = wave; j < 34; j += 4) {
-            const int plane = j >= 17, chunk = j - 17 * plane;
-            const char* src = (plane ? a.plane_lo : a.plane_hi) + (size_t)row0 * kFRowBytes + chunk * 1024 + lane * 16;
-            const uint32_t dst = lds_base + buf * kFBufBytes + plane * kFPlaneBytes + chunk * 1024;
-            DmaToLds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)dst));
-        }
-    };
-    issue(0, row_begin);
-    DmaWaitAll();
-    __syncthreads();
-
-    int buf = 0;
-    for (int64_t row0 = row_begin; row0 < row_end; row0 += kFPT, buf ^= 1) {
-        // no ordinary global load may sit in this loop: beside an LDS-DMA in flight hipcc would wait vmcnt(0) for it before
-        // the first LDS read and serialise DMA and MFMA (the row norms therefore travel inside the hi plane's row padding)
-        const bool late = (a.debug & 8) != 0;
-        if (row0 + kFPT < row_end && !(a.debug & 2) && !late) issue(buf ^ 1, row0 + kFPT);   // (debug bits: timing experiments only)
-        if (NQT > 0 && !(a.debug & 1)) {
-            const __bf16* sHi = reinterpret_cast<const __bf16*>(lds + buf * kFBufBytes) + (32 * pt0 + c) * kFRowStride + 8 * h;
-            const __bf16* sLo = sHi + kFPlane;
-            const char* sN = lds + buf * kFBufBytes + 2 * 128;   // -|p|^2/2 of row r: float at byte r * 272 + 256 of the hi plane
-
-            f32x16 acc[NPT][NQT > 0 ? NQT : 1];
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (METRIC == GPANN_METRIC_L2) {
-                        const char* n0 = sN + (32 * (pt0 + pt) + 8 * g + 4 * h) * kFRowBytes;
-                        nv.x = *reinterpret_cast<const float*>(n0);
-                        nv.y = *reinterpret_cast<const float*>(n0 + kFRowBytes);
-                        nv.z = *reinterpret_cast<const float*>(n0 + 2 * kFRowBytes);
-                        nv.w = *reinterpret_cast<const float*>(n0 + 3 * kFRowBytes);
-                    }
-#pragma unroll
-                    for (int qt = 0; qt < NQT; ++qt) {
-                        acc[pt][qt][4 * g + 0] = nv.x;
-                        acc[pt][qt][4 * g + 1] = nv.y;
-                        acc[pt][qt][4 * g + 2] = nv.z;
-                        acc[pt][qt][4 * g + 3] = nv.w;
-                    }
-                }
-            Frag ah[2][NPT], al[2][NPT];   // double buffered over the k-steps
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) {
-                ah[0][pt].q = *reinterpret_cast<const uint4*>(sHi + 32 * pt * kFRowStride);
-                al[0][pt].q = *reinterpret_cast<const uint4*>(sLo + 32 * pt * kFRowStride);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) {
-#pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt) {
-                        ah[(ks + 1) & 1][pt].q = *reinterpret_cast<const uint4*>(sHi + 32 * pt * kFRowStride + 16 * (ks + 1));
-                        al[(ks + 1) & 1][pt].q = *reinterpret_cast<const uint4*>(sLo + 32 * pt * kFRowStride + 16 * (ks + 1));
-                    }
-                }
-#pragma unroll
-                for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt) {
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1][pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks & 1][pt].v, ql[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks & 1][pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                    }
-            }
-
-            // candidates: acc >= U.  First the maximum of each accumulator block against U (U = +inf for absent tasks)
-            bool any = false;
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                for (int qt = 0; qt < NQT; ++qt) {
-                    float m = acc[pt][qt][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[pt][qt][r]);
-                    any |= m >= U[qt];
-                }
-            if (__any(any) && !(a.debug & 4)) {
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (acc[pt][qt][r] >= U[qt]) {
-                                const int64_t row = row0 + 32 * (pt0 + pt) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                const uint32_t tl = qbase + 32u * qt + c;
-                                if (row < row_end && tl < task_count) {
-                                    const uint32_t task = task_begin + tl;
-                                    const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                                    if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
-                                }
-                            }
-                        }
-            }
-        }
-        if (row0 + kFPT < row_end && !(a.debug & 2) && late) issue(buf ^ 1, row0 + kFPT);
-        DmaWaitAll();      // this wave's share of the next tile has landed ...
-        __syncthreads();   // ... and so has everyone else's; all waves are done reading `buf`
-    }
-}
-
-// TAG: profiling label as for ScanTileKernel (1 = auxiliary pass such as ground truth).  KS: k-steps of 16 dimensions
-// (4: d <= 64, 8: d <= 128; dimensions beyond d are zero in the planes and in the query fragments).
-template <int METRIC, int TAG, int KS>
-__global__ void __launch_bounds__(256, 2) FilterKernelDma(FilterArgs a) {
-    extern __shared__ uint4 fsm4[];
-    char* lds = reinterpret_cast<char*>(fsm4);
-
-    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
-    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const uint32_t ld = a.ld;
-
-    // Wave roles.  A wave owns up to 2 query tiles of 32 tasks (their bf16 fragments live in registers) and 1 or 2 of the two
-    // 32-row point tiles; the time of a 64-row tile is the largest (query tiles x point tiles) product among the 4 waves.
-    // Units with few tasks split the ROWS between waves instead of leaving waves idle (mode, see FilterUnit).
-    const uint32_t mode = a.units[blockIdx.x].mode;
-    const uint32_t qbase = mode == 0 ? 64u * wave : (mode == 1 ? 64u * (wave & 1) : 32u * (wave & 1));
-    const int nqt = (int)min(mode == 2 ? 1u : 2u, (task_count > qbase ? task_count - qbase + 31u : 0u) / 32u);
-    Frag qh[2][KS], ql[2][KS];
-    float U[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t tl = qbase + 32u * t + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        U[t] = (tl < task_count && t < nqt) ? a.task_U[task] : INFINITY;
-        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            const uint32_t k0 = 16u * ks + 8u * h;
-            if (k0 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            }
-            if (k0 + 4 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
-                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], qh[t][ks].u[j], ql[t][ks].u[j]);
-        }
-    }
-
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
-#define GPANN_FILTER_LOOP(NPT, NQT, PT0) \
-    FilterTileLoop<METRIC, NPT, NQT, KS>(a, lds, lds_base, row_begin, row_end, task_begin, task_count, qbase, PT0, qh, ql, U, wave, lane)
-    if (nqt == 0) GPANN_FILTER_LOOP(1, 0, 0);
-    else if (mode == 0) {
-        if (nqt == 2) GPANN_FILTER_LOOP(2, 2, 0);
-        else GPANN_FILTER_LOOP(2, 1, 0);
-    } else {
-        if (nqt == 2) GPANN_FILTER_LOOP(1, 2, wave >> 1);
-        else GPANN_FILTER_LOOP(1, 1, wave >> 1);
-    }
-#undef GPANN_FILTER_LOOP
-}
-
 // ---- the filter with the QUERIES stationary in LDS and the points streamed through registers --------------------------------
-// FilterKernelDma stages point tiles in LDS for 256 tasks and keeps the query fragments in registers; every tile costs a
-// workgroup barrier, and an LDS-DMA fill landing in LDS and the ds_read/MFMA stream slow each other down (measured: filter time
-// = fill-only time + compute-only time, no overlap).  FilterKernelReg turns the roles around:
+// FilterKernel above (and an LDS-DMA fed variant of it that this file used to hold) stages POINT tiles in LDS for 256 tasks and
+// keeps the query fragments in registers: every tile costs a workgroup barrier, and an LDS-DMA fill landing in LDS and the
+// ds_read/MFMA stream slowed each other down (measured: filter time = fill-only time + compute-only time, no overlap).
+// FilterKernelReg turns the roles around:
 //   * the bf16 hi/lo fragments of the unit's <= 256 tasks are built ONCE into LDS (128 KiB, in MFMA B-operand order: a
 //     ds_read_b128 with lane-linear addresses, conflict free) and stay there for the unit's whole row segment;
 //   * the points are pre-split in HBM in MFMA A-operand order — per 32-row tile and k-step one contiguous KiB per plane
@@ -593,27 +398,6 @@ static __global__ void __launch_bounds__(256) SplitFragPlanesKernel(const float*
         char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
         *reinterpret_cast<uint4*>(base) = fh.q;
         *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
-    }
-}
-
-// f32 rows -> the two bf16 planes in the padded LDS image ([row][136], pad = 0); one thread per pair of elements
-static __global__ void __launch_bounds__(256) SplitPlanesKernel(const float* points, const float* neg_half_norm, uint64_t rows, uint32_t ld, char* plane_hi,
-                                                                char* plane_lo) {
-    const uint64_t pairs_per_row = kFRowStride / 2;   // 68
-    const uint64_t total = rows * pairs_per_row;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i / pairs_per_row;
-        const uint32_t c = (uint32_t)(i % pairs_per_row) * 2;
-        float x0 = 0.f, x1 = 0.f;
-        if (c < ld) {
-            x0 = points[r * ld + c];
-            x1 = points[r * ld + c + 1];   // ld is even (multiple of 4)
-        }
-        uint32_t hi, lo;
-        SplitBf16(x0, x1, hi, lo);
-        if (c == 128) hi = __float_as_uint(neg_half_norm[r]);   // the row's -|p|^2/2 rides in the first 4 pad bytes of the hi plane
-        *reinterpret_cast<uint32_t*>(plane_hi + r * kFRowBytes + c * 2) = hi;
-        *reinterpret_cast<uint32_t*>(plane_lo + r * kFRowBytes + c * 2) = lo;
     }
 }
 

@@ -22,9 +22,7 @@ struct ScanUnit {
 struct FilterUnit {
     int64_t row_begin, row_end;
     uint32_t task_begin, task_count;
-    uint32_t mode;   // how the 4 wavefronts share (tasks x 64-row tile): 0 = 64 tasks each, all rows (<= 256 tasks);
-                     // 1 = 64 tasks x half the rows (<= 128 tasks); 2 = 32 tasks x half the rows (<= 64 tasks)
-    uint32_t pad;
+    uint32_t pad[2];
 };
 
 // Host-side launch plan of one scan call; kept alive in the handle until the next call because its arrays are the
@@ -66,8 +64,6 @@ struct gpann_shards {
     // MFMA pre-filter support (scan_filter.h): -|p|^2/2 per row, max |p| per shard, and whether the data is fit for it
     float* neg_half_norm = nullptr;  // [rows]
     double* d_shard_rmax = nullptr;  // [S]
-    char* plane_hi = nullptr;        // optional [rows + 64][136] bf16: the points pre-split for FilterKernelDma
-    char* plane_lo = nullptr;
     char* frag_planes = nullptr;     // optional: bf16 hi/lo planes in MFMA fragment order, 16 KiB per 32 rows (FilterKernelReg)
 
     // Cells (cells.hip): with them the planes hold the rows of every shard GROUPED BY CELL (a k-means sub-cluster of the shard,

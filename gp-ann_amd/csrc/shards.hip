@@ -192,21 +192,20 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         (void)hipFree(d_bad);
         s->filter_ok = bad == 0;
         // pre-split bf16 planes for the filter (about as many bytes as the rows once more); optional: without them (allocation
-        // failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly.  Default layout: MFMA fragment order for
-        // FilterKernelReg; GPANN_FILTER_PLANES=dma builds the row-major padded planes of FilterKernelDma instead.
+        // failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly (FilterKernel).  Layout: MFMA fragment order.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
-        const bool want_none = want && want[0] == '0', want_dma = want && std::string(want) == "dma";
+        const bool want_none = want && want[0] == '0';
         // cells (cells.hip): rows grouped by sub-cluster so that the filter can skip what a bound excludes.  Default for stores of
         // a million rows and more; GPANN_FILTER_CELLS=0|1 forces, GPANN_CELL_ROWS sets the target cell size.
         const char* wc = std::getenv("GPANN_FILTER_CELLS");
         const char* cr = std::getenv("GPANN_CELL_ROWS");
         const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
         const bool want_cells = wc ? wc[0] == '1' : rows >= (1u << 20);
-        if (s->filter_ok && d <= 128 && !want_none && !want_dma && want_cells) {
+        if (s->filter_ok && d <= 128 && !want_none && want_cells) {
             gpann_status cst = BuildCells(s, cell_rows);
             if (cst != GPANN_OK) return fail(cst);
         }
-        if (s->filter_ok && d <= 128 && !want_none && !want_dma && !s->frag_planes) {
+        if (s->filter_ok && d <= 128 && !want_none && !s->frag_planes) {
             const uint64_t tiles = (rows + kGTileRows - 1) / kGTileRows + 2;
             if (hipMalloc(&s->frag_planes, tiles * (size_t)kGTileBytes) == hipSuccess) {
                 const uint64_t first_partial = rows / kGTileRows;
@@ -218,22 +217,6 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
             } else {
                 (void)hipGetLastError();
                 s->frag_planes = nullptr;
-            }
-        }
-        if (s->filter_ok && d <= 128 && want_dma) {
-            const size_t plane_bytes = (rows + 64) * (size_t)kFRowBytes;
-            if (hipMalloc(&s->plane_hi, plane_bytes) == hipSuccess && hipMalloc(&s->plane_lo, plane_bytes) == hipSuccess) {
-                TRY_OR_FAIL(hipMemsetAsync(s->plane_hi + rows * (size_t)kFRowBytes, 0, 64 * (size_t)kFRowBytes, 0));
-                TRY_OR_FAIL(hipMemsetAsync(s->plane_lo + rows * (size_t)kFRowBytes, 0, 64 * (size_t)kFRowBytes, 0));
-                const uint64_t total = rows * (kFRowStride / 2);
-                const int g2 = (int)std::min<uint64_t>((total + 255) / 256, 256 * 64);
-                hipLaunchKernelGGL(SplitPlanesKernel, dim3(g2), dim3(256), 0, 0, s->points, s->neg_half_norm, rows, s->ld, s->plane_hi, s->plane_lo);
-                TRY_OR_FAIL(hipGetLastError());
-                TRY_OR_FAIL(hipDeviceSynchronize());
-            } else {
-                (void)hipGetLastError();
-                if (s->plane_hi) (void)hipFree(s->plane_hi);
-                s->plane_hi = s->plane_lo = nullptr;
             }
         }
     }
@@ -257,8 +240,6 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->d_offsets) (void)hipFree(s->d_offsets);
     if (s->neg_half_norm) (void)hipFree(s->neg_half_norm);
     if (s->d_shard_rmax) (void)hipFree(s->d_shard_rmax);
-    if (s->plane_hi) (void)hipFree(s->plane_hi);
-    if (s->plane_lo) (void)hipFree(s->plane_lo);
     if (s->frag_planes) (void)hipFree(s->frag_planes);
     ReleaseCells(s);
     s->ws_lists.Release();
