@@ -384,6 +384,94 @@ __global__ void MinBitsToFloatKernel(uint32_t* io, size_t n) {
     }
 }
 
+// FrequencyQuery's TopN(num_voting) on the device: the V lexicographically smallest (distance, shard) pairs of a query's
+// evaluated centroids, ascending (= TopN::Take() then FrequencyQueryData::Init(), kmeans_tree_router.h:19-21).  One workgroup per
+// query: 8-pass byte-wise radix select of the V-th smallest 64-bit key (order-preserving distance bits << 32 | shard), then the
+// keys below it (and as many copies of it as are still missing) are sorted in LDS.  V <= 2048.
+__global__ void __launch_bounds__(256) VoteSelectKernel(const float* rec_dist, const int32_t* rec_shard, const uint32_t* rec_count, uint64_t rec_cap,
+                                                        uint32_t V, float* out_dist, uint32_t* out_shard, uint32_t* out_count) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long buf[2048];
+    __shared__ uint32_t s_cursor, s_bin, s_below;
+    const uint32_t q = blockIdx.x;
+    const uint32_t cnt = rec_count[q];
+    const float* dist = rec_dist + (size_t)q * rec_cap;
+    const int32_t* shard = rec_shard + (size_t)q * rec_cap;
+    const uint32_t keep = min(V, cnt);
+    auto key_of = [&](uint32_t i) -> unsigned long long { return ((unsigned long long)OrderedBitsD(dist[i]) << 32) | (uint32_t)shard[i]; };
+    uint32_t N = 1;
+    while (N < max(keep, 2u)) N <<= 1;
+    unsigned long long kth = ~0ull;
+    uint32_t below = 0;   // keys strictly below the prefix found so far
+    if (cnt > V) {
+        unsigned long long prefix = 0, mask = 0;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const unsigned long long k = key_of(i);
+                if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t acc = below, b = 0;
+                for (; b < 256; ++b) {
+                    if (acc + hist[b] >= V) break;
+                    acc += hist[b];
+                }
+                s_bin = b;
+                s_below = acc;
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)s_bin << shift;
+            mask |= 255ull << shift;
+            below = s_below;
+            __syncthreads();
+        }
+        kth = prefix;   // the V-th smallest key; `below` keys are smaller
+    }
+    if (threadIdx.x == 0) s_cursor = 0;
+    for (uint32_t i = threadIdx.x; i < N; i += 256) buf[i] = ~0ull;
+    __syncthreads();
+    if (cnt > V) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+            const unsigned long long k = key_of(i);
+            if (k < kth) buf[atomicAdd(&s_cursor, 1u)] = k;
+        }
+        __syncthreads();
+        for (uint32_t i = below + threadIdx.x; i < V; i += 256) buf[i] = kth;   // equal pairs are interchangeable
+    } else {
+        for (uint32_t i = threadIdx.x; i < cnt; i += 256) buf[i] = key_of(i);
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= N; k2 <<= 1)
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t p = i | j;
+                const bool up = (i & k2) == 0;
+                const unsigned long long ei = buf[i], ep = buf[p];
+                if ((ei > ep) == up) {
+                    buf[i] = ep;
+                    buf[p] = ei;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < keep; i += 256) {
+        const unsigned long long k = buf[i];
+        const uint32_t o = (uint32_t)(k >> 32);
+        out_dist[(size_t)q * V + i] = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+        out_shard[(size_t)q * V + i] = (uint32_t)k;
+    }
+    for (uint32_t i = keep + threadIdx.x; i < V; i += 256) {
+        out_dist[(size_t)q * V + i] = INFINITY;
+        out_shard[(size_t)q * V + i] = 0xFFFFFFFFu;
+    }
+    if (threadIdx.x == 0) out_count[q] = keep;
+}
+
 struct ReplayArgs {
     const float* dense;       // [nq][C] exact distances
     const int32_t* node_shard;
@@ -1353,8 +1441,18 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     float* d_rec_dist = rec.as<float>();
     int32_t* d_rec_shard = reinterpret_cast<int32_t*>(d_rec_dist + (size_t)batch * rec_cap);
     uint32_t* d_rec_count = reinterpret_cast<uint32_t*>(d_rec_shard + (size_t)batch * rec_cap);
-    std::vector<float> h_dist((size_t)batch * rec_cap);
-    std::vector<int32_t> h_shard((size_t)batch * rec_cap);
+    const bool device_select = num_voting >= 1 && num_voting <= 2048;
+    DeviceBuffer sel;
+    float* d_sel_dist = nullptr;
+    uint32_t *d_sel_shard = nullptr, *d_sel_count = nullptr;
+    if (device_select) {
+        GPANN_TRY(sel.Reserve((size_t)batch * num_voting * 8 + (size_t)batch * 4));
+        d_sel_dist = sel.as<float>();
+        d_sel_shard = reinterpret_cast<uint32_t*>(d_sel_dist + (size_t)batch * num_voting);
+        d_sel_count = d_sel_shard + (size_t)batch * num_voting;
+    }
+    std::vector<float> h_dist(device_select ? 0 : (size_t)batch * rec_cap);
+    std::vector<int32_t> h_shard(device_select ? 0 : (size_t)batch * rec_cap);
     std::vector<uint32_t> h_count(batch);
     const size_t qstride = (flags & GPANN_QUERIES_ON_DEVICE) ? r->d : r->d;
     float total_ms = 0.f;
@@ -1364,6 +1462,25 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
         status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap);
         if (status != GPANN_OK) break;
         hipError_t e = hipMemcpyAsync(out_min_dist + (size_t)q0 * S, r->ws_out.ptr, (size_t)m * S * 4, hipMemcpyDeviceToHost, st);
+        if (device_select) {
+            // the votes are selected on the device; only [m][num_voting] pairs travel
+            hipLaunchKernelGGL(VoteSelectKernel, dim3(m), dim3(256), 0, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap, num_voting, d_sel_dist, d_sel_shard,
+                               d_sel_count);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(out_nn_dist + (size_t)q0 * num_voting, d_sel_dist, (size_t)m * num_voting * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_nn_shard + (size_t)q0 * num_voting, d_sel_shard, (size_t)m * num_voting * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_nn_count + q0, d_sel_count, (size_t)m * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                SetLastError("frequency query transfer failed: %s", hipGetErrorString(e));
+                status = GPANN_ERR_HIP;
+                break;
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r->ev[0], r->ev[1]);
+            total_ms += ms;
+            continue;
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(h_count.data(), d_rec_count, (size_t)m * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(h_dist.data(), d_rec_dist, (size_t)m * rec_cap * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(h_shard.data(), d_rec_shard, (size_t)m * rec_cap * 4, hipMemcpyDeviceToHost, st);
@@ -1391,6 +1508,7 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
         }
     }
     rec.Release();
+    sel.Release();
     if (elapsed_ms) *elapsed_ms = total_ms;
     return status;
 }

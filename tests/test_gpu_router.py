@@ -150,3 +150,22 @@ def test_router_deep_tree_with_duplicates(orc, gp):
         probes, md, _ = router.query_batch(queries, budget)
         wp, wm = tree.query_batch(queries, budget, nthreads=4)
         assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp), budget
+
+
+def test_frequency_query_vote_selection_ties_and_short_lists(orc, gp):
+    """device-side TopN of the votes: equal (distance, shard) pairs, fewer evaluated centroids than votes asked for"""
+    n, d, S = 8000, 8, 4
+    rng = np.random.default_rng(12)
+    base = make_mixture(orc, 40, d, n_centers=4)
+    pts = base[rng.integers(0, 40, size=n)]
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=16, min_cluster_size=20, budget=800, metric=0, nthreads=4)
+    queries = base[rng.integers(0, 40, size=60)]
+    router = gp.Router(tree.flat(), 0, 0)
+    for budget, votes in ((60, 500), (100000, 37), (100000, 2048)):
+        md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, votes)
+        for q in range(len(queries)):
+            wmd, wnd, wns = tree.frequency_query(queries[q], budget, votes)
+            assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32))
+            assert nc[q] == len(wnd), (budget, votes, q)
+            assert np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns)
