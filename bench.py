@@ -223,6 +223,7 @@ def main():
         return out
 
     my_ids_host = my_ids.cpu().numpy().astype(np.uint32)
+    my_ids_dev = my_ids.to(torch.int64)
     del my_ids
 
     out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
@@ -235,14 +236,18 @@ def main():
         od = out_dist[:, :nprobe].contiguous() if nprobe != S else out_dist
         ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
         if world > 1:
-            # translate to global ids, then the exchange: all-gather of the fixed-shape slot arrays over RCCL
-            ids_h = to_global(oi.cpu().numpy().view(np.uint32))
-            oi.copy_(torch.from_numpy(ids_h.view(np.int32)))
+            # local row ids -> global ids on the device, then the exchange over RCCL: a slot is non-empty on exactly one rank, so
+            # MIN over the distances / MAX over the ids (multigpu.reduce_slots) is the all-gather + owner selection in one step
+            gi = torch.where(oi >= 0, my_ids_dev[oi.clamp(min=0).long()], torch.full_like(oi, -1, dtype=torch.int64))
             if args.backend == "nccl":
-                gd_h, gi_h = multigpu.all_gather_slots(od, oi, dist, world)
+                multigpu.reduce_slots(od, gi, dist)
+                dist_h = od.cpu().numpy()
+                ids_h = gi.cpu().numpy().astype(np.uint32)
             else:
-                gd_h, gi_h = multigpu.all_gather_slots(od.cpu(), oi.cpu(), dist, world)
-            dist_h, ids_h = multigpu.combine_slots(gd_h, gi_h, probes, owner)
+                od_c, gi_c = od.cpu(), gi.cpu()
+                multigpu.reduce_slots(od_c, gi_c, dist)
+                dist_h = od_c.numpy()
+                ids_h = gi_c.numpy().astype(np.uint32)
         else:
             torch.cuda.current_stream().synchronize()
             dist_h = od.cpu().numpy()

@@ -55,6 +55,15 @@ def all_gather_slots(dist_t, ids_t, torch_dist, world):
     return torch.stack(gd).cpu().numpy(), torch.stack(gi).cpu().numpy().view(np.uint32)
 
 
+def reduce_slots(dist_t, gids_t, torch_dist):
+    """The same exchange as all_gather_slots + combine_slots in one collective per array: a slot is scanned by exactly one rank
+    (the owner of its shard) and reads (+inf, -1) everywhere else, so the element-wise MIN of the distances and MAX of the
+    global ids (int64, -1 = no id) over the ranks is the owner's result.  In place, on whatever device the backend uses."""
+    torch_dist.all_reduce(dist_t, op=torch_dist.ReduceOp.MIN)
+    torch_dist.all_reduce(gids_t, op=torch_dist.ReduceOp.MAX)
+    return dist_t, gids_t
+
+
 def merge_trees(flats, owner):
     """Router trees trained per rank (Router.train over a store that holds only the rank's shards; the other shards get
     empty roots) -> the one tree KMeansTreeRouter::Train builds over all shards.  Shards are independent in training

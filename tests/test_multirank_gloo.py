@@ -48,6 +48,11 @@ def _worker(rank, world, port, out_dir):
     od, oi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, lp, nprobe, 0)
     gd, gi = multigpu.all_gather_slots(torch.from_numpy(od), torch.from_numpy(oi.view(np.int32)), dist, world)
     cd, ci = multigpu.combine_slots(gd, gi, probes, owner)
+    # the one-collective form of the same exchange (what bench.py runs): MIN over distances, MAX over int64 ids (-1 = none)
+    rd = torch.from_numpy(od.copy())
+    ri = torch.from_numpy(np.where(oi == 0xFFFFFFFF, -1, oi.astype(np.int64)))
+    multigpu.reduce_slots(rd, ri, dist)
+    assert np.array_equal(rd.numpy().view(np.uint32), cd.view(np.uint32)) and np.array_equal(ri.numpy().astype(np.uint32), ci)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
