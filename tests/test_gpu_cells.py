@@ -126,3 +126,30 @@ def test_cells_hi_plane_only_last_pass(orc, gp, monkeypatch):
     probes = np.zeros((nq, 1), np.int32)
     for metric in (0, 1):
         _check(orc, gp, pts, clusters, queries, probes, 1, k, metric)
+
+
+def test_cells_default_configuration_midsize(orc, gp, monkeypatch):
+    """a store large enough to get cells by default (>= 1M rows, 32k-row cells, hi-plane last pass): filter mode must equal the
+    plain exact scan bit for bit on every query and the CPU oracle on a sample of them"""
+    monkeypatch.delenv("GPANN_FILTER_CELLS")
+    monkeypatch.delenv("GPANN_CELL_ROWS")
+    rng = np.random.default_rng(41)
+    n, d, S, nq, k = 2_400_000, 64, 2, 320, 10
+    pts = orc.synth_rows(555, 7, 96, 0.35, 0, n, d, nthreads=8)
+    queries = orc.synth_rows(556, 7, 96, 0.35, 0, nq, d, nthreads=8)
+    part = rng.integers(0, S, size=n)
+    clusters = [np.flatnonzero(part == b).astype(np.uint32) for b in range(S)]
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(1)
+    ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
+    st = shards.stats()
+    assert st["filtered"] == 1 and 0 < st["filter_pairs"] < nq * n                # some (query tile, cell) blocks were skipped
+    shards.set_scan_mode(0)
+    ids0, dist0, _ = shards.scan_buckets(queries, k, probes, S)
+    assert np.array_equal(ids0, ids) and np.array_equal(dist0.view(np.uint32), dist.view(np.uint32))
+    shards.close()
+    sub = np.arange(0, nq, 16)
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries[sub], k, probes[sub], S, 0, nthreads=8)
+    assert np.array_equal(ids[sub], wi) and np.array_equal(dist[sub].view(np.uint32), wd.view(np.uint32))
