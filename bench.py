@@ -390,8 +390,7 @@ def main():
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
         plane_bytes = stats["filter_rows"] * 256.0   # row tiles streamed x 32 rows x 256 B (hi plane; the small first passes read 512 B)
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
-                              "traffic": traffic, "kernel": "gpann::FilterKernelCells" if n_local >= (1 << 20) else "gpann::FilterKernelReg",
-                              "kernel_ms": 1000.0 * f_s,
+                              "traffic": traffic, "kernel": "gpann::FilterKernelCells", "kernel_ms": 1000.0 * f_s,
                               "note": "achieved = algorithmic bytes of the reference's scan (rows x d x 4 per (query, probed shard), SURVEY 8d) / "
                                       "HIP-event time of all scan kernels; frac > 1 because the exact answer needs far fewer bytes: cells whose "
                                       "bounding ball cannot reach a task's k-th distance are skipped, the rest is bounded by bf16 MFMA products on "

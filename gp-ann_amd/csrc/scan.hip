@@ -480,7 +480,7 @@ struct FilterGroup {
 };
 static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb) {
     std::vector<FilterGroup> out;
-    const uint32_t nqb = (tb + kFQB - 1) / kFQB;
+    const uint32_t nqb = (tb + kGTasks - 1) / kGTasks;
     const uint32_t tiles = (tb + 31) / 32;
     uint32_t done = 0;
     for (uint32_t qb = 0; qb < nqb; ++qb) {
@@ -492,204 +492,7 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb) {
     return out;
 }
 
-// The MFMA-filtered pipeline (scan_filter.h).  On return *overflow tells whether a candidate bucket overflowed, in which
-// case the outputs are not written and the caller runs the plain exact scan instead.
-static gpann_status RunFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
-                                    hipStream_t st, DeviceLists out, bool* overflow) {
-    *overflow = false;
-    s->filter_passes_timed = 0;
-    const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
-    if (T == 0) return GPANN_OK;
-    const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
-    const int64_t m1 = std::max<int64_t>(m0, (int64_t)EnvU32("GPANN_FILTER_MID_ROWS", 131072) / kPT * kPT);
-    // candidate bucket per task: as large as ~1.5 GB of workspace allows, within [1024, 4096] (expected fill: a few hundred)
-    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (1536ull << 20) / (4ull * T))));
-
-    // per-task exact lists (dist | row), thresholds, candidate buckets, overflow word
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
-    float* list_dist = s->ws_lists.as<float>();
-    uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
-    float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
-    uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T + ((T & 1) ? 1 : 0));   // [0] overflow count, [2..3] candidate total (u64)
-    unsigned long long* d_cand_total = reinterpret_cast<unsigned long long*>(d_overflow + 2);
-    GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
-    uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
-    uint32_t* cand_row = cand_cnt + T;
-    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 16, st));
-
-    // ---- stage 0: exact scan of the first m0 rows of every shard -> lists
-    std::vector<int64_t> lo(S), hi(S);
-    for (uint32_t b = 0; b < S; ++b) {
-        lo[b] = s->offsets[b];
-        hi[b] = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + m0);
-    }
-    plan.padded_pairs = 0;
-    GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
-    {
-        MergeArgs m{};
-        m.out_index = nullptr;   // identity: list t
-        m.permutation = s->permutation;
-        m.out_dist = list_dist;
-        m.out_rows = list_row;
-        m.out_ids = nullptr;
-        GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
-    }
-
-    // ---- filter passes over [m0, m1) and [m1, end)
-    const int64_t bounds[3] = {m0, m1, std::numeric_limits<int64_t>::max()};
-    const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_TARGET_UNITS", 8192));
-    for (int pass = 0; pass < 2; ++pass) {
-        // units: (<= 256 tasks of a shard) x (row segment of the pass range)
-        std::vector<FilterUnit>& funits = plan.filter_units;
-        funits.clear();
-        uint64_t block_rows = 0;
-        for (uint32_t b = 0; b < S; ++b) {
-            const uint32_t tb = plan.shard_task_begin[b + 1] - plan.shard_task_begin[b];
-            const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
-            const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
-                                                                                       : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
-            if (tb && r1 > r0) block_rows += (uint64_t)PlanFilterGroups(tb).size() * (uint64_t)(r1 - r0);
-        }
-        if (block_rows == 0) continue;
-        uint64_t seg_rows = std::max<uint64_t>(4096, (block_rows + target_units - 1) / target_units);
-        seg_rows = (seg_rows + kFPT - 1) / kFPT * kFPT;
-        for (uint32_t b = 0; b < S; ++b) {
-            const uint32_t t0 = plan.shard_task_begin[b], tb = plan.shard_task_begin[b + 1] - t0;
-            const int64_t r0 = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass]);
-            const int64_t r1 = bounds[pass + 1] == std::numeric_limits<int64_t>::max() ? s->offsets[b + 1]
-                                                                                       : std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + bounds[pass + 1]);
-            if (tb == 0 || r1 <= r0) continue;
-            const std::vector<FilterGroup> groups = PlanFilterGroups(tb);
-            const uint32_t nqb = (uint32_t)groups.size();
-            const uint64_t nb = (uint64_t)(r1 - r0);
-            const uint32_t nseg = (uint32_t)((nb + seg_rows - 1) / seg_rows);
-            const uint64_t per = ((nb + nseg - 1) / nseg + kFPT - 1) / kFPT * kFPT;
-            // launch order: 8 consecutive segments of one group, then the same 8 segments of the next group, ...: workgroups are
-            // dealt round-robin to the 8 XCDs, so the groups that stream the same rows land on the same XCD back to back and the
-            // second one finds the rows in that XCD's L2
-            const uint32_t xcds = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_XCD_STRIDE", 8));
-            for (uint32_t sg0 = 0; sg0 < nseg; sg0 += xcds)
-            for (uint32_t qb = 0; qb < nqb; ++qb) {
-                for (uint32_t sg = sg0; sg < std::min(nseg, sg0 + xcds); ++sg) {
-                    FilterUnit u;
-                    u.row_begin = r0 + (int64_t)(sg * per);
-                    u.row_end = std::min<int64_t>(r1, u.row_begin + (int64_t)per);
-                    if (u.row_begin >= u.row_end) continue;
-                    u.task_begin = t0 + groups[qb].task_off;
-                    u.task_count = groups[qb].task_count;
-                    u.pad[0] = u.pad[1] = 0;
-                    funits.push_back(u);
-                    plan.filter_pairs += (uint64_t)((u.task_count + 31) / 32 * 32) * (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
-                    plan.filter_rows += (uint64_t)(((u.row_end - u.row_begin) + kFPT - 1) / kFPT * kFPT);
-                }
-            }
-        }
-        if (funits.empty()) continue;
-        GPANN_TRY((pass == 0 ? s->ws_funits0 : s->ws_funits1).Reserve(funits.size() * sizeof(FilterUnit)));
-        FilterUnit* d_funits = (pass == 0 ? s->ws_funits0 : s->ws_funits1).as<FilterUnit>();
-        // the two passes use separate device arrays, but plan.filter_units is rebuilt: upload synchronously w.r.t. the host
-        GPANN_HIP_TRY(hipMemcpyAsync(d_funits, funits.data(), funits.size() * sizeof(FilterUnit), hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipStreamSynchronize(st));
-
-        ThresholdArgs th;
-        th.list_dist = list_dist;
-        th.queries = d_queries;
-        th.task_query = ta.query;
-        th.task_shard = ta.shard;
-        th.shard_rmax = s->d_shard_rmax;
-        th.task_U = task_U;
-        th.tasks = T;
-        th.k = k;
-        th.d = s->d;
-        th.ld = s->ld;
-        th.hi_only = 0;
-        FilterArgs fa;
-        fa.points = s->points;
-        fa.queries = d_queries;
-        fa.neg_half_norm = s->neg_half_norm;
-        fa.units = d_funits;
-        fa.task_query = ta.query;
-        fa.task_U = task_U;
-        fa.cand_cnt = cand_cnt;
-        fa.cand_row = cand_row;
-        fa.cand_cap = cap;
-        fa.d = s->d;
-        fa.ld = s->ld;
-        fa.frag_planes = s->frag_planes;
-        fa.row_limit = (int64_t)s->rows;
-        const bool aux = (flags & GPANN_AUX_PASS) != 0;
-        RescoreArgs ra;
-        ra.points = s->points;
-        ra.queries = d_queries;
-        ra.task_query = ta.query;
-        ra.cand_cnt = cand_cnt;
-        ra.cand_row = cand_row;
-        ra.list_dist = list_dist;
-        ra.list_row = list_row;
-        ra.task_shard = ta.shard;
-        ra.shard_offsets = s->d_offsets;
-        ra.range_lo = bounds[pass];
-        ra.range_hi = bounds[pass + 1];
-        ra.tasks = T;
-        ra.k = k;
-        ra.d = s->d;
-        ra.ld = s->ld;
-        ra.cand_cap = cap;
-        ra.dedupe = 0;
-        GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-        const size_t flds = (size_t)2 * kFPlane * 2 + kFPT * sizeof(float);
-        const size_t rlds = (size_t)4 * s->ld * sizeof(float);
-        GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
-        if (s->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-        else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-        if (s->frag_planes) {
-            const void* fn = nullptr;
-            const bool l2 = s->metric == GPANN_METRIC_L2, ks4 = s->d <= 64;
-#define GPANN_PICK(M, TAG_, KS_) (const void*)FilterKernelReg<M, TAG_, KS_>
-            if (l2) fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4) : GPANN_PICK(GPANN_METRIC_L2, 1, 8))
-                             : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4) : GPANN_PICK(GPANN_METRIC_L2, 0, 8));
-            else fn = aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8))
-                          : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8));
-#undef GPANN_PICK
-            const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
-            GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            void* kargs[] = {&fa};
-            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)funits.size()), dim3(512), kargs, glds, st));
-        } else if (s->metric == GPANN_METRIC_L2) {
-            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_L2>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-        } else {
-            hipLaunchKernelGGL(FilterKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)funits.size()), dim3(256), flds, st, fa);
-        }
-        GPANN_HIP_TRY(hipGetLastError());
-        GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
-        s->filter_passes_timed++;
-        // a handful of overflowed buckets (tail of the candidate-count distribution) are re-scanned exactly inside
-        // RescoreKernel; wide-spread overflow (masses of equal distances) sends the whole call to the plain exact scan
-        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-        uint32_t h_words[4] = {0, 0, 0, 0};
-        GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipStreamSynchronize(st));
-        const uint32_t h_overflow = h_words[0];
-        plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
-        if (h_overflow > std::max<uint32_t>(8, T / 1000)) {
-            *overflow = true;
-            return GPANN_OK;
-        }
-        if (h_overflow) GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
-        if (s->metric == GPANN_METRIC_L2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        GPANN_HIP_TRY(hipGetLastError());
-        plan.filter_launches++;
-    }
-    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
-    const size_t n = (size_t)T * k;
-    hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k, out.dist,
-                       out.ids, out.rows);
-    GPANN_HIP_TRY(hipGetLastError());
-    return GPANN_OK;
-}
-
-// The MFMA-filtered pipeline over a store with cells (cells.hip, scan_cells.h):
+// The MFMA-filtered pipeline (cells.hip, scan_cells.h, scan_filter.h):
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
@@ -960,7 +763,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 }
 
 static bool FilterWanted(const gpann_shards* s, uint32_t k) {
-    if (!s->filter_ok || s->d > 16u * kFKS || k > GPANN_MAX_K) return false;
+    if (!s->filter_ok || s->cells.n_cells == 0 || s->frag_planes == nullptr || s->d > 16u * kFKS || k > GPANN_MAX_K) return false;
     const char* mode = std::getenv("GPANN_SCAN_MODE");
     if (mode && *mode) return std::string(mode) == "filter";
     return s->scan_mode == 1;
@@ -1005,8 +808,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
-        if (s->cells.n_cells) GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
-        else GPANN_TRY(RunFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
         done = !overflow;
         s->stats.filtered = done ? 1 : 0;
     }
@@ -1027,7 +829,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.pairs = plan.pairs;
     s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)T * k * 8ull;
     s->stats.tasks = T;
-    s->stats.units = plan.units.size() + plan.filter_units.size();
+    s->stats.units = plan.units.size();
     s->stats.padded_pairs = plan.padded_pairs;
     s->stats.filter_pairs = plan.filter_pairs;
     s->stats.filter_rows = plan.filter_rows;

@@ -1,14 +1,26 @@
-// scan_cells.h — cell pruning for the MFMA pre-filter (see cells.hip for what a cell is and why skipping is exact).
+// scan_cells.h — the filtered exact scan: cell pruning + the MFMA kernel (see cells.hip for what a cell is and why skipping it is
+// exact, scan_filter.h for the bound / candidate / re-scoring scheme).
 //
 // Per scan call:
-//   CellDistKernel   |q - c|^2 of every task against every cell of its shard (the exact kernels' 4x4 register tile; plain fp32)
-//   NearestCellKernel the nearest cell of every task (tasks of a shard are then ordered by it so that the 32-task query tiles
-//                    of the filter are spatially coherent)
-//   NeedKernel       which (task group, cell) blocks must be filtered, as a bit per 32-task query tile:
-//                      head pass: the first tiles of each task's nearest cell (tightens the k-th distance cheaply)
-//                      main pass: every cell whose bounding ball reaches the task's current k-th distance
-//   FilterKernelCells FilterKernelReg over one (task group, cell) block per workgroup, running only the query tiles whose bit
-//                    is set; candidates are mapped from plane rows back to store rows
+//   CellDistKernel    |q - c|^2 of every task against every cell of its shard (the exact kernels' 4x4 register tile; plain fp32)
+//   NearestCellKernel the nearest cell of every task; TaskReorderKernel then groups the tasks of a shard by it so that the 32-task
+//                     query tiles of the MFMA kernel are spatially coherent
+//   NeedKernel        which (task group, cell) blocks must be filtered, as a bit per 32-task query tile:
+//                       head pass: the first tiles of each task's nearest cell (tightens the k-th distance cheaply)
+//                       sample / rest passes: every cell whose bounding ball reaches the task's current k-th distance
+//   FilterKernelCells the MFMA kernel.  Queries stationary, points streamed:
+//     * the bf16 hi/lo fragments of a group's <= 256 tasks are built ONCE per block into LDS (128 KiB, in MFMA B-operand order: a
+//       ds_read_b128 with lane-linear addresses, conflict free);
+//     * the points are pre-split in HBM in MFMA A-operand order (scan_filter.h), so a wavefront loads a tile's fragments with
+//       perfectly coalesced global_load_dwordx4 straight into the registers the MFMA reads.  No LDS traffic for the points, no
+//       barrier in the loop: the 8 wavefronts of a workgroup take tiles round robin and run independently, each prefetching
+//       its next tile into a second register set while the matrix core works on the current one.  (An earlier design staged
+//       POINT tiles in LDS by LDS-DMA with the queries in registers: a barrier per tile, and the fill landing in LDS and the
+//       ds_read/MFMA stream slowed each other down — its time was fill-only + compute-only.)
+//     * only the query tiles whose bit is set run on a row tile; candidates of a tile are collected as bit masks and written
+//       after the tile's MFMA phase, when the prefetch has landed (the atomic's vmcnt wait would otherwise stall on the loads
+//       issued before it); they are mapped from plane rows back to store rows;
+//     * one persistent workgroup per CU claims (task group, cell) blocks from a shared cursor.
 #pragma once
 
 #include "scan_filter.h"

@@ -1,22 +1,21 @@
-// scan_filter.h — the MFMA pre-filter of the exact shard scan (included by scan.hip).
+// scan_filter.h — shared pieces of the filtered exact shard scan (included by scan.hip and cells.hip): the bf16 split, the
+// plane layout constants, the threshold of a filter pass and the exact re-scoring of its candidates.  The pipeline and the MFMA
+// kernel are in scan_cells.h.
 //
 // The exact scan is bound by FP32 VALU issue: 3 unfused lane-ops per (pair, dimension).  Only the k best rows of a shard
-// matter, so almost every one of those exact evaluations is spent on rows that are nowhere near the current k-th
-// distance.  The filter replaces them by a matrix-core bound:
-//
-//   1. a first slice of every shard is scanned exactly (ScanTileKernel) and yields, per task, an exact k-th distance tau;
-//   2. FilterKernel streams the remaining rows through v_mfma_f32_32x32x16_bf16 and evaluates
-//          acc = q.p - |p|^2/2                       (L2)        acc = q.p          (MIPS)
-//      with q and p each split into two bf16 planes (hi + lo, three products hi*hi, hi*lo, lo*hi, f32 accumulate);
-//   3. a row is kept as a CANDIDATE iff acc >= U[task], where U is derived from tau and a rigorous bound on
-//      |acc - true value| + |canonical float distance - true value| (ThresholdKernel) — every row whose canonical
-//      distance is <= tau passes, plus a few percent of near misses;
-//   4. RescoreKernel evaluates the canonical binary32 distance (the reference's exact sequence) of the candidates only and
-//      inserts them into the task's exact top-k list.
-// Steps 2-4 run twice (a short slice to tighten tau, then the rest of the shard).  The result lists are the exact lists:
-// the filter only decides which rows get the exact evaluation, and it never drops a row that could belong to the top-k.
-// If the fixed-size candidate bucket of any task overflows (adversarial inputs: masses of equal distances) the caller
-// falls back to the plain exact scan for the whole call.
+// matter, so almost every one of those exact evaluations is spent on rows that are nowhere near the current k-th distance.
+// The filter replaces them by a matrix-core bound:
+//   * per task an exact list with k-th distance tau exists from the rows evaluated so far;
+//   * v_mfma_f32_32x32x16_bf16 evaluates   acc = q.p - |p|^2/2  (L2)   /   acc = q.p  (MIPS)   with q and p each split into two bf16
+//     planes (hi + lo; products hi*hi, hi*lo, lo*hi, f32 accumulate);
+//   * a row is kept as a CANDIDATE iff acc >= U[task], where U is derived from tau and a rigorous bound on
+//     |acc - true value| + |canonical float distance - true value| (ThresholdKernel) — every row whose canonical distance is
+//     <= tau passes, plus a few percent of near misses;
+//   * RescoreKernel evaluates the canonical binary32 distance (the reference's exact sequence) of the candidates only and
+//     inserts them into the task's exact top-k list.
+// The result lists are the exact lists: the filter only decides which rows get the exact evaluation and never drops a row that
+// could belong to the top-k.  If the fixed-size candidate buckets overflow widely (adversarial inputs: masses of equal
+// distances) the caller falls back to the plain exact scan for the whole call.
 #pragma once
 
 #include "shards.h"
@@ -30,26 +29,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kFQB = 256;                 // tasks per filter unit: 4 waves x 64
-constexpr int kFPT = 64;                  // rows per tile
 constexpr int kFKS = 8;                   // k-steps of 16 dims held in registers (d <= 128)
-constexpr int kFRowStride = 128 + 8;      // bf16 elements per LDS row: 272 B puts the 16 rows of a ds_read_b128 lane group on distinct banks
-constexpr int kFPlane = kFPT * kFRowStride;   // bf16 elements per plane
-
-struct FilterArgs {
-    const float* points;          // [rows][ld]
-    const float* queries;         // [nq][ld]
-    const float* neg_half_norm;   // [rows]  -|p|^2/2 (L2 only)
-    const FilterUnit* units;
-    const uint32_t* task_query;   // [tasks]
-    const float* task_U;          // [tasks] pass iff acc >= U
-    uint32_t* cand_cnt;           // [tasks]
-    uint32_t* cand_row;           // [tasks][cand_cap]
-    uint32_t cand_cap;
-    uint32_t d, ld;
-    const char* frag_planes;      // optional: pre-split bf16 planes in MFMA fragment order (FilterKernelReg), see kGTileBytes
-    int64_t row_limit;            // rows of the store (frag_planes and neg_half_norm are readable 64 rows beyond it)
-};
 
 // two floats -> packed bf16 hi pair and bf16 lo pair (round to nearest even; x - float(hi) is exact in binary32)
 __device__ __forceinline__ void SplitBf16(float x0, float x1, uint32_t& hi, uint32_t& lo) {
@@ -68,338 +48,12 @@ union Frag {   // 8 bf16 = 4 VGPRs, the A/B operand of v_mfma_f32_32x32x16_bf16
     uint4 q;
 };
 
-template <int METRIC>
-__global__ void __launch_bounds__(256, 2) FilterKernel(FilterArgs a) {
-    extern __shared__ uint4 fsm4[];
-    __bf16* sHi = reinterpret_cast<__bf16*>(fsm4);   // [64][136]
-    __bf16* sLo = sHi + kFPlane;                     // [64][136]
-    float* sNorm = reinterpret_cast<float*>(sLo + kFPlane);   // [64]
-
-    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
-    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const uint32_t d = a.d, ld = a.ld;
-    const int ksteps = (int)((d + 15) / 16);
-
-    // ---- this wave's 64 queries as B operands, resident in registers: lane (c, h) holds dims 16 ks + 8 h .. + 7 of query c
-    Frag qh[2][kFKS], ql[2][kFKS];
-    float U[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t tl = 64u * wave + 32u * t + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        U[t] = tl < task_count ? a.task_U[task] : INFINITY;   // lanes beyond the unit's tasks never pass
-        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
-#pragma unroll
-        for (int ks = 0; ks < kFKS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (ks < ksteps) {
-                const uint32_t k0 = 16u * ks + 8u * h;
-                if (k0 < ld) {
-                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                }
-                if (k0 + 4 < ld) {
-                    const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
-                    v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], qh[t][ks].u[j], ql[t][ks].u[j]);
-        }
-    }
-
-    // staging role: float4 #(tid + 256 i) of the [64 rows][32 float4] tile
-    for (int64_t row0 = row_begin; row0 < row_end; row0 += kFPT) {
-        __syncthreads();   // the previous tile's fragment reads are done
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = tid + 256 * i;
-            const int r = f >> 5, c4 = f & 31;
-            const int64_t row = min(row0 + r, row_end - 1);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((uint32_t)(4 * c4) < ld) x = *reinterpret_cast<const float4*>(a.points + (size_t)row * ld + 4 * c4);
-            uint2 hi, lo;
-            SplitBf16(x.x, x.y, hi.x, lo.x);
-            SplitBf16(x.z, x.w, hi.y, lo.y);
-            *reinterpret_cast<uint2*>(sHi + r * kFRowStride + 4 * c4) = hi;
-            *reinterpret_cast<uint2*>(sLo + r * kFRowStride + 4 * c4) = lo;
-        }
-        if (METRIC == GPANN_METRIC_L2 && tid < kFPT) sNorm[tid] = a.neg_half_norm[min(row0 + tid, row_end - 1)];
-        __syncthreads();
-
-        f32x16 acc[2][2];   // [point tile][query tile]
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // C rows of register r = 4g + e: 32 pt + 8 g + 4 h + e
-                float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (METRIC == GPANN_METRIC_L2) nv = *reinterpret_cast<const float4*>(sNorm + 32 * pt + 8 * g + 4 * h);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    acc[pt][qt][4 * g + 0] = nv.x;
-                    acc[pt][qt][4 * g + 1] = nv.y;
-                    acc[pt][qt][4 * g + 2] = nv.z;
-                    acc[pt][qt][4 * g + 3] = nv.w;
-                }
-            }
-#pragma unroll
-        for (int ks = 0; ks < kFKS; ++ks) {
-            if (ks < ksteps) {
-                Frag ah[2], al[2];
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const int off = (32 * pt + c) * kFRowStride + 16 * ks + 8 * h;
-                    ah[pt].q = *reinterpret_cast<const uint4*>(sHi + off);
-                    al[pt].q = *reinterpret_cast<const uint4*>(sLo + off);
-                }
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[pt].v, ql[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                        acc[pt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[pt].v, qh[qt][ks].v, acc[pt][qt], 0, 0, 0);
-                    }
-            }
-        }
-
-        // ---- epilogue: a row is a candidate for the lane's query iff acc >= U
-        bool any = false;
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) any |= acc[pt][qt][r] >= U[qt];
-        if (__any(any)) {
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[pt][qt][r] >= U[qt]) {
-                            const int64_t row = row0 + 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const uint32_t tl = 64u * wave + 32u * qt + c;
-                            if (row < row_end && tl < task_count) {
-                                const uint32_t task = task_begin + tl;
-                                const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                                if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
-                            }
-                        }
-                    }
-        }
-    }
-}
-
-// ---- the filter with the QUERIES stationary in LDS and the points streamed through registers --------------------------------
-// FilterKernel above (and an LDS-DMA fed variant of it that this file used to hold) stages POINT tiles in LDS for 256 tasks and
-// keeps the query fragments in registers: every tile costs a workgroup barrier, and an LDS-DMA fill landing in LDS and the
-// ds_read/MFMA stream slowed each other down (measured: filter time = fill-only time + compute-only time, no overlap).
-// FilterKernelReg turns the roles around:
-//   * the bf16 hi/lo fragments of the unit's <= 256 tasks are built ONCE into LDS (128 KiB, in MFMA B-operand order: a
-//     ds_read_b128 with lane-linear addresses, conflict free) and stay there for the unit's whole row segment;
-//   * the points are pre-split in HBM in MFMA A-operand order — per 32-row tile and k-step one contiguous KiB per plane
-//     (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7; the hi plane of a tile is 8 contiguous KiB, then the lo plane) — so a wavefront loads a tile's fragments with 16 perfectly
-//     coalesced global_load_dwordx4 straight into the registers the MFMA reads.  No LDS traffic for the points, no barrier in
-//     the loop: the 8 wavefronts of a workgroup take tiles round robin and run independently, each prefetching its next tile
-//     into a second register set while the matrix core works on the current one;
-//   * every wavefront meets ALL tasks of the unit, so units with few tasks keep all 8 wavefronts busy;
-//   * candidates of a tile are collected as bit masks and written after the tile's MFMA phase, when the prefetch has landed
-//     (the atomic's vmcnt wait would otherwise stall on the loads issued before it).
+// The points' bf16 planes live in HBM in MFMA A-operand order (scan_cells.h): per 32-row tile and k-step one contiguous KiB per
+// plane (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7); the hi plane of a tile is 8 contiguous KiB, then the lo plane.
 constexpr int kGTileRows = 32;
 constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane][16 B]
 constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
-constexpr int kGTasks = 256;                   // tasks per unit: 8 query tiles of 32
-
-template <int METRIC, int TAG, int KS>
-__global__ void __launch_bounds__(512, 1) FilterKernelReg(FilterArgs a) {
-    extern __shared__ uint4 gsm4[];
-    char* lds = reinterpret_cast<char*>(gsm4);   // [8 query tiles][KS][2 planes][1 KiB]
-
-    const int64_t row_begin = a.units[blockIdx.x].row_begin, row_end = a.units[blockIdx.x].row_end;
-    const uint32_t task_begin = a.units[blockIdx.x].task_begin, task_count = a.units[blockIdx.x].task_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const uint32_t ld = a.ld;
-    const int nqt = (int)((task_count + 31u) / 32u);
-
-    // ---- the query image: wavefront w builds query tile w (zeros for absent tasks)
-    {
-        const uint32_t tl = 32u * wave + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        const bool real = tl < task_count;
-        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            const uint32_t k0 = 16u * ks + 8u * h;
-            if (real && k0 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            }
-            if (real && k0 + 4 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
-                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-            }
-            Frag fh, fl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
-            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 0) * 1024 + lane * 16) = fh.q;
-            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 1) * 1024 + lane * 16) = fl.q;
-        }
-    }
-    float U[8];
-#pragma unroll
-    for (int qt = 0; qt < 8; ++qt) {
-        const uint32_t tl = 32u * qt + c;
-        U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
-    }
-    __syncthreads();
-
-    const int64_t t_begin = row_begin >> 5, t_end = (row_end + 31) >> 5;
-    const char* lane_planes = a.frag_planes + lane * 16;
-    const char* lane_lds = lds + lane * 16;
-
-    // the tile's 32 row norms travel as one float per lane and are spread to the accumulator layout through 128 B of
-    // wave-private LDS (16 registers per buffered tile otherwise)
-    float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
-
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
-        const char* base = lane_planes + (size_t)T * kGTileBytes;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
-            Al[ks].q = *reinterpret_cast<const uint4*>(base + kGPlaneBytes + ks * 1024);
-        }
-        if (METRIC == GPANN_METRIC_L2) nrm = a.neg_half_norm[T * kGTileRows + c];
-    };
-
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, int64_t T) {
-        if (METRIC == GPANN_METRIC_L2) {
-            if (h == 0) wave_norms[c] = nrm;
-            __builtin_amdgcn_wave_barrier();
-        }
-        uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
-        // one pass of the k-loop for query tiles 2 qp and (PAIR) 2 qp + 1: two independent accumulator chains
-        auto pass = [&](auto pair_tag, int qp) {
-            constexpr bool PAIR = decltype(pair_tag)::value;
-            f32x16 acc0, acc1;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc0[4 * g + 0] = n.x; acc0[4 * g + 1] = n.y; acc0[4 * g + 2] = n.z; acc0[4 * g + 3] = n.w;
-                if (PAIR) {
-                    acc1[4 * g + 0] = n.x; acc1[4 * g + 1] = n.y; acc1[4 * g + 2] = n.z; acc1[4 * g + 3] = n.w;
-                }
-            }
-            const char* q0 = lane_lds + (2 * qp * KS) * 2048;
-            const char* q1 = lane_lds + ((2 * qp + 1) * KS) * 2048;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                Frag bh0, bl0, bh1, bl1;
-                bh0.q = *reinterpret_cast<const uint4*>(q0 + ks * 2048);
-                bl0.q = *reinterpret_cast<const uint4*>(q0 + ks * 2048 + 1024);
-                if (PAIR) {
-                    bh1.q = *reinterpret_cast<const uint4*>(q1 + ks * 2048);
-                    bl1.q = *reinterpret_cast<const uint4*>(q1 + ks * 2048 + 1024);
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
-            }
-            float m0 = acc0[0], m1 = PAIR ? acc1[0] : -INFINITY;
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                m0 = fmaxf(m0, acc0[r]);
-                if (PAIR) m1 = fmaxf(m1, acc1[r]);
-            }
-            if (__any(m0 >= U[2 * qp] || m1 >= U[2 * qp + 1])) {
-                uint32_t bits = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    bits |= acc0[r] >= U[2 * qp] ? 1u << r : 0u;
-                    if (PAIR) bits |= acc1[r] >= U[2 * qp + 1] ? 0x10000u << r : 0u;
-                }
-                cmask[qp] = bits;
-            }
-        };
-#pragma unroll
-        for (int qp = 0; qp < 4; ++qp) {
-            if (2 * qp + 1 < nqt) pass(std::true_type{}, qp);
-            else if (2 * qp < nqt) pass(std::false_type{}, qp);
-        }
-        if (__any((cmask[0] | cmask[1] | cmask[2] | cmask[3]) != 0u)) {
-#pragma unroll
-            for (int qp = 0; qp < 4; ++qp) {
-                uint32_t bits = cmask[qp];
-                while (bits) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const int r = b & 15;
-                    const int64_t row = T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
-                    if (row >= row_begin && row < row_end && tl < task_count) {
-                        const uint32_t task = task_begin + tl;
-                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = (uint32_t)row;
-                    }
-                }
-            }
-        }
-    };
-
-    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];
-    float n0 = 0.f, n1 = 0.f;
-    int64_t T = t_begin + wave;
-    if (T < t_end) load_tile(A0h, A0l, n0, T);
-    while (T < t_end) {
-        if (T + 8 < t_end) load_tile(A1h, A1l, n1, T + 8);
-        compute_tile(A0h, A0l, n0, T);
-        T += 8;
-        if (T >= t_end) break;
-        if (T + 8 < t_end) load_tile(A0h, A0l, n0, T + 8);
-        compute_tile(A1h, A1l, n1, T);
-        T += 8;
-    }
-}
-
-// f32 rows -> bf16 hi/lo planes in MFMA A-operand order (kGTileBytes per 32 rows); one thread per (row, 8 dimensions)
-static __global__ void __launch_bounds__(256) SplitFragPlanesKernel(const float* points, uint64_t rows, uint32_t ld, char* planes) {
-    const uint64_t total = rows * 16;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i >> 4;
-        const uint32_t g8 = (uint32_t)(i & 15);   // dims 8 g8 .. 8 g8 + 7
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (8 * g8 < ld) {
-            const float4 x = *reinterpret_cast<const float4*>(points + r * ld + 8 * g8);
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        }
-        if (8 * g8 + 4 < ld) {
-            const float4 x = *reinterpret_cast<const float4*>(points + r * ld + 8 * g8 + 4);
-            v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-        }
-        Frag fh, fl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
-        const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
-    }
-}
+constexpr int kGTasks = 256;                   // tasks per filter group: 8 query tiles of 32
 
 // ---- thresholds ------------------------------------------------------------------------------------------------------
 // For task t with exact k-th distance tau (its list's last entry; +inf while the list is not full):  U[t] such that every

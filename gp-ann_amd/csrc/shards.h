@@ -19,18 +19,11 @@ struct ScanUnit {
 };
 
 // One filter workgroup's job: <= 256 tasks of one shard x one row segment (see scan_filter.h).
-struct FilterUnit {
-    int64_t row_begin, row_end;
-    uint32_t task_begin, task_count;
-    uint32_t pad[2];
-};
-
 // Host-side launch plan of one scan call; kept alive in the handle until the next call because its arrays are the
 // sources of asynchronous uploads.
 struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
-    std::vector<FilterUnit> filter_units;
     uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0;
     uint32_t filter_launches = 0;
     void Clear() {
@@ -41,7 +34,6 @@ struct ScanPlan {
         task_shard.clear();
         shard_task_begin.clear();
         units.clear();
-        filter_units.clear();
         n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = 0;
         filter_launches = 0;
     }
@@ -64,7 +56,7 @@ struct gpann_shards {
     // MFMA pre-filter support (scan_filter.h): -|p|^2/2 per row, max |p| per shard, and whether the data is fit for it
     float* neg_half_norm = nullptr;  // [rows]
     double* d_shard_rmax = nullptr;  // [S]
-    char* frag_planes = nullptr;     // optional: bf16 hi/lo planes in MFMA fragment order, 16 KiB per 32 rows (FilterKernelReg)
+    char* frag_planes = nullptr;     // bf16 hi/lo planes in MFMA fragment order, 16 KiB per 32 rows, grouped by cell (with `cells`)
 
     // Cells (cells.hip): with them the planes hold the rows of every shard GROUPED BY CELL (a k-means sub-cluster of the shard,
     // padded to whole 32-row tiles); a cell's bounding ball lets the filter skip it for all tasks it cannot serve.
@@ -85,7 +77,7 @@ struct gpann_shards {
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
     // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_funits0, ws_funits1, ws_celld, ws_need;
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_filter[4] = {nullptr, nullptr, nullptr, nullptr};   // begin/end of the filter kernel of pass 0 and pass 1
     int filter_passes_timed = 0;

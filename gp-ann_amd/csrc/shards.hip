@@ -177,7 +177,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     if (rows) {
         unsigned long long* d_max_bits = nullptr;
         uint32_t* d_bad = nullptr;
-        TRY_OR_FAIL(hipMalloc(&s->neg_half_norm, (rows + 64) * sizeof(float)));   // FilterKernelReg reads whole 32-row tiles
+        TRY_OR_FAIL(hipMalloc(&s->neg_half_norm, (rows + 64) * sizeof(float)));
         TRY_OR_FAIL(hipMemset(s->neg_half_norm + rows, 0, 64 * sizeof(float)));
         TRY_OR_FAIL(hipMalloc(&s->d_shard_rmax, S * sizeof(double)));
         TRY_OR_FAIL(hipMalloc(&d_bad, 4));
@@ -191,33 +191,15 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         TRY_OR_FAIL(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_bad);
         s->filter_ok = bad == 0;
-        // pre-split bf16 planes for the filter (about as many bytes as the rows once more); optional: without them (allocation
-        // failure, GPANN_FILTER_PLANES=0, d > 128) the filter converts on the fly (FilterKernel).  Layout: MFMA fragment order.
+        // filter support (scan mode 1): the rows once more as bf16 hi/lo planes grouped by cell (cells.hip).  Optional: without it
+        // (allocation failure, GPANN_FILTER_PLANES=0, d > 128, non-finite data) the store only offers the plain exact scan.
+        // GPANN_CELL_ROWS sets the target cell size.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
-        const bool want_none = want && want[0] == '0';
-        // cells (cells.hip): rows grouped by sub-cluster so that the filter can skip what a bound excludes.  Default for stores of
-        // a million rows and more; GPANN_FILTER_CELLS=0|1 forces, GPANN_CELL_ROWS sets the target cell size.
-        const char* wc = std::getenv("GPANN_FILTER_CELLS");
         const char* cr = std::getenv("GPANN_CELL_ROWS");
         const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
-        const bool want_cells = wc ? wc[0] == '1' : rows >= (1u << 20);
-        if (s->filter_ok && d <= 128 && !want_none && want_cells) {
+        if (s->filter_ok && d <= 128 && !(want && want[0] == '0')) {
             gpann_status cst = BuildCells(s, cell_rows);
             if (cst != GPANN_OK) return fail(cst);
-        }
-        if (s->filter_ok && d <= 128 && !want_none && !s->frag_planes) {
-            const uint64_t tiles = (rows + kGTileRows - 1) / kGTileRows + 2;
-            if (hipMalloc(&s->frag_planes, tiles * (size_t)kGTileBytes) == hipSuccess) {
-                const uint64_t first_partial = rows / kGTileRows;
-                TRY_OR_FAIL(hipMemsetAsync(s->frag_planes + first_partial * (size_t)kGTileBytes, 0, (tiles - first_partial) * (size_t)kGTileBytes, 0));
-                const int g2 = (int)std::min<uint64_t>((rows * 16 + 255) / 256, 256 * 64);
-                hipLaunchKernelGGL(SplitFragPlanesKernel, dim3(g2), dim3(256), 0, 0, s->points, rows, s->ld, s->frag_planes);
-                TRY_OR_FAIL(hipGetLastError());
-                TRY_OR_FAIL(hipDeviceSynchronize());
-            } else {
-                (void)hipGetLastError();
-                s->frag_planes = nullptr;
-            }
         }
     }
 #undef TRY_OR_FAIL
@@ -244,8 +226,6 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     ReleaseCells(s);
     s->ws_lists.Release();
     s->ws_cand.Release();
-    s->ws_funits0.Release();
-    s->ws_funits1.Release();
     s->ws_celld.Release();
     s->ws_need.Release();
     s->ws_queries.Release();

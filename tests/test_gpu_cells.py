@@ -10,8 +10,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _cells_on(monkeypatch):
-    monkeypatch.setenv("GPANN_FILTER_CELLS", "1")     # stores of any size get cells
-    monkeypatch.setenv("GPANN_CELL_ROWS", "1500")
+    monkeypatch.setenv("GPANN_CELL_ROWS", "1500")     # small cells: many cells even in small test stores
 
 
 def _check(orc, gp, pts, clusters, queries, probes, nprobe, k, metric, expect_filtered=True):
@@ -131,7 +130,6 @@ def test_cells_hi_plane_only_last_pass(orc, gp, monkeypatch):
 def test_cells_default_configuration_midsize(orc, gp, monkeypatch):
     """a store large enough to get cells by default (>= 1M rows, 32k-row cells, hi-plane last pass): filter mode must equal the
     plain exact scan bit for bit on every query and the CPU oracle on a sample of them"""
-    monkeypatch.delenv("GPANN_FILTER_CELLS")
     monkeypatch.delenv("GPANN_CELL_ROWS")
     rng = np.random.default_rng(41)
     n, d, S, nq, k = 2_400_000, 64, 2, 320, 10

@@ -40,7 +40,7 @@ def test_filtered_scan_matches_oracle(orc, gp, metric, d):
 
 
 def test_filtered_scan_two_passes_and_many_tasks(orc, gp):
-    """a shard longer than the mid boundary (131072 rows) and more than 256 tasks per shard"""
+    """a 200k-row shard (several cells) and more than 256 tasks per shard (several task groups)"""
     rng = np.random.default_rng(17)
     n, d, nq, k = 200000, 32, 600, 10
     pts = make_mixture(orc, n, d, n_centers=40)
@@ -122,7 +122,8 @@ def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, mo
 
 
 def test_filter_without_precomputed_planes(orc, gp, monkeypatch):
-    """GPANN_FILTER_PLANES=0: no bf16 planes in HBM, the filter kernel splits the rows on the fly (FilterKernel)"""
+    """GPANN_FILTER_PLANES=0: a store without bf16 planes / cells offers only the plain exact scan; asking for filter mode
+    must silently give the exact answer"""
     rng = np.random.default_rng(41)
     n, d, S, nq, k = 30000, 100, 2, 140, 10
     pts = make_mixture(orc, n, d, n_centers=24)
@@ -131,4 +132,5 @@ def test_filter_without_precomputed_planes(orc, gp, monkeypatch):
     probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
     monkeypatch.setenv("GPANN_FILTER_PLANES", "0")
     for metric in (0, 1):
-        _check(orc, gp, pts, clusters, queries, probes, S, k, metric)
+        st = _check(orc, gp, pts, clusters, queries, probes, S, k, metric, expect_filtered=False)
+        assert st["filter_pairs"] == 0
