@@ -251,7 +251,7 @@ def main():
         else:
             torch.cuda.current_stream().synchronize()
             dist_h = od.cpu().numpy()
-            ids_h = to_global(oi.cpu().numpy().view(np.uint32))
+            ids_h = oi.cpu().numpy().view(np.uint32)   # one rank holds every row in global-id order: local row id = global id
         return dist_h, ids_h, ms
 
     chunk_q = (nq + world - 1) // world

@@ -665,6 +665,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.work = d_work;
     fa.next_item = d_next_item;
     fa.n_groups = G;
+    // enough work items for every CU even when the store has few cells: cut the blocks' tile ranges
+    fa.n_seg = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_SEGMENTS", (uint32_t)std::min<uint64_t>(16, (4096 + (uint64_t)G * kmax - 1) / ((uint64_t)G * kmax))));
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -724,7 +726,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
         GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 4, st));
-        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, (uint64_t)G * kmax)), dim3(512), kargs, glds, st));
+        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, (uint64_t)G * kmax * fa.n_seg)), dim3(512), kargs, glds, st));
         GPANN_HIP_TRY(hipGetLastError());
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
         if (pass == 0 || pass == 2) {

@@ -236,8 +236,9 @@ struct CellFilterArgs {
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
     unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
-    uint32_t* next_item;         // work-stealing cursor over the (group, cell) index space (zeroed before the launch)
+    uint32_t* next_item;         // work-stealing cursor over the (group, cell, segment) index space (zeroed before the launch)
     uint32_t n_groups;
+    uint32_t n_seg;              // a block's tile range is cut into n_seg work items (small stores: enough items for all CUs)
 };
 
 // HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
 
     // persistent workgroups: one per CU, each claims (group, cell) blocks with work from a shared cursor
     __shared__ uint32_t s_item;
-    const uint32_t n_items = a.n_groups * a.kmax;
+    const uint32_t n_items = a.n_groups * a.kmax * a.n_seg;
     uint32_t my_products = 0, my_tiles = 0;
     for (;;) {
     __syncthreads();   // everyone is done with the previous block's query image (and has read s_item)
@@ -257,26 +258,32 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         uint32_t it;
         do {
             it = atomicAdd(a.next_item, 1u);
-        } while (it < n_items && a.need[it] == 0);
+        } while (it < n_items && a.need[it / a.n_seg] == 0);
         s_item = it;
     }
     __syncthreads();
     const uint32_t item = s_item;
     if (item >= n_items) break;
-    const uint32_t g = item / a.kmax, j = item - g * a.kmax;
+    const uint32_t block = item / a.n_seg, seg = item - block * a.n_seg;
+    const uint32_t g = block / a.kmax, j = block - g * a.kmax;
     const uint32_t shard = a.groups[g].shard;
     const uint32_t cell0 = a.shard_cell_begin[shard];
     if (j >= a.shard_cell_begin[shard + 1] - cell0) continue;
     const uint32_t mask = a.need[(size_t)g * a.kmax + j];
     const uint32_t d0 = a.done0 ? a.done0[(size_t)g * a.kmax + j] : 0u;
     const uint32_t d1 = a.done1 ? a.done1[(size_t)g * a.kmax + j] : 0u;
-    const int64_t t_begin = (int64_t)a.cell_tile_begin[cell0 + j];
+    const int64_t t_cell = (int64_t)a.cell_tile_begin[cell0 + j];
     const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
-    const int64_t t_a = min(t_cell_end, t_begin + (int64_t)a.head_tiles);                                      // end of the head segment
-    const int64_t t_b = min(t_cell_end, max(t_a, t_begin + (t_cell_end - t_begin + a.sample_div - 1) / a.sample_div));   // end of the sample
-    const int64_t t_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
+    const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);                                      // end of the head segment
+    const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));   // end of the sample
+    const int64_t t_pass_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
+    // this work item's share of the pass's tile range
+    const int64_t per = (t_pass_end - t_cell + a.n_seg - 1) / a.n_seg;
+    const int64_t t_begin = t_cell + (int64_t)seg * per;
+    const int64_t t_end = min(t_pass_end, t_begin + per);
+    if (t_begin >= t_end) continue;
     // anything to do?  (segment 2 exists only in pass 2 and has no `done` mask)
-    if (!(((mask & ~d0) && t_a > t_begin) || ((mask & ~d1) && t_b > t_a && a.pass >= 1) || (a.pass == 2 && t_cell_end > t_b))) continue;
+    if (!(((mask & ~d0) && t_begin < t_a) || ((mask & ~d1) && t_end > t_a && t_begin < t_b) || t_end > t_b)) continue;
     const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
