@@ -21,6 +21,10 @@
 #include <cstdlib>
 #include <numeric>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -43,12 +47,80 @@ struct gpann_router {
     uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
+    float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
+    size_t pinned_floats = 0;
     uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
     bool leaves_only = false;                                   // every non-root node is a leaf
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 namespace gpann {
+
+// Host worker pool for the per-query host steps that stay libstdc++'s (the final std::sort over min_dist, DedupNeighbors):
+// threads are created once per process — creating them per call costs more than the work of a 10k-query batch.
+class HostPool {
+public:
+    static HostPool& Get() {
+        static HostPool* pool = new HostPool();   // intentionally never destroyed (no join during static destruction)
+        return *pool;
+    }
+    // runs fn(chunk) for chunk in [0, n_chunks) on the pool and the calling thread; returns when all are done
+    void Run(uint32_t n_chunks, const std::function<void(uint32_t)>& fn) {
+        if (n_chunks <= 1 || workers_.empty()) {
+            for (uint32_t c = 0; c < n_chunks; ++c) fn(c);
+            return;
+        }
+        std::unique_lock<std::mutex> run_lock(run_mutex_);   // one batch at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_chunks_ = n_chunks;
+            next_.store(0);
+            pending_ = n_chunks;
+            ++epoch_;
+        }
+        cv_work_.notify_all();
+        Work();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned n = std::min(31u, hw > 1 ? hw - 1 : 0u);
+        for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { Loop(); });
+        for (auto& t : workers_) t.detach();
+    }
+    void Work() {
+        for (;;) {
+            const uint32_t c = next_.fetch_add(1);
+            if (c >= n_chunks_) return;
+            (*fn_)(c);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    void Loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+            }
+            Work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, run_mutex_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    uint32_t n_chunks_ = 0, pending_ = 0;
+    std::atomic<uint32_t> next_{0};
+    uint64_t epoch_ = 0;
+};
 
 constexpr int kRDC = 32;                 // dims per staged chunk
 constexpr int kRStride = kRDC + 4;       // LDS row stride (floats)
@@ -1146,6 +1218,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_dense.Release();
     r->ws_redo.Release();
     r->ws_pi.Release();
+    if (r->pinned_min) (void)hipHostFree(r->pinned_min);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     delete r;
@@ -1388,9 +1461,19 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         local_min.resize((size_t)nq * S);
         md = local_min.data();
     }
-    GPANN_HIP_TRY(hipMemcpyAsync(md, r->ws_out.ptr, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
+    if (r->pinned_floats < (size_t)nq * S) {
+        if (r->pinned_min) (void)hipHostFree(r->pinned_min);
+        r->pinned_min = nullptr;
+        r->pinned_floats = 0;
+        if (hipHostMalloc((void**)&r->pinned_min, (size_t)nq * S * 4, hipHostMallocDefault) == hipSuccess) r->pinned_floats = (size_t)nq * S;
+        else (void)hipGetLastError();
+    }
+    float* stage = r->pinned_floats >= (size_t)nq * S ? r->pinned_min : md;
+    GPANN_HIP_TRY(hipMemcpyAsync(stage, r->ws_out.ptr, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
     if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
+    if (stage != md && out_min_dist) std::memcpy(md, stage, (size_t)nq * S * 4);
+    if (stage != md) md = stage;
 
     if (out_probes) {
         // kmeans_tree_router.cpp:125-127 — the reference's own call, on the GPU-computed min_dist; queries are independent,
@@ -1404,15 +1487,8 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
                 std::copy(probes.begin(), probes.end(), out_probes + (size_t)q * S);
             }
         };
-        const uint32_t threads = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ((uint64_t)nq * S) / 32768));
-        if (threads <= 1) {
-            sort_range(0, nq);
-        } else {
-            std::vector<std::thread> pool;
-            for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(sort_range, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads));
-            sort_range(0, nq / threads);
-            for (auto& th : pool) th.join();
-        }
+        const uint32_t chunks = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nq * S) / 8192));
+        HostPool::Get().Run(chunks, [&](uint32_t c) { sort_range((uint32_t)((uint64_t)nq * c / chunks), (uint32_t)((uint64_t)nq * (c + 1) / chunks)); });
     }
     return GPANN_OK;
 }
@@ -1539,15 +1615,8 @@ gpann_status gpann_merge_dedup(const float* in_dist, const uint32_t* in_ids, uin
             if (out_count) out_count[q] = (uint32_t)n.size();
         }
     };
-    const uint32_t threads = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ((uint64_t)nq * nprobe_used * k) / 16384));
-    if (threads <= 1) {
-        merge_range(0, nq);
-    } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(merge_range, (uint32_t)((uint64_t)nq * t / threads), (uint32_t)((uint64_t)nq * (t + 1) / threads));
-        merge_range(0, nq / threads);
-        for (auto& th : pool) th.join();
-    }
+    const uint32_t chunks = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nq * nprobe_used * k) / 4096));
+    HostPool::Get().Run(chunks, [&](uint32_t c) { merge_range((uint32_t)((uint64_t)nq * c / chunks), (uint32_t)((uint64_t)nq * (c + 1) / chunks)); });
     return GPANN_OK;
 }
 
