@@ -15,9 +15,11 @@
 //   * min_dist is returned to the host, where the final std::sort is the same libstdc++ call the reference makes
 //     (:125-127), so the order among equal min_dist (unvisited shards = FLT_MAX) is inherited, not imitated.
 #include "common.h"
+#include "router_bound.h"
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <numeric>
 #include <string>
@@ -45,6 +47,10 @@ struct gpann_router {
     uint32_t* path_cent = nullptr;       // [n_nodes][kPathMax] centroids whose distances are the keys on the path root -> node (threshold replay)
     uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
     uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
+    char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
+    float* cent_nhn = nullptr;           // [n_centroids + 64] -|c|^2/2
+    double cent_rmax = 0.0;              // largest centroid norm
+    gpann::DeviceBuffer ws_bound;
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
@@ -1172,6 +1178,34 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         for (size_t c = 0; c < nc; ++c) cent_shard[c] = (uint32_t)node_shard[cent_node[c]];
         TRY_OR_FAIL(hipMalloc(&r->cent_shard, cent_shard.size() * 4));
         TRY_OR_FAIL(hipMemcpy(r->cent_shard, cent_shard.data(), cent_shard.size() * 4, hipMemcpyHostToDevice));
+        // matrix-core bound for the visit-everything case (router_bound.h)
+        bool finite = true;
+        double rmax2 = 0.0;
+        for (size_t c = 0; c < nc && finite; ++c) {
+            double s2 = 0.0;
+            for (uint32_t x = 0; x < d; ++x) {
+                const double v = centroids[c * d + x];
+                finite = finite && std::isfinite(v);
+                s2 += v * v;
+            }
+            rmax2 = std::max(rmax2, s2);
+        }
+        if (finite && d <= 16u * kFKS && nc > 0) {
+            const uint64_t tiles = (nc + kGTileRows - 1) / kGTileRows + 1;
+            if (hipMalloc(&r->cent_planes, tiles * (size_t)kGTileBytes) == hipSuccess && hipMalloc(&r->cent_nhn, (nc + 64) * 4) == hipSuccess) {
+                TRY_OR_FAIL(hipMemset(r->cent_planes, 0, tiles * (size_t)kGTileBytes));
+                TRY_OR_FAIL(hipMemset(r->cent_nhn, 0, (nc + 64) * 4));
+                hipLaunchKernelGGL(CentroidPlanesKernel, dim3((uint32_t)std::min<uint64_t>((nc * 16 + 255) / 256, 4096)), dim3(256), 0, 0, r->centroids, (uint64_t)nc, d,
+                                   r->ld, r->cent_planes, r->cent_nhn);
+                TRY_OR_FAIL(hipGetLastError());
+                TRY_OR_FAIL(hipDeviceSynchronize());
+                r->cent_rmax = std::sqrt(rmax2) * (1.0 + 1e-9);
+            } else {
+                (void)hipGetLastError();
+                if (r->cent_planes) (void)hipFree(r->cent_planes);
+                r->cent_planes = nullptr;
+            }
+        }
         TRY_OR_FAIL(hipMalloc(&r->cent_node, cent_node.size() * 4));
         TRY_OR_FAIL(hipMemcpy(r->path_cent, path.data(), path.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_FAIL(hipMemcpy(r->cent_node, cent_node.data(), cent_node.size() * 4, hipMemcpyHostToDevice));
@@ -1210,7 +1244,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->cent_planes, (void*)r->cent_nhn})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -1218,6 +1252,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_dense.Release();
     r->ws_redo.Release();
     r->ws_pi.Release();
+    r->ws_bound.Release();
     if (r->pinned_min) (void)hipHostFree(r->pinned_min);
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1289,6 +1324,67 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 // the budget exceeds the tree and nobody asked for the evaluated distances: the per-shard minima are the whole answer
                 const size_t nb_s = (size_t)nb * S;
                 hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+                const char* bmode = std::getenv("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
+                if (r->cent_planes && !(bmode && bmode[0] == '0')) {
+                    // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h)
+                    // (slots are handed out in chunks of 256 per wavefront: room for every wavefront's last, partly used chunk)
+                    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)nb_s * 4 + (uint64_t)((nb + 255) / 256) * 80 * 8 * 256 + 1024);
+                    GPANN_TRY(r->ws_bound.Reserve(nb_s * 8 + (size_t)cand_cap * 8 + 64));
+                    BoundArgs ba;
+                    ba.queries = da.queries;
+                    ba.cent_planes = r->cent_planes;
+                    ba.cent_nhn = r->cent_nhn;
+                    ba.cent_shard = r->cent_shard;
+                    ba.max_bits = r->ws_bound.as<uint32_t>();
+                    float* thr = reinterpret_cast<float*>(ba.max_bits + nb_s);
+                    ba.thr = thr;
+                    ba.cand = reinterpret_cast<uint2*>(thr + nb_s + (nb_s & 1));
+                    ba.cand_count = reinterpret_cast<uint32_t*>(ba.cand + cand_cap);
+                    ba.cand_cap = cand_cap;
+                    ba.nq = nb;
+                    ba.C = (uint32_t)C;
+                    ba.S = S;
+                    ba.ld = ld;
+                    const uint32_t groups = (nb + 255) / 256;
+                    const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
+                    ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
+                    if (const char* ns = std::getenv("GPANN_ROUTER_BOUND_SEG")) ba.n_seg = std::max(1, std::atoi(ns));
+                    GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
+                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 4, st));
+                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
+                    const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
+                    const size_t blds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+                    const void *f1, *f2;
+#define GPANN_PICKB(P_) (l2 ? (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, P_>) \
+                            : (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, P_>))
+                    f1 = GPANN_PICKB(1);
+                    f2 = GPANN_PICKB(2);
+#undef GPANN_PICKB
+                    GPANN_HIP_TRY(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+                    GPANN_HIP_TRY(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+                    void* kargs[] = {&ba};
+                    GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+                    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
+                    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
+                    GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+                    const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
+                    if (l2) hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_L2>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
+                                               r->cent_shard, da.out_min_bits, S, r->d, ld);
+                    else hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_MIPS>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
+                                            r->cent_shard, da.out_min_bits, S, r->d, ld);
+                    GPANN_HIP_TRY(hipGetLastError());
+                    uint32_t n_cand = 0;
+                    GPANN_HIP_TRY(hipMemcpyAsync(&n_cand, ba.cand_count, 4, hipMemcpyDeviceToHost, st));
+                    GPANN_HIP_TRY(hipStreamSynchronize(st));
+                    if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidates for %u x %u (query, shard) pairs\n", n_cand, nb, S);
+                    if (n_cand <= cand_cap) {
+                        hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+                        GPANN_HIP_TRY(hipGetLastError());
+                        continue;
+                    }
+                    // (masses of equal distances) fall through to the canonical evaluation of every pair
+                    hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+                }
                 if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, da);
                 else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, true>), dgrid, dim3(256), dlds, st, da);
                 hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);

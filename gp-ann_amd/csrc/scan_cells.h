@@ -294,28 +294,7 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     if (mask >> wave & 1u) {
         const uint32_t tl = 32u * wave + c;
         const uint32_t task = task_begin + min(tl, task_count - 1);
-        const bool real = tl < task_count;
-        const float* qrow = a.queries + (size_t)a.task_query[task] * ld;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) v[x] = 0.f;
-            const uint32_t k0 = 16u * ks + 8u * h;
-            if (real && k0 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0);
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            }
-            if (real && k0 + 4 < ld) {
-                const float4 x = *reinterpret_cast<const float4*>(qrow + k0 + 4);
-                v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
-            }
-            Frag fh, fl;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) SplitBf16(v[2 * x], v[2 * x + 1], fh.u[x], fl.u[x]);
-            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 0) * 1024 + lane * 16) = fh.q;
-            *reinterpret_cast<uint4*>(lds + ((wave * KS + ks) * 2 + 1) * 1024 + lane * 16) = fl.q;
-        }
+        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)a.task_query[task] * ld, tl < task_count, ld, lane);
     }
     float U[8];
 #pragma unroll

@@ -55,6 +55,36 @@ constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane
 constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
 constexpr int kGTasks = 256;                   // tasks per filter group: 8 query tiles of 32
 
+// One 32-query tile of the LDS query image (MFMA B-operand order: [ks][plane hi|lo][lane][16 B], KS * 2 KiB), built by one
+// wavefront: lane (c, h) converts dims 16 ks + 8 h .. + 7 of query row `qrow` (its row c of the tile; zeros if !real).  All
+// global loads are issued before the first conversion: per-k-step load -> convert -> store chains cost ~2 us each and made the
+// image (rebuilt for every work item) the dominant cost of small items.
+template <int KS>
+__device__ __forceinline__ void BuildQueryTile(char* tile_lds, const float* qrow, bool real, uint32_t ld, int lane) {
+    const int h = lane >> 5;
+    float4 x0[KS], x1[KS];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint32_t k0 = 16u * ks + 8u * h;
+        // (addresses are clamped into the row, the values masked afterwards: no branch between the loads)
+        const float4 a0 = *reinterpret_cast<const float4*>(qrow + min(k0, ld - 4));
+        const float4 a1 = *reinterpret_cast<const float4*>(qrow + min(k0 + 4, ld - 4));
+        x0[ks] = (real && k0 < ld) ? a0 : zero4;
+        x1[ks] = (real && k0 + 4 < ld) ? a1 : zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Frag fh, fl;
+        SplitBf16(x0[ks].x, x0[ks].y, fh.u[0], fl.u[0]);
+        SplitBf16(x0[ks].z, x0[ks].w, fh.u[1], fl.u[1]);
+        SplitBf16(x1[ks].x, x1[ks].y, fh.u[2], fl.u[2]);
+        SplitBf16(x1[ks].z, x1[ks].w, fh.u[3], fl.u[3]);
+        *reinterpret_cast<uint4*>(tile_lds + (ks * 2 + 0) * 1024 + lane * 16) = fh.q;
+        *reinterpret_cast<uint4*>(tile_lds + (ks * 2 + 1) * 1024 + lane * 16) = fl.q;
+    }
+}
+
 // ---- thresholds ------------------------------------------------------------------------------------------------------
 // For task t with exact k-th distance tau (its list's last entry; +inf while the list is not full):  U[t] such that every
 // row whose CANONICAL binary32 distance E satisfies E <= tau has acc >= U.  All in double, rounded towards -inf.
