@@ -114,6 +114,43 @@ __device__ __forceinline__ float ExactDistance(const float* __restrict__ p, cons
     }
 }
 
+// The same sequences with 16-byte loads: `p` and `q` 16-byte aligned, rows padded with zeros to a multiple of 4 floats (the pad
+// never enters the arithmetic: the tail loop stops at d).  Used where one lane evaluates one whole pair (re-scoring).
+template <int METRIC>
+__device__ __forceinline__ float ExactDistanceVec4(const float* __restrict__ p, const float* __restrict__ q, uint32_t d) {
+    float result = 0.f;
+    const uint32_t full = d >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    if (METRIC == GPANN_METRIC_L2) {
+#pragma unroll 4
+        for (uint32_t g = 0; g < full; ++g) {
+            const float4 a = p4[g], b = q4[g];
+            const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+            float s = d0 * d0 + d1 * d1;
+            s = s + d2 * d2;
+            s = s + d3 * d3;
+            result = result + s;
+        }
+        for (uint32_t i = full << 2; i < d; ++i) {
+            const float d0 = p[i] - q[i];
+            result = result + d0 * d0;
+        }
+        return result;
+    } else {
+#pragma unroll 4
+        for (uint32_t g = 0; g < full; ++g) {
+            const float4 a = p4[g], b = q4[g];
+            result = result + b.x * a.x;
+            result = result + b.y * a.y;
+            result = result + b.z * a.z;
+            result = result + b.w * a.w;
+        }
+        for (uint32_t i = full << 2; i < d; ++i) result = result + q[i] * p[i];
+        return 1.0f - result;
+    }
+}
+
 // ---- 4x4 (query x point) register tile, the reference's exact op sequence per group of 4 dimensions ---------------
 template <int METRIC>
 __device__ __forceinline__ void AccumulateGroup(float (&acc)[4][4], const float4 (&qv)[4], const float4 (&pv)[4]) {

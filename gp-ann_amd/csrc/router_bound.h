@@ -256,7 +256,7 @@ __global__ void ExactCandidatesKernel(const float* centroids, const float* queri
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint2 qc = cand[i];
         if (qc.x == 0xFFFFFFFFu) continue;   // unused slot of a wavefront's chunk
-        const float e = ExactDistance<METRIC>(centroids + (size_t)qc.y * ld, queries + (size_t)qc.x * ld, d);
+        const float e = ExactDistanceVec4<METRIC>(centroids + (size_t)qc.y * ld, queries + (size_t)qc.x * ld, d);
         atomicMin(&out_min_bits[(size_t)qc.x * S + cent_shard[qc.y]], OrderedBitsB(e));
     }
 }

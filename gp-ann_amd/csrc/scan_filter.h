@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
         float e = INFINITY;
         if (valid) {
             row = overflowed ? (uint32_t)(scan_lo + (int64_t)(base + lane)) : a.cand_row[(size_t)t * a.cand_cap + base + lane];
-            e = ExactDistance<METRIC>(a.points + (size_t)row * a.ld, sq, a.d);
+            e = ExactDistanceVec4<METRIC>(a.points + (size_t)row * a.ld, sq, a.d);   // (rows and the LDS copy of the query are 16-byte aligned)
         }
         float td = __shfl(ld_, k - 1);
         uint32_t tr = __shfl(lr_, k - 1);
