@@ -357,7 +357,7 @@ static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vecto
     uint64_t tile_rows = 0;
     for (uint32_t b = 0; b < S; ++b) tile_rows += (uint64_t)((count[b + 1] - count[b] + kQT - 1) / kQT) * (uint64_t)std::max<int64_t>(0, hi[b] - lo[b]);
     const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_SCAN_TARGET_UNITS", 8192));
-    const uint32_t min_seg_rows = std::max<uint32_t>(64, EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 2048));
+    const uint32_t min_seg_rows = std::max<uint32_t>(64, EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 1024));
     uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
     seg_rows = (seg_rows + kPT - 1) / kPT * kPT;
     uint64_t lists = 0;
@@ -696,8 +696,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fn_hi = GPANN_PICK2(true);
 #undef GPANN_PICK2
 #undef GPANN_PICK
-    // the last (by far the largest) pass reads only the hi plane of the points: half the HBM bytes and two of the three products for
-    // a slightly looser bound (10.1 -> 6.1 ms on the NS workload, 40% more candidates); GPANN_FILTER_HI_ONLY=0 keeps all three
+    // the sample and rest passes (all but the small head pass) read only the hi plane of the points: half the HBM bytes and two of
+    // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates);
+    // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere
     const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048;   // (small buckets of huge task counts cannot take the extra candidates)
     const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
@@ -711,7 +712,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (int pass = first_pass; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
-        const bool hi_pass = hi_last && pass >= (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 2);
+        const bool hi_pass = hi_last && pass >= (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
         th.hi_only = hi_pass ? 1u : 0u;
         if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
         else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
