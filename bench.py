@@ -380,15 +380,15 @@ def main():
     filtered = bool(stats["filtered"])
     # per step: the filter kernel is launched twice (two row ranges), the exact kernel once
     # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once
-    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"false>": 2, "true>": 1}) if filtered
+    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"false>": 1, "true>": 2}) if filtered
                else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
         # dominant kernel: FilterKernelCells (the three launches of a step).  Since the cells let it skip what a bound excludes and
         # the last launch streams only the hi plane, it is bound by HBM (it reads the needed planes once), not by the matrix cores.
         f_s = float(np.mean(filter_ms)) / 1000.0
-        flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only last pass runs 2 of the 3 products)
+        flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only passes run 2 of the 3 products)
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
-        plane_bytes = stats["filter_rows"] * 256.0   # row tiles streamed x 32 rows x 256 B (hi plane; the small first passes read 512 B)
+        plane_bytes = stats["filter_rows"] * 256.0   # row tiles streamed x 32 rows x 256 B (hi plane; the small head pass reads 512 B)
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
                               "traffic": traffic, "kernel": "gpann::FilterKernelCells", "kernel_ms": 1000.0 * f_s,
                               "note": "achieved = algorithmic bytes of the reference's scan (rows x d x 4 per (query, probed shard), SURVEY 8d) / "
@@ -448,7 +448,7 @@ def main():
 def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
     """HBM bytes per STEP of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
     the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None.  `launches_per_step` maps a kernel
-    name fragment to its launches per step (the cells filter runs as two full-precision launches and one hi-plane launch)."""
+    name fragment to its launches per step (the cells filter runs as one full-precision launch and two hi-plane launches)."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
