@@ -142,3 +142,33 @@ def test_reference_query_attribution_driver_unchanged(orc, dataset):
     assert pareto[0].startswith("partitioning,shard query,routing query,routing index,ef-search-shard") and len(pareto) > 2
     # the best recall on the front is 1.0: all shards probed = exact
     assert max(float(line.split(",")[8]) for line in pareto[1:] if line) > 0.999
+
+
+CONVERT = os.path.join(ROOT, "gp-ann_amd", "bin", "Convert")
+
+
+def test_convert_driver_replays_routes_over_searches(orc, dataset):
+    """this build's Convert (the live branch of the reference's convert.cpp:62-89): .routes + .searches written through the host
+    mirror -> the Pareto file PrintCombinationsOfRoutesAndSearches produces; host-only replay, no GPU work of its own"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "gp-ann_amd"))
+    f, k, S = dataset["files"], dataset["k"], dataset["S"]
+    out = str(dataset["tmp"] / "cv")
+    # routes and searches from the SmallScaleQueries-independent path: run the reference driver's flow through QueryAttribution if
+    # it exists, else skip (the .routes/.searches writers are exercised there)
+    if not os.path.exists(QA):
+        pytest.skip("needs oracle/_ref/QueryAttribution to produce .routes / .searches")
+    env = dict(os.environ, GPANN_MAX_ROUTER_BUDGET="20000")
+    r = subprocess.run([QA, f["points"], f["queries"], f["gt"] + ".cv", str(k), f["clusters"], out, "KMeans", str(S)], capture_output=True, text=True,
+                       timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([CONVERT, out + ".routes", out + ".searches", out + ".converted", "KMeans", f["queries"]], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a = open(out + ".pareto").read().strip().split("\n")
+    b = open(out + ".converted.pareto").read().strip().split("\n")
+    assert a[0] == b[0] and len(b) > 2
+    # same routes and searches; Convert asks for 40 hosts like the reference (convert.cpp:88), the attribution driver for S, so the
+    # fronts differ in length — both must reach the exact answer (all shards probed) and be sorted Pareto fronts of recall
+    for front in (a, b):
+        rec = [float(ln.split(",")[8]) for ln in front[1:]]
+        assert max(rec) > 0.999 and all(0.0 <= x <= 1.0 for x in rec)
