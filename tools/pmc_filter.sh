@@ -17,7 +17,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_filter/p*/")):
         agg = collections.defaultdict(float); n = collections.defaultdict(int)
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if "FilterKernelReg" in k and ("Li0ELi0" in k or "<0, 0" in k):
+            if "FilterKernelCells" in k and ("Li0ELi0" in k or "<0, 0" in k):
                 agg[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
         for c in agg: print(f"{c:28s} {agg[c]:.4e}  over {n[c]} dispatches")
 PY
