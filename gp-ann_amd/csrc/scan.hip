@@ -359,6 +359,8 @@ static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vecto
     const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_SCAN_TARGET_UNITS", 8192));
     const uint32_t min_seg_rows = std::max<uint32_t>(64, EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 1024));
     uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
+    // short scans (stage 0 of the filtered pipeline with few tasks): rather 256-row segments than fewer than ~1000 workgroups
+    if (tile_rows / seg_rows < 1024) seg_rows = std::max<uint64_t>(256, std::min<uint64_t>(seg_rows, tile_rows / 1024));
     seg_rows = (seg_rows + kPT - 1) / kPT * kPT;
     uint64_t lists = 0;
     for (uint32_t b = 0; b < S; ++b) {
