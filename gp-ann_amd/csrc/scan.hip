@@ -359,8 +359,8 @@ static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vecto
     const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_SCAN_TARGET_UNITS", 8192));
     const uint32_t min_seg_rows = std::max<uint32_t>(64, EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 1024));
     uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
-    // short scans (stage 0 of the filtered pipeline with few tasks): rather 256-row segments than fewer than ~1000 workgroups
-    if (tile_rows / seg_rows < 1024) seg_rows = std::max<uint64_t>(256, std::min<uint64_t>(seg_rows, tile_rows / 1024));
+    // short scans (stage 0 of the filtered pipeline with few tasks): rather 256-row segments than fewer than ~500 workgroups
+    if (tile_rows / seg_rows < 512) seg_rows = std::max<uint64_t>(256, std::min<uint64_t>(seg_rows, tile_rows / 1024));
     seg_rows = (seg_rows + kPT - 1) / kPT * kPT;
     uint64_t lists = 0;
     for (uint32_t b = 0; b < S; ++b) {
@@ -687,6 +687,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.ld = s->ld;
     ra.cand_cap = cap;
     ra.dedupe = 1;
+    const uint32_t overflow_limit = std::max<uint32_t>(8, T / 1000);
+    ra.overflow_count = d_overflow;
+    ra.overflow_limit = overflow_limit;
     const void *fn = nullptr, *fn_hi = nullptr;
 #define GPANN_PICK(M, TAG_, KS_, HI_) (const void*)FilterKernelCells<M, TAG_, KS_, HI_>
 #define GPANN_PICK2(HI_)                                                                                                   \
@@ -736,7 +739,26 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
             s->filter_passes_timed++;
         }
+        // Overflowed buckets are counted on the device (cumulatively over the passes) and looked at once, after the last pass: a
+        // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
+        // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
         hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        GPANN_HIP_TRY(hipGetLastError());
+        plan.filter_launches++;
+        if (std::getenv("GPANN_CELLS_DEBUG")) {
+            uint32_t h_words[4] = {0, 0, 0, 0};
+            unsigned long long h_work[2] = {0, 0};
+            GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 16, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipStreamSynchronize(st));
+            fprintf(stderr, "[gpann cells] pass %d: T=%u G=%u kmax=%u cap=%u  pairs so far %.3e (all rows x tasks %.3e)  row tiles so far %llu  candidates so far %llu  overflowed so far %u\n",
+                    pass, T, G, kmax, cap, (double)h_work[0] * 1024.0, (double)plan.pairs, (unsigned long long)h_work[1],
+                    (unsigned long long)((uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32)), h_words[0]);
+        }
+    }
+    {
         uint32_t h_words[4] = {0, 0, 0, 0};
         unsigned long long h_work[2] = {0, 0};
         GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
@@ -745,19 +767,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
         plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
         plan.filter_rows = (uint64_t)h_work[1] * kGTileRows;
-        if (std::getenv("GPANN_CELLS_DEBUG"))
-            fprintf(stderr, "[gpann cells] pass %d: T=%u G=%u kmax=%u cap=%u  pairs so far %.3e (all rows x tasks %.3e)  row tiles so far %llu  candidates %llu  overflowed %u\n",
-                    pass, T, G, kmax, cap, (double)plan.filter_pairs, (double)plan.pairs, (unsigned long long)h_work[1],
-                    (unsigned long long)plan.filter_candidates, h_words[0]);
-        if (h_words[0] > std::max<uint32_t>(8, T / 1000)) {
+        if (h_words[0] > overflow_limit) {
             *overflow = true;
             return GPANN_OK;
         }
-        if (h_words[0]) GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, st));
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        GPANN_HIP_TRY(hipGetLastError());
-        plan.filter_launches++;
     }
     GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
     const size_t n = (size_t)T * k;

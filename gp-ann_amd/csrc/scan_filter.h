@@ -161,6 +161,8 @@ struct RescoreArgs {
     int64_t range_lo, range_hi;
     uint32_t tasks, k, d, ld, cand_cap;
     uint32_t dedupe;              // 1: skip candidates already in the list (cell passes)
+    const uint32_t* overflow_count;   // buckets overflowed so far in this call (device counter) ...
+    uint32_t overflow_limit;          // ... beyond this many the call falls back to the exact scan: no more in-kernel re-reads
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
@@ -202,6 +204,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     const uint32_t cnt = a.cand_cnt[t];
     if (cnt == 0) return;
     const bool overflowed = cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
+    if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
     float* sq = rsm + (size_t)wave * a.ld;
     const float* q = a.queries + (size_t)a.task_query[t] * a.ld;
     for (uint32_t i = lane; i < a.ld; i += 64) sq[i] = q[i];
