@@ -1348,7 +1348,6 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     const uint32_t groups = (nb + 255) / 256;
                     const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
                     ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
-                    if (const char* ns = std::getenv("GPANN_ROUTER_BOUND_SEG")) ba.n_seg = std::max(1, std::atoi(ns));
                     GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
                     GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 4, st));
                     GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));

@@ -713,8 +713,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     int n_cus = 256;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
 
-    const int first_pass = EnvU32("GPANN_FILTER_SKIP_HEAD", 0) ? 1 : 0;   // (experiment: without the head pass)
-    for (int pass = first_pass; pass < 3; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
