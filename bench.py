@@ -123,7 +123,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as e:   # no usable RCCL: the exchange is small enough for gloo over host memory
+                log(f"nccl backend unavailable ({e}); using gloo")
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(args.backend)
     stream = torch.cuda.current_stream().cuda_stream
