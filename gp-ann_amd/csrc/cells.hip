@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members,
 
 // bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
 __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
-                                                                 char* planes) {
+                                                                 char* planes, uint64_t lo_offset) {
     const uint64_t total = plane_rows * 16;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = i >> 4;
@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
+        char* base = planes + (r >> 5) * (uint64_t)kGPlaneBytes + ks * 1024 + lane * 16;   // all hi tiles first, then all lo tiles
         *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
+        *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
     }
 }
 
@@ -209,7 +209,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
               hipMalloc(&C.d_center, (size_t)C.n_cells * ld * 4) == hipSuccess && hipMalloc(&C.d_radius, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.plane_perm, plane_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (plane_rows + 64) * 4) == hipSuccess &&
-              hipMalloc(&s->frag_planes, (C.n_tiles + 2) * (size_t)kGTileBytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
+              hipMalloc(&s->frag_planes, 2 * (C.n_tiles + 2) * (size_t)kGPlaneBytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
               hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess;
     std::vector<float> cnorm(C.n_cells);
     for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
@@ -225,13 +225,15 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemcpy(d_member_begin, member_begin.data(), C.n_cells * 8, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(d_cell_size, cell_size.data(), C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemset(C.plane_norm + plane_rows, 0, 64 * 4) == hipSuccess &&
-             hipMemset(s->frag_planes + C.n_tiles * (size_t)kGTileBytes, 0, 2 * (size_t)kGTileBytes) == hipSuccess;
+             hipMemset(s->frag_planes + C.n_tiles * (size_t)kGPlaneBytes, 0, 2 * (size_t)kGPlaneBytes) == hipSuccess &&
+             hipMemset(s->frag_planes + (2 * C.n_tiles + 2) * (size_t)kGPlaneBytes, 0, 2 * (size_t)kGPlaneBytes) == hipSuccess;
     }
     if (ok) {
         hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
         const int g2 = (int)std::min<uint64_t>((plane_rows * 16 + 255) / 256, 256 * 64);
-        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes);
+        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
+                           (uint64_t)(C.n_tiles + 2) * kGPlaneBytes);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }

@@ -656,6 +656,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.cand_cap = cap;
     fa.ld = s->ld;
     fa.frag_planes = s->frag_planes;
+    fa.plane_lo_offset = (uint64_t)(C.n_tiles + 2) * kGPlaneBytes;
     fa.plane_norm = C.plane_norm;
     fa.plane_perm = C.plane_perm;
     fa.groups = d_groups;

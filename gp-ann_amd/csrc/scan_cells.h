@@ -223,7 +223,8 @@ struct CellFilterArgs {
     uint32_t* cand_cnt;
     uint32_t* cand_row;
     uint32_t cand_cap, ld;
-    const char* frag_planes;
+    const char* frag_planes;     // all hi tiles (kGPlaneBytes each), then at +plane_lo_offset all lo tiles
+    uint64_t plane_lo_offset;
     const float* plane_norm;
     const uint32_t* plane_perm;
     const CellGroup* groups;
@@ -309,11 +310,11 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
 
     auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
-        const char* base = lane_planes + (size_t)T * kGTileBytes;
+        const char* base = lane_planes + (size_t)T * kGPlaneBytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
-            if (!HI_ONLY) Al[ks].q = *reinterpret_cast<const uint4*>(base + kGPlaneBytes + ks * 1024);
+            if (!HI_ONLY) Al[ks].q = *reinterpret_cast<const uint4*>(base + a.plane_lo_offset + ks * 1024);
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[T * kGTileRows + c];
     };

@@ -49,7 +49,9 @@ union Frag {   // 8 bf16 = 4 VGPRs, the A/B operand of v_mfma_f32_32x32x16_bf16
 };
 
 // The points' bf16 planes live in HBM in MFMA A-operand order (scan_cells.h): per 32-row tile and k-step one contiguous KiB per
-// plane (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7); the hi plane of a tile is 8 contiguous KiB, then the lo plane.
+// plane (lane (c, h) holds row 32 T + c, dims 16 ks + 8 h .. + 7), 8 KiB per tile and plane.  The shard store keeps all hi
+// tiles in one array and all lo tiles in a second one (the big passes stream only the hi array, sequentially); the router's
+// centroid planes keep hi and lo of a tile side by side (kGTileBytes).
 constexpr int kGTileRows = 32;
 constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane][16 B]
 constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
