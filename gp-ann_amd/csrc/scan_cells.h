@@ -313,8 +313,9 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         const char* base = lane_planes + (size_t)T * kGPlaneBytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
-            if (!HI_ONLY) Al[ks].q = *reinterpret_cast<const uint4*>(base + a.plane_lo_offset + ks * 1024);
+            // (read-once stream: non-temporal, leaves L2 to the query rows / tables)
+            Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
+            if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + a.plane_lo_offset + ks * 1024));
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[T * kGTileRows + c];
     };
