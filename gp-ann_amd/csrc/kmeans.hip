@@ -838,3 +838,52 @@ extern "C" gpann_status gpann_router_train(gpann_shards* s, uint64_t n_points, u
     return gpann_router_create(d, s->metric, S, (uint32_t)node_shard.size(), node_shard.data(), node_cent_first.data(), node_child_first.data(),
                                node_child_count.data(), shard_root.data(), centroids.data(), s->device, out);
 }
+
+// RandomSample(points, k, seed) + KMeans(points, centroids) (kmeans.cpp:207-244) over ALL rows of the store as one problem — the
+// call every k-means partitioner of the reference starts with (partition.cpp:23-26, partitioning.cpp:19-26, :94-98).
+extern "C" gpann_status gpann_kmeans(gpann_shards* s, uint32_t k, int seed, int32_t* out_partition, float* out_centroids, uint32_t* out_k) {
+    GPANN_REQUIRE(s != nullptr && out_k != nullptr, "null handle / out_k");
+    GPANN_REQUIRE(k >= 1 && k <= 4096, "k must be in [1, 4096]");
+    GPANN_REQUIRE(s->rows >= 1, "k-means over an empty point set");
+    const uint32_t n = (uint32_t)s->rows, d = s->d;
+    LloydSession session;
+    GPANN_TRY(session.Begin(s, s->metric));
+    std::vector<LloydTask> tasks{{0, n, k}};
+    std::vector<uint32_t> pick(k, 0);
+    {   // kmeans.cpp:212-217; with fewer rows than samples the tail of `sample` stays 0
+        std::vector<int> all(n);
+        std::iota(all.begin(), all.end(), 0);
+        std::mt19937 prng(seed);
+        std::vector<int> sample(k);
+        std::sample(all.begin(), all.end(), sample.begin(), k, prng);
+        for (uint32_t x = 0; x < k; ++x) pick[x] = (uint32_t)sample[x];
+    }
+    LloydResult res;
+    GPANN_TRY(session.RunLevel(tasks, pick, 20, res));
+    // survivors in slot order = the ids RemoveEmptyClusters leaves (kmeans.cpp:29-50); their member slabs are the clusters
+    std::vector<uint32_t> rows;
+    if (out_partition) {
+        rows.resize(n);
+        GPANN_TRY(EnsureDevice(s->device));
+        hipError_t e = hipMemcpy(rows.data(), session.rows(), (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            SetLastError("hipMemcpy(rows) failed: %s", hipGetErrorString(e));
+            return GPANN_ERR_HIP;
+        }
+    }
+    uint32_t alive = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        if (res.csize[j] == 0) continue;
+        if (out_partition)
+            for (uint32_t x = 0; x < res.csize[j]; ++x) out_partition[rows[res.coff[j] + x]] = (int32_t)alive;
+        if (out_centroids) std::memcpy(out_centroids + (size_t)alive * d, &res.cent[(size_t)alive * res.ld], d * sizeof(float));
+        ++alive;
+    }
+    if (alive != res.cnum[0]) {
+        SetLastError("k-means: inconsistent cluster bookkeeping (%u clusters with members, %u centroids)", alive, res.cnum[0]);
+        return GPANN_ERR_INTERNAL;
+    }
+    *out_k = alive;
+    session.End();
+    return GPANN_OK;
+}

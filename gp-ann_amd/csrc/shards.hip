@@ -197,7 +197,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         const char* want = std::getenv("GPANN_FILTER_PLANES");
         const char* cr = std::getenv("GPANN_CELL_ROWS");
         const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
-        if (s->filter_ok && d <= 128 && !(want && want[0] == '0')) {
+        if (s->filter_ok && d <= 128 && !(want && want[0] == '0') && !(flags & GPANN_STORE_PLAIN)) {
             gpann_status cst = BuildCells(s, cell_rows);
             if (cst != GPANN_OK) return fail(cst);
         }

@@ -181,6 +181,8 @@ public:
     std::vector<FrequencyQueryData> FrequencyQueryBatch(PointSet& queries, int budget, int num_voting_neighbors);
 
     std::pair<PointSet, std::vector<int>> ExtractPoints();   // :174-201
+    // additive: only the min_dist rows of Query (out[q * S + b]; FLT_MAX = shard never opened) for nq queries stored row-major at Q
+    void MinDistBatch(const float* Q, size_t nq, int budget, float* out);
 
     // Flat tree (the layout gpann_router_create takes, include/gpann.h): nodes per shard in BFS order.
     struct Flat {
@@ -199,6 +201,25 @@ private:
     Flat tree_;
     gpann_router* device_router_ = nullptr;
 };
+
+// ------------------------------------------------------------------------------------------- src/partitioning.h
+// The k-means shard builders (src/partitioning.cpp:12-146); k-means itself runs on the GPU (gpann_kmeans).
+Partition RecursiveKMeansPartitioning(PointSet& points, size_t max_cluster_size, int depth = 0, int num_clusters = -1);
+Partition RebalancingKMeansPartitioning(PointSet& points, size_t max_cluster_size, int num_clusters = -1);
+Partition KMeansPartitioning(PointSet& points, int num_clusters, double epsilon);
+// declared for source compatibility; they throw std::runtime_error (KaMinPar / hnswlib are not part of the reference checkout)
+Partition GraphPartitioning(PointSet& points, int num_clusters, double epsilon, bool strong, const std::string& graph_output_path = "");
+Partition PyramidPartitioning(PointSet& points, int num_clusters, double epsilon, const std::string& routing_index_path = "");
+Partition OurPyramidPartitioning(PointSet& points, int num_clusters, double epsilon, const std::string& routing_index_path,
+                                 double coarsening_rate = 0.002);
+
+// ------------------------------------------------------------------------------- src/overlapping_partitioning.h
+// SPANN-style overlap (src/overlapping_partitioning.cpp:143-235): representatives from the GPU trainer, point x representative
+// minima from the GPU router, greedy extra assignments on the host.
+void MakeOverlappingWithCentroids(PointSet& points, Clusters& clusters, size_t max_cluster_size, size_t num_extra_assignments);
+Clusters OverlappingKMeansPartitioningSPANN(PointSet& points, const Partition& partition, int requested_num_clusters, double epsilon,
+                                            double overlap);
+Clusters OverlappingGraphPartitioning(PointSet& points, int requested_num_clusters, double epsilon, double overlap, bool strong);   // throws
 
 // ------------------------------------------------------------------------------------------ src/inverted_index.h
 struct InvertedIndex {

@@ -82,6 +82,60 @@ int64_t gpann_host_kmeans(const float* points, uint64_t n, uint32_t d, uint32_t 
     }
 }
 
+// the k-means shard builders (partition_host.cpp).  which: 0 = KMeansPartitioning(points, k, eps), 1 = RecursiveKMeansPartitioning(points,
+// max_cluster_size, 0, k), 2 = RebalancingKMeansPartitioning(points, max_cluster_size, k); k < 0 = derive it from max_cluster_size.
+// device != 0: k-means on the GPU.  Returns the number of parts, -1 on error.
+int64_t gpann_host_partition(int which, const float* points, uint64_t n, uint32_t d, int k, double eps, uint64_t max_cluster_size, int device,
+                             int32_t* out_partition) {
+    const bool before = gpann_host::DeviceTraining();
+    try {
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        gpann_host::SetDeviceTraining(device != 0);
+        Partition part = which == 0   ? KMeansPartitioning(ps, k, eps)
+                         : which == 1 ? RecursiveKMeansPartitioning(ps, max_cluster_size, 0, k)
+                                      : RebalancingKMeansPartitioning(ps, max_cluster_size, k);
+        gpann_host::SetDeviceTraining(before);
+        for (uint64_t i = 0; i < n; ++i) out_partition[i] = part[i];
+        return n ? NumPartsInPartition(part) : 0;
+    } catch (const std::exception& e) {
+        gpann_host::SetDeviceTraining(before);
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// OverlappingKMeansPartitioningSPANN(points, partition, requested_num_clusters, eps, overlap); the clusters come back as CSR
+// (out_ids holds up to `capacity` ids).  Returns the number of clusters, -1 on error.
+int64_t gpann_host_overlap_spann(const float* points, uint64_t n, uint32_t d, const int32_t* partition, int requested_num_clusters, double eps,
+                                 double overlap, int device, uint32_t* out_ids, uint64_t capacity, uint64_t* out_offsets) {
+    const bool before = gpann_host::DeviceTraining();
+    try {
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        gpann_host::SetDeviceTraining(device != 0);
+        Clusters clusters = OverlappingKMeansPartitioningSPANN(ps, Partition(partition, partition + n), requested_num_clusters, eps, overlap);
+        gpann_host::SetDeviceTraining(before);
+        uint64_t at = 0;
+        out_offsets[0] = 0;
+        for (size_t b = 0; b < clusters.size(); ++b) {
+            if (at + clusters[b].size() > capacity) throw std::runtime_error("gpann_host_overlap_spann: output capacity too small");
+            std::memcpy(out_ids + at, clusters[b].data(), clusters[b].size() * 4);
+            at += clusters[b].size();
+            out_offsets[b + 1] = at;
+        }
+        return (int64_t)clusters.size();
+    } catch (const std::exception& e) {
+        gpann_host::SetDeviceTraining(before);
+        g_err = e.what();
+        return -1;
+    }
+}
+
 float gpann_host_distance(const float* p, const float* q, uint32_t d) { return distance(const_cast<float*>(p), const_cast<float*>(q), d); }
 
 }   // extern "C"

@@ -259,7 +259,7 @@ void KMeansTreeRouter::Train(PointSet& points, const Clusters& clusters, KMeansT
     gpann_shards* store = nullptr;
     gpann_host::Check(gpann_shards_create(points.coordinates.data(), points.n, (uint32_t)points.d,
                                           gpann_host::MetricIsMIPS() ? GPANN_METRIC_MIPS : GPANN_METRIC_L2, ids.data(), offsets.data(),
-                                          (uint32_t)clusters.size(), gpann_host::Device(), 0, &store),
+                                          (uint32_t)clusters.size(), gpann_host::Device(), GPANN_STORE_PLAIN, &store),
                       "gpann_shards_create");
     try {
         TrainOnDevice(store, points.n, options);
@@ -368,6 +368,11 @@ std::vector<std::vector<int>> KMeansTreeRouter::QueryBatch(PointSet& queries, in
     std::vector<std::vector<int>> out(nq);
     for (uint32_t q = 0; q < nq; ++q) out[q].assign(probes.begin() + (size_t)q * S, probes.begin() + (size_t)(q + 1) * S);
     return out;
+}
+
+void KMeansTreeRouter::MinDistBatch(const float* Q, size_t nq, int budget, float* out) {
+    EnsureOnDevice();
+    gpann_host::Check(gpann_router_query_batch(device_router_, Q, (uint32_t)nq, budget, nullptr, out, 0, nullptr, nullptr), "gpann_router_query_batch");
 }
 
 std::vector<int> KMeansTreeRouter::Query(float* Q, int budget) {

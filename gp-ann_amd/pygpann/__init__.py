@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1
-QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS = 1, 2, 4, 8
+QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN = 1, 2, 4, 8, 16
 MAX_K = 64
 NO_ID = np.uint32(0xFFFFFFFF)
 
@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_router_info", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -87,6 +87,7 @@ def lib():
                                       C.POINTER(C.c_void_p)]
     L.gpann_router_destroy.argtypes = [C.c_void_p]
     L.gpann_router_train.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]
+    L.gpann_kmeans.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _i32p, _f32p, _u32p]
     L.gpann_router_info.argtypes = [C.c_void_p, _u32p, C.POINTER(C.c_int), _u32p, _u32p, _u64p]
     L.gpann_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
     L.gpann_router_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
@@ -135,10 +136,11 @@ def clusters_to_csr(clusters):
 class Shards:
     """Device-resident shard store = InvertedIndex(points, clusters) (reference src/inverted_index.h:12-41)."""
 
-    def __init__(self, points, clusters, metric=METRIC_L2, device=0, n=None, d=None):
-        """points: numpy [n,d] float32 (host) or an int device pointer (then n, d must be given)."""
+    def __init__(self, points, clusters, metric=METRIC_L2, device=0, n=None, d=None, plain=False):
+        """points: numpy [n,d] float32 (host) or an int device pointer (then n, d must be given).
+        plain: rows only, no filter support data (GPANN_STORE_PLAIN) — for stores that only feed training / partitioning."""
         ids, offs = clusters_to_csr(clusters)
-        flags = 0
+        flags = STORE_PLAIN if plain else 0
         if isinstance(points, (int, np.integer)):
             flags |= POINTS_ON_DEVICE
             pts = C.c_void_p(int(points))
@@ -164,6 +166,14 @@ class Shards:
             self.close()
         except Exception:
             pass
+
+    def kmeans(self, k, seed):
+        """RandomSample(k, seed) + KMeans over all rows as one point set (gpann_kmeans): (partition[rows] int32, centroids[k', d])."""
+        part = np.empty(self.rows, np.int32)
+        cent = np.empty((int(k), self.d), np.float32)
+        kk = C.c_uint32(0)
+        _check(lib().gpann_kmeans(self.h, C.c_uint32(int(k)), C.c_int(int(seed)), part.ctypes.data_as(_i32p), cent.ctypes.data_as(_f32p), C.byref(kk)))
+        return part, cent[:kk.value].copy()
 
     def set_scan_mode(self, mode):
         """0 = exact VALU scan, 1 = exact scan with the MFMA pre-filter (same results)"""

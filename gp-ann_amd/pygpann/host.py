@@ -25,6 +25,10 @@ def lib():
         L.gpann_host_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
         L.gpann_host_kmeans.restype = C.c_int64
         L.gpann_host_kmeans.argtypes = [_f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _i32p, _f32p]
+        L.gpann_host_partition.restype = C.c_int64
+        L.gpann_host_partition.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, C.c_int, C.c_double, C.c_uint64, C.c_int, _i32p]
+        L.gpann_host_overlap_spann.restype = C.c_int64
+        L.gpann_host_overlap_spann.argtypes = [_f32p, C.c_uint64, C.c_uint32, _i32p, C.c_int, C.c_double, C.c_double, C.c_int, _u32p, C.c_uint64, _u64p]
         L.gpann_host_distance.restype = C.c_float
         L.gpann_host_distance.argtypes = [_f32p, _f32p, C.c_uint32]
         _lib = L
@@ -76,3 +80,35 @@ def distance(p, q, mips=False):
     p, q = np.ascontiguousarray(p, np.float32), np.ascontiguousarray(q, np.float32)
     configure(mips, 0, 0)
     return np.float32(lib().gpann_host_distance(p.ctypes.data_as(_f32p), q.ctypes.data_as(_f32p), p.shape[0]))
+
+
+PART_KMEANS, PART_RECURSIVE, PART_REBALANCING = 0, 1, 2
+
+
+def partition(which, points, k=-1, eps=0.05, max_cluster_size=0, mips=False, device=False, threads=0):
+    """KMeansPartitioning / RecursiveKMeansPartitioning / RebalancingKMeansPartitioning (reference src/partitioning.cpp:12-146);
+    device=True runs k-means on the GPU (gpann_kmeans)."""
+    points = np.ascontiguousarray(points, np.float32)
+    configure(mips, 0, threads)
+    part = np.empty(points.shape[0], np.int32)
+    r = lib().gpann_host_partition(which, points.ctypes.data_as(_f32p), points.shape[0], points.shape[1], int(k), float(eps), int(max_cluster_size),
+                                   int(device), part.ctypes.data_as(_i32p))
+    if r < 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return part
+
+
+def overlap_spann(points, partition, requested_num_clusters, eps, overlap, mips=False, device=False, threads=0):
+    """OverlappingKMeansPartitioningSPANN (reference src/overlapping_partitioning.cpp:143-235) -> list of id arrays."""
+    points = np.ascontiguousarray(points, np.float32)
+    partition = np.ascontiguousarray(partition, np.int32)
+    configure(mips, 0, threads)
+    n = points.shape[0]
+    cap = 6 * n + 16
+    ids = np.empty(cap, np.uint32)
+    offs = np.empty(int(partition.max()) + 2 if n else 1, np.uint64)
+    S = lib().gpann_host_overlap_spann(points.ctypes.data_as(_f32p), n, points.shape[1], partition.ctypes.data_as(_i32p), int(requested_num_clusters),
+                                       float(eps), float(overlap), int(device), ids.ctypes.data_as(_u32p), cap, offs.ctypes.data_as(_u64p))
+    if S < 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return [ids[int(offs[b]):int(offs[b + 1])].copy() for b in range(S)]

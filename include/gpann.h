@@ -56,6 +56,8 @@ enum {
     GPANN_QUERIES_ON_DEVICE = 1 << 0,  /* `queries` is a device pointer */
     GPANN_OUTPUT_ON_DEVICE = 1 << 1,   /* out_* are device pointers (no synchronisation on return) */
     GPANN_POINTS_ON_DEVICE = 1 << 2,   /* `points` is a device pointer (gpann_shards_create) */
+    GPANN_STORE_PLAIN = 1 << 4,        /* gpann_shards_create: rows, offsets and permutation only — no filter support data (cells,
+                                          bf16 planes); for stores that only feed training / partitioning.  Scans on it are exact-mode */
     GPANN_AUX_PASS = 1 << 3            /* profiling label: run the identical scan kernel under a second symbol name so that
                                           auxiliary passes (ground truth) stay out of the hot path's per-kernel statistics */
 };
@@ -167,6 +169,15 @@ gpann_status gpann_router_destroy(gpann_router* r);
  *   num_centroids, min_cluster_size, budget     KMeansTreeRouterOptions (kmeans_tree_router.h:6-11) */
 gpann_status gpann_router_train(gpann_shards* shards, uint64_t n_points, uint32_t num_centroids, uint32_t min_cluster_size, int64_t budget,
                                 gpann_router** out);
+
+/* RandomSample(points, k, seed) + KMeans(points, centroids) — reference src/kmeans.cpp:207-244, the first step of every k-means
+ * partitioner (partition.cpp:23-26; src/partitioning.cpp:19-26, :94-98) — over all rows of `shards` as ONE point set (row r of the
+ * store = point r of the call; build the store with a single identity shard).  Same engine and the same guarantees as
+ * gpann_router_train.
+ *   out_partition   host, rows x int32: cluster of every row after empty clusters were removed (may be NULL)
+ *   out_centroids   host, k x d (the first *out_k rows are written; may be NULL)
+ *   out_k           surviving centroids (PointSet::n of `centroids` after the call) */
+gpann_status gpann_kmeans(gpann_shards* shards, uint32_t k, int seed, int32_t* out_partition, float* out_centroids, uint32_t* out_k);
 
 /* Size and contents of a router's flattened tree (the arrays gpann_router_create takes; host outputs, any may be NULL). */
 gpann_status gpann_router_info(const gpann_router* r, uint32_t* d, int* metric, uint32_t* S, uint32_t* n_nodes, uint64_t* n_centroids);
