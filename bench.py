@@ -82,8 +82,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", dest="n", type=int, default=int(os.environ.get("GPANN_BENCH_N", 100_000_000)))
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nq", type=int, default=10_000)
@@ -349,14 +349,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    scan_ms, router_ms, algo_bytes, filter_ms, stats = [], [], [], [], None
+    scan_ms, router_ms, algo_bytes, filter_ms, rest_ms, step_wall_ms, stats = [], [], [], [], [], [], None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         md, mi, r_ms, s_ms = step()
+        step_wall_ms.append(round(1e3 * (time.perf_counter() - t_step), 3))
         st = shards.stats()
         scan_ms.append(st["scan_ms"])
         filter_ms.append(st["filter_ms"])
+        rest_ms.append(st["filter_rest_ms"])
         router_ms.append(r_ms)
         algo_bytes.append(st["algorithmic_bytes"])
         stats = st
@@ -383,36 +386,38 @@ def main():
     avg_scan_s = float(np.mean(scan_ms)) / 1000.0
     hbm_alg = float(np.mean(algo_bytes)) / avg_scan_s / 1e9 if avg_scan_s > 0 else 0.0
     filtered = bool(stats["filtered"])
-    # per step: the filter kernel is launched twice (two row ranges), the exact kernel once
-    # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once
-    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"false>": 1, "true>": 2}) if filtered
+    # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once; the rest pass — the
+    # launch that streams (nearly) the whole store once — is the dominant kernel
+    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"true>": 1}, largest_launch=True) if filtered
                else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
-        # dominant kernel: FilterKernelCells (the three launches of a step).  Since the cells let it skip what a bound excludes and
-        # the last launch streams only the hi plane, it is bound by HBM (it reads the needed planes once), not by the matrix cores.
         f_s = float(np.mean(filter_ms)) / 1000.0
+        r_s = float(np.mean(rest_ms)) / 1000.0
         flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only passes run 2 of the 3 products)
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
-        plane_bytes = stats["filter_rows"] * 256.0   # row tiles streamed x 32 rows x 256 B (hi plane; the small head pass reads 512 B)
+        # bytes the rest pass has to read: its row tiles x (bf16 hi plane [+ lo plane] + the row's norm word)
+        rest_bytes = stats["filter_rest_rows"] * (d * (2.0 if stats["filter_rest_hi_only"] else 4.0) + 4.0)
+        rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
-                              "traffic": traffic, "kernel": "gpann::FilterKernelCells", "kernel_ms": 1000.0 * f_s,
+                              "traffic": traffic, "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s,
                               "note": "achieved = algorithmic bytes of the reference's scan (rows x d x 4 per (query, probed shard), SURVEY 8d) / "
                                       "HIP-event time of all scan kernels; frac > 1 because the exact answer needs far fewer bytes: cells whose "
                                       "bounding ball cannot reach a task's k-th distance are skipped, the rest is bounded by bf16 MFMA products on "
-                                      "pre-split planes and only candidates get the canonical VALU evaluation.  The kernel itself streams the needed "
-                                      "planes once: kernel_hbm_* = those bytes / its own time (traffic = the PMC figure for the same launches)",
-                              "kernel_hbm_GBps": plane_bytes / f_s / 1e9 if f_s > 0 else 0.0,
-                              "kernel_hbm_frac": plane_bytes / f_s / 1e9 / HBM_PEAK_GBPS if f_s > 0 else 0.0,
-                              "kernel_mfma_TFLOPs": tflops, "kernel_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
+                                      "pre-split planes and only candidates get the canonical VALU evaluation.  The dominant launch (the rest pass of "
+                                      "FilterKernelCells) streams the needed planes once: kernel_hbm_* = the bytes it has to read / its own HIP-event "
+                                      "time (traffic = the PMC figure for that launch); a bare read loop reaches 6.5-6.8 TB/s on this part "
+                                      "(profiles/r01/hbm_read_peak.txt)",
+                              "kernel_hbm_bytes": rest_bytes, "kernel_hbm_GBps": rest_gbps, "kernel_hbm_frac": rest_gbps / HBM_PEAK_GBPS,
+                              "filter_kernels_ms": 1000.0 * f_s, "filter_mfma_TFLOPs": tflops, "filter_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
-                              "filter_rows": stats["filter_rows"], "filter_plane_bytes": plane_bytes}
+                              "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
                               "traffic": traffic, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
                               "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY 8d) of rank 0 / HIP-event kernel time; each "
                                       "HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
                               "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0}
-    result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)),
+    result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
                         "router_train_s": router_train_s, "router_index_budget": best["index_budget"],
@@ -450,13 +455,16 @@ def main():
         dist.destroy_process_group()
 
 
-def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
+def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=False):
     """HBM bytes per STEP of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
     the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None.  `launches_per_step` maps a kernel
-    name fragment to its launches per step (the cells filter runs as one full-precision launch and two hi-plane launches)."""
+    name fragment to its launches per step (the cells filter runs as one full-precision launch and two hi-plane launches);
+    largest_launch: the biggest single launch of the matching kernels instead (the rest pass among the hi-plane launches)."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json"))):
+    import re
+    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", p)]   # ... v9 < v10: the newest pass wins
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json")), key=natural):
         try:
             j = json.load(open(path))
             w = j["workload"]
@@ -466,7 +474,10 @@ def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step):
             for name, v in j["kernels"].items():
                 for frag, per_step in launches_per_step.items():
                     if kernel in name and frag in name:
-                        total += float(v["hbm_bytes_per_launch"]) * per_step
+                        if largest_launch:
+                            total = max(total, max(2048.0 * f + 1024.0 * w for f, w in zip(v["fetch_kib"], v["write_kib"])))
+                        else:
+                            total += float(v["hbm_bytes_per_launch"]) * per_step
                         found = True
             if found:
                 best = total

@@ -560,10 +560,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
     CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor, [3] = [1] before the rest pass
     uint32_t* d_next_item = reinterpret_cast<uint32_t*>(d_work + 2);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
-    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 24, st));
+    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), hipMemcpyHostToDevice, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_groups, groups.data(), (size_t)G * sizeof(CellGroup), hipMemcpyHostToDevice, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_task_group, task_group.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
@@ -732,8 +732,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
         GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 4, st));
+        if (pass == 2) {   // the big launch on its own: row tiles streamed before it, and its begin / end
+            GPANN_HIP_TRY(hipMemcpyAsync(d_work + 3, d_work + 1, 8, hipMemcpyDeviceToDevice, st));
+            GPANN_HIP_TRY(hipEventRecord(s->ev_filter[4], st));
+            plan.filter_rest_hi_only = hi_pass;
+        }
         GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, (uint64_t)G * kmax * fa.n_seg)), dim3(512), kargs, glds, st));
         GPANN_HIP_TRY(hipGetLastError());
+        if (pass == 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[5], st));
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
         if (pass == 0 || pass == 2) {
             GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
@@ -760,10 +766,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     {
         uint32_t h_words[4] = {0, 0, 0, 0};
-        unsigned long long h_work[2] = {0, 0};
+        unsigned long long h_work[4] = {0, 0, 0, 0};
         GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 16, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 32, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipStreamSynchronize(st));
+        plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
         plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
         plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
         plan.filter_rows = (uint64_t)h_work[1] * kGTileRows;
@@ -851,6 +858,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.padded_pairs = plan.padded_pairs;
     s->stats.filter_pairs = plan.filter_pairs;
     s->stats.filter_rows = plan.filter_rows;
+    s->stats.filter_rest_rows = plan.filter_rest_rows;
+    s->stats.filter_rest_hi_only = plan.filter_rest_hi_only ? 1u : 0u;
     s->stats.filter_candidates = plan.filter_candidates;
     return GPANN_OK;
 }
@@ -869,6 +878,8 @@ static gpann_status FinishTiming(gpann_shards* s, float* elapsed_ms) {
             GPANN_HIP_TRY(hipEventElapsedTime(&f, s->ev_filter[2 * p], s->ev_filter[2 * p + 1]));
             s->stats.filter_ms += f;
         }
+        s->stats.filter_rest_ms = 0.f;
+        if (s->filter_passes_timed == 2) GPANN_HIP_TRY(hipEventElapsedTime(&s->stats.filter_rest_ms, s->ev_filter[4], s->ev_filter[5]));
     }
     if (elapsed_ms) *elapsed_ms = a + b;
     return GPANN_OK;

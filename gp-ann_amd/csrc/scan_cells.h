@@ -278,9 +278,12 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);                                      // end of the head segment
     const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));   // end of the sample
     const int64_t t_pass_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
+    // segments every query tile of this block has already been run on need not be streamed again (the later passes would otherwise
+    // re-read the head and the sample of every cell: 1/sample_div of the store)
+    const int64_t t_first = (mask & ~d0) ? t_cell : ((mask & ~d1) ? t_a : t_b);
     // this work item's share of the pass's tile range
-    const int64_t per = (t_pass_end - t_cell + a.n_seg - 1) / a.n_seg;
-    const int64_t t_begin = t_cell + (int64_t)seg * per;
+    const int64_t per = (t_pass_end - t_first + a.n_seg - 1) / a.n_seg;
+    const int64_t t_begin = t_first + (int64_t)seg * per;
     const int64_t t_end = min(t_pass_end, t_begin + per);
     if (t_begin >= t_end) continue;
     // anything to do?  (segment 2 exists only in pass 2 and has no `done` mask)
@@ -407,18 +410,27 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
         }
     };
 
-    Frag A0h[KS], A0l[KS], A1h[KS], A1l[KS];   // (the lo sets stay untouched, hence unallocated, when HI_ONLY)
-    float n0 = 0.f, n1 = 0.f;
+    // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
+    // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it re-reads the last tile — because
+    // a load under a branch leaves the compiler unable to count the loads in flight at the join, and it then drains them all
+    // (s_waitcnt vmcnt(0)) before the first use of the current tile: no overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).
+    // (a third buffer for the hi-only passes was measured slower: the extra registers spill)
+    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
+    float nrm[2] = {0.f, 0.f};
     int64_t T = t_begin + wave;
-    if (T < t_end) load_tile(A0h, A0l, n0, T);
-    while (T < t_end) {
-        if (T + 8 < t_end) load_tile(A1h, A1l, n1, T + 8);
-        compute_tile(A0h, A0l, n0, T);
-        T += 8;
-        if (T >= t_end) break;
-        if (T + 8 < t_end) load_tile(A0h, A0l, n0, T + 8);
-        compute_tile(A1h, A1l, n1, T);
-        T += 8;
+    if (T < t_end) {
+        const int64_t t_last = t_end - 1;
+        load_tile(Ah[0], Al[0], nrm[0], T);
+        for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], min(T + 8, t_last));
+            compute_tile(Ah[0], Al[0], nrm[0], T);
+            T += 8;
+            if (T >= t_end) break;
+            load_tile(Ah[0], Al[0], nrm[0], min(T + 8, t_last));
+            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
+            T += 8;
+            if (T >= t_end) break;
+        }
     }
     }   // next block
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {

@@ -24,7 +24,8 @@ struct ScanUnit {
 struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
-    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0;
+    bool filter_rest_hi_only = false;
     uint32_t filter_launches = 0;
     void Clear() {
         task_query.clear();
@@ -34,7 +35,7 @@ struct ScanPlan {
         task_shard.clear();
         shard_task_begin.clear();
         units.clear();
-        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = 0;
+        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = 0;
         filter_launches = 0;
     }
 };
@@ -79,7 +80,8 @@ struct gpann_shards {
     // per-call workspace, grown on demand and reused
     gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_filter[4] = {nullptr, nullptr, nullptr, nullptr};   // begin/end of the filter kernel of pass 0 and pass 1
+    hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
+                                                                                          // and of the rest pass's filter launch alone
     int filter_passes_timed = 0;
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;

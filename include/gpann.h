@@ -138,6 +138,9 @@ typedef struct gpann_scan_stats {
     float filter_ms;             /* of scan_ms: the MFMA filter kernels (threshold + filter launches of all passes) */
     float reserved2;
     uint64_t filter_rows;        /* rows streamed by the filter kernels: sum over their workgroups of the row segment (all passes) */
+    uint64_t filter_rest_rows;   /* of filter_rows: the last ("rest") pass, the launch that streams nearly the whole store once */
+    float filter_rest_ms;        /* that one FilterKernelCells launch alone, HIP events */
+    uint32_t filter_rest_hi_only;/* 1 if it read only the hi plane (d * 2 bytes per row), 0 if hi + lo (d * 4) */
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 
