@@ -553,15 +553,24 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     float* d_qnorm = reinterpret_cast<float*>(d_nearest + T);
     uint32_t* d_task_group = reinterpret_cast<uint32_t*>(d_qnorm + T);
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
-    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64));
+    // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
+    const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
+    uint64_t items_cap = 0;
+    for (const CellGroup& g : groups)
+        for (uint32_t c = C.shard_cell_begin[g.shard]; c < C.shard_cell_begin[g.shard + 1]; ++c)
+            items_cap += (C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]) / seg_tiles + 1;
+    GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
+    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
     need_pass[0] = s->ws_need.as<uint32_t>();
     need_pass[1] = need_pass[0] + need_words;
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
     CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor, [3] = [1] before the rest pass
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor + item count, [3] = [1] before the rest pass
     uint32_t* d_next_item = reinterpret_cast<uint32_t*>(d_work + 2);
+    uint32_t* d_n_items = d_next_item + 1;
+    CellItem* d_items = reinterpret_cast<CellItem*>(d_work + 4);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
     GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
     GPANN_HIP_TRY(hipMemcpyAsync(d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), hipMemcpyHostToDevice, st));
@@ -668,8 +677,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.work = d_work;
     fa.next_item = d_next_item;
     fa.n_groups = G;
-    // enough work items for every CU even when the store has few cells: cut the blocks' tile ranges
-    fa.n_seg = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_SEGMENTS", (uint32_t)std::min<uint64_t>(16, (4096 + (uint64_t)G * kmax - 1) / ((uint64_t)G * kmax))));
+    fa.items = d_items;
+    fa.n_items = d_n_items;
+    fa.seg_tiles = seg_tiles;
+    fa.items_cap = (uint32_t)items_cap;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -706,7 +717,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates);
     // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere
     const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048;   // (small buckets of huge task counts cannot take the extra candidates)
-    const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+    const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)4 * s->ld * sizeof(float);
@@ -731,13 +742,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done0 = pass == 0 ? nullptr : (pass == 1 ? need_pass[0] : done_head);
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
-        GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 4, st));
+        GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 8, st));   // cursor and item count
+        hipLaunchKernelGGL(FilterItemsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, fa);
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it, and its begin / end
             GPANN_HIP_TRY(hipMemcpyAsync(d_work + 3, d_work + 1, 8, hipMemcpyDeviceToDevice, st));
             GPANN_HIP_TRY(hipEventRecord(s->ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
         }
-        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, (uint64_t)G * kmax * fa.n_seg)), dim3(512), kargs, glds, st));
+        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
         GPANN_HIP_TRY(hipGetLastError());
         if (pass == 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[5], st));
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)

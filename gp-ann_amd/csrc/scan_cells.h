@@ -31,6 +31,10 @@ struct CellGroup {
     uint32_t task_begin, task_count, shard, pad;
 };
 
+struct CellItem {
+    uint32_t block, t_begin, t_end, pad;   // block = group * kmax + cell index inside the shard; row tiles [t_begin, t_end)
+};
+
 struct CellTileRef {
     uint32_t shard, first, count, pad;   // <= 64 consecutive tasks of one shard
 };
@@ -237,39 +241,75 @@ struct CellFilterArgs {
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
     unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
-    uint32_t* next_item;         // work-stealing cursor over the (group, cell, segment) index space (zeroed before the launch)
+    uint32_t* next_item;         // work-stealing cursor over `items` (zeroed before the launch)
     uint32_t n_groups;
-    uint32_t n_seg;              // a block's tile range is cut into n_seg work items (small stores: enough items for all CUs)
+    // the pass's work items, written by FilterItemsKernel: a (task group, cell) block's tile range cut into pieces of <= seg_tiles
+    CellItem* items;
+    uint32_t* n_items;
+    uint32_t seg_tiles, items_cap;
 };
 
-// HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
-// threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
-template <int METRIC, int TAG, int KS, bool HI_ONLY>
-__global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
-    extern __shared__ uint4 csm4[];
-    char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
-
-    // persistent workgroups: one per CU, each claims (group, cell) blocks with work from a shared cursor
-    __shared__ uint32_t s_item;
-    const uint32_t n_items = a.n_groups * a.kmax * a.n_seg;
-    uint32_t my_products = 0, my_tiles = 0;
-    for (;;) {
-    __syncthreads();   // everyone is done with the previous block's query image (and has read s_item)
-    if (threadIdx.x == 0) {
-        uint32_t it;
-        do {
-            it = atomicAdd(a.next_item, 1u);
-        } while (it < n_items && a.need[it / a.n_seg] == 0);
-        s_item = it;
-    }
-    __syncthreads();
-    const uint32_t item = s_item;
-    if (item >= n_items) break;
-    const uint32_t block = item / a.n_seg, seg = item - block * a.n_seg;
+// The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
+// most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
+// blocks without work never reach them).  Order of the list is irrelevant for the result.
+static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a) {
+    const uint32_t block = blockIdx.x * 256 + threadIdx.x;
+    if (block >= a.n_groups * a.kmax) return;
+    const uint32_t mask = a.need[block];
+    if (mask == 0) return;
     const uint32_t g = block / a.kmax, j = block - g * a.kmax;
     const uint32_t shard = a.groups[g].shard;
     const uint32_t cell0 = a.shard_cell_begin[shard];
-    if (j >= a.shard_cell_begin[shard + 1] - cell0) continue;
+    if (j >= a.shard_cell_begin[shard + 1] - cell0) return;
+    const uint32_t d0 = a.done0 ? a.done0[block] : 0u;
+    const uint32_t d1 = a.done1 ? a.done1[block] : 0u;
+    const int64_t t_cell = (int64_t)a.cell_tile_begin[cell0 + j];
+    const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
+    const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);
+    const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));
+    const int64_t t_pass_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
+    // segments every query tile of this block has already been run on need not be streamed again (the later passes would otherwise
+    // re-read the head and the sample of every cell: 1/sample_div of the store)
+    const int64_t t_first = (mask & ~d0) ? t_cell : ((mask & ~d1) ? t_a : t_b);
+    if (t_first >= t_pass_end) return;
+    const int64_t range = t_pass_end - t_first;
+    const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
+    const int64_t per = (range + n - 1) / n;
+    const uint32_t base = atomicAdd(a.n_items, n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
+        if (base + i < a.items_cap) a.items[base + i] = CellItem{block, (uint32_t)b, (uint32_t)e, 0u};
+    }
+}
+
+// HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
+// threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
+// wavefronts per workgroup (one workgroup per CU): the first 8 build the query image; all stream row tiles round robin
+constexpr int kFWaves = 8;
+
+template <int METRIC, int TAG, int KS, bool HI_ONLY>
+__global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
+    extern __shared__ uint4 csm4[];
+    char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
+
+    // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor; the claim for the
+    // next item is issued while the current one streams
+    __shared__ uint32_t s_item;
+    const uint32_t n_items = min(*a.n_items, a.items_cap);
+    uint32_t my_products = 0, my_tiles = 0;
+    if (threadIdx.x == 0) s_item = atomicAdd(a.next_item, 1u);
+    for (;;) {
+    __syncthreads();   // s_item is written; everyone is done with the previous item's query image
+    const uint32_t item = s_item;
+    if (item >= n_items) break;
+    // (the chain of small table reads below is wave-uniform and compiles to scalar loads: the values stay in scalar registers.  A fat
+    // per-item record read with vector loads was tried: its fields end up spilled to scratch, and a scratch reload inside the tile
+    // loop has to wait for the tile prefetch issued before it — twice the time)
+    const uint32_t block = a.items[item].block;
+    const int64_t t_begin = (int64_t)a.items[item].t_begin, t_end = (int64_t)a.items[item].t_end;
+    const uint32_t g = block / a.kmax, j = block - g * a.kmax;
+    const uint32_t shard = a.groups[g].shard;
+    const uint32_t cell0 = a.shard_cell_begin[shard];
     const uint32_t mask = a.need[(size_t)g * a.kmax + j];
     const uint32_t d0 = a.done0 ? a.done0[(size_t)g * a.kmax + j] : 0u;
     const uint32_t d1 = a.done1 ? a.done1[(size_t)g * a.kmax + j] : 0u;
@@ -277,36 +317,14 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
     const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);                                      // end of the head segment
     const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));   // end of the sample
-    const int64_t t_pass_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
-    // segments every query tile of this block has already been run on need not be streamed again (the later passes would otherwise
-    // re-read the head and the sample of every cell: 1/sample_div of the store)
-    const int64_t t_first = (mask & ~d0) ? t_cell : ((mask & ~d1) ? t_a : t_b);
-    // this work item's share of the pass's tile range
-    const int64_t per = (t_pass_end - t_first + a.n_seg - 1) / a.n_seg;
-    const int64_t t_begin = t_first + (int64_t)seg * per;
-    const int64_t t_end = min(t_pass_end, t_begin + per);
-    if (t_begin >= t_end) continue;
-    // anything to do?  (segment 2 exists only in pass 2 and has no `done` mask)
-    if (!(((mask & ~d0) && t_begin < t_a) || ((mask & ~d1) && t_end > t_a && t_begin < t_b) || t_end > t_b)) continue;
+    uint32_t next_claim = 0;
+    if (threadIdx.x == 0) next_claim = atomicAdd(a.next_item, 1u);   // lands under the first tile loads
     const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t ld = a.ld;
-
-    // ---- the query image: wavefront w builds query tile w if any pass of this workgroup uses it
-    if (mask >> wave & 1u) {
-        const uint32_t tl = 32u * wave + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)a.task_query[task] * ld, tl < task_count, ld, lane);
-    }
-    float U[8];
-#pragma unroll
-    for (int qt = 0; qt < 8; ++qt) {
-        const uint32_t tl = 32u * qt + c;
-        U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
-    }
-    __syncthreads();
+    float U[8];   // thresholds of this lane's task in each query tile (filled with the query image below)
 
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
@@ -413,26 +431,40 @@ __global__ void __launch_bounds__(512, 1) FilterKernelCells(CellFilterArgs a) {
     // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
     // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it re-reads the last tile — because
     // a load under a branch leaves the compiler unable to count the loads in flight at the join, and it then drains them all
-    // (s_waitcnt vmcnt(0)) before the first use of the current tile: no overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).
-    // (a third buffer for the hi-only passes was measured slower: the extra registers spill)
+    // (s_waitcnt vmcnt(0)) before the first use of the current tile: no overlap at all (measured on the rest pass of the NS
+    // workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for the hi-only passes was measured slower: spills.)
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
     int64_t T = t_begin + wave;
+    const int64_t t_last = t_end - 1;
+    load_tile(Ah[0], Al[0], nrm[0], min(T, t_last));   // the item's first tile is on its way while the query image is built
+
+    // ---- the query image: wavefront w builds query tile w if any pass of this workgroup uses it
+    if (mask >> wave & 1u) {
+        const uint32_t tl = 32u * wave + c;
+        const uint32_t task = task_begin + min(tl, task_count - 1);
+        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)a.task_query[task] * ld, tl < task_count, ld, lane);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 8; ++qt) {
+        const uint32_t tl = 32u * qt + c;
+        U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
+    }
+    __syncthreads();
     if (T < t_end) {
-        const int64_t t_last = t_end - 1;
-        load_tile(Ah[0], Al[0], nrm[0], T);
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], min(T + 8, t_last));
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], min(T + kFWaves, t_last));
             compute_tile(Ah[0], Al[0], nrm[0], T);
-            T += 8;
+            T += kFWaves;
             if (T >= t_end) break;
-            load_tile(Ah[0], Al[0], nrm[0], min(T + 8, t_last));
+            load_tile(Ah[0], Al[0], nrm[0], min(T + kFWaves, t_last));
             compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
-            T += 8;
+            T += kFWaves;
             if (T >= t_end) break;
         }
     }
-    }   // next block
+    if (threadIdx.x == 0) s_item = next_claim;
+    }   // next item
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
         atomicAdd(&a.work[1], (unsigned long long)my_tiles);
