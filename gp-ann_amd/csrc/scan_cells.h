@@ -31,8 +31,12 @@ struct CellGroup {
     uint32_t task_begin, task_count, shard, pad;
 };
 
-struct CellItem {
-    uint32_t block, t_begin, t_end, pad;   // block = group * kmax + cell index inside the shard; row tiles [t_begin, t_end)
+struct CellItem {   // everything FilterKernelCells needs to run one piece of a (task group, cell) block: one 32-byte record
+    uint32_t t_begin, t_end;   // row tiles of this piece
+    uint32_t t_a, t_b;         // the cell's head segment ends at tile t_a, its sample segment at t_b
+    uint32_t task_begin, task_count;
+    uint32_t acts;             // query tiles to run on the head | sample << 8 | rest << 16 segment
+    uint32_t pad;
 };
 
 struct CellTileRef {
@@ -249,6 +253,9 @@ struct CellFilterArgs {
     uint32_t seg_tiles, items_cap;
 };
 
+// wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
+constexpr int kFWaves = 8;
+
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
 // blocks without work never reach them).  Order of the list is irrelevant for the result.
@@ -274,19 +281,27 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     if (t_first >= t_pass_end) return;
     const int64_t range = t_pass_end - t_first;
     const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
-    const int64_t per = (range + n - 1) / n;
+    // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
+    // the end of the item for a full memory latency)
+    const int64_t per = ((range + n - 1) / n + kFWaves - 1) / kFWaves * kFWaves;
     const uint32_t base = atomicAdd(a.n_items, n);
+    CellItem it;
+    it.t_a = (uint32_t)t_a;
+    it.t_b = (uint32_t)t_b;
+    it.task_begin = a.groups[g].task_begin;
+    it.task_count = a.groups[g].task_count;
+    it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16;
+    it.pad = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
-        if (base + i < a.items_cap) a.items[base + i] = CellItem{block, (uint32_t)b, (uint32_t)e, 0u};
+        it.t_begin = (uint32_t)b;
+        it.t_end = (uint32_t)e;
+        if (base + i < a.items_cap) a.items[base + i] = it;
     }
 }
 
 // HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
 // threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
-// wavefronts per workgroup (one workgroup per CU): the first 8 build the query image; all stream row tiles round robin
-constexpr int kFWaves = 8;
-
 template <int METRIC, int TAG, int KS, bool HI_ONLY>
 __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
     extern __shared__ uint4 csm4[];
@@ -302,24 +317,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     __syncthreads();   // s_item is written; everyone is done with the previous item's query image
     const uint32_t item = s_item;
     if (item >= n_items) break;
-    // (the chain of small table reads below is wave-uniform and compiles to scalar loads: the values stay in scalar registers.  A fat
-    // per-item record read with vector loads was tried: its fields end up spilled to scratch, and a scratch reload inside the tile
-    // loop has to wait for the tile prefetch issued before it — twice the time)
-    const uint32_t block = a.items[item].block;
-    const int64_t t_begin = (int64_t)a.items[item].t_begin, t_end = (int64_t)a.items[item].t_end;
-    const uint32_t g = block / a.kmax, j = block - g * a.kmax;
-    const uint32_t shard = a.groups[g].shard;
-    const uint32_t cell0 = a.shard_cell_begin[shard];
-    const uint32_t mask = a.need[(size_t)g * a.kmax + j];
-    const uint32_t d0 = a.done0 ? a.done0[(size_t)g * a.kmax + j] : 0u;
-    const uint32_t d1 = a.done1 ? a.done1[(size_t)g * a.kmax + j] : 0u;
-    const int64_t t_cell = (int64_t)a.cell_tile_begin[cell0 + j];
-    const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
-    const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);                                      // end of the head segment
-    const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));   // end of the sample
+    // one 32-byte record per item (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended up in
+    // vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued before it)
+    const uint32_t t_begin = a.items[item].t_begin, t_end = a.items[item].t_end, t_a = a.items[item].t_a, t_b = a.items[item].t_b;
+    const uint32_t task_begin = a.items[item].task_begin, task_count = a.items[item].task_count;
+    const uint32_t acts = a.items[item].acts;
+    const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
     uint32_t next_claim = 0;
     if (threadIdx.x == 0) next_claim = atomicAdd(a.next_item, 1u);   // lands under the first tile loads
-    const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -330,7 +335,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
 
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * kGPlaneBytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -338,11 +343,16 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
             if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + a.plane_lo_offset + ks * 1024));
         }
-        if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[T * kGTileRows + c];
+        if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
     };
 
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, int64_t T) {
-        const uint32_t act = T < t_a ? mask & ~d0 : (T < t_b ? mask & ~d1 : mask);   // query tiles to run on this row tile
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
+        // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
+        // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
+        // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
+        // a flat one.)
+        const uint32_t in_head = T < t_a ? 0xFFu : 0u, in_sample = T < t_b ? 0xFFu & ~in_head : 0u;
+        const uint32_t act = (act_head & in_head) | (act_sample & in_sample) | (mask & ~(in_head | in_sample));
         if (act == 0) return;
         if (METRIC == GPANN_METRIC_L2) {
             if (h == 0) wave_norms[c] = nrm;
@@ -352,7 +362,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         my_tiles += 1;
         uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
         // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
-        auto pass = [&](auto pair_tag, int q0, int qp, int shift) {
+        auto pass = [&](auto pair_tag, int q0, int qp, int shift) __attribute__((always_inline)) {
             constexpr bool PAIR = decltype(pair_tag)::value;
             f32x16 acc0, acc1;
 #pragma unroll
@@ -417,7 +427,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
                     bits &= bits - 1;
                     const int r = b & 15;
                     const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
-                    const uint32_t row = a.plane_perm[T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    const uint32_t row = a.plane_perm[(size_t)T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
                     if (row != 0xFFFFFFFFu && tl < task_count) {
                         const uint32_t task = task_begin + tl;
                         const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
@@ -435,8 +445,8 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for the hi-only passes was measured slower: spills.)
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
-    int64_t T = t_begin + wave;
-    const int64_t t_last = t_end - 1;
+    uint32_t T = t_begin + wave;
+    const uint32_t t_last = t_end - 1;
     load_tile(Ah[0], Al[0], nrm[0], min(T, t_last));   // the item's first tile is on its way while the query image is built
 
     // ---- the query image: wavefront w builds query tile w if any pass of this workgroup uses it
