@@ -378,24 +378,45 @@ __global__ void __launch_bounds__(kKThreads) SumKernel(LloydArgs a) {
         __syncthreads();
         if (b0 + batch_rows < size) GPANN_SUM_FETCH(b0 + batch_rows);   // lands while this batch is summed
 
-        if (!multi && ncols <= (uint32_t)kKThreads) {
-            // the common shape: one column per thread, no slice boundaries
-            if ((uint32_t)tid < ncols) {
-                float p = part[0];
-                const float* col = sX + tid;
-                if (METRIC == GPANN_METRIC_MIPS) {
-                    if ((uint32_t)tid < d) {
+        if (ncols <= (uint32_t)kKThreads) {
+            // the common shape: one column per thread.  Member positions ascend, so a batch crosses a slice boundary of the reference
+            // (kmeans.cpp:186-196) at most a few times in the whole cluster: sum the run of rows up to the boundary, flush, go on.
+            uint32_t r0 = 0;
+            while (r0 < nr) {
+                uint32_t r1 = nr;
+                if (multi && (uint64_t)sPos[nr - 1] >= boundary) {   // first row of the batch at or past the boundary (uniform search)
+                    uint32_t lo = r0, hi = nr - 1;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)sPos[mid] >= boundary) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    r1 = lo;
+                }
+                if ((uint32_t)tid < ncols) {
+                    float p = part[0];
+                    const float* col = sX + tid;
+                    if (METRIC == GPANN_METRIC_MIPS) {
+                        if ((uint32_t)tid < d) {
 #pragma unroll 8
-                        for (uint32_t r = 0; r < nr; ++r) p = p + col[r * ld] * sMul[r];
+                            for (uint32_t r = r0; r < r1; ++r) p = p + col[r * ld] * sMul[r];
+                        } else {
+#pragma unroll 8
+                            for (uint32_t r = r0; r < r1; ++r) p = p + sSq[r];
+                        }
                     } else {
 #pragma unroll 8
-                        for (uint32_t r = 0; r < nr; ++r) p = p + sSq[r];
+                        for (uint32_t r = r0; r < r1; ++r) p = p + col[r * ld];
                     }
-                } else {
-#pragma unroll 8
-                    for (uint32_t r = 0; r < nr; ++r) p = p + col[r * ld];
+                    part[0] = p;
                 }
-                part[0] = p;
+                r0 = r1;
+                if (r0 < nr) {   // the row at r0 belongs to a later slice: the finished slice's partial joins the total
+                    total[0] = total[0] + part[0];
+                    part[0] = 0.f;
+                    boundary += bs;
+                    ++flushed;
+                }
             }
             continue;
         }
