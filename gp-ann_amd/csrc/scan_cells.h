@@ -14,13 +14,14 @@
 //     * the points are pre-split in HBM in MFMA A-operand order (scan_filter.h), so a wavefront loads a tile's fragments with
 //       perfectly coalesced global_load_dwordx4 straight into the registers the MFMA reads.  No LDS traffic for the points, no
 //       barrier in the loop: the 8 wavefronts of a workgroup take tiles round robin and run independently, each prefetching
-//       its next tile into a second register set while the matrix core works on the current one.  (An earlier design staged
+//       its next tile (unconditionally — see the tile loop) into a second register set while the matrix core works on the current one.  (An earlier design staged
 //       POINT tiles in LDS by LDS-DMA with the queries in registers: a barrier per tile, and the fill landing in LDS and the
 //       ds_read/MFMA stream slowed each other down — its time was fill-only + compute-only.)
 //     * only the query tiles whose bit is set run on a row tile; candidates of a tile are collected as bit masks and written
 //       after the tile's MFMA phase, when the prefetch has landed (the atomic's vmcnt wait would otherwise stall on the loads
 //       issued before it); they are mapped from plane rows back to store rows;
-//     * one persistent workgroup per CU claims (task group, cell) blocks from a shared cursor.
+//     * FilterItemsKernel lists a pass's work — every (task group, cell) block with something left to run, cut into pieces of at most
+//       seg_tiles row tiles — and one persistent workgroup per CU claims items from a shared cursor.
 #pragma once
 
 #include "scan_filter.h"
