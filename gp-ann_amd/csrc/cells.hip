@@ -39,11 +39,12 @@ __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members,
 
 // bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
 __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
-                                                                 char* planes, uint64_t lo_offset) {
-    const uint64_t total = plane_rows * 16;
+                                                                 char* planes, uint64_t lo_offset, uint32_t plane_ks) {
+    const uint32_t g_per_row = 2 * plane_ks;   // groups of 8 dims per row: 16 or 32
+    const uint64_t total = plane_rows * g_per_row;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i >> 4;
-        const uint32_t g8 = (uint32_t)(i & 15);
+        const uint64_t r = i / g_per_row;
+        const uint32_t g8 = (uint32_t)(i - r * g_per_row);
         const uint32_t row = plane_perm[r];
         float v[8];
 #pragma unroll
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGPlaneBytes + ks * 1024 + lane * 16;   // all hi tiles first, then all lo tiles
+        char* base = planes + (r >> 5) * ((uint64_t)plane_ks * 1024) + ks * 1024 + lane * 16;   // all hi tiles first, then all lo tiles
         *reinterpret_cast<uint4*>(base) = fh.q;
         *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
     }
@@ -202,6 +203,8 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     C.n_tiles = C.cell_tile_begin.back();
     if (C.n_cells == 0) return give_up("no cells");
     const uint64_t plane_rows = C.n_tiles * kGTileRows;
+    C.plane_ks = s->d <= 128 ? 8u : 16u;
+    const size_t tile_bytes = (size_t)C.plane_ks * 1024;   // one plane of one tile
 
     uint64_t* d_member_begin = nullptr;
     uint32_t* d_cell_size = nullptr;
@@ -209,7 +212,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
               hipMalloc(&C.d_center, (size_t)C.n_cells * ld * 4) == hipSuccess && hipMalloc(&C.d_radius, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.plane_perm, plane_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (plane_rows + 64) * 4) == hipSuccess &&
-              hipMalloc(&s->frag_planes, 2 * (C.n_tiles + 2) * (size_t)kGPlaneBytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
+              hipMalloc(&s->frag_planes, 2 * (C.n_tiles + 2) * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
               hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess;
     std::vector<float> cnorm(C.n_cells);
     for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
@@ -225,15 +228,15 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemcpy(d_member_begin, member_begin.data(), C.n_cells * 8, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(d_cell_size, cell_size.data(), C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemset(C.plane_norm + plane_rows, 0, 64 * 4) == hipSuccess &&
-             hipMemset(s->frag_planes + C.n_tiles * (size_t)kGPlaneBytes, 0, 2 * (size_t)kGPlaneBytes) == hipSuccess &&
-             hipMemset(s->frag_planes + (2 * C.n_tiles + 2) * (size_t)kGPlaneBytes, 0, 2 * (size_t)kGPlaneBytes) == hipSuccess;
+             hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, 2 * tile_bytes) == hipSuccess &&
+             hipMemset(s->frag_planes + (2 * C.n_tiles + 2) * tile_bytes, 0, 2 * tile_bytes) == hipSuccess;
     }
     if (ok) {
         hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
-        const int g2 = (int)std::min<uint64_t>((plane_rows * 16 + 255) / 256, 256 * 64);
+        const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
-                           (uint64_t)(C.n_tiles + 2) * kGPlaneBytes);
+                           (uint64_t)(C.n_tiles + 2) * tile_bytes, C.plane_ks);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }

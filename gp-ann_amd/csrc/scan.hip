@@ -475,14 +475,14 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
     return GPANN_OK;
 }
 
-// Splits the tb tasks of a shard into filter groups of <= 256 tasks, sized in whole 32-task query tiles (only a shard's last
+// Splits the tb tasks of a shard into filter groups of <= group_tasks (256; 128 beyond 128 dimensions) tasks, sized in whole 32-task query tiles (only a shard's last
 // group can end on a partly used tile).
 struct FilterGroup {
     uint32_t task_off, task_count;
 };
-static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb) {
+static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tasks) {
     std::vector<FilterGroup> out;
-    const uint32_t nqb = (tb + kGTasks - 1) / kGTasks;
+    const uint32_t nqb = (tb + group_tasks - 1) / group_tasks;
     const uint32_t tiles = (tb + 31) / 32;
     uint32_t done = 0;
     for (uint32_t qb = 0; qb < nqb; ++qb) {
@@ -518,7 +518,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap);
     const uint32_t sample_div = std::max<uint32_t>(2, EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
-    const bool l2 = s->metric == GPANN_METRIC_L2, aux = (flags & GPANN_AUX_PASS) != 0, ks4 = s->d <= 64;
+    const bool l2 = s->metric == GPANN_METRIC_L2, aux = (flags & GPANN_AUX_PASS) != 0, ks4 = s->d <= 64, ks16 = s->d > 128;
+    const uint32_t group_tasks = ks16 ? 128u : (uint32_t)kGTasks;   // the query image of a group has to fit LDS: 4 query tiles at 16 k-steps
 
     // ---- workspace
     GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
@@ -539,7 +540,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (uint32_t b = 0; b < S; ++b) {
         const uint32_t t0 = plan.shard_task_begin[b], tb = plan.shard_task_begin[b + 1] - t0;
         if (tb == 0) continue;
-        for (const FilterGroup& g : PlanFilterGroups(tb)) {
+        for (const FilterGroup& g : PlanFilterGroups(tb, group_tasks)) {
             for (uint32_t x = 0; x < g.task_count; ++x) task_group[t0 + g.task_off + x] = (uint32_t)groups.size();
             groups.push_back({t0 + g.task_off, g.task_count, b, 0});
         }
@@ -665,7 +666,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.cand_cap = cap;
     fa.ld = s->ld;
     fa.frag_planes = s->frag_planes;
-    fa.plane_lo_offset = (uint64_t)(C.n_tiles + 2) * kGPlaneBytes;
+    fa.plane_tile_bytes = C.plane_ks * 1024u;
+    fa.plane_lo_offset = (uint64_t)(C.n_tiles + 2) * fa.plane_tile_bytes;
     fa.plane_norm = C.plane_norm;
     fa.plane_perm = C.plane_perm;
     fa.groups = d_groups;
@@ -709,15 +711,22 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_L2, 0, 8, HI_)))                    \
         : (aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8, HI_))                 \
                : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8, HI_))))
-    fn = GPANN_PICK2(false);
-    fn_hi = GPANN_PICK2(true);
+    if (ks16) {   // 16 k-steps: hi-plane passes only (two tiles of both planes do not fit the register file)
+        fn_hi = l2 ? (aux ? GPANN_PICK(GPANN_METRIC_L2, 1, 16, true) : GPANN_PICK(GPANN_METRIC_L2, 0, 16, true))
+                   : (aux ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 16, true) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 16, true));
+        fn = fn_hi;
+    } else {
+        fn = GPANN_PICK2(false);
+        fn_hi = GPANN_PICK2(true);
+    }
 #undef GPANN_PICK2
 #undef GPANN_PICK
     // the sample and rest passes (all but the small head pass) read only the hi plane of the points: half the HBM bytes and two of
     // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates);
-    // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere
-    const bool hi_last = EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048;   // (small buckets of huge task counts cannot take the extra candidates)
-    const size_t glds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + kFWaves * kGTileRows * sizeof(float);
+    // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere.  Beyond 128 dimensions every pass is a hi-plane pass.
+    const bool hi_last = ks16 || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
+    const int hi_from_pass = ks16 ? 0 : (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
+    const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)4 * s->ld * sizeof(float);
@@ -728,7 +737,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (int pass = 0; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
-        const bool hi_pass = hi_last && pass >= (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
+        const bool hi_pass = hi_last && pass >= hi_from_pass;
         th.hi_only = hi_pass ? 1u : 0u;
         if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
         else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
@@ -800,7 +809,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 }
 
 static bool FilterWanted(const gpann_shards* s, uint32_t k) {
-    if (!s->filter_ok || s->cells.n_cells == 0 || s->frag_planes == nullptr || s->d > 16u * kFKS || k > GPANN_MAX_K) return false;
+    if (!s->filter_ok || s->cells.n_cells == 0 || s->frag_planes == nullptr || s->d > 256u || k > GPANN_MAX_K) return false;
     const char* mode = std::getenv("GPANN_SCAN_MODE");
     if (mode && *mode) return std::string(mode) == "filter";
     return s->scan_mode == 1;

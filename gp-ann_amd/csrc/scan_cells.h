@@ -232,8 +232,9 @@ struct CellFilterArgs {
     uint32_t* cand_cnt;
     uint32_t* cand_row;
     uint32_t cand_cap, ld;
-    const char* frag_planes;     // all hi tiles (kGPlaneBytes each), then at +plane_lo_offset all lo tiles
+    const char* frag_planes;     // all hi tiles (plane_tile_bytes each), then at +plane_lo_offset all lo tiles
     uint64_t plane_lo_offset;
+    uint32_t plane_tile_bytes;   // KiB per tile and plane = the store's k-steps (8 for d <= 128, 16 for d <= 256)
     const float* plane_norm;
     const uint32_t* plane_perm;
     const CellGroup* groups;
@@ -303,8 +304,13 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
 
 // HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
 // threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
-template <int METRIC, int TAG, int KS, bool HI_ONLY>
+// KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
+// query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
+// tiles do not fit the register file).
+template <int METRIC, int TAG, int KS, bool HI_ONLY, int QT = (KS <= 8 ? 8 : 4)>
 __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
+    static_assert(QT == 4 || QT == 8, "query tiles per group");
+    static_assert(KS <= 8 || HI_ONLY, "16 k-steps: hi-plane passes only");
     extern __shared__ uint4 csm4[];
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
 
@@ -330,14 +336,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t ld = a.ld;
-    float U[8];   // thresholds of this lane's task in each query tile (filled with the query image below)
+    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image below)
 
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
-    float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
+    float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
 
     auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
-        const char* base = lane_planes + (size_t)T * kGPlaneBytes;
+        const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             // (read-once stream: non-temporal, leaves L2 to the query rows / tables)
@@ -361,7 +367,9 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
         my_products += (uint32_t)__builtin_popcount(act);
         my_tiles += 1;
-        uint32_t cmask[4] = {0u, 0u, 0u, 0u};   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
+        uint32_t cmask[QT / 2];   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
+#pragma unroll
+        for (int qp = 0; qp < QT / 2; ++qp) cmask[qp] = 0u;
         // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
         auto pass = [&](auto pair_tag, int q0, int qp, int shift) __attribute__((always_inline)) {
             constexpr bool PAIR = decltype(pair_tag)::value;
@@ -413,15 +421,18 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             }
         };
 #pragma unroll
-        for (int qp = 0; qp < 4; ++qp) {
+        for (int qp = 0; qp < QT / 2; ++qp) {
             const uint32_t two = act >> (2 * qp) & 3u;
             if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
             else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
             else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
         }
-        if (__any((cmask[0] | cmask[1] | cmask[2] | cmask[3]) != 0u)) {
+        uint32_t any_bits = 0;
 #pragma unroll
-            for (int qp = 0; qp < 4; ++qp) {
+        for (int qp = 0; qp < QT / 2; ++qp) any_bits |= cmask[qp];
+        if (__any(any_bits != 0u)) {
+#pragma unroll
+            for (int qp = 0; qp < QT / 2; ++qp) {
                 uint32_t bits = cmask[qp];
                 while (bits) {
                     const int b = __builtin_ctz(bits);
@@ -457,7 +468,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)a.task_query[task] * ld, tl < task_count, ld, lane);
     }
 #pragma unroll
-    for (int qt = 0; qt < 8; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const uint32_t tl = 32u * qt + c;
         U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
     }

@@ -65,6 +65,7 @@ struct gpann_shards {
         uint32_t n_cells = 0, kmax = 0;            // all cells of the store (numbered shard by shard); most cells in one shard
         uint64_t n_tiles = 0;                      // 32-row tiles of the planes
         std::vector<uint32_t> shard_cell_begin;    // [S+1] host
+        uint32_t plane_ks = 8;                     // k-steps (16 dims each) per plane tile: 8 (d <= 128) or 16 (d <= 256); a tile of a plane is plane_ks KiB
         std::vector<uint64_t> cell_tile_begin;     // [n_cells+1] host
         uint32_t* d_shard_cell_begin = nullptr;    // [S+1]
         uint64_t* d_cell_tile_begin = nullptr;     // [n_cells+1]

@@ -192,12 +192,12 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         (void)hipFree(d_bad);
         s->filter_ok = bad == 0;
         // filter support (scan mode 1): the rows once more as bf16 hi/lo planes grouped by cell (cells.hip).  Optional: without it
-        // (allocation failure, GPANN_FILTER_PLANES=0, d > 128, non-finite data) the store only offers the plain exact scan.
+        // (allocation failure, GPANN_FILTER_PLANES=0, d > 256, non-finite data) the store only offers the plain exact scan.
         // GPANN_CELL_ROWS sets the target cell size.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
         const char* cr = std::getenv("GPANN_CELL_ROWS");
         const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
-        if (s->filter_ok && d <= 128 && !(want && want[0] == '0') && !(flags & GPANN_STORE_PLAIN)) {
+        if (s->filter_ok && d <= 256 && !(want && want[0] == '0') && !(flags & GPANN_STORE_PLAIN)) {
             gpann_status cst = BuildCells(s, cell_rows);
             if (cst != GPANN_OK) return fail(cst);
         }

@@ -146,7 +146,7 @@ gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out)
 
 /* Scan mode of a store: 0 = exact VALU scan of every row (default); 1 = the same exact results with a matrix-core
  * pre-filter (bf16x3 MFMA bound + exact re-scoring of the candidates, gp-ann_amd/csrc/scan_filter.h).  Both modes return
- * bit-identical ids and distances; mode 1 silently uses the plain scan where the filter does not apply (d > 128, non-finite
+ * bit-identical ids and distances; mode 1 silently uses the plain scan where the filter does not apply (d > 256, non-finite
  * data, candidate overflow).  The environment variable GPANN_SCAN_MODE=exact|filter overrides the handle setting. */
 gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode);
 

@@ -32,7 +32,7 @@ def _check(orc, gp, pts, clusters, queries, probes, nprobe, k, metric, expect_fi
 
 
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("d", [128, 96, 30, 7])
+@pytest.mark.parametrize("d", [128, 96, 30, 7, 130, 200, 256])   # > 128: 16 k-steps, 128-task groups, hi-plane passes only
 def test_cells_match_oracle(orc, gp, metric, d):
     rng = np.random.default_rng(d * 5 + metric)
     n, S, nq, k = 40000, 3, 300, 10
@@ -150,4 +150,39 @@ def test_cells_default_configuration_midsize(orc, gp, monkeypatch):
     sub = np.arange(0, nq, 16)
     ivf = orc.ivf_build(pts, clusters)
     wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries[sub], k, probes[sub], S, 0, nthreads=8)
+    assert np.array_equal(ids[sub], wi) and np.array_equal(dist[sub].view(np.uint32), wd.view(np.uint32))
+
+
+def test_cells_beyond_256_dimensions_use_the_exact_scan(orc, gp):
+    rng = np.random.default_rng(77)
+    n, d, S, nq, k = 20000, 260, 2, 100, 10
+    pts = make_mixture(orc, n, d, n_centers=8)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=8)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    _check(orc, gp, pts, clusters, queries, probes, S, k, 0, expect_filtered=False)
+
+
+def test_cells_200_dimensions_midsize_inner_product(orc, gp, monkeypatch):
+    """the Text-to-Image shape (200-dim inner product) at a size that gets default cells: filter == exact on every query"""
+    monkeypatch.delenv("GPANN_CELL_ROWS")
+    rng = np.random.default_rng(43)
+    n, d, S, nq, k = 1_500_000, 200, 3, 600, 10
+    pts = orc.synth_rows(555, 7, 64, 0.35, 0, n, d, nthreads=16)
+    queries = orc.synth_rows(556, 7, 64, 0.35, 0, nq, d, nthreads=16)
+    part = rng.integers(0, S, size=n)
+    clusters = [np.flatnonzero(part == b).astype(np.uint32) for b in range(S)]
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    shards = gp.Shards(pts, clusters, 1, 0)
+    shards.set_scan_mode(1)
+    ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
+    st = shards.stats()
+    assert st["filtered"] == 1 and st["filter_pairs"] > 0
+    shards.set_scan_mode(0)
+    ids0, dist0, _ = shards.scan_buckets(queries, k, probes, S)
+    assert np.array_equal(ids0, ids) and np.array_equal(dist0.view(np.uint32), dist.view(np.uint32))
+    shards.close()
+    sub = np.arange(0, nq, 40)
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries[sub], k, probes[sub], S, 1, nthreads=16)
     assert np.array_equal(ids[sub], wi) and np.array_equal(dist[sub].view(np.uint32), wd.view(np.uint32))

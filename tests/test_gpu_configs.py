@@ -108,8 +108,8 @@ def test_c3_deep10m_shape(orc, gp):
 
 
 def test_c4_shape_inner_product_200d(orc, gp):
-    # 200 dimensions: beyond the filter's 128 -> the plain exact scan; inner-product router and scan
-    _run_config(orc, gp, 400_000, 200, 2000, 40, 10, 3, 1, 20_000, 50_000, sample=100, filtered=False)
+    # 200 dimensions: the filter's 16-k-step variant (hi-plane passes, 128-task groups); inner-product router and scan
+    _run_config(orc, gp, 400_000, 200, 2000, 40, 10, 3, 1, 20_000, 50_000, sample=100)
 
 
 def test_c5_shape_overlapping_shards(orc, gp):
