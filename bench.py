@@ -396,7 +396,8 @@ def main():
         flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only passes run 2 of the 3 products)
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
         # bytes the rest pass has to read: its row tiles x (bf16 hi plane [+ lo plane] + the row's norm word)
-        rest_bytes = stats["filter_rest_rows"] * (d * (2.0 if stats["filter_rest_hi_only"] else 4.0) + 4.0)
+        ks_read = 4 if d <= 64 else (8 if d <= 128 else 16)   # 16-dim k-steps the kernel loads per row and plane (32 B each, zero padded)
+        rest_bytes = stats["filter_rest_rows"] * (32.0 * ks_read * (1.0 if stats["filter_rest_hi_only"] else 2.0) + 4.0)
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
                               "traffic": traffic, "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s,
