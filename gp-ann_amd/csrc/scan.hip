@@ -611,6 +611,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     GPANN_TRY(cell_table(true));
 
+    // ---- the groups' query images (bf16 fragments in MFMA B-operand order), once per call
+    const uint32_t img_ks = ks16 ? 16u : (ks4 ? 4u : 8u), img_qt = ks16 ? 4u : 8u;
+    GPANN_TRY(s->ws_image.Reserve((size_t)G * img_qt * img_ks * 2048 + 256));
+    {
+        char* img = s->ws_image.as<char>();
+        if (ks16) hipLaunchKernelGGL((QueryImageKernel<16, 4>), dim3(G * 4), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img);
+        else if (ks4) hipLaunchKernelGGL((QueryImageKernel<4, 8>), dim3(G * 8), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img);
+        else hipLaunchKernelGGL((QueryImageKernel<8, 8>), dim3(G * 8), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img);
+        GPANN_HIP_TRY(hipGetLastError());
+    }
+
     // ---- stage 0: exact scan of the first m0 rows of every shard -> lists
     std::vector<int64_t> lo(S), hi(S);
     for (uint32_t b = 0; b < S; ++b) {
@@ -680,6 +691,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.next_item = d_next_item;
     fa.n_groups = G;
     fa.items = d_items;
+    fa.image = s->ws_image.as<char>();
     fa.n_items = d_n_items;
     fa.seg_tiles = seg_tiles;
     fa.items_cap = (uint32_t)items_cap;

@@ -37,7 +37,7 @@ struct CellItem {   // everything FilterKernelCells needs to run one piece of a 
     uint32_t t_a, t_b;         // the cell's head segment ends at tile t_a, its sample segment at t_b
     uint32_t task_begin, task_count;
     uint32_t acts;             // query tiles to run on the head | sample << 8 | rest << 16 segment
-    uint32_t pad;
+    uint32_t group;            // the task group (its query image)
 };
 
 struct CellTileRef {
@@ -253,6 +253,7 @@ struct CellFilterArgs {
     CellItem* items;
     uint32_t* n_items;
     uint32_t seg_tiles, items_cap;
+    const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel)
 };
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
@@ -293,7 +294,7 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     it.task_begin = a.groups[g].task_begin;
     it.task_count = a.groups[g].task_count;
     it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16;
-    it.pad = 0;
+    it.group = g;
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
         it.t_begin = (uint32_t)b;
@@ -304,6 +305,28 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
 
 // HI_ONLY: the points' lo plane is neither loaded nor multiplied (half the HBM bytes, two of the three products); the
 // threshold of such a pass carries the extra error term (ThresholdArgs::hi_only).
+// The bf16 hi/lo fragments of every task group's queries in MFMA B-operand order, built once per scan call: one wavefront per
+// (group, query tile).  FilterKernelCells copies the tiles it needs into LDS for every work item (LDS-DMA, no registers).
+template <int KS, int QT>
+static __global__ void __launch_bounds__(64) QueryImageKernel(const float* queries, const uint32_t* task_query, const CellGroup* groups, uint32_t ld,
+                                                              char* image) {
+    const uint32_t g = blockIdx.x / QT, qt = blockIdx.x - g * QT;
+    const int lane = threadIdx.x, c = lane & 31;
+    const uint32_t task_begin = groups[g].task_begin, task_count = groups[g].task_count;
+    const uint32_t tl = 32u * qt + c;
+    if (32u * qt >= task_count) return;   // (tiles past the group's tasks are never read)
+    const uint32_t task = task_begin + min(tl, task_count - 1);
+    BuildQueryTile<KS>(image + ((size_t)g * QT + qt) * KS * 2048, queries + (size_t)task_query[task] * ld, tl < task_count, ld, lane);
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm:
+// the compiler neither sees the LDS bytes it writes nor counts it in vmcnt — the caller waits (DmaWaitAll) before the barrier that
+// publishes the data, and issues it BEFORE any load the compiler tracks (a vmcnt(N) wait then only ever waits longer, never shorter).
+__device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "m0", "memory");
+}
+__device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
 // query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
 // tiles do not fit the register file).
@@ -313,6 +336,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     static_assert(KS <= 8 || HI_ONLY, "16 k-steps: hi-plane passes only");
     extern __shared__ uint4 csm4[];
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
     // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor; the claim for the
     // next item is issued while the current one streams
@@ -457,21 +481,23 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for the hi-only passes was measured slower: spills.)
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
+    if (mask >> wave & 1u) {
+        const char* src = a.image + ((size_t)a.items[item].group * QT + wave) * KS * 2048 + lane * 16;
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
+    }
     uint32_t T = t_begin + wave;
     const uint32_t t_last = t_end - 1;
-    load_tile(Ah[0], Al[0], nrm[0], min(T, t_last));   // the item's first tile is on its way while the query image is built
+    load_tile(Ah[0], Al[0], nrm[0], min(T, t_last));   // the item's first tile is on its way while the query image lands
 
-    // ---- the query image: wavefront w builds query tile w if any pass of this workgroup uses it
-    if (mask >> wave & 1u) {
-        const uint32_t tl = 32u * wave + c;
-        const uint32_t task = task_begin + min(tl, task_count - 1);
-        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)a.task_query[task] * ld, tl < task_count, ld, lane);
-    }
+    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const uint32_t tl = 32u * qt + c;
         U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
     }
+    DmaWaitAll();      // this wavefront's part of the image is in LDS (so is its first tile)
     __syncthreads();
     if (T < t_end) {
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
