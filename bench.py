@@ -82,8 +82,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", dest="n", type=int, default=int(os.environ.get("GPANN_BENCH_N", 100_000_000)))
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nq", type=int, default=10_000)
