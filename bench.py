@@ -350,6 +350,9 @@ def main():
     for _ in range(args.warmup):
         step()
     scan_ms, router_ms, algo_bytes, filter_ms, rest_ms, step_wall_ms, stats = [], [], [], [], [], [], None
+    import gc
+    gc.collect()
+    gc.disable()   # (a generation-2 collection in the middle of a 9 ms step is a visible outlier)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -365,6 +368,7 @@ def main():
         stats = st
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
