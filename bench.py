@@ -268,12 +268,14 @@ def main():
         return dist_h, ids_h, ms
 
     chunk_q = (nq + world - 1) // world
+    probes_buf = np.empty((nq, S), np.int32)
 
     def route():
         """KMeansTreeRouter::Query for the whole batch.  N > 1: the router is replicated, every rank routes its slice of the
         queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered."""
-        if world == 1:
-            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq)
+        if world == 1:   # (one reusable host array for the probe lists; min_dist itself is not needed here)
+            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq, out_probes=probes_buf,
+                                             want_min_dist=False)
             return pr, r_ms
         lo = min(nq, rank * chunk_q)
         hi = min(nq, lo + chunk_q)

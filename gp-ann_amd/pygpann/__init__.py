@@ -324,8 +324,9 @@ class Router:
         except Exception:
             pass
 
-    def query_batch(self, queries, budget, stream=None, on_device=False, nq=None):
-        """Batched KMeansTreeRouter::Query.  Returns probes [nq,S] int32, min_dist [nq,S] float32, ms."""
+    def query_batch(self, queries, budget, stream=None, on_device=False, nq=None, out_probes=None, want_min_dist=True):
+        """Batched KMeansTreeRouter::Query.  Returns probes [nq,S] int32, min_dist [nq,S] float32 (None unless want_min_dist), ms.
+        out_probes: a reusable [nq,S] int32 array to fill instead of a fresh one."""
         if on_device:
             qp = C.c_void_p(int(queries))
             flags = QUERIES_ON_DEVICE
@@ -334,11 +335,12 @@ class Router:
             nq = queries.shape[0]
             qp = _vp(queries)
             flags = 0
-        probes = np.empty((nq, self.S), np.int32)
-        md = np.empty((nq, self.S), np.float32)
+        probes = out_probes if out_probes is not None else np.empty((nq, self.S), np.int32)
+        assert probes.shape == (nq, self.S) and probes.dtype == np.int32 and probes.flags.c_contiguous
+        md = np.empty((nq, self.S), np.float32) if want_min_dist else None
         ms = C.c_float(0)
-        _check(lib().gpann_router_query_batch(self.h, qp, nq, budget, probes.ctypes.data_as(_i32p), md.ctypes.data_as(_f32p), flags,
-                                              C.c_void_p(stream or 0), C.byref(ms)))
+        _check(lib().gpann_router_query_batch(self.h, qp, nq, budget, probes.ctypes.data_as(_i32p), md.ctypes.data_as(_f32p) if want_min_dist else None,
+                                              flags, C.c_void_p(stream or 0), C.byref(ms)))
         return probes, md, ms.value
 
 
