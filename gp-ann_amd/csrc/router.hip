@@ -55,6 +55,9 @@ struct gpann_router {
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
     size_t pinned_floats = 0;
+    int32_t* pinned_probes = nullptr;    // pinned staging for the device-sorted probe lists + one tie flag per query
+    size_t pinned_probe_words = 0;
+    gpann::DeviceBuffer ws_probes;
     uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
     bool leaves_only = false;                                   // every non-root node is a leaf
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1254,6 +1257,8 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_pi.Release();
     r->ws_bound.Release();
     if (r->pinned_min) (void)hipHostFree(r->pinned_min);
+    if (r->pinned_probes) (void)hipHostFree(r->pinned_probes);
+    r->ws_probes.Release();
     for (auto& e : r->ev)
         if (e) (void)hipEventDestroy(e);
     delete r;
@@ -1537,6 +1542,40 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     return GPANN_OK;
 }
 
+
+// The final order of KMeansTreeRouter::Query (kmeans_tree_router.cpp:125-127: std::sort of the shard ids by min_dist) on the device,
+// one wavefront per query, S <= 64: a bitonic sort of (min_dist, shard).  Where all min_dist values of a query differ, every correct
+// sort returns the same permutation as the reference's; a query with two equal values (duplicate centroids, unvisited shards at
+// FLT_MAX) is flagged and the host redoes it with the reference's own unstable std::sort call.
+__global__ void __launch_bounds__(256) ProbeOrderKernel(const float* min_dist, uint32_t nq, uint32_t S, int32_t* probes, uint32_t* tie_flag) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    float key = (uint32_t)lane < S ? min_dist[(size_t)q * S + lane] : INFINITY;   // (real values are <= FLT_MAX: the padding sorts last)
+    int id = lane;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float okey = __shfl_xor(key, j);
+            const int oid = __shfl_xor(id, j);
+            const bool up = (lane & k) == 0;            // this block of k lanes sorts ascending
+            const bool lower = (lane & j) == 0;         // this lane keeps the smaller element of the pair when ascending
+            const bool other_less = okey < key || (okey == key && oid < id);
+            const bool take = (up == lower) ? other_less : !other_less;
+            if (take) {
+                key = okey;
+                id = oid;
+            }
+        }
+    }
+    const float next = __shfl_down(key, 1);
+    const bool tie = (uint32_t)lane + 1 < S && next == key;
+    const unsigned long long any = __ballot(tie);
+    if ((uint32_t)lane < S) probes[(size_t)q * S + lane] = id;
+    if (lane == 0) tie_flag[q] = any != 0ull ? 1u : 0u;
+}
+
 }  // namespace
 
 gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
@@ -1550,40 +1589,75 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     const uint32_t S = r->S;
     GPANN_TRY(LaunchWalk(r, queries, nq, budget, flags, st, nullptr, nullptr, nullptr, 0));
 
-    std::vector<float> local_min;
-    float* md = out_min_dist;
-    if (!md) {
-        local_min.resize((size_t)nq * S);
-        md = local_min.data();
-    }
-    if (r->pinned_floats < (size_t)nq * S) {
-        if (r->pinned_min) (void)hipHostFree(r->pinned_min);
-        r->pinned_min = nullptr;
-        r->pinned_floats = 0;
-        if (hipHostMalloc((void**)&r->pinned_min, (size_t)nq * S * 4, hipHostMallocDefault) == hipSuccess) r->pinned_floats = (size_t)nq * S;
+    const size_t words = (size_t)nq * S;
+    auto pinned = [&](void** p, size_t* have, size_t need_words) {
+        if (*have >= need_words) return true;
+        if (*p) (void)hipHostFree(*p);
+        *p = nullptr;
+        *have = 0;
+        if (hipHostMalloc(p, need_words * 4, hipHostMallocDefault) == hipSuccess) *have = need_words;
         else (void)hipGetLastError();
-    }
-    float* stage = r->pinned_floats >= (size_t)nq * S ? r->pinned_min : md;
-    GPANN_HIP_TRY(hipMemcpyAsync(stage, r->ws_out.ptr, (size_t)nq * S * 4, hipMemcpyDeviceToHost, st));
-    GPANN_HIP_TRY(hipStreamSynchronize(st));
-    if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
-    if (stage != md && out_min_dist) std::memcpy(md, stage, (size_t)nq * S * 4);
-    if (stage != md) md = stage;
+        return *have >= need_words;
+    };
+    // min_dist to the host: always when the caller wants it; for the probe order only if the device could not settle it
+    std::vector<float> local_min;
+    float* md = nullptr;
+    auto fetch_min_dist = [&]() -> gpann_status {
+        if (md) return GPANN_OK;
+        md = out_min_dist;
+        if (!md) {
+            local_min.resize(words);
+            md = local_min.data();
+        }
+        float* stage = pinned((void**)&r->pinned_min, &r->pinned_floats, words) ? r->pinned_min : md;
+        GPANN_HIP_TRY(hipMemcpyAsync(stage, r->ws_out.ptr, words * 4, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipStreamSynchronize(st));
+        if (stage != md && out_min_dist) std::memcpy(md, stage, words * 4);
+        if (stage != md) md = stage;
+        return GPANN_OK;
+    };
+    // kmeans_tree_router.cpp:125-127 — the reference's own call on the GPU-computed min_dist
+    auto host_sort = [&](uint32_t q) {
+        const float* min_dist = md + (size_t)q * S;
+        int* probes = out_probes + (size_t)q * S;
+        std::iota(probes, probes + S, 0);
+        std::sort(probes, probes + S, [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
+    };
 
+    if (out_probes && S <= 64 && pinned((void**)&r->pinned_probes, &r->pinned_probe_words, words + nq)) {
+        // the order on the device (ProbeOrderKernel); the host only redoes the queries with equal min_dist values
+        GPANN_TRY(r->ws_probes.Reserve((words + nq) * 4));
+        int32_t* d_probes = r->ws_probes.as<int32_t>();
+        uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_probes + words);
+        hipLaunchKernelGGL(ProbeOrderKernel, dim3((nq + 3) / 4), dim3(256), 0, st, r->ws_out.as<float>(), nq, S, d_probes, d_flags);
+        GPANN_HIP_TRY(hipGetLastError());
+        GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes, d_probes, (words + nq) * 4, hipMemcpyDeviceToHost, st));
+        if (out_min_dist) GPANN_TRY(fetch_min_dist());
+        else GPANN_HIP_TRY(hipStreamSynchronize(st));
+        if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
+        std::memcpy(out_probes, r->pinned_probes, words * 4);
+        const uint32_t* flags = reinterpret_cast<const uint32_t*>(r->pinned_probes + words);
+        std::vector<uint32_t> redo;
+        for (uint32_t q = 0; q < nq; ++q)
+            if (flags[q]) redo.push_back(q);
+        if (!redo.empty()) {
+            GPANN_TRY(fetch_min_dist());
+            const uint32_t chunks = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)redo.size() * S) / 8192));
+            HostPool::Get().Run(chunks, [&](uint32_t c) {
+                for (size_t i = redo.size() * c / chunks; i < redo.size() * (c + 1) / chunks; ++i) host_sort(redo[i]);
+            });
+        }
+        return GPANN_OK;
+    }
+
+    GPANN_TRY(fetch_min_dist());
+    if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
     if (out_probes) {
-        // kmeans_tree_router.cpp:125-127 — the reference's own call, on the GPU-computed min_dist; queries are independent,
-        // so the batch is spread over a few host threads
-        auto sort_range = [&](uint32_t q0, uint32_t q1) {
-            std::vector<int> probes(S);
-            for (uint32_t q = q0; q < q1; ++q) {
-                const float* min_dist = md + (size_t)q * S;
-                std::iota(probes.begin(), probes.end(), 0);
-                std::sort(probes.begin(), probes.end(), [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
-                std::copy(probes.begin(), probes.end(), out_probes + (size_t)q * S);
-            }
-        };
+        // queries are independent, so the batch is spread over a few host threads
         const uint32_t chunks = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nq * S) / 8192));
-        HostPool::Get().Run(chunks, [&](uint32_t c) { sort_range((uint32_t)((uint64_t)nq * c / chunks), (uint32_t)((uint64_t)nq * (c + 1) / chunks)); });
+        HostPool::Get().Run(chunks, [&](uint32_t c) {
+            for (uint32_t q = (uint32_t)((uint64_t)nq * c / chunks); q < (uint32_t)((uint64_t)nq * (c + 1) / chunks); ++q) host_sort(q);
+        });
     }
     return GPANN_OK;
 }

@@ -188,8 +188,9 @@ gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uin
                                  uint32_t* node_child_count, uint32_t* shard_root, float* centroids);
 
 /* Batched KMeansTreeRouter::Query.  The best-first walk (all distance evaluations, the priority queue and the budget
- * rule) runs on the GPU; the final order is std::sort over min_dist on the host, the very call the reference makes
- * (kmeans_tree_router.cpp:125-127), so tie order is inherited from libstdc++.
+ * rule) runs on the GPU.  The final order (std::sort over min_dist, kmeans_tree_router.cpp:125-127) is computed on the device for
+ * the queries whose min_dist values are pairwise different (any correct sort gives the reference's permutation) and, for queries with
+ * equal values, by that very std::sort call on the host, so tie order is inherited from libstdc++.
  *   queries       host|device nq x d
  *   out_probes    host [nq][S] shard ids by ascending min_dist            (may be NULL)
  *   out_min_dist  host [nq][S]; FLT_MAX for shards whose root was never opened (may be NULL)
