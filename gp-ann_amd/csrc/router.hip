@@ -1773,9 +1773,14 @@ gpann_status gpann_merge_dedup(const float* in_dist, const uint32_t* in_ids, uin
                     const size_t idx = ((size_t)q * nprobe + j) * k + x;
                     if (in_ids[idx] != GPANN_NO_ID) n.emplace_back(in_dist[idx], in_ids[idx]);
                 }
-            std::sort(n.begin(), n.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
-            n.erase(std::unique(n.begin(), n.end()), n.end());
-            std::sort(n.begin(), n.end());
+            // (one probed shard, no equal distances: the list is already what the four calls below would make of it)
+            bool settled = true;
+            for (size_t i = 1; i < n.size() && settled; ++i) settled = n[i - 1].first < n[i].first;
+            if (!settled) {
+                std::sort(n.begin(), n.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
+                n.erase(std::unique(n.begin(), n.end()), n.end());
+                std::sort(n.begin(), n.end());
+            }
             n.resize(std::min<size_t>(n.size(), k));
             for (uint32_t x = 0; x < k; ++x) {
                 out_dist[(size_t)q * k + x] = x < n.size() ? n[x].first : std::numeric_limits<float>::infinity();
