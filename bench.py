@@ -234,12 +234,15 @@ def main():
     out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, S, k), dtype=torch.float32, device=dev)
     host_out = {}   # pinned result buffers per (nq, nprobe)
+    dev_out = {}    # device result buffers per nprobe
 
     def scan_slots(probes, nprobe, timed=False, aux=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
         lp = multigpu.mask_probes(np.ascontiguousarray(probes[:, :nprobe]), owner, rank)
-        oi = out_ids[:, :nprobe].contiguous() if nprobe != S else out_ids
-        od = out_dist[:, :nprobe].contiguous() if nprobe != S else out_dist
+        if nprobe not in dev_out:   # (a slice + .contiguous() would allocate and launch a copy kernel in every step)
+            dev_out[nprobe] = ((out_ids, out_dist) if nprobe == S else
+                               (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)))
+        oi, od = dev_out[nprobe]
         ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
         if world > 1:
             # local row ids -> global ids on the device, then the exchange over RCCL: a slot is non-empty on exactly one rank, so

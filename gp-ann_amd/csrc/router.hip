@@ -1273,10 +1273,14 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                         int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap) {
     const uint32_t S = r->S, ld = r->ld;
     const size_t qbytes = (size_t)nq * ld * sizeof(float);
-    GPANN_TRY(r->ws_queries.Reserve(qbytes));
-    if (ld != r->d) GPANN_HIP_TRY(hipMemsetAsync(r->ws_queries.ptr, 0, qbytes, st));
-    GPANN_HIP_TRY(hipMemcpy2DAsync(r->ws_queries.ptr, (size_t)ld * 4, queries, (size_t)r->d * 4, (size_t)r->d * 4, nq,
-                                   (flags & GPANN_QUERIES_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    const float* d_q = queries;   // device queries that already have the padded row layout are read in place
+    if (!((flags & GPANN_QUERIES_ON_DEVICE) && ld == r->d && (reinterpret_cast<uintptr_t>(queries) & 15u) == 0)) {
+        GPANN_TRY(r->ws_queries.Reserve(qbytes));
+        if (ld != r->d) GPANN_HIP_TRY(hipMemsetAsync(r->ws_queries.ptr, 0, qbytes, st));
+        GPANN_HIP_TRY(hipMemcpy2DAsync(r->ws_queries.ptr, (size_t)ld * 4, queries, (size_t)r->d * 4, (size_t)r->d * 4, nq,
+                                       (flags & GPANN_QUERIES_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        d_q = r->ws_queries.as<float>();
+    }
 
     // every node enters the queue at most once (when its parent is popped), so n_nodes bounds the queue; so does
     // S + (#pops <= budget) * max_children
@@ -1314,7 +1318,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             const uint32_t nb = std::min(q_block, nq - q0);
             DenseArgs da;
             da.centroids = r->centroids;
-            da.queries = r->ws_queries.as<float>() + (size_t)q0 * ld;
+            da.queries = d_q + (size_t)q0 * ld;
             da.out = r->ws_dense.as<float>();
             da.d = r->d;
             da.ld = ld;
@@ -1509,7 +1513,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     a.node_child_first = r->node_child_first;
     a.node_child_count = r->node_child_count;
     a.shard_root = r->shard_root;
-    a.queries = r->ws_queries.as<float>();
+    a.queries = d_q;
     a.heap_key = r->ws_heap.as<float>();
     a.heap_node = reinterpret_cast<uint32_t*>(a.heap_key + slots * cap);
     a.out_min_dist = r->ws_out.as<float>();

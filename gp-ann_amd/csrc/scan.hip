@@ -403,6 +403,10 @@ static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vecto
 
 // queries (host or device, stride d) -> device workspace with stride ld, zero padded
 static gpann_status StageQueries(gpann_shards* s, const float* queries, uint32_t nq, bool on_device, hipStream_t st, const float** out) {
+    if (on_device && s->ld == s->d && (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {   // already in the layout the kernels read
+        *out = queries;
+        return GPANN_OK;
+    }
     const size_t bytes = (size_t)nq * s->ld * sizeof(float);
     GPANN_TRY(s->ws_queries.Reserve(std::max<size_t>(bytes, 256)));
     float* dst = s->ws_queries.as<float>();
