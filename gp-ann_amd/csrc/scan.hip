@@ -802,25 +802,24 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         }
     }
     {
+        // the lists go out before the overflow words are looked at (one host round trip less on the way; an overflowed call rewrites
+        // them in the plain exact scan)
         uint32_t h_words[4] = {0, 0, 0, 0};
         unsigned long long h_work[4] = {0, 0, 0, 0};
         GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 32, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+        const size_t n = (size_t)T * k;
+        hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k,
+                           out.dist, out.ids, out.rows);
+        GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipStreamSynchronize(st));
         plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
         plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
         plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
         plan.filter_rows = (uint64_t)h_work[1] * kGTileRows;
-        if (h_words[0] > overflow_limit) {
-            *overflow = true;
-            return GPANN_OK;
-        }
+        if (h_words[0] > overflow_limit) *overflow = true;
     }
-    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
-    const size_t n = (size_t)T * k;
-    hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k, out.dist,
-                       out.ids, out.rows);
-    GPANN_HIP_TRY(hipGetLastError());
     return GPANN_OK;
 }
 
