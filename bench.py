@@ -271,7 +271,7 @@ def main():
         return dist_h, ids_h, ms
 
     chunk_q = (nq + world - 1) // world
-    probes_buf = np.empty((nq, S), np.int32)
+    probes_buf = torch.empty((nq, S), dtype=torch.int32).pin_memory().numpy()   # pinned: the router's D2H copy lands in it directly
 
     def route():
         """KMeansTreeRouter::Query for the whole batch.  N > 1: the router is replicated, every rank routes its slice of the

@@ -1635,11 +1635,20 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_probes + words);
         hipLaunchKernelGGL(ProbeOrderKernel, dim3((nq + 3) / 4), dim3(256), 0, st, r->ws_out.as<float>(), nq, S, d_probes, d_flags);
         GPANN_HIP_TRY(hipGetLastError());
-        GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes, d_probes, (words + nq) * 4, hipMemcpyDeviceToHost, st));
+        // a caller-provided pinned array receives the lists directly; otherwise they pass through the handle's pinned staging
+        hipPointerAttribute_t attr{};
+        const bool direct = hipPointerGetAttributes(&attr, out_probes) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!direct) (void)hipGetLastError();
+        if (direct) {
+            GPANN_HIP_TRY(hipMemcpyAsync(out_probes, d_probes, words * 4, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes + words, d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        } else {
+            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes, d_probes, (words + nq) * 4, hipMemcpyDeviceToHost, st));
+        }
         if (out_min_dist) GPANN_TRY(fetch_min_dist());
         else GPANN_HIP_TRY(hipStreamSynchronize(st));
         if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
-        std::memcpy(out_probes, r->pinned_probes, words * 4);
+        if (!direct) std::memcpy(out_probes, r->pinned_probes, words * 4);
         const uint32_t* flags = reinterpret_cast<const uint32_t*>(r->pinned_probes + words);
         std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; ++q)
