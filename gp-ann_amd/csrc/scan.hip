@@ -745,7 +745,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    const size_t rlds = (size_t)4 * s->ld * sizeof(float);
+    const size_t rlds = (size_t)4 * RescoreLdsFloats(s->ld) * sizeof(float);
+    if (rlds > (48u << 10)) {
+        if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+    }
     const uint64_t need_threads = (uint64_t)T * kmax;
     int n_cus = 256;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);

@@ -195,8 +195,13 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
     }
 }
 
-// one wavefront per task: lane i evaluates candidate i (canonical distance against the query row in LDS), then the
-// survivors are inserted into the task's list (one entry per lane)
+// One wavefront per task.  Candidates are taken 16 at a time: their rows are fetched COALESCED (half a wavefront per row: one
+// 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row costs the texture path 64 cache lines per load
+// instruction) and staged through LDS, the next 16 rows being in flight while lanes 0..15 evaluate the canonical distance of the
+// current ones against the query row in LDS; the survivors are inserted into the task's list (one entry per lane).
+constexpr int kRescoreSub = 16;                                                   // candidates per round
+__host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
+
 template <int METRIC>
 __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
@@ -207,10 +212,11 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     if (cnt == 0) return;
     const bool overflowed = cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
     if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
-    float* sq = rsm + (size_t)wave * a.ld;
-    const float* q = a.queries + (size_t)a.task_query[t] * a.ld;
-    for (uint32_t i = lane; i < a.ld; i += 64) sq[i] = q[i];
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
+    float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
+    float* srow = sq + ld;   // [16][ld + 4]
+    const float* q = a.queries + (size_t)a.task_query[t] * ld;
+    for (uint32_t i = lane; i < ld; i += 64) sq[i] = q[i];
     const uint32_t k = a.k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
@@ -225,22 +231,69 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
         scan_hi = a.range_hi == INT64_MAX ? a.shard_offsets[b + 1] : min(a.shard_offsets[b + 1], a.shard_offsets[b] + a.range_hi);
     }
     const uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
-    for (uint64_t base = 0; base < n_items; base += 64) {
-        const bool valid = base + lane < n_items;
-        uint32_t row = kNoId;
-        float e = INFINITY;
-        if (valid) {
-            row = overflowed ? (uint32_t)(scan_lo + (int64_t)(base + lane)) : a.cand_row[(size_t)t * a.cand_cap + base + lane];
-            e = ExactDistanceVec4<METRIC>(a.points + (size_t)row * a.ld, sq, a.d);   // (rows and the LDS copy of the query are 16-byte aligned)
+    const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 float4 (128 dimensions) of a row per load instruction and half wavefront
+    const int half = lane >> 5, c4l = lane & 31;
+
+    // row ids are read 64 candidates at a time (one coalesced load, a block ahead); round `sub` of a block takes its 16 from there
+    auto load_block = [&](uint64_t first) -> uint32_t {
+        const uint64_t idx = first + lane;
+        if (idx >= n_items) return kNoId;
+        return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + idx];
+    };
+    auto round_rows = [&](uint32_t block_rows, uint32_t sub) -> uint32_t {
+        const uint32_t r = __shfl(block_rows, (int)(kRescoreSub * sub + (lane & (kRescoreSub - 1))));
+        return lane < kRescoreSub ? r : kNoId;
+    };
+    // the 16 rows of a round, one chunk of 128 dimensions: instruction i serves rows 2 i (lanes 0..31) and 2 i + 1 (lanes 32..63)
+    auto fetch = [&](float4 (&v)[8], uint32_t row, uint32_t chunk) {
+        const uint32_t c4 = 32u * chunk + c4l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t r = __shfl(row, 2 * i + half);
+            v[i] = (r != kNoId && c4 < ld4) ? *reinterpret_cast<const float4*>(a.points + (size_t)r * ld + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto stage = [&](const float4 (&v)[8], uint32_t chunk) {
+        const uint32_t c4 = 32u * chunk + c4l;
+        if (c4 < ld4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(srow + (size_t)(2 * i + half) * stride + 4u * c4) = v[i];
+        }
+    };
+
+    float4 v[8];
+    uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
+    uint32_t row = round_rows(block_rows, 0);
+    fetch(v, row, 0);
+    for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
+        const uint32_t sub = (uint32_t)(base / kRescoreSub) & 3u;
+        __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
+        stage(v, 0);
+        for (uint32_t ch = 1; ch < n_chunks; ++ch) {   // (rows wider than 128 dimensions: the further chunks of this round)
+            fetch(v, row, ch);
+            stage(v, ch);
+        }
+        const uint32_t cur_row = row;
+        if (sub == 3u) {
+            block_rows = next_block_rows;
+            next_block_rows = load_block(base + kRescoreSub + 64);
+            row = round_rows(block_rows, 0);
+        } else {
+            row = round_rows(block_rows, sub + 1);
+        }
+        fetch(v, row, 0);                  // the next round's rows are in flight while this one is evaluated
+        __builtin_amdgcn_wave_barrier();
+        const bool valid = cur_row != kNoId;
+        float e = INFINITY;
+        if (valid) e = ExactDistanceVec4<METRIC>(srow + (size_t)lane * stride, sq, a.d);   // (rows and the query copy are 16-byte aligned)
         float td = __shfl(ld_, k - 1);
         uint32_t tr = __shfl(lr_, k - 1);
-        bool pass = valid && PairLess(e, row, td, tr);
+        bool pass = valid && PairLess(e, cur_row, td, tr);
         unsigned long long mask = __ballot(pass);
         while (mask) {
             const int l = __builtin_ctzll(mask);
             const float cd = __shfl(e, l);
-            const uint32_t cr = __shfl(row, l);
+            const uint32_t cr = __shfl(cur_row, l);
             // a row may be offered twice (cell passes overlap a stage-0 row; an overflowed bucket re-reads its range): a row that is
             // in the list stays once, one that was pushed out cannot pass the k-th entry again
             if (a.dedupe && __ballot(lane < (int)k && lr_ == cr) != 0ull) {
@@ -251,7 +304,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
             ListInsertF(ld_, lr_, cd, cr, k, lane);
             td = __shfl(ld_, k - 1);
             tr = __shfl(lr_, k - 1);
-            pass = pass && lane != l && PairLess(e, row, td, tr);
+            pass = pass && lane != l && PairLess(e, cur_row, td, tr);
             mask = __ballot(pass);
         }
     }
