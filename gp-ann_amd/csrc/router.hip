@@ -26,6 +26,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -80,54 +81,61 @@ public:
             return;
         }
         std::unique_lock<std::mutex> run_lock(run_mutex_);   // one batch at a time
+        // every batch has its own claim counter: a worker that wakes up late for a finished batch finds that batch exhausted and
+        // can never claim (or re-run) a chunk of the batch that follows it
+        auto batch = std::make_shared<Batch>();
+        batch->fn = &fn;
+        batch->n_chunks = n_chunks;
+        batch->pending = n_chunks;
         {
             std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            n_chunks_ = n_chunks;
-            next_.store(0);
-            pending_ = n_chunks;
+            current_ = batch;
             ++epoch_;
         }
         cv_work_.notify_all();
-        Work();
+        Work(*batch);
         std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
+        cv_done_.wait(lk, [&] { return batch->pending == 0; });
     }
 
 private:
+    struct Batch {
+        const std::function<void(uint32_t)>* fn = nullptr;   // valid until Run returns, i.e. until every chunk has completed
+        uint32_t n_chunks = 0, pending = 0;                  // pending: guarded by m_
+        std::atomic<uint32_t> next{0};
+    };
     HostPool() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const unsigned n = std::min(31u, hw > 1 ? hw - 1 : 0u);
         for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { Loop(); });
         for (auto& t : workers_) t.detach();
     }
-    void Work() {
+    void Work(Batch& b) {
         for (;;) {
-            const uint32_t c = next_.fetch_add(1);
-            if (c >= n_chunks_) return;
-            (*fn_)(c);
+            const uint32_t c = b.next.fetch_add(1);
+            if (c >= b.n_chunks) return;
+            (*b.fn)(c);
             std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) cv_done_.notify_all();
+            if (--b.pending == 0) cv_done_.notify_all();
         }
     }
     void Loop() {
         uint64_t seen = 0;
         for (;;) {
+            std::shared_ptr<Batch> batch;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_work_.wait(lk, [&] { return epoch_ != seen; });
                 seen = epoch_;
+                batch = current_;
             }
-            Work();
+            Work(*batch);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, run_mutex_;
     std::condition_variable cv_work_, cv_done_;
-    const std::function<void(uint32_t)>* fn_ = nullptr;
-    uint32_t n_chunks_ = 0, pending_ = 0;
-    std::atomic<uint32_t> next_{0};
+    std::shared_ptr<Batch> current_;   // guarded by m_
     uint64_t epoch_ = 0;
 };
 
