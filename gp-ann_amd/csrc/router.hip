@@ -48,6 +48,7 @@ struct gpann_router {
     uint32_t* path_cent = nullptr;       // [n_nodes][kPathMax] centroids whose distances are the keys on the path root -> node (threshold replay)
     uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
     uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
+    uint32_t* shard_has_cent = nullptr;  // [S] 1 if the shard has at least one centroid (its min_dist cannot stay at FLT_MAX after a full visit)
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
     float* cent_nhn = nullptr;           // [n_centroids + 64] -|c|^2/2
     double cent_rmax = 0.0;              // largest centroid norm
@@ -464,6 +465,12 @@ __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
 __global__ void FillMinBitsKernel(uint32_t* out, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = 0xFF7FFFFFu;   // OrderedBits(FLT_MAX)
+}
+// (query, shard) minima a full visit has left at FLT_MAX although the shard has centroids — counted into *unset (self-check of the
+// matrix-core bound path: the caller then evaluates every pair canonically instead)
+__global__ void CountUnsetMinBitsKernel(const uint32_t* bits, size_t n, uint32_t S, const uint32_t* shard_has_cent, uint32_t* unset) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n && bits[i] == 0xFF7FFFFFu && shard_has_cent[i % S] != 0u) atomicAdd(unset, 1u);
 }
 __global__ void MinBitsToFloatKernel(uint32_t* io, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -1189,6 +1196,13 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         for (size_t c = 0; c < nc; ++c) cent_shard[c] = (uint32_t)node_shard[cent_node[c]];
         TRY_OR_FAIL(hipMalloc(&r->cent_shard, cent_shard.size() * 4));
         TRY_OR_FAIL(hipMemcpy(r->cent_shard, cent_shard.data(), cent_shard.size() * 4, hipMemcpyHostToDevice));
+        {
+            std::vector<uint32_t> has(S, 0);
+            for (uint32_t b : cent_shard)
+                if (b < S) has[b] = 1;
+            TRY_OR_FAIL(hipMalloc(&r->shard_has_cent, (size_t)S * 4));
+            TRY_OR_FAIL(hipMemcpy(r->shard_has_cent, has.data(), (size_t)S * 4, hipMemcpyHostToDevice));
+        }
         // matrix-core bound for the visit-everything case (router_bound.h)
         bool finite = true;
         double rmax2 = 0.0;
@@ -1255,7 +1269,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->cent_planes, (void*)r->cent_nhn})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -1366,7 +1380,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
                     ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
                     GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
-                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 4, st));
+                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 8, st));   // candidate counter + the self-check's counter
                     GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
                     const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
                     const size_t blds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
@@ -1389,11 +1403,18 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     else hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_MIPS>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
                                             r->cent_shard, da.out_min_bits, S, r->d, ld);
                     GPANN_HIP_TRY(hipGetLastError());
-                    uint32_t n_cand = 0;
-                    GPANN_HIP_TRY(hipMemcpyAsync(&n_cand, ba.cand_count, 4, hipMemcpyDeviceToHost, st));
+                    // self-check: after a full visit every shard with centroids has a minimum.  (cand_count + 1 = the counter)
+                    hipLaunchKernelGGL(CountUnsetMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent,
+                                       ba.cand_count + 1);
+                    uint32_t counters[2] = {0, 0};   // candidates, unset minima
+                    GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
                     GPANN_HIP_TRY(hipStreamSynchronize(st));
+                    const uint32_t n_cand = counters[0];
                     if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidates for %u x %u (query, shard) pairs\n", n_cand, nb, S);
-                    if (n_cand <= cand_cap) {
+                    if (counters[1] != 0)
+                        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n",
+                                counters[1], nb_s);
+                    if (n_cand <= cand_cap && counters[1] == 0) {
                         hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                         GPANN_HIP_TRY(hipGetLastError());
                         continue;

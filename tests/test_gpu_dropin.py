@@ -135,7 +135,7 @@ def test_reference_query_attribution_driver_unchanged(orc, dataset):
             bad = np.flatnonzero((np.asarray(got[0]["probes"]) != want).any(axis=1))
             raise AssertionError(f"budget {budget}: driver routes differ from the oracle's for {len(bad)} of {nq} queries (first {bad[:5]}); in-process device "
                                  f"training gives the oracle's tree: {same_tree}; in-process routes equal the oracle's: {np.array_equal(pr, want)}; "
-                                 f"in-process min_dist equal: {np.array_equal(md.view(np.uint32), omd.view(np.uint32))}; driver stdout tail: {r.stdout[-1500:]}")
+                                 f"in-process min_dist equal: {np.array_equal(md.view(np.uint32), omd.view(np.uint32))}; driver stdout tail: {r.stdout[-1200:]} stderr tail: {r.stderr[-800:]}")
         # frequency routing (kmeans_tree_router.cpp:132-172 + kmeans_tree_router.h:23-44)
         for rt in (x for x in routes if x["budget"] == budget and x["algo"] == "KMeansTree-Frequency"):
             for q in (0, 7, nq - 1):
