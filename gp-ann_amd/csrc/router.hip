@@ -1411,6 +1411,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     GPANN_HIP_TRY(hipStreamSynchronize(st));
                     const uint32_t n_cand = counters[0];
                     if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidates for %u x %u (query, shard) pairs\n", n_cand, nb, S);
+                    if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
                     if (counters[1] != 0)
                         fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n",
                                 counters[1], nb_s);

@@ -169,3 +169,19 @@ def test_frequency_query_vote_selection_ties_and_short_lists(orc, gp):
             assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32))
             assert nc[q] == len(wnd), (budget, votes, q)
             assert np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns)
+
+
+def test_router_bound_self_check_falls_back_to_canonical_evaluation(orc, gp, monkeypatch, capfd):
+    """the matrix-core bound path re-evaluates every pair canonically when its self-check fires (here: forced) — same results"""
+    rng = np.random.default_rng(5)
+    n, d, S = 12000, 32, 5
+    pts = make_mixture(orc, n, d, n_centers=20)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, 300, d, seed=556, n_centers=20)
+    tree = orc.kmtr_train(pts, clusters, 64, 350, 20000, 0, nthreads=4)
+    want_p, want_md = tree.query_batch(queries, 50000, nthreads=4)
+    router = gp.Router(tree.flat(), 0)
+    monkeypatch.setenv("GPANN_ROUTER_FORCE_RECHECK", "1")
+    p, md, _ = router.query_batch(queries, 50000)
+    assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+    assert "minima unset" in capfd.readouterr().err
