@@ -126,6 +126,8 @@ def test_reference_query_attribution_driver_unchanged(orc, dataset):
         want, _ = tree.query_batch(dataset["queries"], 50000, nthreads=4)
         got = [rt for rt in routes if rt["budget"] == budget and rt["algo"] == "KMeansTree"]
         assert len(got) == 1 and got[0]["num_centroids"] == 64 and got[0]["min_cluster"] == 350 and got[0]["increasing"] == "true"
+        if os.environ.get("GPANN_TEST_FORCE_ROUTE_MISMATCH"):   # exercises the reporting branch below (it must end in AssertionError)
+            want = want[:, ::-1].copy()
         if not np.array_equal(np.asarray(got[0]["probes"]), want):   # say which stage differs before failing
             import pygpann as gp
             shards = gp.Shards(dataset["pts"], dataset["clusters"], plain=True)
