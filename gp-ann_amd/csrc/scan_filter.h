@@ -200,6 +200,7 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
 // instruction) and staged through LDS, the next 16 rows being in flight while lanes 0..15 evaluate the canonical distance of the
 // current ones against the query row in LDS; the survivors are inserted into the task's list (one entry per lane).
 constexpr int kRescoreSub = 16;                                                   // candidates per round
+constexpr int kRescoreRounds = 64 / kRescoreSub;                                  // rounds per block of 64 row ids
 __host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
 
 template <int METRIC>
@@ -245,28 +246,28 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
         return lane < kRescoreSub ? r : kNoId;
     };
     // the 16 rows of a round, one chunk of 128 dimensions: instruction i serves rows 2 i (lanes 0..31) and 2 i + 1 (lanes 32..63)
-    auto fetch = [&](float4 (&v)[8], uint32_t row, uint32_t chunk) {
+    auto fetch = [&](float4 (&v)[kRescoreSub / 2], uint32_t row, uint32_t chunk) {
         const uint32_t c4 = 32u * chunk + c4l;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kRescoreSub / 2; ++i) {
             const uint32_t r = __shfl(row, 2 * i + half);
             v[i] = (r != kNoId && c4 < ld4) ? *reinterpret_cast<const float4*>(a.points + (size_t)r * ld + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stage = [&](const float4 (&v)[8], uint32_t chunk) {
+    auto stage = [&](const float4 (&v)[kRescoreSub / 2], uint32_t chunk) {
         const uint32_t c4 = 32u * chunk + c4l;
         if (c4 < ld4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(srow + (size_t)(2 * i + half) * stride + 4u * c4) = v[i];
+            for (int i = 0; i < kRescoreSub / 2; ++i) *reinterpret_cast<float4*>(srow + (size_t)(2 * i + half) * stride + 4u * c4) = v[i];
         }
     };
 
-    float4 v[8];
+    float4 v[kRescoreSub / 2];
     uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
     uint32_t row = round_rows(block_rows, 0);
     fetch(v, row, 0);
     for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
-        const uint32_t sub = (uint32_t)(base / kRescoreSub) & 3u;
+        const uint32_t sub = (uint32_t)(base / kRescoreSub) % (uint32_t)kRescoreRounds;
         __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
         stage(v, 0);
         for (uint32_t ch = 1; ch < n_chunks; ++ch) {   // (rows wider than 128 dimensions: the further chunks of this round)
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
             stage(v, ch);
         }
         const uint32_t cur_row = row;
-        if (sub == 3u) {
+        if (sub + 1u == (uint32_t)kRescoreRounds) {
             block_rows = next_block_rows;
             next_block_rows = load_block(base + kRescoreSub + 64);
             row = round_rows(block_rows, 0);
