@@ -52,7 +52,9 @@ struct gpann_router {
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
     float* cent_nhn = nullptr;           // [n_centroids + 64] -|c|^2/2
     double cent_rmax = 0.0;              // largest centroid norm
-    gpann::DeviceBuffer ws_bound;
+    gpann::DeviceBuffer ws_bound, ws_verify;
+    uint64_t stat_bound_calls = 0, stat_bound_selfcheck = 0, stat_bound_overflow = 0, stat_verified = 0, stat_verify_failures = 0;
+    uint64_t stat_host_sorted = 0, stat_heap_redo = 0;
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
@@ -1115,6 +1117,13 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         max_children = std::max(max_children, node_child_count[u]);
     }
     for (uint32_t b = 0; b < S; ++b) GPANN_REQUIRE(shard_root[b] < n_nodes, "shard_root out of range");
+    // the layout the kernels rely on (ExtractPoints order, kmeans_tree_router.cpp:174-201): nodes grouped per shard in ascending shard
+    // order, the root of a shard first — tiles of consecutive centroids then hold the shards shard_first..shard_last
+    for (uint32_t u = 1; u < n_nodes; ++u) GPANN_REQUIRE(node_shard[u - 1] <= node_shard[u], "nodes must be grouped per shard, shards ascending");
+    for (uint32_t b = 0; b < S; ++b) {
+        const uint32_t u = shard_root[b];
+        GPANN_REQUIRE((uint32_t)node_shard[u] == b && (u == 0 || (uint32_t)node_shard[u - 1] < b), "shard_root[b] must be the first node of shard b");
+    }
     GPANN_TRY(EnsureDevice(device));
 
     auto* r = new gpann_router();
@@ -1250,6 +1259,18 @@ gpann_status gpann_router_info(const gpann_router* r, uint32_t* d, int* metric, 
     return GPANN_OK;
 }
 
+gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* out) {
+    GPANN_REQUIRE(r != nullptr && out != nullptr, "null argument");
+    out->bound_calls = r->stat_bound_calls;
+    out->bound_selfcheck = r->stat_bound_selfcheck;
+    out->bound_overflow = r->stat_bound_overflow;
+    out->verified = r->stat_verified;
+    out->verify_failures = r->stat_verify_failures;
+    out->host_sorted = r->stat_host_sorted;
+    out->heap_redo = r->stat_heap_redo;
+    return GPANN_OK;
+}
+
 gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uint32_t* node_cent_first, uint32_t* node_child_first,
                                  uint32_t* node_child_count, uint32_t* shard_root, float* centroids) {
     GPANN_REQUIRE(r != nullptr, "router is null");
@@ -1278,6 +1299,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_redo.Release();
     r->ws_pi.Release();
     r->ws_bound.Release();
+    r->ws_verify.Release();
     if (r->pinned_min) (void)hipHostFree(r->pinned_min);
     if (r->pinned_probes) (void)hipHostFree(r->pinned_probes);
     r->ws_probes.Release();
@@ -1288,6 +1310,230 @@ gpann_status gpann_router_destroy(gpann_router* r) {
 }
 
 namespace {
+
+// ---- the matrix-core bound path of the visit-everything case (router_bound.h), with its self-check and the verify mode ------------
+__global__ void DiffBitsKernel(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out /* [0] count, [1] first index */) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) {
+        atomicAdd(out, 1u);
+        atomicMin(out + 1, (uint32_t)i);
+    }
+}
+
+// Enqueues pass 1, the margins, pass 2, the canonical evaluation of the candidates and the unset-minima count for the query block of
+// `da` (whose out_min_bits the caller has filled with OrderedBits(FLT_MAX)).  On return `ba` describes the workspace that was used.
+gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float*& thr) {
+    const uint32_t S = r->S, ld = r->ld;
+    const uint64_t C = r->n_centroids;
+    const size_t nb_s = (size_t)nb * S;
+    // (slots are handed out in chunks of 256 per wavefront: room for every wavefront's last, partly used chunk)
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)nb_s * 4 + (uint64_t)((nb + 255) / 256) * 80 * 8 * 256 + 1024);
+    const size_t cand_off = (nb_s * 8 + 15) & ~(size_t)15;   // bytes: max_bits | thr | (pad to 16) | cand | counters
+    GPANN_TRY(r->ws_bound.Reserve(cand_off + (size_t)cand_cap * 8 + 64));
+    ba.queries = da.queries;
+    ba.cent_planes = r->cent_planes;
+    ba.cent_nhn = r->cent_nhn;
+    ba.cent_shard = r->cent_shard;
+    ba.max_bits = r->ws_bound.as<uint32_t>();
+    thr = reinterpret_cast<float*>(ba.max_bits + nb_s);
+    ba.thr = thr;
+    ba.cand = reinterpret_cast<uint2*>(r->ws_bound.as<char>() + cand_off);
+    ba.cand_count = reinterpret_cast<uint32_t*>(ba.cand + cand_cap);
+    ba.cand_cap = cand_cap;
+    ba.nq = nb;
+    ba.C = (uint32_t)C;
+    ba.S = S;
+    ba.ld = ld;
+    const uint32_t groups = (nb + 255) / 256;
+    const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
+    ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
+    GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
+    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 16, st));   // candidate counter, the self-check's counter, (verify mode) two more words
+    GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
+    const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
+    const size_t blds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+    const void *f1, *f2;
+#define GPANN_PICKB(P_) (l2 ? (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, P_>) \
+                            : (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, P_>))
+    f1 = GPANN_PICKB(1);
+    f2 = GPANN_PICKB(2);
+#undef GPANN_PICKB
+    GPANN_HIP_TRY(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+    GPANN_HIP_TRY(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+    void* kargs[] = {&ba};
+    GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
+    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
+    GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+    const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
+    if (l2) hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_L2>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
+                               r->cent_shard, da.out_min_bits, S, r->d, ld);
+    else hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_MIPS>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
+                            r->cent_shard, da.out_min_bits, S, r->d, ld);
+    GPANN_HIP_TRY(hipGetLastError());
+    // self-check: after a full visit every shard with centroids has a minimum.  (cand_count + 1 = the counter)
+    hipLaunchKernelGGL(CountUnsetMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent, ba.cand_count + 1);
+    GPANN_HIP_TRY(hipGetLastError());
+    return GPANN_OK;
+}
+
+// GPANN_ROUTER_VERIFY=1: every bound-path result is compared, minimum by minimum, with the canonical evaluation of ALL pairs
+// (DenseDistKernel<.., MIN_ONLY>).  A difference ends the call with GPANN_ERR_INTERNAL after a second run of the bound path on the same
+// inputs and a report that says which stage's data differed between the two runs (stderr, and appended to $GPANN_VERIFY_REPORT).
+gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float* thr, const float* caller_queries,
+                         bool caller_on_device) {
+    const uint32_t S = r->S, ld = r->ld, d = r->d;
+    const uint64_t C = r->n_centroids;
+    const size_t nb_s = (size_t)nb * S;
+    GPANN_TRY(r->ws_verify.Reserve(nb_s * 4 + 16));
+    DenseArgs dv = da;
+    dv.out_min_bits = r->ws_verify.as<uint32_t>();
+    uint32_t* d_diff = ba.cand_count + 2;   // zeroed by EnqueueBound
+    const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
+    const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+    const uint32_t fgrid = (uint32_t)((nb_s + 255) / 256);
+    hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, dv.out_min_bits, nb_s);
+    if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, dv);
+    else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, true>), dgrid, dim3(256), dlds, st, dv);
+    GPANN_HIP_TRY(hipMemsetAsync(d_diff + 1, 0xFF, 4, st));
+    hipLaunchKernelGGL(DiffBitsKernel, dim3(fgrid), dim3(256), 0, st, da.out_min_bits, dv.out_min_bits, nb_s, d_diff);
+    GPANN_HIP_TRY(hipGetLastError());
+    uint32_t diff[2] = {0, 0};
+    GPANN_HIP_TRY(hipMemcpyAsync(diff, d_diff, 8, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    ++r->stat_verified;
+    if (diff[0] == 0) return GPANN_OK;
+    ++r->stat_verify_failures;
+
+    // ---- evidence: run 1's data, then the same pipeline once more on the same inputs
+    struct Snap { std::vector<uint32_t> max_bits, min_bits; std::vector<float> thr, queries; uint32_t counters[2]; };
+    auto snap = [&](Snap& s) -> hipError_t {
+        s.max_bits.resize(nb_s); s.min_bits.resize(nb_s); s.thr.resize(nb_s); s.queries.resize((size_t)nb * ld);
+        hipError_t e = hipMemcpy(s.max_bits.data(), ba.max_bits, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.thr.data(), thr, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.min_bits.data(), da.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.queries.data(), da.queries, (size_t)nb * ld * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.counters, ba.cand_count, 8, hipMemcpyDeviceToHost);
+        return e;
+    };
+    Snap s1, s2;
+    GPANN_HIP_TRY(snap(s1));
+    std::vector<uint2> cand1(std::min<uint32_t>(s1.counters[0], ba.cand_cap));
+    if (!cand1.empty()) GPANN_HIP_TRY(hipMemcpy(cand1.data(), ba.cand, cand1.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> want(nb_s);
+    GPANN_HIP_TRY(hipMemcpy(want.data(), dv.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, da.out_min_bits, nb_s);
+    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    GPANN_HIP_TRY(snap(s2));
+    std::vector<float> cents((size_t)C * ld);
+    std::vector<uint32_t> cshard(C);
+    GPANN_HIP_TRY(hipMemcpy(cents.data(), r->centroids, cents.size() * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(cshard.data(), r->cent_shard, C * 4, hipMemcpyDeviceToHost));
+    std::vector<float> nhn(C);
+    GPANN_HIP_TRY(hipMemcpy(nhn.data(), r->cent_nhn, C * 4, hipMemcpyDeviceToHost));
+
+    auto bits_to_float = [](uint32_t o) { uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; std::memcpy(&f, &b, 4); return f; };
+    size_t bad1 = 0, bad2 = 0, unset1 = 0, max_diff = 0, thr_diff = 0, thr_nan1 = 0, max_zero1 = 0, q_diff = 0, q_vs_caller = 0;
+    for (size_t i = 0; i < nb_s; ++i) {
+        bad1 += s1.min_bits[i] != want[i];
+        bad2 += s2.min_bits[i] != want[i];
+        unset1 += s1.min_bits[i] == 0xFF7FFFFFu;
+        max_diff += s1.max_bits[i] != s2.max_bits[i];
+        thr_diff += std::memcmp(&s1.thr[i], &s2.thr[i], 4) != 0;
+        thr_nan1 += std::isnan(s1.thr[i]);
+        max_zero1 += s1.max_bits[i] == 0;
+    }
+    for (size_t i = 0; i < s1.queries.size(); ++i) q_diff += std::memcmp(&s1.queries[i], &s2.queries[i], 4) != 0;
+    if (caller_queries && !caller_on_device)
+        for (uint32_t q = 0; q < nb; ++q)
+            for (uint32_t x = 0; x < d; ++x) q_vs_caller += std::memcmp(&s1.queries[(size_t)q * ld + x], &caller_queries[(size_t)q * d + x], 4) != 0;
+    std::string rep;
+    char line[1024];
+    snprintf(line, sizeof line,
+             "[gpann router VERIFY] bound path differs from the canonical evaluation: %zu of %zu minima (run 1), %zu (run 2 on the same inputs); run 1: %zu unset, "
+             "%zu thr NaN, %zu max_bits zero, candidates %u (cap %u), self-check counter %u; between the runs: %zu max_bits differ, %zu thr differ, %zu query words "
+             "differ; device queries vs caller's host queries: %zu words differ; nq %u S %u C %llu d %u n_seg %u\n",
+             bad1, nb_s, bad2, unset1, thr_nan1, max_zero1, s1.counters[0], ba.cand_cap, s1.counters[1], max_diff, thr_diff, q_diff, q_vs_caller, nb, S,
+             (unsigned long long)C, d, ba.n_seg);
+    rep += line;
+    int shown = 0;
+    for (size_t i = 0; i < nb_s && shown < 6; ++i) {
+        if (s1.min_bits[i] == want[i]) continue;
+        ++shown;
+        const uint32_t q = (uint32_t)(i / S), b = (uint32_t)(i % S);
+        // in double: the true acc of every centroid of the shard, the true minimiser
+        double best_acc = -1e300, best_dist = 1e300, acc_of_min = 0;
+        uint64_t arg_acc = 0, arg_min = 0, n_in = 0;
+        const float* qv = &s1.queries[(size_t)q * ld];
+        for (uint64_t c = 0; c < C; ++c) {
+            if (cshard[c] != b) continue;
+            ++n_in;
+            double dot = 0, dist = 0;
+            for (uint32_t x = 0; x < d; ++x) {
+                dot += (double)qv[x] * cents[c * ld + x];
+                const double df = (double)qv[x] - cents[c * ld + x];
+                dist += df * df;
+            }
+            const double acc = r->metric == GPANN_METRIC_L2 ? dot + (double)nhn[c] : dot;
+            const double key = r->metric == GPANN_METRIC_L2 ? dist : 1.0 - dot;
+            if (acc > best_acc) { best_acc = acc; arg_acc = c; }
+            if (key < best_dist) { best_dist = key; arg_min = c; acc_of_min = acc; }
+        }
+        size_t in_list = 0, list_has_min = 0;
+        for (const uint2& qc : cand1)
+            if (qc.x == q && qc.y != 0xFFFFFFFFu && cshard[qc.y] == b) { ++in_list; list_has_min += qc.y == arg_min; }
+        snprintf(line, sizeof line,
+                 "  (q %u, shard %u, %llu centroids): got %08x (%g) want %08x (%g); run 1 max %g thr %g | run 2 max %g thr %g min %08x; host: max acc %.9g at %llu, "
+                 "minimiser %llu dist %.9g acc %.9g (%s thr 1); candidates of the pair in run 1's list: %zu, minimiser among them: %zu\n",
+                 q, b, (unsigned long long)n_in, s1.min_bits[i], bits_to_float(s1.min_bits[i]), want[i], bits_to_float(want[i]), bits_to_float(s1.max_bits[i]),
+                 s1.thr[i], bits_to_float(s2.max_bits[i]), s2.thr[i], s2.min_bits[i], best_acc, (unsigned long long)arg_acc, (unsigned long long)arg_min, best_dist,
+                 acc_of_min, acc_of_min >= (double)s1.thr[i] ? ">=" : "<", in_list, list_has_min);
+        rep += line;
+    }
+    fputs(rep.c_str(), stderr);
+    if (const char* path = std::getenv("GPANN_VERIFY_REPORT")) {
+        if (FILE* f = fopen(path, "a")) {
+            fputs(rep.c_str(), f);
+            fclose(f);
+        }
+    }
+    SetLastError("router bound path failed verification: %zu of %zu minima differ from the canonical evaluation (GPANN_ROUTER_VERIFY)", bad1, nb_s);
+    return GPANN_ERR_INTERNAL;
+}
+
+gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, bool* settled, const float* caller_queries, bool caller_on_device) {
+    *settled = false;
+    const size_t nb_s = (size_t)nb * r->S;
+    BoundArgs ba;
+    float* thr = nullptr;
+    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
+    uint32_t counters[2] = {0, 0};   // candidate slots handed out, unset minima
+    GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    ++r->stat_bound_calls;
+    const uint32_t n_cand = counters[0];
+    if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidate slots for %u x %u (query, shard) pairs\n", n_cand, nb, r->S);
+    if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
+    if (counters[1] != 0) {
+        ++r->stat_bound_selfcheck;
+        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n", counters[1], nb_s);
+        if (std::getenv("GPANN_ROUTER_STRICT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
+            SetLastError("router bound path left %u of %zu minima unset (GPANN_ROUTER_STRICT)", counters[1], nb_s);
+            return GPANN_ERR_INTERNAL;
+        }
+        return GPANN_OK;
+    }
+    if (n_cand > ba.cand_cap) {
+        ++r->stat_bound_overflow;
+        return GPANN_OK;
+    }
+    if (std::getenv("GPANN_ROUTER_VERIFY")) GPANN_TRY(VerifyBound(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
+    hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+    GPANN_HIP_TRY(hipGetLastError());
+    *settled = true;
+    return GPANN_OK;
+}
 
 // Stages the queries, sizes the queue workspace and launches the walk for queries [0, nq); min_dist lands in r->ws_out.
 // rec_* (device, optional) receive every evaluated (distance, shard) pair.
@@ -1358,69 +1604,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 const char* bmode = std::getenv("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
                 if (r->cent_planes && !(bmode && bmode[0] == '0')) {
                     // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h)
-                    // (slots are handed out in chunks of 256 per wavefront: room for every wavefront's last, partly used chunk)
-                    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)nb_s * 4 + (uint64_t)((nb + 255) / 256) * 80 * 8 * 256 + 1024);
-                    GPANN_TRY(r->ws_bound.Reserve(nb_s * 8 + (size_t)cand_cap * 8 + 64));
-                    BoundArgs ba;
-                    ba.queries = da.queries;
-                    ba.cent_planes = r->cent_planes;
-                    ba.cent_nhn = r->cent_nhn;
-                    ba.cent_shard = r->cent_shard;
-                    ba.max_bits = r->ws_bound.as<uint32_t>();
-                    float* thr = reinterpret_cast<float*>(ba.max_bits + nb_s);
-                    ba.thr = thr;
-                    ba.cand = reinterpret_cast<uint2*>(thr + nb_s + (nb_s & 1));
-                    ba.cand_count = reinterpret_cast<uint32_t*>(ba.cand + cand_cap);
-                    ba.cand_cap = cand_cap;
-                    ba.nq = nb;
-                    ba.C = (uint32_t)C;
-                    ba.S = S;
-                    ba.ld = ld;
-                    const uint32_t groups = (nb + 255) / 256;
-                    const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
-                    ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
-                    GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
-                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 8, st));   // candidate counter + the self-check's counter
-                    GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
-                    const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
-                    const size_t blds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
-                    const void *f1, *f2;
-#define GPANN_PICKB(P_) (l2 ? (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, P_>) \
-                            : (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, P_>))
-                    f1 = GPANN_PICKB(1);
-                    f2 = GPANN_PICKB(2);
-#undef GPANN_PICKB
-                    GPANN_HIP_TRY(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
-                    GPANN_HIP_TRY(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
-                    void* kargs[] = {&ba};
-                    GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
-                    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
-                    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
-                    GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
-                    const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
-                    if (l2) hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_L2>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
-                                               r->cent_shard, da.out_min_bits, S, r->d, ld);
-                    else hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_MIPS>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
-                                            r->cent_shard, da.out_min_bits, S, r->d, ld);
-                    GPANN_HIP_TRY(hipGetLastError());
-                    // self-check: after a full visit every shard with centroids has a minimum.  (cand_count + 1 = the counter)
-                    hipLaunchKernelGGL(CountUnsetMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent,
-                                       ba.cand_count + 1);
-                    uint32_t counters[2] = {0, 0};   // candidates, unset minima
-                    GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
-                    GPANN_HIP_TRY(hipStreamSynchronize(st));
-                    const uint32_t n_cand = counters[0];
-                    if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidates for %u x %u (query, shard) pairs\n", n_cand, nb, S);
-                    if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
-                    if (counters[1] != 0)
-                        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n",
-                                counters[1], nb_s);
-                    if (n_cand <= cand_cap && counters[1] == 0) {
-                        hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
-                        GPANN_HIP_TRY(hipGetLastError());
-                        continue;
-                    }
-                    // (masses of equal distances) fall through to the canonical evaluation of every pair
+                    bool settled = false;
+                    GPANN_TRY(RunBoundPath(r, da, nb, st, &settled, queries + (size_t)q0 * r->d, (flags & GPANN_QUERIES_ON_DEVICE) != 0));
+                    if (settled) continue;
+                    // (masses of equal distances / self-check) fall through to the canonical evaluation of every pair
                     hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                 }
                 if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, da);
@@ -1506,6 +1693,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
                 GPANN_HIP_TRY(hipStreamSynchronize(st));
                 need_heap = marked != 0;
+                r->stat_heap_redo += marked;
                 if (std::getenv("GPANN_ROUTER_DEBUG"))
                     fprintf(stderr, "[gpann router] %s replay: %u of %u queries go to the heap kernel\n", sorted_ok ? "sorted" : "threshold", marked, nb);
                 hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
@@ -1683,6 +1871,7 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; ++q)
             if (flags[q]) redo.push_back(q);
+        r->stat_host_sorted += redo.size();
         if (!redo.empty()) {
             GPANN_TRY(fetch_min_dist());
             const uint32_t chunks = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)redo.size() * S) / 8192));

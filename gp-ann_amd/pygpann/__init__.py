@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -44,6 +44,10 @@ class ScanStats(C.Structure):
                 ("padded_pairs", C.c_uint64), ("filter_pairs", C.c_uint64), ("filter_candidates", C.c_uint64), ("filtered", C.c_uint32), ("reserved", C.c_uint32),
                 ("scan_ms", C.c_float), ("merge_ms", C.c_float), ("filter_ms", C.c_float), ("reserved2", C.c_float),
                 ("filter_rows", C.c_uint64), ("filter_rest_rows", C.c_uint64), ("filter_rest_ms", C.c_float), ("filter_rest_hi_only", C.c_uint32)]
+
+
+class RouterStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("bound_calls", "bound_selfcheck", "bound_overflow", "verified", "verify_failures", "host_sorted", "heap_redo")]
 
 
 def build(force=False):
@@ -89,6 +93,7 @@ def lib():
     L.gpann_router_train.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.POINTER(C.c_void_p)]
     L.gpann_kmeans.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _i32p, _f32p, _u32p]
     L.gpann_router_info.argtypes = [C.c_void_p, _u32p, C.POINTER(C.c_int), _u32p, _u32p, _u64p]
+    L.gpann_router_get_stats.argtypes = [C.c_void_p, C.POINTER(RouterStats)]
     L.gpann_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
     L.gpann_router_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
     L.gpann_router_frequency_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, _f32p, _f32p, _u32p, _u32p,
@@ -312,6 +317,12 @@ class Router:
                                          flat["node_child_first"].ctypes.data_as(_u32p), flat["node_child_count"].ctypes.data_as(_u32p),
                                          flat["shard_root"].ctypes.data_as(_u32p), flat["centroids"].ctypes.data_as(_f32p)))
         return flat
+
+    def stats(self):
+        """Counters of this handle (gpann_router_get_stats); bound_selfcheck and verify_failures must stay 0."""
+        st = RouterStats()
+        _check(lib().gpann_router_get_stats(self.h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in RouterStats._fields_}
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

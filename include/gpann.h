@@ -187,6 +187,21 @@ gpann_status gpann_router_info(const gpann_router* r, uint32_t* d, int* metric, 
 gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uint32_t* node_cent_first, uint32_t* node_child_first,
                                  uint32_t* node_child_count, uint32_t* shard_root, float* centroids);
 
+/* Counters of a router handle since its creation (additive; no reference counterpart).  `bound_selfcheck` and `verify_failures` must stay 0:
+ * the first counts query blocks whose matrix-core bound path (visit-everything case) left a minimum unset and were re-evaluated
+ * canonically, the second the blocks that differed from the canonical evaluation under GPANN_ROUTER_VERIFY=1 (those calls return
+ * GPANN_ERR_INTERNAL). */
+typedef struct gpann_router_stats {
+    uint64_t bound_calls;       /* query blocks answered through the matrix-core bound path */
+    uint64_t bound_selfcheck;   /* ... whose self-check fired (canonical evaluation of every pair instead) */
+    uint64_t bound_overflow;    /* ... whose candidate list overflowed (canonical evaluation instead) */
+    uint64_t verified;          /* GPANN_ROUTER_VERIFY=1: blocks compared, minimum by minimum, with the canonical evaluation */
+    uint64_t verify_failures;
+    uint64_t host_sorted;       /* queries whose final order came from the host's std::sort (equal min_dist values) */
+    uint64_t heap_redo;         /* queries replayed with the real priority queue after a sorted / threshold replay */
+} gpann_router_stats;
+gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* out);
+
 /* Batched KMeansTreeRouter::Query.  The best-first walk (all distance evaluations, the priority queue and the budget
  * rule) runs on the GPU.  The final order (std::sort over min_dist, kmeans_tree_router.cpp:125-127) is computed on the device for
  * the queries whose min_dist values are pairwise different (any correct sort gives the reference's permutation) and, for queries with

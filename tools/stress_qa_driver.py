@@ -42,11 +42,14 @@ first, bad = None, 0
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     out = f"{tmp}/qa{i}"
     r = subprocess.run([QA, tmp + "/base.fbin", tmp + "/query.fbin", f"{tmp}/gt{i}.bin", str(k), tmp + "/base.partition.k=5.KMeans", out, "KMeans", str(S)],
-                       capture_output=True, text=True, env=dict(os.environ, GPANN_MAX_ROUTER_BUDGET="100000"))
+                       capture_output=True, text=True, env=dict(os.environ, GPANN_MAX_ROUTER_BUDGET="100000", GPANN_ROUTER_VERIFY="1", GPANN_ROUTER_STRICT="1"))
     if r.returncode != 0:
         print("run", i, "failed:", r.stderr[-500:])
         bad += 1
         continue
+    if "VERIFY" in r.stderr or "minima unset" in r.stderr:
+        bad += 1
+        print("run", i, "router report:", r.stderr[-3000:], flush=True)
     lines = probe_lines(out + ".routes")
     if first is None:
         first = lines
