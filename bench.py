@@ -8,7 +8,7 @@ One "step" = one pass of the hot path over one batch of 10 000 queries that are 
     ->  [N > 1: all-gather of the per-slot partial results over RCCL]  ->  host merge (DedupNeighbors).
 The workload is BASELINE.json's north-star configuration (SURVEY.md §8 "NS"): 100M x 128 f32 Gaussian-mixture points
 (1024 centres, sigma 0.35, seed 555), 10k queries (seed 556), 40 k-means shards, k = 10, nprobe = the smallest value whose
-recall@10 reaches 0.9 (found by a sweep before the timed region; the ground truth is computed with the same scan kernel).
+recall@10 reaches 0.9 (found by a sweep before the timed region; the ground truth is computed with the exact scan mode).
 With N GPUs the 40 shards are spread over the ranks (LPT by size); total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (the scan kernel: algorithmic bytes / HIP-event kernel time against
@@ -31,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+VALU_F32_PEAK_TLANEOPS = 78.65   # 157.3 TFLOP/s fp32 vector counts an FMA as 2: unfused lane-ops (sub, mul, add) issue at half of it
 POINT_SEED, QUERY_SEED, CENTER_SEED = 555, 556, 7
 N_CENTERS, SIGMA = 1024, 0.35
 
@@ -122,15 +123,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-            except Exception as e:   # no usable RCCL: the exchange is small enough for gloo over host memory
-                log(f"nccl backend unavailable ({e}); using gloo")
-                args.backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(args.backend)
+        # nccl (= RCCL over xGMI) is the measured configuration: if it cannot be initialised the run FAILS — a number taken over
+        # gloo / host memory must be asked for explicitly (--backend gloo) and says so in the JSON line ("backend")
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     stream = torch.cuda.current_stream().cuda_stream
     n, d, nq, S, k = args.n, args.d, args.nq, args.shards, args.k
 
@@ -197,10 +194,14 @@ def main():
     bounds = np.searchsorted(sorted_assign, np.arange(S + 1))
     clusters_local = [local_rows_by_shard[bounds[b]:bounds[b + 1]] for b in range(S)]
     torch.cuda.synchronize()
+    t_index = time.time()
     shards = pygpann.Shards(local_points.data_ptr(), clusters_local, 0, local_rank, n=n_local, d=d)
+    index_build_s = time.time() - t_index   # InvertedIndex gather + (filter mode support data) bf16 planes, cells, radii
     shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
     del local_points
     torch.cuda.empty_cache()
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    hbm_resident_gb = (total_b - free_b) / 1e9   # everything this process holds in HBM once the store is built (rows, planes, queries, workspaces)
     def train_router(index_budget):
         """KMeansTreeRouter::Train (reference src/kmeans_tree_router.cpp:9-78; options as routes.cpp:130-157) on the GPU over ALL rows
         of the shards this rank holds; with several ranks every rank trains the subtrees of its own shards and the parts are merged"""
@@ -297,7 +298,11 @@ def main():
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
     all_probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    # the ground truth comes from the plain exact (VALU) scan whatever mode is timed: a defect of the filtered pipeline cannot
+    # hide in its own ground truth
+    shards.set_scan_mode(0)
     gt_slot_d, gt_slot_i, _ = scan_slots(all_probes, S, aux=True)
+    shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
     gt_slot_d, gt_slot_i = gt_slot_d.copy(), gt_slot_i.copy()   # (scan_slots hands out views of its reusable pinned buffers)
     gt_d, gt_i, _ = pygpann.merge_dedup(gt_slot_d, gt_slot_i, S, k)
     kth = gt_d[:, k - 1].copy()
@@ -364,6 +369,7 @@ def main():
     for _ in range(args.warmup):
         step()
     scan_ms, router_ms, algo_bytes, filter_ms, rest_ms, step_wall_ms, stats = [], [], [], [], [], [], None
+    router_bound_ms, router_bound_flops = [], 0.0
     import gc
     gc.collect()
     gc.disable()   # (a generation-2 collection in the middle of a 9 ms step is a visible outlier)
@@ -378,6 +384,9 @@ def main():
         filter_ms.append(st["filter_ms"])
         rest_ms.append(st["filter_rest_ms"])
         router_ms.append(r_ms)
+        rst = router.stats()
+        router_bound_ms.append(rst["last_bound_ms"])
+        router_bound_flops = rst["last_bound_flops"]
         algo_bytes.append(st["algorithmic_bytes"])
         stats = st
     barrier()
@@ -406,8 +415,8 @@ def main():
     filtered = bool(stats["filtered"])
     # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once; the rest pass — the
     # launch that streams (nearly) the whole store once — is the dominant kernel
-    traffic = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"true>": 1}, largest_launch=True) if filtered
-               else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
+    traffic, traffic_src = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"true>": 1}, largest_launch=True) if filtered
+                            else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
         f_s = float(np.mean(filter_ms)) / 1000.0
         r_s = float(np.mean(rest_ms)) / 1000.0
@@ -417,25 +426,39 @@ def main():
         ks_read = 4 if d <= 64 else (8 if d <= 128 else 16)   # 16-dim k-steps the kernel loads per row and plane (32 B each, zero padded)
         rest_bytes = stats["filter_rest_rows"] * (32.0 * ks_read * (1.0 if stats["filter_rest_hi_only"] else 2.0) + 4.0)
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
-        result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
-                              "traffic": traffic, "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s,
-                              "note": "achieved = algorithmic bytes of the reference's scan (rows x d x 4 per (query, probed shard), SURVEY 8d) / "
-                                      "HIP-event time of all scan kernels; frac > 1 because the exact answer needs far fewer bytes: cells whose "
-                                      "bounding ball cannot reach a task's k-th distance are skipped, the rest is bounded by bf16 MFMA products on "
-                                      "pre-split planes and only candidates get the canonical VALU evaluation.  The dominant launch (the rest pass of "
-                                      "FilterKernelCells) streams the needed planes once: kernel_hbm_* = the bytes it has to read / its own HIP-event "
-                                      "time (traffic = the PMC figure for that launch); a bare read loop reaches 6.5-6.8 TB/s on this part "
-                                      "(profiles/r01/hbm_read_peak.txt)",
-                              "kernel_hbm_bytes": rest_bytes, "kernel_hbm_GBps": rest_gbps, "kernel_hbm_frac": rest_gbps / HBM_PEAK_GBPS,
+        result["roofline"] = {"bound": "hbm", "achieved": rest_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rest_gbps / HBM_PEAK_GBPS,
+                              "traffic": traffic, "traffic_source": traffic_src,
+                              "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s, "kernel_bytes": rest_bytes,
+                              "note": "achieved = the bytes the dominant launch (the rest pass of FilterKernelCells) HAS TO read — its row tiles x (bf16 hi "
+                                      "plane + norm word) — / its own HIP-event time on the scan's stream; frac = achieved / 8 TB/s.  traffic = the PMC "
+                                      "figure (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) of that launch from the committed pass named in "
+                                      "traffic_source (null if there is none for this workload).  algorithmic_GBps = SURVEY 8d's figure — rows x d x 4 "
+                                      "per (query, probed shard), the bytes the REFERENCE streams — / HIP-event time of all scan kernels of the step; it "
+                                      "exceeds the HBM peak because the exact answer is produced without that work (cell pruning, bf16 matrix-core bound, "
+                                      "canonical re-scoring of the candidates only) and is not a roofline fraction",
+                              "algorithmic_GBps": hbm_alg, "algorithmic_bytes_per_step": float(np.mean(algo_bytes)),
                               "filter_kernels_ms": 1000.0 * f_s, "filter_mfma_TFLOPs": tflops, "filter_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
                               "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
-        result["roofline"] = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBPS,
-                              "traffic": traffic, "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
-                              "note": "algorithmic bytes (rows x d x 4 per (query, probed shard), SURVEY 8d) of rank 0 / HIP-event kernel time; each "
-                                      "HBM row is reused by up to 64 queries per workgroup, so the kernel is FP32-VALU bound and frac may exceed 1",
-                              "valu_lane_ops_per_s": stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0}
+        lane_ops = stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0
+        result["roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_F32_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                              "frac": lane_ops / 1e12 / VALU_F32_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_src,
+                              "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
+                              "note": "exact mode: every HBM row is reused by up to 64 queries per workgroup, so the kernel is bound by FP32 VALU issue (3 unfused "
+                                      "lane-ops per pair and dimension; peak = 157.3 TFLOP/s / 2 since nothing may be fused); algorithmic_GBps = SURVEY 8d's bytes "
+                                      "/ kernel time",
+                              "algorithmic_GBps": hbm_alg, "algorithmic_bytes_per_step": float(np.mean(algo_bytes)),
+                              "valu_lane_ops_per_s": lane_ops}
+    rb_s = float(np.mean(router_bound_ms)) / 1000.0 if router_bound_ms else 0.0
+    if rb_s > 0:
+        result["roofline"].update({"router_mfma_ms": 1000.0 * rb_s, "router_mfma_TFLOPs": router_bound_flops / rb_s / 1e12,
+                                   "router_mfma_frac": router_bound_flops / rb_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                   "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
+    result["backend"] = args.backend if world > 1 else "none (1 rank)"
+    result["world_size_seen"] = dist.get_world_size() if world > 1 else 1
+    result["index_build_s"] = index_build_s
+    result["hbm_resident_GB"] = hbm_resident_gb
     result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
@@ -445,7 +468,8 @@ def main():
                         "router_centroids": int(tree["centroids"].shape[0]), "setup_s": time.time() - t_setup}
 
     # the same steps with the plain exact (VALU) scan, for reference: identical results, no matrix cores
-    if args.scan_mode == "filter" and not args.no_exact_compare:
+    # (always: a filtered result that differs from the exact one fails the run — --no-exact-compare is accepted and ignored)
+    if args.scan_mode == "filter":
         shards.set_scan_mode(0)
         step()
         barrier()
@@ -460,13 +484,17 @@ def main():
                                           "hbm_algorithmic_GBps": st0["algorithmic_bytes"] / (st0["scan_ms"] / 1000.0) / 1e9,
                                           "results_identical_to_filter_mode": same}
         shards.set_scan_mode(1)
+        if not same:
+            raise SystemExit("bench: the filtered scan's ids / distances differ from the exact scan's on the same step — no result")
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts)
+            result["cpu_baseline"] = cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, md, mi)
         except Exception as e:   # the baseline must never take the headline number down with it
             result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if result["cpu_baseline"].get("results_match_gpu") is False:
+            raise SystemExit("bench: the GPU's neighbours differ from the CPU oracle's on the sampled queries — no result\n" + json.dumps(result["cpu_baseline"]))
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
@@ -499,66 +527,111 @@ def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=Fa
                             total += float(v["hbm_bytes_per_launch"]) * per_step
                         found = True
             if found:
-                best = total
+                best = (total, os.path.relpath(path, ROOT))
         except Exception:
             continue
-    return best
+    return best if best else (None, None)
 
 
-def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts):
-    """Time the strict CPU oracle (oracle/liboracle.so, `kind: port`) on the host cores over a bounded sample of the same
-    workload: the queries whose first `nprobe` probes fall into a few shards, scanned against those shards' real rows."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_dist, gpu_ids):
+    """Time the strict CPU oracle (oracle/liboracle.so, `kind: port`) on the host cores over a bounded sample of the same workload —
+    the queries whose first `nprobe` probes fall into a few shards, scanned against those shards' real rows — and compare its
+    neighbours with the GPU's for those queries (`results_match_gpu`).  Threads: all hardware threads, and min(32, hw) beside it
+    (the reference caps its query loops at 32 workers, routes.cpp:194 / shard_searches.cpp:48)."""
+    import concurrent.futures
     import pyoracle
     orc = pyoracle.Oracle("strict")
     cores = os.cpu_count() or 1
     S, k, d = args.shards, args.k, args.d
-    # choose shards until the sample holds ~1e10 (query, row) pairs
+    want_queries = min(len(probes), int(os.environ.get("GPANN_BENCH_CPU_QUERIES", 2560)))
+    # shards in ascending size until the sample holds enough queries (bounded host memory: <= 16 shards / 24 GB of rows)
     first = probes[:, :nprobe]
     chosen, sel_q, pairs = [], np.zeros(len(first), bool), 0
     for b in np.argsort(counts, kind="stable"):
-        qs = np.all(np.isin(first, chosen + [int(b)]), axis=1)
-        chosen.append(int(b))
-        sel_q = qs
-        pairs = int(sum(counts[first[q]].sum() for q in np.flatnonzero(qs)))
-        if pairs >= 1.2e10 or len(chosen) >= 8:
+        if (sum(int(counts[x]) for x in chosen) + int(counts[b])) * d * 4 > 24e9:
             break
-    qidx = np.flatnonzero(sel_q)
+        chosen.append(int(b))
+        sel_q = np.all(np.isin(first, chosen), axis=1)
+        if int(sel_q.sum()) >= want_queries or len(chosen) >= 16:
+            break
+    qidx = np.flatnonzero(sel_q)[:want_queries]
     if len(qidx) == 0:
         return {"value": None, "unit": "queries/s", "cores": cores, "kind": "port", "sample": "no query falls entirely into the sampled shards"}
-    # pull the sampled shards' rows to the host
+    pairs = int(sum(int(counts[first[q]].sum()) for q in qidx))
+    # the sampled shards' rows on the host: the pages are first touched by many threads, each taking every cores-th 2 MiB block, so
+    # they are spread over the host's memory nodes (a single-threaded concatenate puts the whole sample on one node)
     offs = shards.offsets()
     new_id = {b: i for i, b in enumerate(chosen)}
-    parts = [shards.export_range(int(offs[b]), int(offs[b + 1] - offs[b])) for b in chosen]
-    clustered = np.concatenate([p[1] for p in parts]) if len(parts) > 1 else parts[0][1]
-    ivf_perm = np.concatenate([p[0] for p in parts]).astype(np.uint32)
-    sizes = np.array([len(p[0]) for p in parts], np.int64)
+    sizes = np.array([int(offs[b + 1] - offs[b]) for b in chosen], np.int64)
+    total_rows = int(sizes.sum())
+    clustered = np.empty((total_rows, d), np.float32)
+    flat = clustered.reshape(-1).view(np.uint8)
+    block = 2 << 20
+    n_blocks = (flat.size + block - 1) // block
+    touchers = min(cores, 64)
+
+    def touch(i):
+        for blk in range(i, n_blocks, touchers):
+            flat[blk * block:min(flat.size, (blk + 1) * block)] = 0
+    with concurrent.futures.ThreadPoolExecutor(touchers) as ex:
+        list(ex.map(touch, range(touchers)))
+    ivf_perm = np.empty(total_rows, np.uint32)
+    pos = 0
+    for b, m in zip(chosen, sizes):
+        perm_b, rows_b = shards.export_range(int(offs[b]), int(m))
+        clustered[pos:pos + m] = rows_b
+        ivf_perm[pos:pos + m] = perm_b
+        pos += int(m)
+        del rows_b
     ivf_offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-    q_host = queries.cpu().numpy()[qidx]
-    ivf = (np.ascontiguousarray(clustered, np.float32), ivf_offsets, ivf_perm)
+    q_host = np.ascontiguousarray(queries.cpu().numpy()[qidx])
+    ivf = (clustered, ivf_offsets, ivf_perm)
     pr = np.vectorize(new_id.get)(first[qidx]).astype(np.int32)
-    otree = orc.kmtr_from_flat(tree, 0)
-    t0 = time.perf_counter()
-    otree.query_batch(q_host, args.search_budget, nthreads=cores)                         # route
-    od, oi, _ = orc.ivf_query_bucket_batch(ivf, q_host, k, pr, nprobe, 0, nthreads=cores)  # scan
-    offsets = np.arange(len(qidx) + 1, dtype=np.uint64) * (nprobe * k)
-    orc.dedup_neighbors(od.reshape(-1), oi.reshape(-1), offsets, k)                      # merge
-    dt = time.perf_counter() - t0
+    offsets_all = np.arange(len(qidx) + 1, dtype=np.uint64) * (nprobe * k)
+
+    def run(o, qsel, threads):
+        """route + scan + merge of the sampled queries `qsel` on `threads` host threads; returns (seconds, dist, ids)"""
+        otree = o.kmtr_from_flat(tree, 0)
+        t0 = time.perf_counter()
+        otree.query_batch(q_host[qsel], args.search_budget, nthreads=threads)
+        od, oi, _ = o.ivf_query_bucket_batch(ivf, q_host[qsel], k, pr[qsel], nprobe, 0, nthreads=threads)
+        md, mi, _ = o.dedup_neighbors(od.reshape(-1), oi.reshape(-1), offsets_all[:len(qsel) + 1], k)
+        return time.perf_counter() - t0, md, mi
+
+    everything = np.arange(len(qidx))
+    dt, cd, ci = run(orc, everything, cores)
+    # parity of the timed GPU path with the CPU path on the sample: ids and distance bits
+    cd, ci = np.asarray(cd).reshape(len(qidx), k), np.asarray(ci).reshape(len(qidx), k)
+    match = bool(np.array_equal(ci, gpu_ids[qidx]) and np.array_equal(cd.view(np.uint32), np.ascontiguousarray(gpu_dist[qidx]).view(np.uint32)))
+    # the reference's own thread cap, on a quarter of the sample
+    t32 = min(32, cores)
+    sub = everything[:max(1, len(qidx) // 4)]
+    dt32, _, _ = run(orc, sub, t32)
     # the same sample with the flags upstream ships (-O3 -march=native -ffast-math, CMakeLists.txt:15): not the parity oracle
     # (results may differ in the last bits), reported so the strict flags do not flatter the GPU
     fast = None
     try:
-        orc_fast = pyoracle.Oracle("refflags")
-        ftree = orc_fast.kmtr_from_flat(tree, 0)
-        t1 = time.perf_counter()
-        ftree.query_batch(q_host, args.search_budget, nthreads=cores)
-        fd, fi, _ = orc_fast.ivf_query_bucket_batch(ivf, q_host, k, pr, nprobe, 0, nthreads=cores)
-        orc_fast.dedup_neighbors(fd.reshape(-1), fi.reshape(-1), offsets, k)
-        fast = len(qidx) / (time.perf_counter() - t1)
+        dtf, _, _ = run(pyoracle.Oracle("refflags"), everything, cores)
+        fast = len(qidx) / dtf
     except Exception:
         pass
-    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port", "value_reference_flags": fast,
+    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_reference_flags": fast, "value_32_threads": len(sub) / dt32, "threads_32": t32, "results_match_gpu": match,
+            "sample_queries": int(len(qidx)), "sample_pairs": pairs, "sample_GBps": pairs * d * 4 / dt / 1e9,
             "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
-                      f"{pairs:.3g} (query,row) pairs in {dt:.1f}s on {cores} threads; strict build (-O2, no fast-math/FMA/AVX)",
+                      f"{pairs:.3g} (query,row) pairs = {pairs * d * 4 / 1e9:.0f} GB streamed in {dt:.1f}s on {cores} threads (rows first-touched by {touchers} "
+                      f"threads in interleaved 2 MiB blocks); strict build (-O2, no fast-math/FMA/AVX); value_32_threads: {len(sub)} of them on "
+                      f"{t32} threads in {dt32:.1f}s; value_reference_flags: -O3 -march=native -ffast-math on {cores} threads",
             "seconds": dt}
 
 

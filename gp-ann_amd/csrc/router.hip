@@ -55,6 +55,8 @@ struct gpann_router {
     gpann::DeviceBuffer ws_bound, ws_verify;
     uint64_t stat_bound_calls = 0, stat_bound_selfcheck = 0, stat_bound_overflow = 0, stat_verified = 0, stat_verify_failures = 0;
     uint64_t stat_host_sorted = 0, stat_heap_redo = 0;
+    hipEvent_t ev_bound[2] = {nullptr, nullptr};   // around the two RouterBoundKernel launches of the most recent bound block
+    double stat_bound_ms = 0.0, stat_bound_flops = 0.0;   // accumulated over the blocks of the most recent call
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
     gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
     float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
@@ -1162,6 +1164,7 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
     TRY_OR_FAIL(hipMemcpy(r->node_child_count, node_child_count, n_nodes * 4, hipMemcpyHostToDevice));
     TRY_OR_FAIL(hipMemcpy(r->shard_root, shard_root, S * 4, hipMemcpyHostToDevice));
     for (auto& e : r->ev) TRY_OR_FAIL(hipEventCreate(&e));
+    for (auto& e : r->ev_bound) TRY_OR_FAIL(hipEventCreate(&e));
     {
         hipDeviceProp_t prop;
         TRY_OR_FAIL(hipGetDeviceProperties(&prop, device));
@@ -1268,6 +1271,8 @@ gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* o
     out->verify_failures = r->stat_verify_failures;
     out->host_sorted = r->stat_host_sorted;
     out->heap_redo = r->stat_heap_redo;
+    out->last_bound_ms = r->stat_bound_ms;
+    out->last_bound_flops = r->stat_bound_flops;
     return GPANN_OK;
 }
 
@@ -1304,6 +1309,8 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (r->pinned_probes) (void)hipHostFree(r->pinned_probes);
     r->ws_probes.Release();
     for (auto& e : r->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->ev_bound)
         if (e) (void)hipEventDestroy(e);
     delete r;
     return GPANN_OK;
@@ -1361,10 +1368,12 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     GPANN_HIP_TRY(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
     GPANN_HIP_TRY(hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
     void* kargs[] = {&ba};
+    GPANN_HIP_TRY(hipEventRecord(r->ev_bound[0], st));
     GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
     if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
     else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
     GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+    GPANN_HIP_TRY(hipEventRecord(r->ev_bound[1], st));
     const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
     if (l2) hipLaunchKernelGGL(ExactCandidatesKernel<GPANN_METRIC_L2>, dim3(egrid), dim3(256), 0, st, r->centroids, ba.queries, ba.cand, ba.cand_count, cand_cap,
                                r->cent_shard, da.out_min_bits, S, r->d, ld);
@@ -1512,6 +1521,11 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
     ++r->stat_bound_calls;
+    {   // matrix-core work of this block: both passes run 3 bf16 products over nb x C x d
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r->ev_bound[0], r->ev_bound[1]) == hipSuccess) r->stat_bound_ms += ms;
+        r->stat_bound_flops += 2.0 * 2.0 * 3.0 * (double)nb * (double)r->n_centroids * (double)r->d;
+    }
     const uint32_t n_cand = counters[0];
     if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidate slots for %u x %u (query, shard) pairs\n", n_cand, nb, r->S);
     if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
@@ -1541,6 +1555,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                         int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap) {
     const uint32_t S = r->S, ld = r->ld;
     const size_t qbytes = (size_t)nq * ld * sizeof(float);
+    r->stat_bound_ms = r->stat_bound_flops = 0.0;
     const float* d_q = queries;   // device queries that already have the padded row layout are read in place
     if (!((flags & GPANN_QUERIES_ON_DEVICE) && ld == r->d && (reinterpret_cast<uintptr_t>(queries) & 15u) == 0)) {
         GPANN_TRY(r->ws_queries.Reserve(qbytes));

@@ -165,6 +165,13 @@ struct RescoreArgs {
     uint32_t dedupe;              // 1: skip candidates already in the list (cell passes)
     const uint32_t* overflow_count;   // buckets overflowed so far in this call (device counter) ...
     uint32_t overflow_limit;          // ... beyond this many the call falls back to the exact scan: no more in-kernel re-reads
+    // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
+    // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
+    uint32_t seed_rows;
+    const uint32_t* nearest;            // [tasks] nearest cell of the task, relative to its shard's first cell
+    const uint32_t* shard_cell_begin;   // [S+1]
+    const uint64_t* cell_tile_begin;    // [cells+1] first 32-row plane tile of every cell
+    const uint32_t* plane_perm;         // [tiles*32] plane row -> store row (0xFFFFFFFF: padding)
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
@@ -209,9 +216,22 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * 4 + wave;
     if (t >= a.tasks) return;
-    const uint32_t cnt = a.cand_cnt[t];
-    if (cnt == 0) return;
-    const bool overflowed = cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
+    const bool seed = a.seed_rows != 0;
+    uint64_t seed_first = 0;   // first plane row of the task's nearest cell
+    uint32_t cnt;
+    if (seed) {
+        // plane rows [seed_first, seed_first + cnt): from the nearest cell's first row onwards, inside the shard's plane range (the
+        // following cells are its neighbours along the cell chain); the loop below stops after seed_rows rows once the list is full
+        const uint32_t b = a.task_shard[t];
+        const uint64_t p0 = a.cell_tile_begin[a.shard_cell_begin[b]] * kGTileRows, p1 = a.cell_tile_begin[a.shard_cell_begin[b + 1]] * kGTileRows;
+        seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[t]] * kGTileRows;
+        if (seed_first + a.seed_rows > p1) seed_first = p1 - p0 > a.seed_rows ? p1 - a.seed_rows : p0;
+        cnt = (uint32_t)min((uint64_t)1 << 20, p1 - seed_first);
+    } else {
+        cnt = a.cand_cnt[t];
+        if (cnt == 0) return;
+    }
+    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
     if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
     float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
@@ -221,7 +241,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     const uint32_t k = a.k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
-    if (lane < (int)k) {
+    if (lane < (int)k && !seed) {
         ld_ = a.list_dist[(size_t)t * k + lane];
         lr_ = a.list_row[(size_t)t * k + lane];
     }
@@ -239,6 +259,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     auto load_block = [&](uint64_t first) -> uint32_t {
         const uint64_t idx = first + lane;
         if (idx >= n_items) return kNoId;
+        if (seed) return a.plane_perm[seed_first + idx];   // (kNoId on the padding of a cell's last tile: skipped like an absent candidate)
         return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + idx];
     };
     auto round_rows = [&](uint32_t block_rows, uint32_t sub) -> uint32_t {
@@ -267,6 +288,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     uint32_t row = round_rows(block_rows, 0);
     fetch(v, row, 0);
     for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
+        if (seed && base >= a.seed_rows && __shfl(ld_, (int)k - 1) < INFINITY) break;   // (wave-uniform) enough rows seen, list full
         const uint32_t sub = (uint32_t)(base / kRescoreSub) % (uint32_t)kRescoreRounds;
         __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
         stage(v, 0);

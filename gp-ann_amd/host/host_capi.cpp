@@ -136,6 +136,61 @@ int64_t gpann_host_overlap_spann(const float* points, uint64_t n, uint32_t d, co
     }
 }
 
+// ---- the file formats of the hot path's callers (points_io.cpp, metis_io.cpp): thin access for tests
+// ReadPoints(path, size): header -> *n, *d; coordinates -> out (capacity floats; may be null to query the shape).  Returns 0, -1 on error.
+int gpann_host_read_points(const char* path, int64_t size, uint64_t* n, uint32_t* d, float* out, uint64_t capacity) {
+    try {
+        PointSet ps = ReadPoints(path, size);
+        *n = ps.n;
+        *d = (uint32_t)ps.d;
+        if (out) {
+            if (ps.coordinates.size() > capacity) throw std::runtime_error("gpann_host_read_points: output capacity too small");
+            std::memcpy(out, ps.coordinates.data(), ps.coordinates.size() * 4);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+int gpann_host_write_points(const char* path, const float* points, uint64_t n, uint32_t d) {
+    try {
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        WritePoints(ps, path);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// WriteGroundTruth / ReadGroundTruth round trip: writes [nq][k] (dist, id) pairs, reads them back into out_*
+int gpann_host_ground_truth_roundtrip(const char* path, const float* dist, const uint32_t* ids, uint32_t nq, uint32_t k, float* out_dist, uint32_t* out_ids) {
+    try {
+        std::vector<NNVec> gt(nq, NNVec(k));
+        for (uint32_t q = 0; q < nq; ++q)
+            for (uint32_t j = 0; j < k; ++j) gt[q][j] = {dist[(size_t)q * k + j], ids[(size_t)q * k + j]};
+        WriteGroundTruth(path, gt);
+        std::vector<NNVec> back = ReadGroundTruth(path);
+        if (back.size() != nq) throw std::runtime_error("ground truth round trip: query count differs");
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (back[q].size() != k) throw std::runtime_error("ground truth round trip: k differs");
+            for (uint32_t j = 0; j < k; ++j) {
+                out_dist[(size_t)q * k + j] = back[q][j].first;
+                out_ids[(size_t)q * k + j] = back[q][j].second;
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 float gpann_host_distance(const float* p, const float* q, uint32_t d) { return distance(const_cast<float*>(p), const_cast<float*>(q), d); }
 
 }   // extern "C"

@@ -29,6 +29,9 @@ def lib():
         L.gpann_host_partition.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, C.c_int, C.c_double, C.c_uint64, C.c_int, _i32p]
         L.gpann_host_overlap_spann.restype = C.c_int64
         L.gpann_host_overlap_spann.argtypes = [_f32p, C.c_uint64, C.c_uint32, _i32p, C.c_int, C.c_double, C.c_double, C.c_int, _u32p, C.c_uint64, _u64p]
+        L.gpann_host_read_points.argtypes = [C.c_char_p, C.c_int64, _u64p, _u32p, _f32p, C.c_uint64]
+        L.gpann_host_write_points.argtypes = [C.c_char_p, _f32p, C.c_uint64, C.c_uint32]
+        L.gpann_host_ground_truth_roundtrip.argtypes = [C.c_char_p, _f32p, _u32p, C.c_uint32, C.c_uint32, _f32p, _u32p]
         L.gpann_host_distance.restype = C.c_float
         L.gpann_host_distance.argtypes = [_f32p, _f32p, C.c_uint32]
         _lib = L
@@ -112,3 +115,30 @@ def overlap_spann(points, partition, requested_num_clusters, eps, overlap, mips=
     if S < 0:
         raise RuntimeError(lib().gpann_host_last_error().decode())
     return [ids[int(offs[b]):int(offs[b + 1])].copy() for b in range(S)]
+
+
+def read_points(path, size=-1):
+    """ReadPoints (reference src/points_io.cpp:114-124): .fbin / .u8bin / .i8bin -> float32 [n, d]; `size` overrides n for .fbin only."""
+    n, d = C.c_uint64(), C.c_uint32()
+    if lib().gpann_host_read_points(path.encode(), size, C.byref(n), C.byref(d), None, 0) != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    out = np.empty((n.value, d.value), np.float32)
+    if lib().gpann_host_read_points(path.encode(), size, C.byref(n), C.byref(d), out.ctypes.data_as(_f32p), out.size) != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return out
+
+
+def write_points(path, points):
+    points = np.ascontiguousarray(points, np.float32)
+    if lib().gpann_host_write_points(path.encode(), points.ctypes.data_as(_f32p), points.shape[0], points.shape[1]) != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+
+
+def ground_truth_roundtrip(path, dist, ids):
+    """WriteGroundTruth then ReadGroundTruth (reference src/points_io.cpp:136-179)."""
+    dist, ids = np.ascontiguousarray(dist, np.float32), np.ascontiguousarray(ids, np.uint32)
+    od, oi = np.empty_like(dist), np.empty_like(ids)
+    if lib().gpann_host_ground_truth_roundtrip(path.encode(), dist.ctypes.data_as(_f32p), ids.ctypes.data_as(_u32p), dist.shape[0], dist.shape[1],
+                                               od.ctypes.data_as(_f32p), oi.ctypes.data_as(_u32p)) != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return od, oi

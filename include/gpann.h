@@ -199,6 +199,8 @@ typedef struct gpann_router_stats {
     uint64_t verify_failures;
     uint64_t host_sorted;       /* queries whose final order came from the host's std::sort (equal min_dist values) */
     uint64_t heap_redo;         /* queries replayed with the real priority queue after a sorted / threshold replay */
+    double last_bound_ms;       /* most recent call: HIP-event time of its RouterBoundKernel launches (pass 1 + margins + pass 2) */
+    double last_bound_flops;    /* most recent call: matrix-core flops of those launches, 2 passes x 3 bf16 products x 2 nq C d */
 } gpann_router_stats;
 gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* out);
 
