@@ -1,0 +1,90 @@
+/* gpann_comm.h — C-ABI of libgpann_comm.so: the exchange steps of the multi-GPU route + shard-scan path.
+ *
+ * One process per GPU, shards are the unit of distribution (rank = owner of a set of shards).  What this library replaces in the
+ * reference is the MPI layer of its (unfinished) distributed driver:
+ *
+ *   gpann_comm_init / _init_from_env   <- MPI_Init, MPI_Comm_rank, MPI_Comm_size          distributed_bench.cpp:27-31
+ *   gpann_comm_barrier                 <- MPI_Barrier                                     distributed_bench.cpp:45,52
+ *   gpann_comm_max_double              <- MPI_Reduce(MPI_MAX) of the elapsed time         distributed_bench.cpp:53-55
+ *   gpann_comm_broadcast               <- every rank reading the query file itself        distributed_bench.cpp:39 (here: rank 0 reads, RCCL broadcast)
+ *   gpann_comm_allgather               <- (probe lists of the routed query slices)        src/distributed_query_benchmark.h:104-108
+ *   gpann_comm_gather_slots            <- the request / response queues that carry a query to the owners of its probed shards and the
+ *                                         neighbours back                                src/distributed_query_benchmark.h:110-208
+ *   gpann_lpt_owner, gpann_mask_probes <- "partition[point] == rank" (one shard per rank) src/distributed_query_benchmark.h:49-53
+ *   gpann_merge_router_parts           <- LoadRouter on every rank                        src/distributed_query_benchmark.h:99-101
+ *
+ * Backends: GPANN_COMM_RCCL — device buffers, RCCL collectives over xGMI on the caller's HIP stream (ncclBroadcast / ncclAllGather);
+ * GPANN_COMM_TCP — host buffers over plain sockets through rank 0 (CPU-only tests of the same exchange logic; never chosen silently).
+ * Both bootstrap over one TCP connection per rank to rank 0 (address / port: arguments, or MASTER_ADDR and GPANN_COMM_PORT, default
+ * MASTER_PORT + 1, as exported by torch.distributed.run), which also carries the host-side scalars (barrier, max of a double) and,
+ * for RCCL, the ncclUniqueId.
+ *
+ * Conventions as in gpann.h: status codes, no exceptions, caller-allocated outputs; gpann_comm_last_error() describes the last failure
+ * in the calling thread.
+ */
+#ifndef GPANN_COMM_H
+#define GPANN_COMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gpann.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    GPANN_COMM_RCCL = 0,
+    GPANN_COMM_TCP = 1
+};
+
+typedef struct gpann_comm gpann_comm;
+
+const char* gpann_comm_last_error(void);
+
+/* device: HIP device of this rank (RCCL backend; ignored by TCP).  timeout_s: how long to wait for the other ranks to show up. */
+gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int port, int backend, int device, int timeout_s, gpann_comm** out);
+/* RANK, WORLD_SIZE, MASTER_ADDR, GPANN_COMM_PORT (default MASTER_PORT + 1), LOCAL_RANK (device) from the environment */
+gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out);
+gpann_status gpann_comm_destroy(gpann_comm* c);
+gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend);
+/* "rccl <version>" / "tcp": what the JSON line of bench.py reports as the backend that actually ran */
+const char* gpann_comm_backend_name(const gpann_comm* c);
+
+gpann_status gpann_comm_barrier(gpann_comm* c);
+gpann_status gpann_comm_max_double(gpann_comm* c, double* value /* in: this rank's; out: max over ranks */);
+/* small host buffers through the bootstrap connections (setup: shapes, tree parts): recv holds world * bytes */
+gpann_status gpann_comm_allgather_host(gpann_comm* c, const void* send, void* recv, size_t bytes);
+gpann_status gpann_comm_broadcast_host(gpann_comm* c, void* buf, size_t bytes, int root);
+
+/* Data path.  RCCL: device pointers, enqueued on `stream` (hipStream_t; the call returns without synchronising).  TCP: host pointers. */
+gpann_status gpann_comm_broadcast(gpann_comm* c, void* buf, size_t bytes, int root, void* stream);
+gpann_status gpann_comm_allgather(gpann_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+
+/* The result exchange.  dist / ids: this rank's per-slot lists [n] (n = queries * probes * k) with (+inf, GPANN_NO_ID) wherever the
+ * probed shard belongs to another rank — a slot is non-empty on exactly one rank.  out_dist / out_ids [n]: every slot from its owner.
+ * One all-gather of the (dist, id) lists + an owner-selection pass (device kernel / host loop).  `scratch` must hold
+ * gpann_comm_gather_slots_scratch(world, n) bytes in the backend's memory space. */
+size_t gpann_comm_gather_slots_scratch(int world, size_t n);
+gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uint32_t* ids, size_t n, float* out_dist, uint32_t* out_ids, void* scratch,
+                                     void* stream);
+
+/* ---- placement helpers (host) ---- */
+/* Longest-processing-time bin packing of S shards onto `world` ranks by descending size (ties: lower shard id first; the lighter
+ * rank, then the lower rank, takes the shard).  owner[S], load[world] (rows per rank; may be NULL). */
+gpann_status gpann_lpt_owner(const uint64_t* shard_rows, uint32_t S, uint32_t world, int32_t* owner, uint64_t* load);
+/* out[q][j] = probes[q][j] if owner[probes[q][j]] == rank else -1 (the probe slots this rank scans) */
+gpann_status gpann_mask_probes(const int32_t* probes, uint32_t nq, uint32_t probe_stride, uint32_t nprobe, const int32_t* owner, uint32_t S, int rank,
+                               int32_t* out /* [nq][nprobe] */);
+
+/* ---- router parts ---- */
+/* Every rank trains the subtrees of ITS shards (gpann_router_train on a store whose other shards are empty gives those shards an
+ * empty root).  This call all-gathers the parts through the bootstrap connections and builds, on every rank, the router over all S
+ * shards: shard b's subtree is taken from rank owner[b].  The result is the tree a single process would have trained. */
+gpann_status gpann_comm_merge_router(gpann_comm* c, gpann_router* mine, const int32_t* owner, int device, gpann_router** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPANN_COMM_H */
