@@ -172,6 +172,11 @@ __global__ void SelectSlotsKernel(const float* gathered_dist, const uint32_t* ga
     out_ids[i] = id;
 }
 
+__global__ void MapIdsKernel(const uint32_t* ids, const uint32_t* id_map, size_t n, uint32_t* out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ids[i] == GPANN_NO_ID ? GPANN_NO_ID : id_map[ids[i]];
+}
+
 int ConnectTo(const char* addr, int port, int timeout_s) {
     addrinfo hints{}, *res = nullptr;
     hints.ai_family = AF_INET;
@@ -369,7 +374,7 @@ gpann_status gpann_comm_allgather(gpann_comm* c, const void* send, void* recv, s
 size_t gpann_comm_gather_slots_scratch(int world, size_t n) { return (size_t)2 * (size_t)std::max(world, 1) * n * 4 + 2 * n * 4; }
 
 gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uint32_t* ids, size_t n, float* out_dist, uint32_t* out_ids, void* scratch,
-                                     void* stream) {
+                                     const uint32_t* id_map, void* stream) {
     COMM_REQUIRE(c != nullptr && (n == 0 || (dist && ids && out_dist && out_ids && scratch)), "null argument");
     if (n == 0) return GPANN_OK;
     const int W = c->world;
@@ -378,7 +383,12 @@ gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uin
     char* gathered = pack + 2 * n * 4;                          // [W][2n words]
     if (c->backend == GPANN_COMM_TCP) {
         std::memcpy(pack, dist, n * 4);
-        std::memcpy(pack + n * 4, ids, n * 4);
+        if (id_map) {
+            uint32_t* mapped = reinterpret_cast<uint32_t*>(pack + n * 4);
+            for (size_t i = 0; i < n; ++i) mapped[i] = ids[i] == GPANN_NO_ID ? GPANN_NO_ID : id_map[ids[i]];
+        } else {
+            std::memcpy(pack + n * 4, ids, n * 4);
+        }
         COMM_TRY(StarAllgather(c, pack, gathered, 2 * n * 4));
         for (size_t i = 0; i < n; ++i) {
             float d = std::numeric_limits<float>::infinity();
@@ -400,6 +410,12 @@ gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uin
     // the two lists are gathered as two collectives into [W][n] arrays (no packing copy); grouped, they go out as one launch
     float* g_dist = reinterpret_cast<float*>(gathered);
     uint32_t* g_ids = reinterpret_cast<uint32_t*>(gathered + (size_t)W * n * 4);
+    if (id_map) {   // local rows -> point ids (into the head of the scratch area)
+        uint32_t* mapped = reinterpret_cast<uint32_t*>(pack);
+        hipLaunchKernelGGL(MapIdsKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, ids, id_map, n, mapped);
+        COMM_HIP(hipGetLastError());
+        ids = mapped;
+    }
     COMM_NCCL(ncclGroupStart());
     COMM_NCCL(ncclAllGather(dist, g_dist, n, ncclFloat, c->nccl, st));
     COMM_NCCL(ncclAllGather(ids, g_ids, n, ncclUint32, c->nccl, st));

@@ -38,7 +38,7 @@ def lib():
         L.gpann_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gpann_comm_gather_slots_scratch.restype = C.c_size_t
         L.gpann_comm_gather_slots_scratch.argtypes = [C.c_int, C.c_size_t]
-        L.gpann_comm_gather_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gpann_comm_gather_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gpann_lpt_owner.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.gpann_mask_probes.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_int,
                                         C.POINTER(C.c_int32)]
@@ -134,9 +134,11 @@ class Comm:
     def gather_slots_scratch(self, n):
         return lib().gpann_comm_gather_slots_scratch(self.world, n)
 
-    def gather_slots(self, dist, ids, n, out_dist, out_ids, scratch, stream=None):
-        """per-slot lists of this rank -> every slot from its owner.  Arguments: device pointers (RCCL) or numpy arrays (TCP)."""
-        _check(lib().gpann_comm_gather_slots(self.h, _ptr(dist), _ptr(ids), n, _ptr(out_dist), _ptr(out_ids), _ptr(scratch), C.c_void_p(stream or 0)))
+    def gather_slots(self, dist, ids, n, out_dist, out_ids, scratch, id_map=None, stream=None):
+        """per-slot lists of this rank -> every slot from its owner.  Arguments: device pointers (RCCL) or numpy arrays (TCP).
+        id_map: local row id -> global point id, applied to this rank's ids before the exchange."""
+        _check(lib().gpann_comm_gather_slots(self.h, _ptr(dist), _ptr(ids), n, _ptr(out_dist), _ptr(out_ids), _ptr(scratch),
+                                             None if id_map is None else _ptr(id_map), C.c_void_p(stream or 0)))
 
     def merge_router(self, router, owner, device=0):
         """all ranks: Router trained over this rank's shards -> the Router over all shards (gpann_comm_merge_router)"""

@@ -11,7 +11,7 @@
  *   gpann_comm_gather_slots            <- the request / response queues that carry a query to the owners of its probed shards and the
  *                                         neighbours back                                src/distributed_query_benchmark.h:110-208
  *   gpann_lpt_owner, gpann_mask_probes <- "partition[point] == rank" (one shard per rank) src/distributed_query_benchmark.h:49-53
- *   gpann_merge_router_parts           <- LoadRouter on every rank                        src/distributed_query_benchmark.h:99-101
+ *   gpann_comm_merge_router            <- LoadRouter on every rank                        src/distributed_query_benchmark.h:99-101
  *
  * Backends: GPANN_COMM_RCCL — device buffers, RCCL collectives over xGMI on the caller's HIP stream (ncclBroadcast / ncclAllGather);
  * GPANN_COMM_TCP — host buffers over plain sockets through rank 0 (CPU-only tests of the same exchange logic; never chosen silently).
@@ -67,8 +67,10 @@ gpann_status gpann_comm_allgather(gpann_comm* c, const void* send, void* recv, s
  * One all-gather of the (dist, id) lists + an owner-selection pass (device kernel / host loop).  `scratch` must hold
  * gpann_comm_gather_slots_scratch(world, n) bytes in the backend's memory space. */
 size_t gpann_comm_gather_slots_scratch(int world, size_t n);
+/* id_map (may be NULL; same memory space as ids): ids[i] != GPANN_NO_ID is replaced by id_map[ids[i]] before the exchange — a rank's store
+ * is built over its own rows, so its scan reports LOCAL row ids; the map holds their global point ids. */
 gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uint32_t* ids, size_t n, float* out_dist, uint32_t* out_ids, void* scratch,
-                                     void* stream);
+                                     const uint32_t* id_map, void* stream);
 
 /* ---- placement helpers (host) ---- */
 /* Longest-processing-time bin packing of S shards onto `world` ranks by descending size (ties: lower shard id first; the lighter

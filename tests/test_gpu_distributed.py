@@ -1,0 +1,103 @@
+"""GPU: this build's DistributedBench (gp-ann_amd/drivers/distributed_bench.cpp = the reference's distributed_bench.cpp:13-62 over the
+multi-GPU DistributedQueryBenchmark) end to end through the C-ABI exchange layer (include/gpann_comm.h):
+  * one rank, RCCL backend (ncclBroadcast / ncclAllGather with world size 1, the owner-selection kernel);
+  * two and three ranks sharing GPU 0 over the TCP backend (RCCL refuses two ranks on one device; the exchange LOGIC is the same) — every
+    rank holds only its shards, trains only their subtrees, routes only its slice of the queries.
+The merged neighbours of all queries must equal the CPU oracle's single-process route + scan + DedupNeighbors, bit for bit."""
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_mixture
+
+pytestmark = pytest.mark.gpu
+
+DB = os.path.join(ROOT, "gp-ann_amd", "bin", "DistributedBench")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def data(orc, tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("dist")
+    n, d, nq, S, k, nprobe = 20000, 32, 301, 6, 10, 2
+    pts = make_mixture(orc, n, d, n_centers=32)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=32)
+    part, _ = orc.kmeans(pts, S, 555, 0, nthreads=4)
+    clusters = orc.partition_to_clusters(part)
+    f = dict(points=str(tmp / "base.fbin"), queries=str(tmp / "query.fbin"), gt=str(tmp / "gt.bin"), part=str(tmp / "base.partition"))
+    for path, a in ((f["points"], pts), (f["queries"], queries)):
+        with open(path, "wb") as fh:
+            np.array(a.shape, np.uint32).tofile(fh)
+            np.ascontiguousarray(a, np.float32).tofile(fh)
+    with open(f["part"], "w") as fh:
+        fh.write("".join(f"{int(p)}\n" for p in part))
+    gd, gi = orc.ground_truth(pts, queries, k, 0, nthreads=4)
+    with open(f["gt"], "wb") as fh:
+        np.array([nq, k], np.uint32).tofile(fh)
+        gi.astype(np.uint32).tofile(fh)
+        gd.astype(np.float32).tofile(fh)
+    # expected: Train{64, 350, n / S} -> Query(50000) -> first 2 probes -> QueryBucket -> DedupNeighbors
+    tree = orc.kmtr_train(pts, clusters, 64, 350, n // S, 0, nthreads=4)
+    probes, _ = tree.query_batch(queries, 50000, nthreads=4)
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, nprobe, 0, nthreads=4)
+    offs = np.arange(nq + 1, dtype=np.uint64) * (nprobe * k)
+    md, mi, _ = orc.dedup_neighbors(wd[:, :nprobe].reshape(-1), wi[:, :nprobe].reshape(-1), offs, k)
+    recall = orc.recall(md.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * k, gd[:, k - 1].copy(), k)
+    return dict(tmp=tmp, files=f, nq=nq, k=k, want_d=md.reshape(nq, k), want_i=mi.reshape(nq, k), recall=recall)
+
+
+def _run(data, world, backend, tag, router_name):
+    f = data["files"]
+    out = str(data["tmp"] / f"out_{tag}.bin")
+    router = str(data["tmp"] / router_name)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GPANN_COMM_BACKEND=backend, GPANN_DIST_DEVICE="0", GPANN_DIST_OUT=out, GPANN_DIST_REPS="2", GPANN_ROUTER_VERIFY="1", GPANN_ROUTER_STRICT="1")
+        procs.append(subprocess.Popen([DB, f["points"], f["queries"], f["gt"], str(data["k"]), f["part"], router], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-2000:]
+    raw = np.fromfile(out, np.uint32)
+    nq, k = int(raw[0]), int(raw[1])
+    assert (nq, k) == (data["nq"], data["k"])
+    ids = raw[2:2 + nq * k].reshape(nq, k)
+    dist = raw[2 + nq * k:2 + 2 * nq * k].reshape(nq, k)
+    assert np.array_equal(ids, data["want_i"]) and np.array_equal(dist, data["want_d"].view(np.uint32)), tag
+    line = [ln for ln in outs[0][0].split("\n") if ln.startswith("backend ")][0]
+    assert f"ranks {world}" in line and abs(float(line.split("recall ")[1].split(",")[0]) - data["recall"]) < 1e-6
+    assert "End-to-end time" in outs[0][0]
+    return line
+
+
+def test_one_rank_rccl(data):
+    assert os.path.exists(DB), "gp-ann_amd/bin/DistributedBench missing: run __graft_entry__.build()"
+    line = _run(data, 1, "rccl", "r1", "router_r1.tree")
+    assert line.startswith("backend rccl ")
+    # second run: the router is loaded from the tree file the first run wrote
+    assert os.path.exists(str(data["tmp"] / "router_r1.tree"))
+    _run(data, 1, "rccl", "r1b", "router_r1.tree")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_over_tcp(data, world):
+    line = _run(data, world, "tcp", f"t{world}", f"router_t{world}.tree")
+    assert line.startswith("backend tcp")
+    # ... and the tree the ranks trained part by part is the tree one rank trains
+    a = open(str(data["tmp"] / f"router_t{world}.tree"), "rb").read()
+    single = str(data["tmp"] / "router_r1.tree")
+    if os.path.exists(single):
+        assert a == open(single, "rb").read()
