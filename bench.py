@@ -99,16 +99,16 @@ def main():
                          "with the best QPS at the target recall is the one timed, as in the reference's Pareto evaluation")
     ap.add_argument("--scan-mode", choices=["exact", "filter"], default=os.environ.get("GPANN_BENCH_SCAN_MODE", "filter"),
                     help="exact: VALU scan of every row; filter: same exact results with the MFMA pre-filter (scan_filter.h)")
-    ap.add_argument("--backend", default=os.environ.get("GPANN_BENCH_BACKEND", "nccl"),
-                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI) or gloo (debugging: exchanges go through host tensors)")
+    ap.add_argument("--backend", default=os.environ.get("GPANN_BENCH_BACKEND", "rccl"), choices=["rccl", "tcp"],
+                    help="exchange backend of libgpann_comm.so for N > 1: rccl (RCCL over xGMI, device buffers) or tcp (debugging: the same "
+                         "payloads through host sockets, e.g. several ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     import pygpann
-    from pygpann import multigpu
+    from pygpann import comm as gcomm
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,11 +123,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        # nccl (= RCCL over xGMI) is the measured configuration: if it cannot be initialised the run FAILS — a number taken over
-        # gloo / host memory must be asked for explicitly (--backend gloo) and says so in the JSON line ("backend")
-        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        # the exchange layer is the C-ABI library libgpann_comm.so (include/gpann_comm.h): RCCL collectives on this process's HIP stream.
+        # RCCL over xGMI is the measured configuration: if it cannot be initialised the run FAILS — a number taken over host sockets must
+        # be asked for explicitly (--backend tcp) and says so in the JSON line ("backend")
+        comm = gcomm.Comm(gcomm.RCCL if args.backend == "rccl" else gcomm.TCP)   # RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK from the environment
+        if comm.world != args.gpus or comm.rank != rank:
+            raise SystemExit(f"communicator has {comm.world} ranks (this is rank {comm.rank}), --gpus {args.gpus}")
+    else:
+        comm = None
+    on_dev = args.backend == "rccl"
     stream = torch.cuda.current_stream().cuda_stream
     n, d, nq, S, k = args.n, args.d, args.nq, args.shards, args.k
 
@@ -142,12 +146,12 @@ def main():
     if world > 1:
         # the device k-means sums with float atomics, so its centroids differ in the last bits from run to run: every rank
         # must cut the cloud with rank 0's centroids or rows would be owned by two ranks / by none
-        if args.backend == "nccl":
-            dist.broadcast(shard_cent, src=0)
+        if on_dev:
+            comm.broadcast(shard_cent.data_ptr(), shard_cent.numel() * 4, 0, stream)
         else:
-            c = shard_cent.cpu()
-            dist.broadcast(c, src=0)
-            shard_cent.copy_(c)
+            c = shard_cent.cpu().numpy()
+            comm.broadcast(c, c.nbytes, 0)
+            shard_cent.copy_(torch.from_numpy(c))
         pygpann.nearest_centroid_device(sample.data_ptr(), n_sample, d, 0, shard_cent.data_ptr(), S, sample_assign.data_ptr(), stream)
     del sample, sample_assign
     log(f"shard centroids ready in {time.time() - t_setup:.1f}s")
@@ -162,7 +166,7 @@ def main():
         pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
         pygpann.nearest_centroid_device(buf.data_ptr(), m, d, 0, shard_cent.data_ptr(), S, assign_all[r0:r0 + m].data_ptr(), stream)
     counts = torch.bincount(assign_all.to(torch.int64), minlength=S).cpu().numpy()
-    owner, load = multigpu.lpt_owner(counts, world)
+    owner, load = gcomm.lpt_owner(counts, world)
     mine = np.flatnonzero(owner == rank)
     log(f"shard sizes min/max {counts.min()}/{counts.max()}, rank loads {load.tolist()}")
     # local point set = rows of my shards, in global-id order; Clusters hold GLOBAL ids, local_rows maps them to local rows
@@ -208,11 +212,9 @@ def main():
         t_train = time.time()
         rt = pygpann.Router.train(shards, n, args.router_centroids, args.router_min_cluster, index_budget)
         if world > 1:
-            part = rt.export()
-            parts = [None] * world
-            dist.all_gather_object(parts, part)
-            rt.close()
-            rt = pygpann.Router(multigpu.merge_trees(parts, owner), 0, local_rank)
+            part = rt
+            rt = comm.merge_router(part, owner, local_rank)   # every rank's subtrees -> the router over all shards, replicated
+            part.close()
         train_s = time.time() - t_train
         tr = rt.export()
         log(f"router (index budget {index_budget}) trained on the GPU in {train_s:.2f}s: {len(tr['node_shard'])} nodes, {tr['centroids'].shape[0]} centroids")
@@ -229,7 +231,7 @@ def main():
         return out
 
     my_ids_host = my_ids.cpu().numpy().astype(np.uint32)
-    my_ids_dev = my_ids.to(torch.int64)
+    my_ids_dev = my_ids.to(torch.int32)   # local row -> global point id (the id map of gpann_comm_gather_slots; ids < 2^31 here)
     del my_ids
 
     out_ids = torch.empty((nq, S, k), dtype=torch.int32, device=dev)
@@ -239,28 +241,37 @@ def main():
 
     def scan_slots(probes, nprobe, timed=False, aux=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
-        lp = multigpu.mask_probes(np.ascontiguousarray(probes[:, :nprobe]), owner, rank)
+        lp = gcomm.mask_probes(probes, nprobe, owner, rank) if world > 1 else np.ascontiguousarray(probes[:, :nprobe])
         if nprobe not in dev_out:   # (a slice + .contiguous() would allocate and launch a copy kernel in every step)
             dev_out[nprobe] = ((out_ids, out_dist) if nprobe == S else
                                (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)))
         oi, od = dev_out[nprobe]
         ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
+        key = (nq, nprobe)
         if world > 1:
-            # local row ids -> global ids on the device, then the exchange over RCCL: a slot is non-empty on exactly one rank, so
-            # MIN over the distances / MAX over the ids (multigpu.reduce_slots) is the all-gather + owner selection in one step
-            gi = torch.where(oi >= 0, my_ids_dev[oi.clamp(min=0).long()], torch.full_like(oi, -1, dtype=torch.int64))
-            if args.backend == "nccl":
-                multigpu.reduce_slots(od, gi, dist)
-                dist_h = od.cpu().numpy()
-                ids_h = gi.cpu().numpy().astype(np.uint32)
+            # the result exchange (gpann_comm_gather_slots): local row ids -> global ids, ONE all-gather of the per-slot lists over RCCL
+            # on this stream, owner selection on the device; the selected lists come back through pinned host buffers
+            n_slots = nq * nprobe * k
+            if key not in host_out:
+                host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory(),
+                                 torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev),
+                                 torch.empty(comm.gather_slots_scratch(n_slots), dtype=torch.uint8, device=dev if on_dev else "cpu"))
+            hd, hi, gd, gi, scratch = host_out[key]
+            if on_dev:
+                comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(), stream=stream)
+                hd.copy_(gd, non_blocking=True)
+                hi.copy_(gi, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
             else:
-                od_c, gi_c = od.cpu(), gi.cpu()
-                multigpu.reduce_slots(od_c, gi_c, dist)
-                dist_h = od_c.numpy()
-                ids_h = gi_c.numpy().astype(np.uint32)
+                hd.copy_(od, non_blocking=True)
+                hi.copy_(oi, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                sd_, si_ = hd.numpy().copy(), hi.numpy().view(np.uint32).copy()
+                comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
+            dist_h = hd.numpy()
+            ids_h = hi.numpy().view(np.uint32)
         else:
             # one rank holds every row in global-id order: local row id = global id.  Results come back through pinned host buffers
-            key = (nq, nprobe)
             if key not in host_out:
                 host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory())
             hd, hi = host_out[key]
@@ -283,17 +294,27 @@ def main():
             return pr, r_ms
         lo = min(nq, rank * chunk_q)
         hi = min(nq, lo + chunk_q)
-        mine = np.full((chunk_q, S), -1, np.int32)
         r_ms = 0.0
+        route_mine[:] = -1
         if hi > lo:
-            pr, _, r_ms = router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo)
-            mine[:hi - lo] = pr
-        t = torch.from_numpy(mine)
-        if args.backend == "nccl":
-            t = t.to(dev)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
-        return torch.cat(parts).cpu().numpy()[:nq], r_ms
+            _, _, r_ms = router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo,
+                                            out_probes=route_mine[:hi - lo], want_min_dist=False)
+        if on_dev:   # all-gather of the probe lists over RCCL on this stream
+            route_dev_mine.copy_(route_mine_t, non_blocking=True)
+            comm.allgather(route_dev_mine.data_ptr(), route_dev_all.data_ptr(), route_mine.nbytes, stream)
+            route_all_t.copy_(route_dev_all, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            comm.allgather(route_mine, route_all, route_mine.nbytes)
+        return route_all.reshape(-1, S)[:nq], r_ms
+
+    if world > 1:
+        route_mine_t = torch.empty((chunk_q, S), dtype=torch.int32).pin_memory()
+        route_all_t = torch.empty((world, chunk_q, S), dtype=torch.int32).pin_memory()
+        route_mine, route_all = route_mine_t.numpy(), route_all_t.numpy()
+        if on_dev:
+            route_dev_mine = torch.empty((chunk_q, S), dtype=torch.int32, device=dev)
+            route_dev_all = torch.empty((world, chunk_q, S), dtype=torch.int32, device=dev)
 
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
@@ -339,7 +360,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            comm.barrier()
         torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- router configurations (the reference's grid), best one is timed
@@ -355,11 +376,11 @@ def main():
         for _ in range(2):
             step()
         barrier()
-        trial = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=dev if (world > 1 and args.backend == "nccl") else "cpu")
+        trial = (time.perf_counter() - t0) / 2
         if world > 1:
-            dist.all_reduce(trial, op=dist.ReduceOp.MAX)
+            trial = comm.max_double(trial)
         candidates.append(dict(index_budget=index_budget, router=router, tree=tree, train_s=router_train_s, nprobe=nprobe, recall_curve=recall_curve,
-                               trial_ms=1000.0 * float(trial.item())))
+                               trial_ms=1000.0 * trial))
         log(f"index budget {index_budget}: {candidates[-1]['trial_ms']:.2f} ms per step")
     del gt_slot_d, gt_slot_i
     best = min(candidates, key=lambda c: c["trial_ms"])
@@ -393,9 +414,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = comm.max_double(elapsed)
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
     qps = nq * args.steps / elapsed
 
@@ -455,8 +474,8 @@ def main():
         result["roofline"].update({"router_mfma_ms": 1000.0 * rb_s, "router_mfma_TFLOPs": router_bound_flops / rb_s / 1e12,
                                    "router_mfma_frac": router_bound_flops / rb_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                    "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
-    result["backend"] = args.backend if world > 1 else "none (1 rank)"
-    result["world_size_seen"] = dist.get_world_size() if world > 1 else 1
+    result["backend"] = comm.name if world > 1 else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
+    result["world_size_seen"] = comm.world if world > 1 else 1
     result["index_build_s"] = index_build_s
     result["hbm_resident_GB"] = hbm_resident_gb
     result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
@@ -499,7 +518,8 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if world > 1:
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
 
 
 def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=False):

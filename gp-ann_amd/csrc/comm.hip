@@ -453,6 +453,106 @@ gpann_status gpann_mask_probes(const int32_t* probes, uint32_t nq, uint32_t prob
     return GPANN_OK;
 }
 
+// ---- replicas -------------------------------------------------------------------------------------------------------------------
+gpann_status gpann_plan_replicas(const uint64_t* shard_rows, const double* shard_work, uint32_t S, uint32_t world, uint64_t capacity_rows,
+                                 double max_imbalance, uint32_t* rep_begin, int32_t* rep_rank, double* rank_work_out, uint64_t* rank_rows_out) {
+    COMM_REQUIRE(world >= 1 && S >= 1 && shard_rows && shard_work && rep_begin && rep_rank, "argument");
+    COMM_REQUIRE(max_imbalance >= 1.0, "max_imbalance < 1");
+    std::vector<uint32_t> n_rep(S, 1);
+    std::vector<std::vector<int32_t>> where(S);
+    std::vector<double> work(world);
+    std::vector<uint64_t> rows(world);
+    // LPT placement of the current replica multiset: heaviest (work per replica, then rows) first onto the lightest rank that has room
+    // and does not hold the shard yet.  Returns false if some replica finds no rank.
+    auto place = [&]() -> bool {
+        struct Item { uint32_t shard; double w; };
+        std::vector<Item> items;
+        for (uint32_t b = 0; b < S; ++b)
+            for (uint32_t i = 0; i < n_rep[b]; ++i) items.push_back({b, shard_work[b] / n_rep[b]});
+        std::stable_sort(items.begin(), items.end(), [&](const Item& l, const Item& r) {
+            if (l.w != r.w) return l.w > r.w;
+            return shard_rows[l.shard] > shard_rows[r.shard];
+        });
+        std::fill(work.begin(), work.end(), 0.0);
+        std::fill(rows.begin(), rows.end(), 0ull);
+        for (auto& w : where) w.clear();
+        for (const Item& it : items) {
+            int best = -1;
+            for (uint32_t r = 0; r < world; ++r) {
+                if (rows[r] + shard_rows[it.shard] > capacity_rows) continue;
+                if (std::find(where[it.shard].begin(), where[it.shard].end(), (int32_t)r) != where[it.shard].end()) continue;
+                if (best < 0 || work[r] < work[best] || (work[r] == work[best] && rows[r] < rows[best])) best = (int)r;
+            }
+            if (best < 0) return false;
+            where[it.shard].push_back(best);
+            work[best] += it.w;
+            rows[best] += shard_rows[it.shard];
+        }
+        return true;
+    };
+    if (!place()) {
+        SetErr("the shards do not fit: capacity %llu rows per rank", (unsigned long long)capacity_rows);
+        return GPANN_ERR_INVALID;
+    }
+    std::vector<uint32_t> good_rep = n_rep;
+    std::vector<std::vector<int32_t>> good_where = where;
+    std::vector<double> good_work = work;
+    std::vector<uint64_t> good_rows = rows;
+    auto ratio_of = [&](const std::vector<double>& w) {
+        const double total = std::accumulate(w.begin(), w.end(), 0.0);
+        return total > 0.0 ? *std::max_element(w.begin(), w.end()) / (total / world) : 1.0;
+    };
+    double best_ratio = ratio_of(work);
+    std::vector<uint8_t> frozen(S, 0);
+    for (uint32_t round = 0; round < S * world && best_ratio > max_imbalance; ++round) {
+        // the shard with the most work per replica that can still get one (route_search_combination.cpp:152,181-182)
+        int pick = -1;
+        for (uint32_t b = 0; b < S; ++b)
+            if (!frozen[b] && n_rep[b] < world && (pick < 0 || shard_work[b] / n_rep[b] > shard_work[pick] / n_rep[pick])) pick = (int)b;
+        if (pick < 0) break;
+        n_rep[pick]++;
+        if (!place()) {   // no room for it: this shard stays as it was
+            n_rep[pick]--;
+            frozen[pick] = 1;
+            continue;
+        }
+        const double r = ratio_of(work);
+        if (r < best_ratio) {
+            best_ratio = r;
+            good_rep = n_rep;
+            good_where = where;
+            good_work = work;
+            good_rows = rows;
+        }
+    }
+    uint32_t at = 0;
+    for (uint32_t b = 0; b < S; ++b) {
+        rep_begin[b] = at;
+        for (int32_t r : good_where[b]) rep_rank[at++] = r;
+    }
+    rep_begin[S] = at;
+    if (rank_work_out) std::copy(good_work.begin(), good_work.end(), rank_work_out);
+    if (rank_rows_out) std::copy(good_rows.begin(), good_rows.end(), rank_rows_out);
+    return GPANN_OK;
+}
+
+gpann_status gpann_mask_probes_replicated(const int32_t* probes, uint32_t nq, uint32_t probe_stride, uint32_t nprobe, const uint32_t* rep_begin,
+                                          const int32_t* rep_rank, uint32_t S, int rank, int32_t* out) {
+    COMM_REQUIRE(nq == 0 || nprobe == 0 || (probes && rep_begin && rep_rank && out), "null argument");
+    COMM_REQUIRE(probe_stride >= nprobe, "probe_stride < nprobe");
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t j = 0; j < nprobe; ++j) {
+            const int32_t b = probes[(size_t)q * probe_stride + j];
+            int32_t v = -1;
+            if (b >= 0 && (uint32_t)b < S) {
+                const uint32_t r = rep_begin[b + 1] - rep_begin[b];
+                if (r && rep_rank[rep_begin[b] + q % r] == rank) v = b;
+            }
+            out[(size_t)q * nprobe + j] = v;
+        }
+    return GPANN_OK;
+}
+
 // ---- router parts ---------------------------------------------------------------------------------------------------------------
 gpann_status gpann_comm_merge_router(gpann_comm* c, gpann_router* mine, const int32_t* owner, int device, gpann_router** out) {
     COMM_REQUIRE(c != nullptr && mine != nullptr && owner != nullptr && out != nullptr, "null argument");

@@ -12,7 +12,7 @@ COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_comm.so")
 RCCL, TCP = 0, 1
 EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_destroy", "gpann_comm_info", "gpann_comm_backend_name",
            "gpann_comm_barrier", "gpann_comm_max_double", "gpann_comm_allgather_host", "gpann_comm_broadcast_host", "gpann_comm_broadcast",
-           "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_lpt_owner", "gpann_mask_probes",
+           "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
            "gpann_comm_merge_router"]
 _lib = None
 
@@ -42,6 +42,10 @@ def lib():
         L.gpann_lpt_owner.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.gpann_mask_probes.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_int,
                                         C.POINTER(C.c_int32)]
+        L.gpann_plan_replicas.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.gpann_mask_probes_replicated.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_uint32,
+                                                   C.c_int, C.POINTER(C.c_int32)]
         L.gpann_comm_merge_router.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
         _lib = L
     return _lib
@@ -78,6 +82,35 @@ def mask_probes(probes, nprobe, owner, rank, out=None):
         out = np.empty((nq, nprobe), np.int32)
     _check(lib().gpann_mask_probes(probes.ctypes.data_as(C.POINTER(C.c_int32)), nq, stride, nprobe, owner.ctypes.data_as(C.POINTER(C.c_int32)), len(owner),
                                    rank, out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
+def plan_replicas(shard_rows, shard_work, world, capacity_rows, max_imbalance=1.05):
+    """Replica placement for query-load balance (gpann_plan_replicas): returns (rep_begin[S+1] uint32, rep_rank int32 (CSR of the ranks
+    holding each shard, primary first), rank_work[world], rank_rows[world])."""
+    rows = np.ascontiguousarray(shard_rows, np.uint64)
+    work = np.ascontiguousarray(shard_work, np.float64)
+    S = len(rows)
+    rep_begin = np.empty(S + 1, np.uint32)
+    rep_rank = np.empty(S * world, np.int32)
+    rank_work = np.empty(world, np.float64)
+    rank_rows = np.empty(world, np.uint64)
+    _check(lib().gpann_plan_replicas(rows.ctypes.data_as(C.POINTER(C.c_uint64)), work.ctypes.data_as(C.POINTER(C.c_double)), S, world, int(capacity_rows),
+                                     float(max_imbalance), rep_begin.ctypes.data_as(C.POINTER(C.c_uint32)), rep_rank.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     rank_work.ctypes.data_as(C.POINTER(C.c_double)), rank_rows.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return rep_begin, rep_rank[:int(rep_begin[S])].copy(), rank_work, rank_rows.astype(np.int64)
+
+
+def mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, rank, out=None):
+    """the probe slots this rank scans under a replica placement: slot (q, b) belongs to replica q mod r_b of shard b"""
+    probes = np.ascontiguousarray(probes, np.int32)
+    rep_begin = np.ascontiguousarray(rep_begin, np.uint32)
+    rep_rank = np.ascontiguousarray(rep_rank, np.int32)
+    nq, stride = probes.shape
+    if out is None:
+        out = np.empty((nq, nprobe), np.int32)
+    _check(lib().gpann_mask_probes_replicated(probes.ctypes.data_as(C.POINTER(C.c_int32)), nq, stride, nprobe, rep_begin.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              rep_rank.ctypes.data_as(C.POINTER(C.c_int32)), len(rep_begin) - 1, rank, out.ctypes.data_as(C.POINTER(C.c_int32))))
     return out
 
 

@@ -80,6 +80,21 @@ gpann_status gpann_lpt_owner(const uint64_t* shard_rows, uint32_t S, uint32_t wo
 gpann_status gpann_mask_probes(const int32_t* probes, uint32_t nq, uint32_t probe_stride, uint32_t nprobe, const int32_t* owner, uint32_t S, int rank,
                                int32_t* out /* [nq][nprobe] */);
 
+/* ---- replicas: query-load balance (the reference MODELS replicas of the slowest shard when it predicts QPS, src/route_search_combination.cpp:149-183;
+ * here the same greedy rule produces a real placement) ----
+ * shard_work[b]: the work shard b attracts per batch, e.g. (queries routed to b) x rows_b from a routed sample batch.  Every shard starts
+ * with one replica; while the heaviest rank exceeds max_imbalance x the mean, the shard with the largest work PER REPLICA gets one more
+ * replica (`assigned_hosts[max_shard]++`, :181-182), as long as some rank that does not hold it yet has room (capacity_rows per rank);
+ * replicas are placed LPT by work per replica.  The tasks of a shard are split evenly over its replicas (gpann_mask_probes_replicated:
+ * query q goes to replica q mod r_b).
+ *   rep_begin[S+1], rep_rank[<= S * world]: CSR of the ranks holding each shard; rep_rank[rep_begin[b]] is the shard's primary (trains its subtree)
+ *   rank_work[world], rank_rows[world] (may be NULL): per-rank totals of the returned placement */
+gpann_status gpann_plan_replicas(const uint64_t* shard_rows, const double* shard_work, uint32_t S, uint32_t world, uint64_t capacity_rows,
+                                 double max_imbalance, uint32_t* rep_begin, int32_t* rep_rank, double* rank_work, uint64_t* rank_rows);
+/* out[q][j] = probes[q][j] if this rank is replica (q mod r_b) of shard b = probes[q][j], else -1 */
+gpann_status gpann_mask_probes_replicated(const int32_t* probes, uint32_t nq, uint32_t probe_stride, uint32_t nprobe, const uint32_t* rep_begin,
+                                          const int32_t* rep_rank, uint32_t S, int rank, int32_t* out /* [nq][nprobe] */);
+
 /* ---- router parts ---- */
 /* Every rank trains the subtrees of ITS shards (gpann_router_train on a store whose other shards are empty gives those shards an
  * empty root).  This call all-gathers the parts through the bootstrap connections and builds, on every rank, the router over all S
