@@ -91,6 +91,15 @@ def main():
     ap.add_argument("--shards", type=int, default=40)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--target-recall", type=float, default=0.9)
+    ap.add_argument("--config", choices=["ns", "c2", "c3", "c4"], default="ns",
+                    help="BASELINE.json configuration shapes: ns = the metric's own (100M x 128 L2, 40 shards; the default), c2 = 1M x 128, 8 shards, "
+                         "c3 = 10M x 96, 16 shards, nprobe 4, c4 = 100M x 200 inner product, 40 shards (sets --points/--d/--shards/--metric/--nprobe)")
+    ap.add_argument("--metric", choices=["l2", "ip"], default="l2", help="ip = the reference's MIPS_DISTANCE build: 1 - <p, q>")
+    ap.add_argument("--nprobe", type=int, default=0, help="probe exactly this many shards (0: the smallest count that reaches --target-recall)")
+    ap.add_argument("--dist", choices=["mixture", "uniform", "offset"], default="mixture",
+                    help="synthetic cloud: mixture = 1024 Gaussian clusters (the metric's workload); uniform = ONE Gaussian blob (no cluster structure: "
+                         "cells cannot prune); offset = the mixture moved by +100 in every coordinate (non-centred, SIFT-like: the bf16 bound's error "
+                         "term grows with (R + |q|)^2)")
     ap.add_argument("--search-budget", type=int, default=50000)
     ap.add_argument("--router-centroids", type=int, default=64)
     ap.add_argument("--router-min-cluster", type=int, default=350)
@@ -102,9 +111,21 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("GPANN_BENCH_BACKEND", "rccl"), choices=["rccl", "tcp"],
                     help="exchange backend of libgpann_comm.so for N > 1: rccl (RCCL over xGMI, device buffers) or tcp (debugging: the same "
                          "payloads through host sockets, e.g. several ranks on one GPU)")
+    ap.add_argument("--replica-capacity", type=float, default=float(os.environ.get("GPANN_BENCH_REPLICA_CAPACITY", 2.0)),
+                    help="N > 1: rows a rank may hold, in units of its fair share (rows / N); the room beyond 1.0 is filled with replicas of the "
+                         "shards that attract the most query work (0: no replicas, LPT by rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
+    preset = {"ns": {}, "c2": dict(n=1_000_000, d=128, shards=8), "c3": dict(n=10_000_000, d=96, shards=16, nprobe=4),
+              "c4": dict(n=100_000_000, d=200, shards=40, metric="ip")}[args.config]
+    for key, val in preset.items():
+        setattr(args, key, val)
+    metric = 1 if args.metric == "ip" else 0
+    n_centers, sigma = (1, 1.0) if args.dist == "uniform" else (N_CENTERS, SIGMA)
+    offset = 100.0 if args.dist == "offset" else 0.0
+    args.metric_id = metric
+    ops_per_dim = 2 if metric else 3   # unfused VALU lane-ops per (pair, dimension): mul + add (inner product) / sub + mul + add (L2)
 
     import torch
     import pygpann
@@ -138,10 +159,14 @@ def main():
     t_setup = time.time()
     # ---------------------------------------------------------------- synthetic inputs, generated straight into HBM
     queries = torch.empty((nq, d), dtype=torch.float32, device=dev)
-    pygpann.synth_rows_device(queries.data_ptr(), QUERY_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, nq, d, stream)
+    def synth(t, seed, row0, rows):
+        pygpann.synth_rows_device(t.data_ptr(), seed, CENTER_SEED, n_centers, sigma, row0, rows, d, stream)
+        if offset:
+            t[:rows] += offset
+    synth(queries, QUERY_SEED, 0, nq)
     n_sample = min(n, 2_000_000)
     sample = torch.empty((n_sample, d), dtype=torch.float32, device=dev)
-    pygpann.synth_rows_device(sample.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, 0, n_sample, d, stream)
+    synth(sample, POINT_SEED, 0, n_sample)
     shard_cent, sample_assign = lloyd_gpu(torch, pygpann, sample, S, 20, 555, stream)
     if world > 1:
         # the device k-means sums with float atomics, so its centroids differ in the last bits from run to run: every rank
@@ -163,12 +188,28 @@ def main():
     buf = torch.empty((min(chunk, n), d), dtype=torch.float32, device=dev)
     for r0 in range(0, n, chunk):
         m = min(chunk, n - r0)
-        pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
+        synth(buf, POINT_SEED, r0, m)
         pygpann.nearest_centroid_device(buf.data_ptr(), m, d, 0, shard_cent.data_ptr(), S, assign_all[r0:r0 + m].data_ptr(), stream)
     counts = torch.bincount(assign_all.to(torch.int64), minlength=S).cpu().numpy()
-    owner, load = gcomm.lpt_owner(counts, world)
-    mine = np.flatnonzero(owner == rank)
-    log(f"shard sizes min/max {counts.min()}/{counts.max()}, rank loads {load.tolist()}")
+    # Placement.  Rows alone (LPT) balance memory, not work: a shard's work per batch is (queries routed to it) x rows, and the popular
+    # shards are also the big ones.  The query load is estimated before anything is built — queries per shard = nearest shard centroid —
+    # and the hottest shards get replicas while a rank has room (gpann_plan_replicas; the reference models exactly this when it
+    # predicts QPS, route_search_combination.cpp:149-183).  A replicated shard's tasks are split over its replicas by query id.
+    placement = None
+    if world > 1 and args.replica_capacity > 0:
+        qa = torch.empty(nq, dtype=torch.int32, device=dev)
+        pygpann.nearest_centroid_device(queries.data_ptr(), nq, d, 0, shard_cent.data_ptr(), S, qa.data_ptr(), stream)
+        est_tasks = np.bincount(qa.cpu().numpy().astype(np.int64), minlength=S).astype(np.float64) + 0.5
+        cap_rows = int(max(args.replica_capacity * counts.sum() / world, 1.25 * counts.max()))
+        rep_begin, rep_rank, rank_work, load = gcomm.plan_replicas(counts, est_tasks * counts, world, cap_rows, 1.05)
+        owner = rep_rank[rep_begin[:-1]].astype(np.int32)          # the primary of every shard (trains its subtree)
+        mine = np.array([b for b in range(S) if rank in rep_rank[rep_begin[b]:rep_begin[b + 1]]], np.int64)
+        placement = {"replicas": int(rep_begin[S]) - S, "capacity_rows": cap_rows, "rank_rows": [int(x) for x in load],
+                     "estimated_work_max_over_mean": float(rank_work.max() / rank_work.mean())}
+    else:
+        owner, load = gcomm.lpt_owner(counts, world)
+        mine = np.flatnonzero(owner == rank)
+    log(f"shard sizes min/max {counts.min()}/{counts.max()}, rank rows {[int(x) for x in load]}" + (f", placement {placement}" if placement else ""))
     # local point set = rows of my shards, in global-id order; Clusters hold GLOBAL ids, local_rows maps them to local rows
     mine_mask = torch.zeros(S, dtype=torch.bool, device=dev)
     mine_mask[torch.as_tensor(mine, device=dev)] = True
@@ -183,7 +224,7 @@ def main():
         c = int(kc.sum())
         if c == 0:
             continue
-        pygpann.synth_rows_device(buf.data_ptr(), POINT_SEED, CENTER_SEED, N_CENTERS, SIGMA, r0, m, d, stream)
+        synth(buf, POINT_SEED, r0, m)
         local_points[pos:pos + c] = buf[:m][kc]
         pos += c
     del buf, keep
@@ -199,11 +240,15 @@ def main():
     clusters_local = [local_rows_by_shard[bounds[b]:bounds[b + 1]] for b in range(S)]
     torch.cuda.synchronize()
     t_index = time.time()
-    shards = pygpann.Shards(local_points.data_ptr(), clusters_local, 0, local_rank, n=n_local, d=d)
-    index_build_s = time.time() - t_index   # InvertedIndex gather + (filter mode support data) bf16 planes, cells, radii
-    shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
+    # two steps: the rows (InvertedIndex gather) while the generated point array still exists, the filter's planes / cells after it is gone
+    # (100M x 200: 80 GB + 80 GB + 102 GB would not fit)
+    shards = pygpann.Shards(local_points.data_ptr(), clusters_local, metric, local_rank, n=n_local, d=d, plain=True)
     del local_points
     torch.cuda.empty_cache()
+    if args.scan_mode == "filter":
+        shards.build_filter()
+    index_build_s = time.time() - t_index   # InvertedIndex gather + (filter mode support data) bf16 planes, cells, radii
+    shards.set_scan_mode(1 if args.scan_mode == "filter" else 0)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_resident_gb = (total_b - free_b) / 1e9   # everything this process holds in HBM once the store is built (rows, planes, queries, workspaces)
     def train_router(index_budget):
@@ -241,7 +286,12 @@ def main():
 
     def scan_slots(probes, nprobe, timed=False, aux=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host"""
-        lp = gcomm.mask_probes(probes, nprobe, owner, rank) if world > 1 else np.ascontiguousarray(probes[:, :nprobe])
+        if world == 1:
+            lp = np.ascontiguousarray(probes[:, :nprobe])
+        elif placement:
+            lp = gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, rank)
+        else:
+            lp = gcomm.mask_probes(probes, nprobe, owner, rank)
         if nprobe not in dev_out:   # (a slice + .contiguous() would allocate and launch a copy kernel in every step)
             dev_out[nprobe] = ((out_ids, out_dist) if nprobe == S else
                                (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)))
@@ -339,7 +389,7 @@ def main():
             md, mi, _ = pygpann.merge_dedup(routed_d, routed_i, np_try, k)
             rec = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
             curve.append(round(rec, 6))
-            if rec >= args.target_recall:
+            if (args.nprobe and np_try == args.nprobe) or (not args.nprobe and rec >= args.target_recall):
                 return np_try, curve
         return S, curve
 
@@ -419,14 +469,16 @@ def main():
     qps = nq * args.steps / elapsed
 
     result = {
-        "metric": "QPS @ recall@10=0.9, 10k batched queries",
+        "metric": "QPS @ recall@10=0.9, 10k batched queries" if not args.nprobe else f"QPS @ nprobe={args.nprobe}, 10k batched queries",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"NS: {n}x{d} f32 Gaussian mixture ({N_CENTERS} centres, sigma {SIGMA}), {nq} queries, {S} k-means shards, "
+        "config": {"workload": f"{args.config.upper()}: {n}x{d} f32 {'inner product' if metric else 'L2'}, "
+                               + (f"Gaussian mixture ({n_centers} centres, sigma {sigma})" if args.dist != "uniform" else "one Gaussian blob (no clusters)")
+                               + (f" + {offset:g} in every coordinate" if offset else "") + f", {nq} queries, {S} k-means shards, "
                                f"k={k}, KMeansTreeRouter ({tree['centroids'].shape[0]} centroids in {len(tree['node_shard'])} nodes, search budget {args.search_budget}) + exact "
                                f"shard scan, nprobe={nprobe}",
-                   "n": n, "d": d, "queries": nq, "shards": S, "k": k, "nprobe": nprobe, "recall_at_k": recall,
+                   "n": n, "d": d, "metric": args.metric, "dist": args.dist, "queries": nq, "shards": S, "k": k, "nprobe": nprobe, "recall_at_k": recall,
                    "parallelism": f"shards over {world} GPU(s), LPT"},
     }
     avg_scan_s = float(np.mean(scan_ms)) / 1000.0
@@ -460,7 +512,7 @@ def main():
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
                               "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
-        lane_ops = stats["padded_pairs"] * d * 3 / avg_scan_s if avg_scan_s > 0 else 0.0
+        lane_ops = stats["padded_pairs"] * d * ops_per_dim / avg_scan_s if avg_scan_s > 0 else 0.0
         result["roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_F32_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                               "frac": lane_ops / 1e12 / VALU_F32_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gpann::ScanTileKernel", "kernel_ms": 1000.0 * avg_scan_s,
@@ -476,6 +528,11 @@ def main():
                                    "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
     result["backend"] = comm.name if world > 1 else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
     result["world_size_seen"] = comm.world if world > 1 else 1
+    if world > 1:
+        # the work every rank actually did in the last timed step: task rows (pairs) of its scan
+        per_rank = comm.allgather_host(np.array([float(stats["pairs"])], np.float64)).reshape(-1)
+        result["placement"] = dict(placement or {"replicas": 0}, rank_task_rows=[float(x) for x in per_rank],
+                                   task_rows_max_over_mean=float(per_rank.max() / max(per_rank.mean(), 1.0)))
     result["index_build_s"] = index_build_s
     result["hbm_resident_GB"] = hbm_resident_gb
     result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
@@ -485,6 +542,31 @@ def main():
                         "router_configs": [{kk: c[kk] for kk in ("index_budget", "nprobe", "trial_ms", "train_s", "recall_curve")} | {"centroids": int(c["tree"]["centroids"].shape[0]), "nodes": int(len(c["tree"]["node_shard"]))} for c in candidates],
                         "router_nodes": int(len(tree["node_shard"])),
                         "router_centroids": int(tree["centroids"].shape[0]), "setup_s": time.time() - t_setup}
+
+    # tuning aid (off by default): GPANN_BENCH_SWEEP="GPANN_FILTER_SEED_ROWS=64,128;GPANN_FILTER_HEAD_ROWS=512,0" times a few steps for every
+    # combination of the listed library knobs (they are read per call) and checks that the results do not change
+    if os.environ.get("GPANN_BENCH_SWEEP") and world == 1:
+        import itertools
+        knobs = [(kv.split("=")[0], kv.split("=")[1].split(",")) for kv in os.environ["GPANN_BENCH_SWEEP"].split(";") if kv]
+        sweep = []
+        for combo in itertools.product(*[v for _, v in knobs]):
+            for (name, _), val in zip(knobs, combo):
+                os.environ[name] = val
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                md_s, mi_s, _, _ = step()
+            barrier()
+            dt = (time.perf_counter() - t0) / 6
+            st_s = shards.stats()
+            same = bool(np.array_equal(mi_s, mi) and np.array_equal(md_s.view(np.uint32), md.view(np.uint32)))
+            sweep.append({"knobs": dict(zip([n_ for n_, _ in knobs], combo)), "ms_per_step": 1000.0 * dt, "scan_kernels_ms": st_s["scan_ms"], "rest_ms": st_s["filter_rest_ms"],
+                          "candidates": st_s["filter_candidates"], "rest_rows": st_s["filter_rest_rows"], "filtered": st_s["filtered"], "identical": same})
+            log(f"sweep {sweep[-1]}")
+        for name, _ in knobs:
+            os.environ.pop(name, None)
+        result["detail"]["sweep"] = sweep
 
     # the same steps with the plain exact (VALU) scan, for reference: identical results, no matrix cores
     # (always: a filtered result that differs from the exact one fails the run — --no-exact-compare is accepted and ignored)
@@ -499,7 +581,7 @@ def main():
         st0 = shards.stats()
         same = bool(np.array_equal(mi0, mi) and np.array_equal(md0.view(np.uint32), md.view(np.uint32)))
         result["detail"]["exact_mode"] = {"qps": nq / dt, "ms_per_step": 1000.0 * dt, "scan_kernel_ms": st0["scan_ms"],
-                                          "valu_lane_ops_per_s": st0["padded_pairs"] * d * 3 / (st0["scan_ms"] / 1000.0),
+                                          "valu_lane_ops_per_s": st0["padded_pairs"] * d * ops_per_dim / (st0["scan_ms"] / 1000.0),
                                           "hbm_algorithmic_GBps": st0["algorithmic_bytes"] / (st0["scan_ms"] / 1000.0) / 1e9,
                                           "results_identical_to_filter_mode": same}
         shards.set_scan_mode(1)
@@ -621,10 +703,10 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
 
     def run(o, qsel, threads):
         """route + scan + merge of the sampled queries `qsel` on `threads` host threads; returns (seconds, dist, ids)"""
-        otree = o.kmtr_from_flat(tree, 0)
+        otree = o.kmtr_from_flat(tree, args.metric_id)
         t0 = time.perf_counter()
         otree.query_batch(q_host[qsel], args.search_budget, nthreads=threads)
-        od, oi, _ = o.ivf_query_bucket_batch(ivf, q_host[qsel], k, pr[qsel], nprobe, 0, nthreads=threads)
+        od, oi, _ = o.ivf_query_bucket_batch(ivf, q_host[qsel], k, pr[qsel], nprobe, args.metric_id, nthreads=threads)
         md, mi, _ = o.dedup_neighbors(od.reshape(-1), oi.reshape(-1), offsets_all[:len(qsel) + 1], k)
         return time.perf_counter() - t0, md, mi
 

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <numeric>
+#include <queue>
 #include <string>
 #include <atomic>
 #include <condition_variable>
@@ -67,6 +68,12 @@ struct gpann_router {
     uint32_t root_total = 0, root_min = 0, root_children = 0;   // over the S roots: sum / min of sizes, number of children
     bool leaves_only = false;                                   // every non-root node is a leaf
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // host copy of the flat tree: the few queries of a batch whose walk needs the real priority queue are replayed on host threads
+    std::vector<int32_t> h_node_shard;
+    std::vector<uint32_t> h_node_cent_first, h_node_child_first, h_node_child_count, h_shard_root;
+    gpann::DeviceBuffer ws_host_redo;      // packed table rows / results of those queries
+    float* pinned_redo = nullptr;          // their table rows on the host
+    size_t pinned_redo_floats = 0;
 };
 
 namespace gpann {
@@ -1163,6 +1170,11 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
     TRY_OR_FAIL(hipMemcpy(r->node_child_first, node_child_first, n_nodes * 4, hipMemcpyHostToDevice));
     TRY_OR_FAIL(hipMemcpy(r->node_child_count, node_child_count, n_nodes * 4, hipMemcpyHostToDevice));
     TRY_OR_FAIL(hipMemcpy(r->shard_root, shard_root, S * 4, hipMemcpyHostToDevice));
+    r->h_node_shard.assign(node_shard, node_shard + n_nodes);
+    r->h_node_cent_first.assign(node_cent_first, node_cent_first + n_nodes + 1);
+    r->h_node_child_first.assign(node_child_first, node_child_first + n_nodes);
+    r->h_node_child_count.assign(node_child_count, node_child_count + n_nodes);
+    r->h_shard_root.assign(shard_root, shard_root + S);
     for (auto& e : r->ev) TRY_OR_FAIL(hipEventCreate(&e));
     for (auto& e : r->ev_bound) TRY_OR_FAIL(hipEventCreate(&e));
     {
@@ -1305,6 +1317,8 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_pi.Release();
     r->ws_bound.Release();
     r->ws_verify.Release();
+    r->ws_host_redo.Release();
+    if (r->pinned_redo) (void)hipHostFree(r->pinned_redo);
     if (r->pinned_min) (void)hipHostFree(r->pinned_min);
     if (r->pinned_probes) (void)hipHostFree(r->pinned_probes);
     r->ws_probes.Release();
@@ -1317,6 +1331,130 @@ gpann_status gpann_router_destroy(gpann_router* r) {
 }
 
 namespace {
+
+// ---- host replay of the queries a sorted / threshold replay could not settle ---------------------------------------------------------
+// Equal keys in the cut-off group: only libstdc++'s own heap order says which of the tied nodes is popped before the budget runs out.
+// One wavefront replaying a whole walk takes ~5 us per pop (25k sequential pops on the 139k-centroid NS tree: 136 ms for a batch in which
+// 60 of 10 000 queries were marked); a host core does a pop in ~50 ns.  So the marked queries' rows of the distance table go to the host
+// (GatherRowsF32Kernel + one copy), host threads run the reference's loop (kmeans_tree_router.cpp:103-123) with the real
+// std::priority_queue on them, and the resulting min_dist rows (and FrequencyQuery records) are scattered back.
+__global__ void GatherRowsF32Kernel(const float* table, const uint32_t* rows, uint32_t n_rows, uint64_t width, float* out) {
+    const uint64_t total = (uint64_t)n_rows * width;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / width, c = i - r * width;
+        out[i] = table[(uint64_t)rows[r] * width + c];
+    }
+}
+__global__ void ScatterRowsF32Kernel(const float* packed, const uint32_t* rows, uint32_t n_rows, uint64_t width, uint64_t out_stride, float* out) {
+    const uint64_t total = (uint64_t)n_rows * width;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / width, c = i - r * width;
+        out[(uint64_t)rows[r] * out_stride + c] = packed[i];
+    }
+}
+
+// kmeans_tree_router.cpp:93-123 on a row of exact distances (D[c] = distance(centroid c, Q)); records as FrequencyQuery sees them (:155)
+void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, float* min_dist, float* rec_dist, int32_t* rec_shard, uint32_t* rec_count,
+                     uint64_t rec_cap) {
+    struct PQEntry {
+        float dist;
+        uint32_t node;
+        bool operator>(const PQEntry& other) const { return dist > other.dist; }
+    };
+    std::priority_queue<PQEntry, std::vector<PQEntry>, std::greater<>> pq;
+    const uint32_t S = r->S;
+    for (uint32_t b = 0; b < S; ++b) min_dist[b] = std::numeric_limits<float>::max();
+    for (uint32_t b = 0; b < S; ++b) pq.push(PQEntry{std::numeric_limits<float>::lowest(), r->h_shard_root[b]});
+    uint64_t n_rec = 0;
+    while (!pq.empty() && budget > 0) {
+        const PQEntry top = pq.top();
+        pq.pop();
+        const uint32_t first = r->h_node_cent_first[top.node], n = r->h_node_cent_first[top.node + 1] - first;
+        const uint32_t shard = (uint32_t)r->h_node_shard[top.node];
+        budget -= (int32_t)n;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float dist = D[first + i];
+            min_dist[shard] = std::min(min_dist[shard], dist);
+            if (rec_dist && n_rec < rec_cap) {
+                rec_dist[n_rec] = dist;
+                rec_shard[n_rec] = (int32_t)shard;
+            }
+            ++n_rec;
+            if (i < r->h_node_child_count[top.node]) pq.push(PQEntry{dist, r->h_node_child_first[top.node] + i});
+        }
+    }
+    if (rec_count) *rec_count = (uint32_t)std::min<uint64_t>(n_rec, rec_cap);
+}
+
+// Replays the marked queries of a block on the host.  `flags` [nb] (device): 1 = marked.  Returns false (nothing done) if the rows do not
+// fit the staging budget — the caller then runs the device heap kernel as before.
+gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint32_t* d_flags, uint32_t nb, uint32_t marked, int32_t budget, float* d_min_dist,
+                              float* d_rec_dist, int32_t* d_rec_shard, uint32_t* d_rec_count, uint64_t rec_cap, hipStream_t st, bool* done) {
+    *done = false;
+    const uint64_t C = r->n_centroids;
+    const uint32_t S = r->S;
+    const bool rec = d_rec_dist != nullptr;
+    const size_t row_floats = (size_t)C + S + (rec ? 2 * rec_cap + 1 : 0);
+    if ((uint64_t)marked * row_floats * 4 > (512ull << 20)) return GPANN_OK;
+    std::vector<uint32_t> flags(nb);
+    GPANN_HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> list;
+    for (uint32_t q = 0; q < nb; ++q)
+        if (flags[q]) list.push_back(q);
+    const uint32_t m = (uint32_t)list.size();
+    if (m == 0) {
+        *done = true;
+        return GPANN_OK;
+    }
+    // device: [list m] [rows m x C]; host (pinned): rows m x C | min_dist m x S | records
+    GPANN_TRY(r->ws_host_redo.Reserve((size_t)m * 4 + (size_t)m * row_floats * 4 + 64));
+    uint32_t* d_list = r->ws_host_redo.as<uint32_t>();
+    float* d_rows = reinterpret_cast<float*>(d_list + ((m + 15) & ~15u));
+    if (r->pinned_redo_floats < (size_t)m * row_floats) {
+        if (r->pinned_redo) (void)hipHostFree(r->pinned_redo);
+        r->pinned_redo = nullptr;
+        r->pinned_redo_floats = 0;
+        GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_redo), (size_t)m * row_floats * 4, hipHostMallocDefault));
+        r->pinned_redo_floats = (size_t)m * row_floats;
+    }
+    float* h_rows = r->pinned_redo;
+    float* h_min = h_rows + (size_t)m * C;
+    float* h_rec_dist = h_min + (size_t)m * S;
+    int32_t* h_rec_shard = reinterpret_cast<int32_t*>(h_rec_dist + (rec ? (size_t)m * rec_cap : 0));
+    uint32_t* h_rec_count = reinterpret_cast<uint32_t*>(h_rec_shard + (rec ? (size_t)m * rec_cap : 0));
+    GPANN_HIP_TRY(hipMemcpyAsync(d_list, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(GatherRowsF32Kernel, dim3((uint32_t)std::min<uint64_t>(4096, ((uint64_t)m * C + 255) / 256)), dim3(256), 0, st, d_table, d_list, m, C, d_rows);
+    GPANN_HIP_TRY(hipGetLastError());
+    GPANN_HIP_TRY(hipMemcpyAsync(h_rows, d_rows, (size_t)m * C * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t chunks = std::min<uint32_t>(m, 64);
+    HostPool::Get().Run(chunks, [&](uint32_t c) {
+        for (uint32_t i = (uint32_t)((uint64_t)m * c / chunks); i < (uint32_t)((uint64_t)m * (c + 1) / chunks); ++i)
+            HostWalkOnTable(r, h_rows + (size_t)i * C, budget, h_min + (size_t)i * S, rec ? h_rec_dist + (size_t)i * rec_cap : nullptr,
+                            rec ? h_rec_shard + (size_t)i * rec_cap : nullptr, rec ? h_rec_count + i : nullptr, rec_cap);
+    });
+    // results back: min_dist rows (and the records) of the marked queries
+    float* d_min_packed = d_rows;   // (the table rows are no longer needed)
+    GPANN_HIP_TRY(hipMemcpyAsync(d_min_packed, h_min, (size_t)m * S * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ScatterRowsF32Kernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)m * S + 255) / 256)), dim3(256), 0, st, d_min_packed, d_list, m, (uint64_t)S,
+                       (uint64_t)S, d_min_dist);
+    if (rec) {
+        float* d_pack = d_min_packed + (size_t)m * S;
+        GPANN_HIP_TRY(hipMemcpyAsync(d_pack, h_rec_dist, (size_t)m * rec_cap * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ScatterRowsF32Kernel, dim3(4096), dim3(256), 0, st, d_pack, d_list, m, rec_cap, rec_cap, d_rec_dist);
+        float* d_pack2 = d_pack + (size_t)m * rec_cap;
+        GPANN_HIP_TRY(hipMemcpyAsync(d_pack2, h_rec_shard, (size_t)m * rec_cap * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ScatterRowsF32Kernel, dim3(4096), dim3(256), 0, st, d_pack2, d_list, m, rec_cap, rec_cap, reinterpret_cast<float*>(d_rec_shard));
+        float* d_pack3 = d_pack2 + (size_t)m * rec_cap;
+        GPANN_HIP_TRY(hipMemcpyAsync(d_pack3, h_rec_count, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ScatterRowsF32Kernel, dim3(1), dim3(256), 0, st, d_pack3, d_list, m, (uint64_t)1, (uint64_t)1, reinterpret_cast<float*>(d_rec_count));
+    }
+    GPANN_HIP_TRY(hipGetLastError());
+    GPANN_HIP_TRY(hipStreamSynchronize(st));   // (the pinned buffers are reused by the next block)
+    *done = true;
+    return GPANN_OK;
+}
 
 // ---- the matrix-core bound path of the visit-everything case (router_bound.h), with its self-check and the verify mode ------------
 __global__ void DiffBitsKernel(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out /* [0] count, [1] first index */) {
@@ -1703,15 +1841,23 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             // after a sorted / threshold replay the heap kernel is needed only for the marked queries — usually none
             bool need_heap = true;
             uint32_t hgrid = grid;
+            uint32_t marked = 0;
             if (ra.only_redo) {
-                uint32_t marked = 0;
                 GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
                 GPANN_HIP_TRY(hipStreamSynchronize(st));
                 need_heap = marked != 0;
                 r->stat_heap_redo += marked;
                 if (std::getenv("GPANN_ROUTER_DEBUG"))
-                    fprintf(stderr, "[gpann router] %s replay: %u of %u queries go to the heap kernel\n", sorted_ok ? "sorted" : "threshold", marked, nb);
+                    fprintf(stderr, "[gpann router] %s replay: %u of %u queries need the real priority queue\n", sorted_ok ? "sorted" : "threshold", marked, nb);
                 hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
+            }
+            if (need_heap && ra.only_redo && !(std::getenv("GPANN_ROUTER_HOST_REDO") && std::getenv("GPANN_ROUTER_HOST_REDO")[0] == '0')) {
+                // the marked queries go to host threads and the real std::priority_queue (HostReplayMarked); the device heap kernel
+                // stays for batches whose marked rows would not fit the staging budget
+                bool done = false;
+                GPANN_TRY(HostReplayMarked(r, ra.dense, ra.redo, nb, marked, budget, ra.out_min_dist, ra.rec_dist, ra.rec_shard,
+                                           ra.rec_count, ra.rec_cap, st, &done));
+                need_heap = !done;
             }
             if (need_heap) {
                 if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);

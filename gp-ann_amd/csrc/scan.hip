@@ -305,6 +305,15 @@ __global__ void ShardHitsKernel(const float* dist, const uint32_t* ids, const fl
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------------------
+// host -> device copy of a small per-call array through the handle's pinned staging area (asynchronous; pageable fallback if it is full)
+static hipError_t UploadAsync(gpann_shards* s, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    void* p = s->stage.Take(bytes);
+    if (!p) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    std::memcpy(p, src, bytes);
+    return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st);
+}
+
 static uint32_t EnvU32(const char* name, uint32_t dflt) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
@@ -436,11 +445,11 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
     float* d_part_dist = s->ws_partials.as<float>();
     uint32_t* d_part_row = reinterpret_cast<uint32_t*>(d_part_dist + plan.n_lists * k);
     if (T) {
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.part, plan.task_part.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.nseg, plan.task_nseg.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(UploadAsync(s, ta.part, plan.task_part.data(), T * 4, st));
+        GPANN_HIP_TRY(UploadAsync(s, ta.nseg, plan.task_nseg.data(), T * 4, st));
     }
     if (!plan.units.empty()) {
-        GPANN_HIP_TRY(hipMemcpyAsync(s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(UploadAsync(s, s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), st));
         ScanArgs a;
         a.points = s->points;
         a.queries = d_queries;
@@ -516,7 +525,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // a random sample of the cell, so after a pass over a fraction 1/f of the needed rows only about f * k rows of the rest can
     // still beat the k-th distance.  Pass 0 = the head of each task's nearest cell (at most half a bucket of rows), pass 1 =
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
-    const uint32_t head_tiles = std::max<uint32_t>(1, std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows);
+    // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
+    const uint32_t head_tiles = std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows;
     int64_t max_rows = 1;
     for (uint32_t b = 0; b < S; ++b) max_rows = std::max<int64_t>(max_rows, s->offsets[b + 1] - s->offsets[b]);
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
@@ -552,7 +562,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 24 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     float* cell_dist = s->ws_celld.as<float>();
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
     float* d_qnorm = reinterpret_cast<float*>(d_nearest + T);
@@ -578,9 +588,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     CellItem* d_items = reinterpret_cast<CellItem*>(d_work + 4);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
     GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
-    GPANN_HIP_TRY(hipMemcpyAsync(d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), hipMemcpyHostToDevice, st));
-    GPANN_HIP_TRY(hipMemcpyAsync(d_groups, groups.data(), (size_t)G * sizeof(CellGroup), hipMemcpyHostToDevice, st));
-    GPANN_HIP_TRY(hipMemcpyAsync(d_task_group, task_group.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+    GPANN_HIP_TRY(UploadAsync(s, d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), st));
+    GPANN_HIP_TRY(UploadAsync(s, d_groups, groups.data(), (size_t)G * sizeof(CellGroup), st));
+    GPANN_HIP_TRY(UploadAsync(s, d_task_group, task_group.data(), (size_t)T * 4, st));
 
     CellDistArgs cd;
     cd.queries = d_queries;
@@ -601,19 +611,21 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     };
 
     // ---- order the tasks of every shard by their nearest cell (on the device; the host copies of task_query / task_out are
-    //      not consulted again in this call)
-    GPANN_TRY(cell_table(false));
+    //      not consulted again in this call).  The table, the nearest cells and |q|^2 keep the old order: d_task_src maps.
+    GPANN_TRY(cell_table(true));
+    uint32_t* d_task_src = nullptr;
     {
         uint32_t* tmp_q = reinterpret_cast<uint32_t*>(d_dtiles + dtiles.size());
         uint32_t* tmp_o = tmp_q + T;
-        uint32_t* d_stb = tmp_o + T;
-        GPANN_HIP_TRY(hipMemcpyAsync(d_stb, plan.shard_task_begin.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(TaskReorderKernel, dim3(S), dim3(256), (size_t)(kmax + 1) * 4, st, d_stb, d_nearest, C.d_shard_cell_begin, ta.query, ta.out, tmp_q, tmp_o);
+        d_task_src = tmp_o + T;
+        uint32_t* d_stb = d_task_src + T;
+        GPANN_HIP_TRY(UploadAsync(s, d_stb, plan.shard_task_begin.data(), (size_t)(S + 1) * 4, st));
+        hipLaunchKernelGGL(TaskReorderKernel, dim3(S), dim3(256), (size_t)(kmax + 1) * 4, st, d_stb, d_nearest, C.d_shard_cell_begin, ta.query, ta.out, tmp_q, tmp_o,
+                           d_task_src);
         GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipMemcpyAsync(ta.query, tmp_q, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
         GPANN_HIP_TRY(hipMemcpyAsync(ta.out, tmp_o, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
     }
-    GPANN_TRY(cell_table(true));
 
     // ---- the groups' query images (bf16 fragments in MFMA B-operand order), once per call
     const uint32_t img_ks = ks16 ? 16u : (ks4 ? 4u : 8u), img_qt = ks16 ? 4u : 8u;
@@ -672,6 +684,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.task_qnorm = d_qnorm;
     na.list_dist = list_dist;
     na.nearest = d_nearest;
+    na.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
     na.k = k;
@@ -726,6 +739,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.overflow_limit = overflow_limit;
     ra.seed_rows = 0;
     ra.nearest = d_nearest;
+    ra.task_src = d_task_src;
     ra.shard_cell_begin = C.d_shard_cell_begin;
     ra.cell_tile_begin = C.d_cell_tile_begin;
     ra.plane_perm = C.plane_perm;
@@ -771,7 +785,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
     }
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
@@ -825,8 +839,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     {
         // the lists go out before the overflow words are looked at (one host round trip less on the way; an overflowed call rewrites
         // them in the plain exact scan)
-        uint32_t h_words[4] = {0, 0, 0, 0};
-        unsigned long long h_work[4] = {0, 0, 0, 0};
+        uint32_t words_local[4] = {0, 0, 0, 0};
+        unsigned long long work_local[4] = {0, 0, 0, 0};
+        void* pin = s->stage.Take(48);   // pinned landing area: the two copies do not stall the stream
+        uint32_t* h_words = pin ? static_cast<uint32_t*>(pin) : words_local;
+        unsigned long long* h_work = pin ? reinterpret_cast<unsigned long long*>(static_cast<char*>(pin) + 16) : work_local;
         GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 32, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
@@ -858,6 +875,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     plan.Clear();
     GPANN_TRY(BuildTasks(s, nq, probes, probe_stride, nprobe, plan));
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
+    // (task arrays, group / tile tables, unit lists: ~32 bytes per task + per-shard tables; exact-mode unit lists fall back to pageable copies if larger)
+    s->stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
     const size_t n_out = (size_t)nq * nprobe;
 
     const float* d_queries = nullptr;
@@ -872,9 +891,9 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     ta.nseg = ta.part + T;
     ta.shard = ta.nseg + T;
     if (T) {
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, plan.task_query.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, plan.task_out.data(), T * 4, hipMemcpyHostToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.shard, plan.task_shard.data(), T * 4, hipMemcpyHostToDevice, st));
+        GPANN_HIP_TRY(UploadAsync(s, ta.query, plan.task_query.data(), T * 4, st));
+        GPANN_HIP_TRY(UploadAsync(s, ta.out, plan.task_out.data(), T * 4, st));
+        GPANN_HIP_TRY(UploadAsync(s, ta.shard, plan.task_shard.data(), T * 4, st));
     }
     // (the plan's host arrays live in the handle until the next scan call, so the async uploads stay valid)
 
@@ -936,7 +955,7 @@ static gpann_status FinishTiming(gpann_shards* s, float* elapsed_ms) {
             s->stats.filter_ms += f;
         }
         s->stats.filter_rest_ms = 0.f;
-        if (s->filter_passes_timed == 2) GPANN_HIP_TRY(hipEventElapsedTime(&s->stats.filter_rest_ms, s->ev_filter[4], s->ev_filter[5]));
+        if (s->filter_passes_timed >= 1) GPANN_HIP_TRY(hipEventElapsedTime(&s->stats.filter_rest_ms, s->ev_filter[4], s->ev_filter[5]));
     }
     if (elapsed_ms) *elapsed_ms = a + b;
     return GPANN_OK;

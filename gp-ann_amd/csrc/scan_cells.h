@@ -137,8 +137,11 @@ static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t*
 }
 
 // Tasks of one shard -> grouped by nearest cell (counting sort; the order inside a cell does not matter).  One workgroup per shard.
+// out_src[new position] = old position: the task x cell distance table, the nearest cells and |q|^2 stay in the OLD order and are read
+// through it (a second CellDistKernel / NearestCellKernel round in the new order cost more than the indirection).
 static __global__ void __launch_bounds__(256) TaskReorderKernel(const uint32_t* shard_task_begin, const uint32_t* nearest, const uint32_t* shard_cell_begin,
-                                                                const uint32_t* in_query, const uint32_t* in_out, uint32_t* out_query, uint32_t* out_out) {
+                                                                const uint32_t* in_query, const uint32_t* in_out, uint32_t* out_query, uint32_t* out_out,
+                                                                uint32_t* out_src) {
     extern __shared__ uint32_t s_cnt[];   // [K + 1]
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = shard_task_begin[b], t1 = shard_task_begin[b + 1];
@@ -155,6 +158,7 @@ static __global__ void __launch_bounds__(256) TaskReorderKernel(const uint32_t* 
         const uint32_t pos = t0 + atomicAdd(&s_cnt[min(nearest[t], K - 1)], 1u);
         out_query[pos] = in_query[t];
         out_out[pos] = in_out[t];
+        out_src[pos] = t;
     }
 }
 
@@ -170,6 +174,7 @@ struct NeedArgs {
     const float* task_qnorm;            // [tasks] |q|^2, rounded up
     const float* list_dist;             // [tasks][k]
     const uint32_t* nearest;            // [tasks]
+    const uint32_t* task_src;           // [tasks] row of cell_dist / nearest / task_qnorm that belongs to task t (the order before TaskReorderKernel)
     uint32_t* need;                     // [groups][kmax] bit per query tile
     uint32_t tasks, kmax, k, d;
     uint32_t head;                      // 1: only the nearest cell of each task
@@ -185,12 +190,13 @@ static __global__ void NeedKernel(NeedArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)a.tasks * a.kmax) return;
     const uint32_t t = (uint32_t)(i / a.kmax), j = (uint32_t)(i % a.kmax);
+    const uint32_t src = a.task_src[t];
     const uint32_t b = a.task_shard[t];
     const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
     if (j >= K) return;
     bool need;
     if (a.head) {
-        need = a.nearest[t] == j;
+        need = a.nearest[src] == j;
     } else {
         const double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
         if (!(tau < (double)INFINITY)) {
@@ -198,14 +204,14 @@ static __global__ void NeedKernel(NeedArgs a) {
         } else {
             const double dd = (double)a.d;
             const double s = (dd + 64.0) * 0x1p-22;
-            const double D = (double)a.cell_dist[(size_t)t * a.kmax + j];
+            const double D = (double)a.cell_dist[(size_t)src * a.kmax + j];
             const double r = (double)a.radius[cell0 + j];
             if (METRIC == GPANN_METRIC_L2) {
                 const double g1 = (dd + 32.0) * 0x1p-23;
                 const double lb = sqrt(fmax(D, 0.0)) * (1.0 - s) - r;
                 need = !(lb > 0.0 && lb * lb > tau * (1.0 + 2.0 * g1) * (1.0 + s) + 1e-30);
             } else {
-                const double nq = (double)a.task_qnorm[t], nc = (double)a.cell_cnorm[cell0 + j];
+                const double nq = (double)a.task_qnorm[src], nc = (double)a.cell_cnorm[cell0 + j];
                 const double R = a.shard_rmax[b];
                 const double qn = sqrt(nq);
                 const double dot_ub = 0.5 * (nq + nc - D) + s * (nq + nc + fabs(D));

@@ -168,7 +168,8 @@ struct RescoreArgs {
     // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
     // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
     uint32_t seed_rows;
-    const uint32_t* nearest;            // [tasks] nearest cell of the task, relative to its shard's first cell
+    const uint32_t* nearest;            // [tasks] nearest cell of the task, relative to its shard's first cell (indexed through task_src)
+    const uint32_t* task_src;           // [tasks]
     const uint32_t* shard_cell_begin;   // [S+1]
     const uint64_t* cell_tile_begin;    // [cells+1] first 32-row plane tile of every cell
     const uint32_t* plane_perm;         // [tiles*32] plane row -> store row (0xFFFFFFFF: padding)
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
         // following cells are its neighbours along the cell chain); the loop below stops after seed_rows rows once the list is full
         const uint32_t b = a.task_shard[t];
         const uint64_t p0 = a.cell_tile_begin[a.shard_cell_begin[b]] * kGTileRows, p1 = a.cell_tile_begin[a.shard_cell_begin[b + 1]] * kGTileRows;
-        seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[t]] * kGTileRows;
+        seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[a.task_src[t]]] * kGTileRows;
         if (seed_first + a.seed_rows > p1) seed_first = p1 - p0 > a.seed_rows ? p1 - a.seed_rows : p0;
         cnt = (uint32_t)min((uint64_t)1 << 20, p1 - seed_first);
     } else {

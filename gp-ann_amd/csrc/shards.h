@@ -40,6 +40,34 @@ struct ScanPlan {
     }
 };
 
+// Pinned host staging area of a handle: the small per-call arrays (task lists, group tables, counters) travel through it, so their
+// hipMemcpyAsync calls are real asynchronous copies — from pageable memory every one of them is a synchronous staging copy of the runtime
+// (12 us of idle GPU each, a dozen per scan call).  Reset at the start of a call; the previous call has synchronised by then.
+struct PinnedStage {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    void Reserve(size_t bytes) {   // only between calls
+        used = 0;
+        if (bytes <= cap) return;
+        if (base) (void)hipHostFree(base);
+        base = nullptr;
+        cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&base), bytes, hipHostMallocDefault) == hipSuccess) cap = bytes;
+        else (void)hipGetLastError();
+    }
+    void* Take(size_t bytes) {
+        const size_t at = (used + 63) & ~(size_t)63;
+        if (!base || at + bytes > cap) return nullptr;
+        used = at + bytes;
+        return base + at;
+    }
+    void Release() {
+        if (base) (void)hipHostFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
+
 }  // namespace gpann
 
 struct gpann_shards {
@@ -86,6 +114,7 @@ struct gpann_shards {
     int filter_passes_timed = 0;
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;
+    gpann::PinnedStage stage;
 };
 
 namespace gpann {

@@ -207,6 +207,20 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     return GPANN_OK;
 }
 
+gpann_status gpann_shards_build_filter(gpann_shards* s) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    GPANN_TRY(EnsureDevice(s->device));
+    if (s->cells.n_cells != 0 && s->frag_planes != nullptr) return GPANN_OK;   // already there
+    if (s->rows == 0) return GPANN_OK;
+    if (!s->filter_ok || s->d > 256) {
+        SetLastError("the store's data is not fit for the filter (non-finite values or d > 256)");
+        return GPANN_ERR_UNSUPPORTED;
+    }
+    const char* cr = std::getenv("GPANN_CELL_ROWS");
+    const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
+    return BuildCells(s, cell_rows);
+}
+
 gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode) {
     GPANN_REQUIRE(s != nullptr, "shards handle is null");
     GPANN_REQUIRE(mode == 0 || mode == 1, "scan mode must be 0 (exact) or 1 (filter)");
@@ -235,6 +249,7 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     s->ws_partials.Release();
     s->ws_out.Release();
     s->ws_misc.Release();
+    s->stage.Release();
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev_filter)

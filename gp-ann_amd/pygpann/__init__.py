@@ -26,7 +26,7 @@ _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 
 EXPORTS = [
-    "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_info",
+    "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_build_filter", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
     "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
@@ -76,6 +76,7 @@ def lib():
     L.gpann_shards_create.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, _u32p, _u64p, C.c_uint32, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
     L.gpann_shards_destroy.argtypes = [C.c_void_p]
+    L.gpann_shards_build_filter.argtypes = [C.c_void_p]
     L.gpann_shards_info.argtypes = [C.c_void_p, _u64p, _u32p, _u32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gpann_shards_export.argtypes = [C.c_void_p, _i64p, _u32p, _f32p]
     L.gpann_shards_export_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _u32p, _f32p]
@@ -172,6 +173,10 @@ class Shards:
             self.close()
         except Exception:
             pass
+
+    def build_filter(self):
+        """filter support data of a store created with plain=True, built after the caller freed its own copy of the points"""
+        _check(lib().gpann_shards_build_filter(self.h))
 
     def kmeans(self, k, seed):
         """RandomSample(k, seed) + KMeans over all rows as one point set (gpann_kmeans): (partition[rows] int32, centroids[k', d])."""

@@ -83,6 +83,10 @@ gpann_status gpann_device_count(int* count);
 gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, int metric, const uint32_t* ids_concat,
                                  const uint64_t* shard_offsets, uint32_t S, int device, int flags, gpann_shards** out);
 gpann_status gpann_shards_destroy(gpann_shards* s);
+/* Builds the filter support data (bf16 planes grouped by cell, radii) of a store created with GPANN_STORE_PLAIN — i.e. in a second step,
+ * after the caller has released its own copy of the points: at 100M x 200 the rows are 80 GB and the planes 102 GB, and three copies
+ * do not fit one GPU.  No-op if the data is already there; GPANN_ERR_UNSUPPORTED if the store's data is unfit (non-finite, d > 256). */
+gpann_status gpann_shards_build_filter(gpann_shards* s);
 /* rows = sum of shard sizes; any out pointer may be NULL */
 gpann_status gpann_shards_info(const gpann_shards* s, uint64_t* rows, uint32_t* d, uint32_t* S, int* metric, int* device);
 /* copies offsets (S+1 x int64) / permutation (rows x u32) / clustered points (rows x d f32, unpadded) to host */

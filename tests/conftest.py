@@ -10,8 +10,17 @@ for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# Every router call of the test session (and of the driver binaries the tests start: they inherit the environment) runs with the
+# library's checks armed: GPANN_ROUTER_VERIFY compares every minimum of the matrix-core bound path with the canonical evaluation of all
+# (query, centroid) pairs, GPANN_ROUTER_STRICT turns a fired self-check into GPANN_ERR_INTERNAL instead of a silent re-evaluation.
+os.environ.setdefault("GPANN_ROUTER_VERIFY", "1")
+os.environ.setdefault("GPANN_ROUTER_STRICT", "1")
+os.environ.setdefault("GPANN_VERIFY_REPORT", os.path.join(ROOT, "gpurun_out", "router_verify_report.txt"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 
 
 @pytest.fixture(scope="session")

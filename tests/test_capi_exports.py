@@ -9,8 +9,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "gpann.h")).read()
+def _declared(header="gpann.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gpann_[a-z_0-9]+)\s*\(", text)))
 
@@ -24,6 +24,19 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/gpann.h but not exported"
     assert set(pygpann.EXPORTS) == set(names)
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """include/gpann_comm.h (the multi-GPU exchange layer) against libgpann_comm.so; loading it needs RCCL but no GPU"""
+    import pygpann
+    pygpann.build()
+    from pygpann import comm
+    L = comm.lib()
+    names = _declared("gpann_comm.h")
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/gpann_comm.h but not exported"
+    assert set(comm.EXPORTS) == set(names)
 
 
 def test_host_mirror_library_loads():

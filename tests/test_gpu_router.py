@@ -185,3 +185,42 @@ def test_router_bound_self_check_falls_back_to_canonical_evaluation(orc, gp, mon
     p, md, _ = router.query_batch(queries, 50000)
     assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
     assert "minima unset" in capfd.readouterr().err
+    st = router.stats()
+    assert st["bound_calls"] >= 1 and st["bound_selfcheck"] >= 1 and st["verify_failures"] == 0
+
+
+def test_bound_path_is_verified_and_counted(orc, gp):
+    """the session runs with GPANN_ROUTER_VERIFY (conftest): every bound block is compared with the canonical evaluation inside the library;
+    the handle's counters say that it happened and that nothing differed"""
+    rng = np.random.default_rng(8)
+    n, d, S = 30000, 128, 9
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, 64, 350, 9000, 0, nthreads=4)
+    queries = make_mixture(orc, 777, d, seed=556, n_centers=24)     # an odd count: partly filled query tiles, odd nq * S
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    router = gp.Router(tree.flat(), 0)
+    for _ in range(3):
+        p, md, _ = router.query_batch(queries, 10 ** 6)
+        assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+    st = router.stats()
+    assert st["bound_calls"] == 3 and st["verified"] == 3 and st["verify_failures"] == 0 and st["bound_selfcheck"] == 0 and st["bound_overflow"] == 0
+    assert st["last_bound_ms"] > 0 and st["last_bound_flops"] > 0
+
+
+def test_router_create_rejects_shards_out_of_order(orc, gp):
+    """the kernels rely on ExtractPoints order (nodes grouped per shard, shards ascending, the root first): anything else is refused"""
+    rng = np.random.default_rng(9)
+    pts = make_mixture(orc, 6000, 16, n_centers=8)
+    clusters = random_clusters(rng, 6000, 3)
+    flat = orc.kmtr_train(pts, clusters, 16, 50, 600, 0, nthreads=2).flat()
+    bad = dict(flat)
+    bad["node_shard"] = flat["node_shard"].copy()
+    bad["node_shard"][-1] = 0                       # the last node claims shard 0: shards no longer ascending
+    with pytest.raises(gp.GpannError):
+        gp.Router(bad, 0)
+    bad = dict(flat)
+    bad["shard_root"] = flat["shard_root"].copy()
+    bad["shard_root"][1] += 1                       # not the first node of its shard
+    with pytest.raises(gp.GpannError):
+        gp.Router(bad, 0)
