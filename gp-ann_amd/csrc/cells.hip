@@ -67,6 +67,12 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
     }
 }
 
+// norms of the shard-sample rows (padding: -inf)
+__global__ void SampleNormKernel(const uint32_t* sample_perm, uint64_t n, const float* neg_half_norm, float* sample_norm) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) sample_norm[i] = sample_perm[i] != kNoRow ? neg_half_norm[sample_perm[i]] : -INFINITY;
+}
+
 // radius of every cell: max over its rows of |p - c| (double accumulation), rounded up.  One workgroup per cell.
 __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, const uint32_t* plane_perm, const uint64_t* cell_tile_begin,
                                                         const float* center, uint32_t d, uint32_t ld, float* radius) {
@@ -103,7 +109,7 @@ __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, con
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm})
+                    (void*)c.plane_norm, (void*)c.sample_planes, (void*)c.sample_perm, (void*)c.sample_norm})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -243,6 +249,38 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     if (d_member_begin) (void)hipFree(d_member_begin);
     if (d_cell_size) (void)hipFree(d_cell_size);
     if (!ok) return give_up("device");
+
+    // the shard sample: the first kSampleRows store rows of every shard (store order = the order of Clusters[b] = a random sample)
+    {
+        const char* sr = std::getenv("GPANN_FILTER_EXACT_ROWS");   // (historic name: the rows of the first, shard-wide sample)
+        const uint64_t want = sr ? (uint64_t)std::max(64L, std::atol(sr)) : 4096;
+        C.sample_tile_begin.assign(S + 1, 0);
+        std::vector<uint32_t> perm;
+        for (uint32_t b = 0; b < S; ++b) {
+            const uint64_t n = (uint64_t)(s->offsets[b + 1] - s->offsets[b]), m = std::min(n, want);
+            const uint64_t tiles = (m + kGTileRows - 1) / kGTileRows;
+            C.sample_tile_begin[b + 1] = C.sample_tile_begin[b] + tiles;
+            for (uint64_t i = 0; i < tiles * kGTileRows; ++i) perm.push_back(i < m ? (uint32_t)(s->offsets[b] + i) : kNoRow);
+        }
+        C.n_sample_tiles = C.sample_tile_begin[S];
+        const uint64_t srows = C.n_sample_tiles * kGTileRows;
+        bool sok = hipMalloc(&C.sample_perm, std::max<size_t>(srows * 4, 256)) == hipSuccess &&
+                   hipMalloc(&C.sample_norm, (srows + 64) * 4) == hipSuccess &&
+                   hipMalloc(&C.sample_planes, 2 * (C.n_sample_tiles + 2) * tile_bytes) == hipSuccess;
+        if (sok && srows) {
+            sok = hipMemcpy(C.sample_perm, perm.data(), srows * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemset(C.sample_norm + srows, 0, 64 * 4) == hipSuccess &&
+                  hipMemset(C.sample_planes, 0, 2 * (C.n_sample_tiles + 2) * tile_bytes) == hipSuccess;
+            if (sok) {
+                hipLaunchKernelGGL(SampleNormKernel, dim3((uint32_t)((srows + 255) / 256)), dim3(256), 0, 0, C.sample_perm, srows, s->neg_half_norm, C.sample_norm);
+                const int g3 = (int)std::min<uint64_t>((srows * 2 * C.plane_ks + 255) / 256, 256 * 64);
+                hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, C.sample_perm, srows, ld, C.sample_planes,
+                                   (uint64_t)(C.n_sample_tiles + 2) * tile_bytes, C.plane_ks);
+                sok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            }
+        }
+        if (!sok) return give_up("sample planes");
+    }
     return GPANN_OK;
 }
 

@@ -768,7 +768,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    const size_t rlds = (size_t)4 * RescoreLdsFloats(s->ld) * sizeof(float);
+    const size_t rlds = (size_t)kRescoreWaves * RescoreLdsFloats(s->ld) * sizeof(float);
     if (rlds > (48u << 10)) {
         if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
         else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
@@ -779,11 +779,65 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
         GPANN_HIP_TRY(hipGetLastError());
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
+    }
+    // ---- the shard-sample pass (with the seed lists): the first rows of every shard (store order: a random sample of the shard; built
+    //      as planes of their own at store build) go through the matrix cores against the seed thresholds, the candidates are re-scored.
+    //      Afterwards every list's k-th distance is at most the k-th of ~4096 random rows of the shard — what bounds the number of rows
+    //      the later passes can still find below it (and so the bucket fill) WHATEVER the query's position; the nearest-cell seed alone
+    //      gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
+    if (seed_rows != 0 && C.n_sample_tiles != 0) {
+        const uint32_t piece = 32;   // row tiles per work item
+        std::vector<CellItem> sitems;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint64_t t0 = C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_begin[groups[g].shard + 1];
+            const uint32_t qtiles = (groups[g].task_count + 31) / 32, mask = (1u << qtiles) - 1u;
+            for (uint64_t t = t0; t < t1; t += piece) {
+                CellItem it;
+                it.t_begin = (uint32_t)t;
+                it.t_end = (uint32_t)std::min<uint64_t>(t1, t + piece);
+                it.t_a = it.t_b = it.t_begin;   // no head / sample segment: every query tile runs on every row tile
+                it.task_begin = groups[g].task_begin;
+                it.task_count = groups[g].task_count;
+                it.acts = mask | mask << 8 | mask << 16;
+                it.group = g;
+                sitems.push_back(it);
+            }
+        }
+        if (!sitems.empty()) {
+            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + 64));
+            uint32_t* s_cursor = s->ws_misc.as<uint32_t>();   // [0] cursor, [1] item count
+            CellItem* d_sitems = reinterpret_cast<CellItem*>(s_cursor + 16);
+            const uint32_t head[2] = {0u, (uint32_t)sitems.size()};
+            GPANN_HIP_TRY(UploadAsync(s, s_cursor, head, 8, st));
+            GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
+            GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
+            th.hi_only = ks16 ? 1u : 0u;
+            if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            CellFilterArgs fs = fa;
+            fs.frag_planes = C.sample_planes;
+            fs.plane_lo_offset = (uint64_t)(C.n_sample_tiles + 2) * fa.plane_tile_bytes;
+            fs.plane_norm = C.sample_norm;
+            fs.plane_perm = C.sample_perm;
+            fs.items = d_sitems;
+            fs.n_items = s_cursor + 1;
+            fs.next_item = s_cursor;
+            fs.items_cap = (uint32_t)sitems.size();
+            fs.pass = 0;
+            fs.need = nullptr;
+            fs.done0 = fs.done1 = nullptr;
+            void* sargs[] = {&fs};
+            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
+            hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
+            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+            GPANN_HIP_TRY(hipGetLastError());
+        }
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
@@ -821,8 +875,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
         // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
         hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + 3) / 4), dim3(256), rlds, st, ra);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
         GPANN_HIP_TRY(hipGetLastError());
         plan.filter_launches++;
         if (std::getenv("GPANN_CELLS_DEBUG")) {

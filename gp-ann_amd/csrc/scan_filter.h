@@ -203,36 +203,42 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
     }
 }
 
-// One wavefront per task.  Candidates are taken 16 at a time: their rows are fetched COALESCED (half a wavefront per row: one
-// 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row costs the texture path 64 cache lines per load
-// instruction) and staged through LDS, the next 16 rows being in flight while lanes 0..15 evaluate the canonical distance of the
-// current ones against the query row in LDS; the survivors are inserted into the task's list (one entry per lane).
+// One WORKGROUP (4 wavefronts) per task.  The kernel's time is its slowest task — candidate counts are long-tailed, and a task's
+// candidates are a sequential chain of fetch rounds — so the four wavefronts share a task's candidates block-wise (blocks of 64 row ids,
+// block b to wavefront b mod 4), each with a private copy of the task's list, and the copies are merged at the end (the union of the four
+// top-k lists, de-duplicated, IS the top-k of everything seen).  Within a wavefront, candidates are taken 16 at a time: their rows are
+// fetched COALESCED (half a wavefront per row: one 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row
+// costs the texture path 64 cache lines per load instruction) and staged through LDS, the next 16 rows being in flight while lanes
+// 0..15 evaluate the canonical distance of the current ones against the query row in LDS; the survivors are inserted into the list
+// (one entry per lane).
 constexpr int kRescoreSub = 16;                                                   // candidates per round
 constexpr int kRescoreRounds = 64 / kRescoreSub;                                  // rounds per block of 64 row ids
+constexpr int kRescoreWaves = 4;                                                  // wavefronts per task
 __host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
 
 template <int METRIC>
-__global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
+__global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
+    __shared__ float s_merge_d[kRescoreWaves][64];
+    __shared__ uint32_t s_merge_r[kRescoreWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * 4 + wave;
-    if (t >= a.tasks) return;
+    const uint32_t t = blockIdx.x;
     const bool seed = a.seed_rows != 0;
     uint64_t seed_first = 0;   // first plane row of the task's nearest cell
     uint32_t cnt;
     if (seed) {
         // plane rows [seed_first, seed_first + cnt): from the nearest cell's first row onwards, inside the shard's plane range (the
-        // following cells are its neighbours along the cell chain); the loop below stops after seed_rows rows once the list is full
+        // following cells are its neighbours along the cell chain)
         const uint32_t b = a.task_shard[t];
         const uint64_t p0 = a.cell_tile_begin[a.shard_cell_begin[b]] * kGTileRows, p1 = a.cell_tile_begin[a.shard_cell_begin[b + 1]] * kGTileRows;
         seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[a.task_src[t]]] * kGTileRows;
         if (seed_first + a.seed_rows > p1) seed_first = p1 - p0 > a.seed_rows ? p1 - a.seed_rows : p0;
-        cnt = (uint32_t)min((uint64_t)1 << 20, p1 - seed_first);
+        cnt = (uint32_t)min((uint64_t)a.seed_rows, p1 - seed_first);
     } else {
         cnt = a.cand_cnt[t];
-        if (cnt == 0) return;
+        if (cnt == 0) return;   // (the whole workgroup)
     }
-    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
+    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: the workgroup then evaluates the pass's whole row range of the shard itself
     if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
     float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
@@ -253,13 +259,17 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
         scan_hi = a.range_hi == INT64_MAX ? a.shard_offsets[b + 1] : min(a.shard_offsets[b + 1], a.shard_offsets[b] + a.range_hi);
     }
     const uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
+    // this wavefront's share: the blocks b = wave, wave + 4, ... of 64 items; local position i <-> global ((i / 64) * 4 + wave) * 64 + i % 64
+    const uint64_t n_blocks = (n_items + 63) / 64;
+    const uint64_t my_blocks = n_blocks > (uint64_t)wave ? (n_blocks - wave + kRescoreWaves - 1) / kRescoreWaves : 0;
+    const uint64_t n_local = my_blocks * 64;
     const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 float4 (128 dimensions) of a row per load instruction and half wavefront
     const int half = lane >> 5, c4l = lane & 31;
 
     // row ids are read 64 candidates at a time (one coalesced load, a block ahead); round `sub` of a block takes its 16 from there
-    auto load_block = [&](uint64_t first) -> uint32_t {
-        const uint64_t idx = first + lane;
-        if (idx >= n_items) return kNoId;
+    auto load_block = [&](uint64_t first_local) -> uint32_t {
+        const uint64_t idx = ((first_local >> 6) * kRescoreWaves + wave) * 64 + lane;
+        if (first_local >= n_local || idx >= n_items) return kNoId;
         if (seed) return a.plane_perm[seed_first + idx];   // (kNoId on the padding of a cell's last tile: skipped like an absent candidate)
         return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + idx];
     };
@@ -288,8 +298,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
     uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
     uint32_t row = round_rows(block_rows, 0);
     fetch(v, row, 0);
-    for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
-        if (seed && base >= a.seed_rows && __shfl(ld_, (int)k - 1) < INFINITY) break;   // (wave-uniform) enough rows seen, list full
+    for (uint64_t base = 0; base < n_local; base += kRescoreSub) {
         const uint32_t sub = (uint32_t)(base / kRescoreSub) % (uint32_t)kRescoreRounds;
         __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
         stage(v, 0);
@@ -318,7 +327,7 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
             const int l = __builtin_ctzll(mask);
             const float cd = __shfl(e, l);
             const uint32_t cr = __shfl(cur_row, l);
-            // a row may be offered twice (cell passes overlap a stage-0 row; an overflowed bucket re-reads its range): a row that is
+            // a row may be offered twice (cell passes overlap a sample row; an overflowed bucket re-reads its range): a row that is
             // in the list stays once, one that was pushed out cannot pass the k-th entry again
             if (a.dedupe && __ballot(lane < (int)k && lr_ == cr) != 0ull) {
                 pass = pass && lane != l;
@@ -330,6 +339,23 @@ __global__ void __launch_bounds__(256) RescoreKernel(RescoreArgs a) {
             tr = __shfl(lr_, k - 1);
             pass = pass && lane != l && PairLess(e, cur_row, td, tr);
             mask = __ballot(pass);
+        }
+    }
+    // ---- merge the four private lists: wavefront 0 takes the entries of the others that beat its k-th entry and are not in its list yet
+    s_merge_d[wave][lane] = ld_;
+    s_merge_r[wave][lane] = lr_;
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < kRescoreWaves; ++w) {
+        for (uint32_t i = 0; i < k; ++i) {
+            const float cd = s_merge_d[w][i];
+            const uint32_t cr = s_merge_r[w][i];
+            if (cr == kNoId) break;   // (lists are ascending: the rest is empty)
+            const float td = __shfl(ld_, k - 1);
+            const uint32_t tr = __shfl(lr_, k - 1);
+            if (!PairLess(cd, cr, td, tr)) break;   // nor can any later entry of this list beat it
+            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+            ListInsertF(ld_, lr_, cd, cr, k, lane);
         }
     }
     if (lane < (int)k) {

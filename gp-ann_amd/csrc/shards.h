@@ -102,6 +102,13 @@ struct gpann_shards {
         float* d_cnorm = nullptr;                  // [n_cells] |center|^2
         uint32_t* plane_perm = nullptr;            // [n_tiles*32] plane row -> store row, 0xFFFFFFFF for padding
         float* plane_norm = nullptr;               // [n_tiles*32 + 64] -|p|^2/2 in plane order (-inf for padding)
+        // the shard SAMPLE: the first rows of every shard in store order (a random sample of the shard) once more as planes, so that
+        // the filter's first threshold comes from a matrix-core pass over them instead of an exact VALU scan (scan.hip, sample pass)
+        std::vector<uint64_t> sample_tile_begin;   // [S+1] host: first sample tile of every shard
+        uint64_t n_sample_tiles = 0;
+        char* sample_planes = nullptr;             // hi tiles, then (n_sample_tiles + 2) tiles further the lo tiles
+        uint32_t* sample_perm = nullptr;           // [n_sample_tiles*32] sample row -> store row (0xFFFFFFFF: padding)
+        float* sample_norm = nullptr;              // [n_sample_tiles*32 + 64]
     } cells;
     bool filter_ok = false;
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
