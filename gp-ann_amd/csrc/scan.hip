@@ -562,11 +562,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * kmax * 4 + (size_t)T * 24 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
-    float* cell_dist = s->ws_celld.as<float>();
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 8 + (size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
+    double* d_task_nq = s->ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
+    float* cell_dist = reinterpret_cast<float*>(d_task_nq + T);
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
-    float* d_qnorm = reinterpret_cast<float*>(d_nearest + T);
-    uint32_t* d_task_group = reinterpret_cast<uint32_t*>(d_qnorm + T);
+    uint32_t* d_task_group = d_nearest + T;
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
     const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
@@ -605,7 +605,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     auto cell_table = [&](bool with_qnorm) -> gpann_status {
         hipLaunchKernelGGL(CellDistKernel, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
         hipLaunchKernelGGL(NearestCellKernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
-                           s->d, s->ld, d_nearest, with_qnorm ? d_qnorm : nullptr);
+                           s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr);
         GPANN_HIP_TRY(hipGetLastError());
         return GPANN_OK;
     };
@@ -672,6 +672,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     th.d = s->d;
     th.ld = s->ld;
     th.hi_only = 0;
+    th.task_nq = d_task_nq;
+    th.task_src = nullptr;   // (set once the tasks are reordered)
     NeedArgs na;
     na.cell_dist = cell_dist;
     na.task_shard = ta.shard;
@@ -681,10 +683,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.radius = C.d_radius;
     na.cell_cnorm = C.d_cnorm;
     na.shard_rmax = s->d_shard_rmax;
-    na.task_qnorm = d_qnorm;
+    na.task_nq = d_task_nq;
     na.list_dist = list_dist;
     na.nearest = d_nearest;
     na.task_src = d_task_src;
+    na.task_U = task_U;
+    na.cand_cnt = cand_cnt;
+    na.zero2 = d_next_item;
+    th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
     na.k = k;
@@ -768,7 +774,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    const size_t rlds = (size_t)kRescoreWaves * RescoreLdsFloats(s->ld) * sizeof(float);
+    const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
     if (rlds > (48u << 10)) {
         if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
         else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
@@ -779,8 +785,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
         GPANN_HIP_TRY(hipGetLastError());
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
@@ -830,33 +836,30 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             fs.items_cap = (uint32_t)sitems.size();
             fs.pass = 0;
             fs.need = nullptr;
-            fs.done0 = fs.done1 = nullptr;
+            fs.done0 = fs.done0b = fs.done1 = nullptr;
             void* sargs[] = {&fs};
             GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
             hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
-            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
             GPANN_HIP_TRY(hipGetLastError());
         }
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
-        GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
-        th.hi_only = hi_pass ? 1u : 0u;
-        if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-        else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+        // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
+        na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];
         if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
-        if (pass == 1) hipLaunchKernelGGL(OrWordsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, need_pass[0], need_pass[1], done_head, need_words);
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
-        fa.done0 = pass == 0 ? nullptr : (pass == 1 ? need_pass[0] : done_head);
+        fa.done0 = pass == 0 ? nullptr : need_pass[0];
+        fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
-        GPANN_HIP_TRY(hipMemsetAsync(d_next_item, 0, 8, st));   // cursor and item count
         hipLaunchKernelGGL(FilterItemsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, fa);
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it, and its begin / end
             GPANN_HIP_TRY(hipMemcpyAsync(d_work + 3, d_work + 1, 8, hipMemcpyDeviceToDevice, st));
@@ -875,8 +878,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
         // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
         hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(T), dim3(64 * kRescoreWaves), rlds, st, ra);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
         GPANN_HIP_TRY(hipGetLastError());
         plan.filter_launches++;
         if (std::getenv("GPANN_CELLS_DEBUG")) {

@@ -113,7 +113,7 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
 // nearest cell (smallest |q - c|^2, first minimum) and |q|^2 of every task
 static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t* task_shard, const uint32_t* shard_cell_begin, const float* queries,
                                          const uint32_t* task_query, uint32_t tasks, uint32_t kmax, uint32_t d, uint32_t ld, uint32_t* nearest,
-                                         float* task_qnorm) {
+                                         double* task_nq) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tasks) return;
     const uint32_t b = task_shard[t];
@@ -128,11 +128,11 @@ static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t*
         }
     }
     nearest[t] = best;
-    if (task_qnorm) {
+    if (task_nq) {
         const float* q = queries + (size_t)task_query[t] * ld;
         double nq = 0.0;
         for (uint32_t i = 0; i < d; ++i) nq += (double)q[i] * (double)q[i];
-        task_qnorm[t] = (float)(nq * (1.0 + 1e-6));
+        task_nq[t] = nq;
     }
 }
 
@@ -171,13 +171,19 @@ struct NeedArgs {
     const float* radius;                // [cells]
     const float* cell_cnorm;            // [cells] |c|^2 (MIPS)
     const double* shard_rmax;           // [S]
-    const float* task_qnorm;            // [tasks] |q|^2, rounded up
+    const double* task_nq;              // [tasks] |q|^2 (double sum; indexed through task_src)
     const float* list_dist;             // [tasks][k]
     const uint32_t* nearest;            // [tasks]
     const uint32_t* task_src;           // [tasks] row of cell_dist / nearest / task_qnorm that belongs to task t (the order before TaskReorderKernel)
     uint32_t* need;                     // [groups][kmax] bit per query tile
     uint32_t tasks, kmax, k, d;
     uint32_t head;                      // 1: only the nearest cell of each task
+    // the pass's per-task set-up rides along (thread j == 0 of every task): its threshold U, its candidate counter back to zero; thread
+    // 0 of the launch zeroes the item cursor / count of the pass
+    float* task_U;
+    uint32_t* cand_cnt;
+    uint32_t* zero2;
+    uint32_t hi_only;
 };
 
 // One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
@@ -193,6 +199,11 @@ static __global__ void NeedKernel(NeedArgs a) {
     const uint32_t src = a.task_src[t];
     const uint32_t b = a.task_shard[t];
     const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
+    if (j == 0) {
+        a.task_U[t] = ThresholdOf<METRIC>((double)a.list_dist[(size_t)t * a.k + a.k - 1], a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
+        a.cand_cnt[t] = 0;
+        if (t == 0) a.zero2[0] = a.zero2[1] = 0;
+    }
     if (j >= K) return;
     bool need;
     if (a.head) {
@@ -211,7 +222,7 @@ static __global__ void NeedKernel(NeedArgs a) {
                 const double lb = sqrt(fmax(D, 0.0)) * (1.0 - s) - r;
                 need = !(lb > 0.0 && lb * lb > tau * (1.0 + 2.0 * g1) * (1.0 + s) + 1e-30);
             } else {
-                const double nq = (double)a.task_qnorm[src], nc = (double)a.cell_cnorm[cell0 + j];
+                const double nq = a.task_nq[src] * (1.0 + 1e-6), nc = (double)a.cell_cnorm[cell0 + j];
                 const double R = a.shard_rmax[b];
                 const double qn = sqrt(nq);
                 const double dot_ub = 0.5 * (nq + nc - D) + s * (nq + nc + fabs(D));
@@ -224,11 +235,6 @@ static __global__ void NeedKernel(NeedArgs a) {
         const uint32_t g = a.task_group[t];
         atomicOr(&a.need[(size_t)g * a.kmax + j], 1u << ((t - a.groups[g].task_begin) >> 5));
     }
-}
-
-static __global__ void OrWordsKernel(const uint32_t* x, const uint32_t* y, uint32_t* out, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = x[i] | y[i];
 }
 
 struct CellFilterArgs {
@@ -250,6 +256,7 @@ struct CellFilterArgs {
     // A cell's tiles form three segments: head [0, head_tiles), sample [head_tiles, max(head_tiles, tiles / sample_div)), rest.
     // Pass p (0 head, 1 sample, 2 rest) covers segments 0..p; done0 / done1 are the query tiles that already ran on segment 0 / 1.
     const uint32_t* done0;
+    const uint32_t* done0b;      // (optional) OR-ed into done0
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
     unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
@@ -277,7 +284,7 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     const uint32_t shard = a.groups[g].shard;
     const uint32_t cell0 = a.shard_cell_begin[shard];
     if (j >= a.shard_cell_begin[shard + 1] - cell0) return;
-    const uint32_t d0 = a.done0 ? a.done0[block] : 0u;
+    const uint32_t d0 = (a.done0 ? a.done0[block] : 0u) | (a.done0b ? a.done0b[block] : 0u);
     const uint32_t d1 = a.done1 ? a.done1[block] : 0u;
     const int64_t t_cell = (int64_t)a.cell_tile_begin[cell0 + j];
     const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];

@@ -113,40 +113,48 @@ struct ThresholdArgs {
     float* task_U;
     uint32_t tasks, k, d, ld;
     uint32_t hi_only;             // the filter pass reads only the hi plane of the points: the dropped q.p_lo term joins the error bound
+    const double* task_nq;        // optional [tasks]: |q|^2 of every task (NearestCellKernel), indexed through task_src; else summed here
+    const uint32_t* task_src;
 };
+
+// nq = |q|^2 (double, summed in the query's dimension order), R = max |p| over the shard
+template <int METRIC>
+__device__ __forceinline__ float ThresholdOf(double tau, double nq, double R, double dd, bool hi_only) {
+    if (!(tau < (double)INFINITY)) return -INFINITY;   // list not full yet (or NaN): everything is a candidate
+    const double qn = sqrt(nq) * (1.0 + 1e-12);
+    double U;
+    if (METRIC == GPANN_METRIC_L2) {
+        const double g1 = (dd + 32.0) * 0x1p-23;
+        const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20;
+        // hi plane only: |(q_h + q_l).(p_l + r_p) + r_q.p| <= (2^-9 * 1.01 + 2^-17) |q||p| of the dot product is missing, twice that in D
+        const double e_hi = hi_only ? 2.0 * 1.02 * 0x1p-9 * qn * R : 0.0;
+        const double e2 = c2 * (R + qn) * (R + qn) + e_hi + 1e-30;
+        U = -(tau * (1.0 + 2.0 * g1) - nq * (1.0 - 0x1p-40) + e2) * 0.5;
+    } else {
+        const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
+        const double e_hi = hi_only ? 1.02 * 0x1p-9 * qn * R : 0.0;
+        const double e2 = (4.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24) * qn * R + e_hi + 1e-30;
+        U = 1.0 - tau - e1 - e2;
+    }
+    float Uf = (float)U;
+    if ((double)Uf > U) Uf = nextafterf(Uf, -INFINITY);
+    return Uf;
+}
 
 template <int METRIC>
 __global__ void ThresholdKernel(ThresholdArgs a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.tasks) return;
     const double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
-    if (!(tau < (double)INFINITY)) {   // list not full yet (or NaN): everything is a candidate
-        a.task_U[t] = -INFINITY;
-        return;
-    }
-    const float* q = a.queries + (size_t)a.task_query[t] * a.ld;
-    double nq = 0.0;
-    for (uint32_t i = 0; i < a.d; ++i) nq += (double)q[i] * (double)q[i];
-    const double R = a.shard_rmax[a.task_shard[t]];
-    const double qn = sqrt(nq) * (1.0 + 1e-12);
-    const double dd = (double)a.d;
-    double U;
-    if (METRIC == GPANN_METRIC_L2) {
-        const double g1 = (dd + 32.0) * 0x1p-23;
-        const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20;
-        // hi plane only: |(q_h + q_l).(p_l + r_p) + r_q.p| <= (2^-9 * 1.01 + 2^-17) |q||p| of the dot product is missing, twice that in D
-        const double e_hi = a.hi_only ? 2.0 * 1.02 * 0x1p-9 * qn * R : 0.0;
-        const double e2 = c2 * (R + qn) * (R + qn) + e_hi + 1e-30;
-        U = -(tau * (1.0 + 2.0 * g1) - nq * (1.0 - 0x1p-40) + e2) * 0.5;
+    double nq;
+    if (a.task_nq) {
+        nq = a.task_nq[a.task_src ? a.task_src[t] : t];
     } else {
-        const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
-        const double e_hi = a.hi_only ? 1.02 * 0x1p-9 * qn * R : 0.0;
-        const double e2 = (4.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24) * qn * R + e_hi + 1e-30;
-        U = 1.0 - tau - e1 - e2;
+        const float* q = a.queries + (size_t)a.task_query[t] * a.ld;
+        nq = 0.0;
+        for (uint32_t i = 0; i < a.d; ++i) nq += (double)q[i] * (double)q[i];
     }
-    float Uf = (float)U;
-    if ((double)Uf > U) Uf = nextafterf(Uf, -INFINITY);
-    a.task_U[t] = Uf;
+    a.task_U[t] = ThresholdOf<METRIC>(tau, nq, a.shard_rmax[a.task_shard[t]], (double)a.d, a.hi_only != 0);
 }
 
 // ---- rescoring ---------------------------------------------------------------------------------------------------------
@@ -203,32 +211,29 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
     }
 }
 
-// One WORKGROUP (4 wavefronts) per task.  The kernel's time is its slowest task — candidate counts are long-tailed, and a task's
-// candidates are a sequential chain of fetch rounds — so the four wavefronts share a task's candidates block-wise (blocks of 64 row ids,
-// block b to wavefront b mod 4), each with a private copy of the task's list, and the copies are merged at the end (the union of the four
-// top-k lists, de-duplicated, IS the top-k of everything seen).  Within a wavefront, candidates are taken 16 at a time: their rows are
-// fetched COALESCED (half a wavefront per row: one 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row
-// costs the texture path 64 cache lines per load instruction) and staged through LDS, the next 16 rows being in flight while lanes
-// 0..15 evaluate the canonical distance of the current ones against the query row in LDS; the survivors are inserted into the list
-// (one entry per lane).
+// One wavefront per task.  Candidates are taken 16 at a time: their rows are fetched COALESCED (half a wavefront per row: one
+// 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row costs the texture path 64 cache lines per load
+// instruction) and staged through LDS, the next 16 rows being in flight while lanes 0..15 evaluate the canonical distance of the
+// current ones against the query row in LDS; the survivors are inserted into the task's list (one entry per lane).
 constexpr int kRescoreSub = 16;                                                   // candidates per round
 constexpr int kRescoreRounds = 64 / kRescoreSub;                                  // rounds per block of 64 row ids
-constexpr int kRescoreWaves = 4;                                                  // wavefronts per task
+constexpr int kRescoreTasksPerWG = 1;   // wavefronts (= tasks) per workgroup: candidate counts are long-tailed and a workgroup lasts as long as its
+                                        // slowest task, so single-wavefront workgroups pack the CUs best
 __host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
 
 template <int METRIC>
-__global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs a) {
+__global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
-    __shared__ float s_merge_d[kRescoreWaves][64];
-    __shared__ uint32_t s_merge_r[kRescoreWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = blockIdx.x * kRescoreTasksPerWG + wave;
+    if (t >= a.tasks) return;
     const bool seed = a.seed_rows != 0;
     uint64_t seed_first = 0;   // first plane row of the task's nearest cell
     uint32_t cnt;
     if (seed) {
         // plane rows [seed_first, seed_first + cnt): from the nearest cell's first row onwards, inside the shard's plane range (the
-        // following cells are its neighbours along the cell chain)
+        // following cells are its neighbours along the cell chain).  (A workgroup of four wavefronts per task with merged private lists
+        // was measured slower: 10k workgroups cost more to start than the long tail of the candidate counts costs to sit out.)
         const uint32_t b = a.task_shard[t];
         const uint64_t p0 = a.cell_tile_begin[a.shard_cell_begin[b]] * kGTileRows, p1 = a.cell_tile_begin[a.shard_cell_begin[b + 1]] * kGTileRows;
         seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[a.task_src[t]]] * kGTileRows;
@@ -236,9 +241,9 @@ __global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs 
         cnt = (uint32_t)min((uint64_t)a.seed_rows, p1 - seed_first);
     } else {
         cnt = a.cand_cnt[t];
-        if (cnt == 0) return;   // (the whole workgroup)
+        if (cnt == 0) return;
     }
-    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: the workgroup then evaluates the pass's whole row range of the shard itself
+    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
     if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
     float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
@@ -259,17 +264,13 @@ __global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs 
         scan_hi = a.range_hi == INT64_MAX ? a.shard_offsets[b + 1] : min(a.shard_offsets[b + 1], a.shard_offsets[b] + a.range_hi);
     }
     const uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
-    // this wavefront's share: the blocks b = wave, wave + 4, ... of 64 items; local position i <-> global ((i / 64) * 4 + wave) * 64 + i % 64
-    const uint64_t n_blocks = (n_items + 63) / 64;
-    const uint64_t my_blocks = n_blocks > (uint64_t)wave ? (n_blocks - wave + kRescoreWaves - 1) / kRescoreWaves : 0;
-    const uint64_t n_local = my_blocks * 64;
     const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 float4 (128 dimensions) of a row per load instruction and half wavefront
     const int half = lane >> 5, c4l = lane & 31;
 
     // row ids are read 64 candidates at a time (one coalesced load, a block ahead); round `sub` of a block takes its 16 from there
-    auto load_block = [&](uint64_t first_local) -> uint32_t {
-        const uint64_t idx = ((first_local >> 6) * kRescoreWaves + wave) * 64 + lane;
-        if (first_local >= n_local || idx >= n_items) return kNoId;
+    auto load_block = [&](uint64_t first) -> uint32_t {
+        const uint64_t idx = first + lane;
+        if (idx >= n_items) return kNoId;
         if (seed) return a.plane_perm[seed_first + idx];   // (kNoId on the padding of a cell's last tile: skipped like an absent candidate)
         return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + idx];
     };
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs 
     uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
     uint32_t row = round_rows(block_rows, 0);
     fetch(v, row, 0);
-    for (uint64_t base = 0; base < n_local; base += kRescoreSub) {
+    for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
         const uint32_t sub = (uint32_t)(base / kRescoreSub) % (uint32_t)kRescoreRounds;
         __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
         stage(v, 0);
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs 
             const int l = __builtin_ctzll(mask);
             const float cd = __shfl(e, l);
             const uint32_t cr = __shfl(cur_row, l);
-            // a row may be offered twice (cell passes overlap a sample row; an overflowed bucket re-reads its range): a row that is
+            // a row may be offered twice (cell passes overlap a stage-0 row; an overflowed bucket re-reads its range): a row that is
             // in the list stays once, one that was pushed out cannot pass the k-th entry again
             if (a.dedupe && __ballot(lane < (int)k && lr_ == cr) != 0ull) {
                 pass = pass && lane != l;
@@ -339,23 +340,6 @@ __global__ void __launch_bounds__(64 * kRescoreWaves) RescoreKernel(RescoreArgs 
             tr = __shfl(lr_, k - 1);
             pass = pass && lane != l && PairLess(e, cur_row, td, tr);
             mask = __ballot(pass);
-        }
-    }
-    // ---- merge the four private lists: wavefront 0 takes the entries of the others that beat its k-th entry and are not in its list yet
-    s_merge_d[wave][lane] = ld_;
-    s_merge_r[wave][lane] = lr_;
-    __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < kRescoreWaves; ++w) {
-        for (uint32_t i = 0; i < k; ++i) {
-            const float cd = s_merge_d[w][i];
-            const uint32_t cr = s_merge_r[w][i];
-            if (cr == kNoId) break;   // (lists are ascending: the rest is empty)
-            const float td = __shfl(ld_, k - 1);
-            const uint32_t tr = __shfl(lr_, k - 1);
-            if (!PairLess(cd, cr, td, tr)) break;   // nor can any later entry of this list beat it
-            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
-            ListInsertF(ld_, lr_, cd, cr, k, lane);
         }
     }
     if (lane < (int)k) {
