@@ -71,6 +71,11 @@ struct gpann_router {
     // host copy of the flat tree: the few queries of a batch whose walk needs the real priority queue are replayed on host threads
     std::vector<int32_t> h_node_shard;
     std::vector<uint32_t> h_node_cent_first, h_node_child_first, h_node_child_count, h_shard_root;
+    // a bound block whose counters (candidate slots, unset minima) have not been looked at yet: they travel to the host with the results and
+    // are checked after the call's one synchronisation (a bad block is rare; the call is then repeated canonically)
+    struct { bool active = false; uint32_t nb = 0, cand_cap = 0; } pending_bound;
+    uint32_t* pinned_counters = nullptr;   // [2]
+    bool canonical_once = false;           // the repeated call: no bound path
     gpann::DeviceBuffer ws_host_redo;      // packed table rows / results of those queries
     float* pinned_redo = nullptr;          // their table rows on the host
     size_t pinned_redo_floats = 0;
@@ -1319,6 +1324,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_verify.Release();
     r->ws_host_redo.Release();
     if (r->pinned_redo) (void)hipHostFree(r->pinned_redo);
+    if (r->pinned_counters) (void)hipHostFree(r->pinned_counters);
     if (r->pinned_min) (void)hipHostFree(r->pinned_min);
     if (r->pinned_probes) (void)hipHostFree(r->pinned_probes);
     r->ws_probes.Release();
@@ -1491,7 +1497,9 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     ba.ld = ld;
     const uint32_t groups = (nb + 255) / 256;
     const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
-    ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), (320 + groups - 1) / groups));
+    // one round of workgroups: (query groups) x (centroid segments) <= the CUs (a workgroup per CU, 132 KiB of LDS each) — 40 groups x 8
+    // segments = 320 workgroups on 256 CUs ran as 256 + 64, i.e. at the pace of 160
+    ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), std::max(1u, (uint32_t)r->num_cus / groups)));
     GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
     GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 16, st));   // candidate counter, the self-check's counter, (verify mode) two more words
     GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
@@ -1649,12 +1657,25 @@ gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipS
     return GPANN_ERR_INTERNAL;
 }
 
-gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, bool* settled, const float* caller_queries, bool caller_on_device) {
+gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, bool* settled, const float* caller_queries, bool caller_on_device,
+                          bool may_defer) {
     *settled = false;
     const size_t nb_s = (size_t)nb * r->S;
     BoundArgs ba;
     float* thr = nullptr;
     GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
+    if (may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
+        // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
+        if (!r->pinned_counters) GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_counters), 16, hipHostMallocDefault));
+        GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+        GPANN_HIP_TRY(hipGetLastError());
+        r->pending_bound.active = true;
+        r->pending_bound.nb = nb;
+        r->pending_bound.cand_cap = ba.cand_cap;
+        *settled = true;
+        return GPANN_OK;
+    }
     uint32_t counters[2] = {0, 0};   // candidate slots handed out, unset minima
     GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
@@ -1684,6 +1705,32 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
     GPANN_HIP_TRY(hipGetLastError());
     *settled = true;
+    return GPANN_OK;
+}
+
+// After the call's synchronisation: the deferred look at a bound block's counters.  *repeat = the block has to be evaluated canonically.
+gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
+    *repeat = false;
+    if (!r->pending_bound.active) return GPANN_OK;
+    r->pending_bound.active = false;
+    ++r->stat_bound_calls;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r->ev_bound[0], r->ev_bound[1]) == hipSuccess) r->stat_bound_ms += ms;
+    r->stat_bound_flops += 2.0 * 2.0 * 3.0 * (double)r->pending_bound.nb * (double)r->n_centroids * (double)r->d;
+    const uint32_t n_cand = r->pinned_counters[0], unset = r->pinned_counters[1];
+    if (unset != 0) {
+        ++r->stat_bound_selfcheck;
+        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n", unset,
+                (size_t)r->pending_bound.nb * r->S);
+        if (std::getenv("GPANN_ROUTER_STRICT")) {
+            SetLastError("router bound path left %u minima unset (GPANN_ROUTER_STRICT)", unset);
+            return GPANN_ERR_INTERNAL;
+        }
+        *repeat = true;
+    } else if (n_cand > r->pending_bound.cand_cap) {
+        ++r->stat_bound_overflow;
+        *repeat = true;
+    }
     return GPANN_OK;
 }
 
@@ -1755,10 +1802,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 const size_t nb_s = (size_t)nb * S;
                 hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                 const char* bmode = std::getenv("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
-                if (r->cent_planes && !(bmode && bmode[0] == '0')) {
+                if (r->cent_planes && !(bmode && bmode[0] == '0') && !r->canonical_once) {
                     // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h)
                     bool settled = false;
-                    GPANN_TRY(RunBoundPath(r, da, nb, st, &settled, queries + (size_t)q0 * r->d, (flags & GPANN_QUERIES_ON_DEVICE) != 0));
+                    GPANN_TRY(RunBoundPath(r, da, nb, st, &settled, queries + (size_t)q0 * r->d, (flags & GPANN_QUERIES_ON_DEVICE) != 0, /*may_defer=*/nb == nq));
                     if (settled) continue;
                     // (masses of equal distances / self-check) fall through to the canonical evaluation of every pair
                     hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
@@ -2026,6 +2073,16 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         }
         if (out_min_dist) GPANN_TRY(fetch_min_dist());
         else GPANN_HIP_TRY(hipStreamSynchronize(st));
+        {
+            bool repeat = false;
+            GPANN_TRY(ResolvePendingBound(r, &repeat));
+            if (repeat) {   // (rare) the whole call again without the bound path
+                r->canonical_once = true;
+                const gpann_status again = gpann_router_query_batch(r, queries, nq, budget, out_probes, out_min_dist, flags, stream, elapsed_ms);
+                r->canonical_once = false;
+                return again;
+            }
+        }
         if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
         if (!direct) std::memcpy(out_probes, r->pinned_probes, words * 4);
         const uint32_t* flags = reinterpret_cast<const uint32_t*>(r->pinned_probes + words);
@@ -2044,6 +2101,16 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     }
 
     GPANN_TRY(fetch_min_dist());
+    {
+        bool repeat = false;
+        GPANN_TRY(ResolvePendingBound(r, &repeat));
+        if (repeat) {
+            r->canonical_once = true;
+            const gpann_status again = gpann_router_query_batch(r, queries, nq, budget, out_probes, out_min_dist, flags, stream, elapsed_ms);
+            r->canonical_once = false;
+            return again;
+        }
+    }
     if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
     if (out_probes) {
         // queries are independent, so the batch is spread over a few host threads

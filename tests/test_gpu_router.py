@@ -224,3 +224,23 @@ def test_router_create_rejects_shards_out_of_order(orc, gp):
     bad["shard_root"][1] += 1                       # not the first node of its shard
     with pytest.raises(gp.GpannError):
         gp.Router(bad, 0)
+
+
+def test_bound_path_without_verify_defers_its_counter_check(orc, gp, monkeypatch):
+    """production setting (no GPANN_ROUTER_VERIFY): the bound block's counters are looked at after the call's single synchronisation"""
+    monkeypatch.delenv("GPANN_ROUTER_VERIFY", raising=False)
+    rng = np.random.default_rng(10)
+    n, d, S = 30000, 96, 7
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, 64, 350, 9000, 0, nthreads=4)
+    queries = make_mixture(orc, 1500, d, seed=556, n_centers=24)
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    router = gp.Router(tree.flat(), 0)
+    for want_min in (True, False):
+        p, md, _ = router.query_batch(queries, 10 ** 6, want_min_dist=want_min)
+        assert np.array_equal(p, want_p)
+        if want_min:
+            assert np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+    st = router.stats()
+    assert st["bound_calls"] == 2 and st["verified"] == 0 and st["bound_selfcheck"] == 0 and st["bound_overflow"] == 0 and st["last_bound_ms"] > 0
