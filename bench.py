@@ -727,8 +727,12 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
         fast = len(qidx) / dtf
     except Exception:
         pass
-    return {"value": len(qidx) / dt, "unit": "queries/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "value_reference_flags": fast, "value_32_threads": len(sub) / dt32, "threads_32": t32, "results_match_gpu": match,
+    # `value` = the better of the two thread counts (on a 256-thread host the reference's own cap of 32 workers is the faster setting: the
+    # per-query streams of 256 threads thrash the memory system); both are reported
+    v_all, v_32 = len(qidx) / dt, len(sub) / dt32
+    return {"value": max(v_all, v_32), "unit": "queries/s", "cores": cores if v_all >= v_32 else t32, "kind": "port", "cpu_model": cpu_model(),
+            "value_all_threads": v_all, "threads_all": cores,
+            "value_reference_flags": fast, "value_32_threads": v_32, "threads_32": t32, "results_match_gpu": match,
             "sample_queries": int(len(qidx)), "sample_pairs": pairs, "sample_GBps": pairs * d * 4 / dt / 1e9,
             "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
                       f"{pairs:.3g} (query,row) pairs = {pairs * d * 4 / 1e9:.0f} GB streamed in {dt:.1f}s on {cores} threads (rows first-touched by {touchers} "
