@@ -34,6 +34,67 @@ constexpr int kPT = 64;          // rows per tile
 constexpr int kDC = 32;          // dims per staged chunk
 constexpr int kLdsStride = kDC + 4;   // floats; +4 keeps the 16 row addresses of a ds_read_b128 lane group on distinct banks
 constexpr int kThreads = 256;
+// The 64 point rows of a tile lie in LDS as 32 PAIRS (rows r and r + 16, r in [0,16) or [32,48)): [pair][dim][member], so that one
+// ds_read_b128 delivers two dimensions of both rows and every operation of the distance sequence is a packed (two-lane) fp32
+// instruction on a natural register pair — (x_a - q.x, x_b - q.x) and so on, the query operand broadcast by the instruction's op_sel.
+// (With one row per float4 the pairs had to be formed across dimensions: 32 v_mov per 192 packed operations.)
+constexpr int kPairStride = 2 * kDC + 4;   // floats per pair row; +4: the 16 pair addresses of a lane group on distinct banks
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// one group of 4 dimensions of the reference's sequence (src/dist.cpp:23-31 / :44-46) for a thread's 4 queries x 2 point pairs
+template <int METRIC>
+__device__ __forceinline__ void AccumulatePairs(f32x2_t (&acc)[4][2], const float4 (&qv)[4], const f32x4_t (&p0)[2], const f32x4_t (&p1)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const f32x2_t px = p0[pr].xy, py = p0[pr].zw, pz = p1[pr].xy, pw = p1[pr].zw;
+            const f32x2_t qx = {qv[i].x, qv[i].x}, qy = {qv[i].y, qv[i].y}, qz = {qv[i].z, qv[i].z}, qw = {qv[i].w, qv[i].w};
+            if (METRIC == GPANN_METRIC_L2) {
+                const f32x2_t d0 = px - qx, d1 = py - qy, d2 = pz - qz, d3 = pw - qw;
+                f32x2_t t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                acc[i][pr] = acc[i][pr] + t;
+            } else {
+                f32x2_t r = acc[i][pr];
+                r = r + qx * px;
+                r = r + qy * py;
+                r = r + qz * pz;
+                r = r + qw * pw;
+                acc[i][pr] = r;
+            }
+        }
+    }
+}
+
+// the 1..3 trailing dimensions (src/dist.cpp:33-36), one at a time
+template <int METRIC>
+__device__ __forceinline__ void AccumulatePairsTail(f32x2_t (&acc)[4][2], const float4 (&qv)[4], const f32x4_t (&p0)[2], const f32x4_t (&p1)[2], int tail) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            f32x2_t r = acc[i][pr];
+            const f32x2_t pe[3] = {p0[pr].xy, p0[pr].zw, p1[pr].xy};
+            const float qe[3] = {qv[i].x, qv[i].y, qv[i].z};
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                if (x < tail) {
+                    const f32x2_t qb = {qe[x], qe[x]};
+                    if (METRIC == GPANN_METRIC_L2) {
+                        const f32x2_t d0 = pe[x] - qb;
+                        r = r + d0 * d0;
+                    } else {
+                        r = r + qb * pe[x];
+                    }
+                }
+            }
+            acc[i][pr] = r;
+        }
+    }
+}
 constexpr int kQueriesPerWave = kQT / 4;
 
 struct ScanArgs {
@@ -69,8 +130,8 @@ template <int METRIC, int TAG>
 __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
     extern __shared__ float4 smem4[];
     float* sQ = reinterpret_cast<float*>(smem4);          // [64][36]
-    float* sP = sQ + kQT * kLdsStride;                    // [64][36]
-    float* sD = sP + kPT * kLdsStride;                    // [64][64] distances of the current tile
+    float* sP = sQ + kQT * kLdsStride;                    // [32 pairs][68]
+    float* sD = sP + (kPT / 2) * kPairStride;             // [64][64] distances of the current tile
 
     // (fields are read one by one: a by-value struct copy ends up in scratch memory)
     struct {
@@ -110,15 +171,18 @@ __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
     }
 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // point staging role: pair st_pair = rows st_prow0 and st_prow0 + 16 of the tile, float4 #st_c4 of both
+    const int st_pair = tid >> 3;
+    const int st_prow0 = (st_pair & 15) + 32 * (st_pair >> 4);
     for (int64_t row0 = u.row_begin; row0 < u.row_end; row0 += kPT) {
-        float acc[4][4];
+        f32x2_t acc[4][2];   // acc[i][pr] = queries ty + 16 i x rows (tx + 32 pr, tx + 32 pr + 16)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+            for (int pr = 0; pr < 2; ++pr) acc[i][pr] = (f32x2_t){0.f, 0.f};
 
-        const int64_t pr0 = min(row0 + st_row0, u.row_end - 1);
-        const int64_t pr1 = min(row0 + st_row1, u.row_end - 1);
+        const int64_t pr0 = min(row0 + st_prow0, u.row_end - 1);
+        const int64_t pr1 = min(row0 + st_prow0 + 16, u.row_end - 1);
         const float* prow0 = a.points + (size_t)pr0 * ld;
         const float* prow1 = a.points + (size_t)pr1 * ld;
 
@@ -136,8 +200,9 @@ __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
             __syncthreads();   // previous chunk's LDS reads (and the previous tile's selection reads of sD) are done
             *reinterpret_cast<float4*>(sQ + st_row0 * kLdsStride + 4 * st_c4) = gq0;
             *reinterpret_cast<float4*>(sQ + st_row1 * kLdsStride + 4 * st_c4) = gq1;
-            *reinterpret_cast<float4*>(sP + st_row0 * kLdsStride + 4 * st_c4) = gp0;
-            *reinterpret_cast<float4*>(sP + st_row1 * kLdsStride + 4 * st_c4) = gp1;
+            // the two rows of the pair, interleaved dimension by dimension
+            *reinterpret_cast<float4*>(sP + st_pair * kPairStride + 8 * st_c4) = make_float4(gp0.x, gp1.x, gp0.y, gp1.y);
+            *reinterpret_cast<float4*>(sP + st_pair * kPairStride + 8 * st_c4 + 4) = make_float4(gp0.z, gp1.z, gp0.w, gp1.w);
             __syncthreads();
             if (ch + 1 < nchunks) {   // issue the next chunk's global loads; they complete under the arithmetic below
                 const uint32_t c = (ch + 1) * kDC + 4u * st_c4;
@@ -149,42 +214,52 @@ __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
             }
             const uint32_t g0 = ch * (kDC / 4);                        // first group index of this chunk
             const float* q_base = sQ + ty * kLdsStride;
-            const float* p_base = sP + tx * kLdsStride;
+            const float* p_base = sP + tx * kPairStride;               // pairs tx (rows tx, tx + 16) and tx + 16 (rows tx + 32, tx + 48)
             if (g0 + kDC / 4 <= full_groups) {
-                // fast path: 8 complete groups (unroll 2: two groups of LDS operands in flight keeps the tile under 168 VGPRs)
+                // fast path: 8 complete groups
 #pragma unroll 2
                 for (int g = 0; g < kDC / 4; ++g) {
-                    float4 qv[4], pv[4];
+                    float4 qv[4];
+                    f32x4_t p0[2], p1[2];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kLdsStride + 4 * g);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kLdsStride + 4 * g);
-                    AccumulateGroup<METRIC>(acc, qv, pv);
+                    for (int pr = 0; pr < 2; ++pr) {
+                        p0[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g);
+                        p1[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g + 4);
+                    }
+                    AccumulatePairs<METRIC>(acc, qv, p0, p1);
                 }
             } else {
                 for (int g = 0; g < kDC / 4; ++g) {
                     const uint32_t G = g0 + g;
                     if (G > full_groups || (G == full_groups && tail == 0)) break;
-                    float4 qv[4], pv[4];
+                    float4 qv[4];
+                    f32x4_t p0[2], p1[2];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kLdsStride + 4 * g);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kLdsStride + 4 * g);
-                    if (G < full_groups) AccumulateGroup<METRIC>(acc, qv, pv);
-                    else AccumulateTail<METRIC>(acc, qv, pv, tail);
+                    for (int pr = 0; pr < 2; ++pr) {
+                        p0[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g);
+                        p1[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g + 4);
+                    }
+                    if (G < full_groups) AccumulatePairs<METRIC>(acc, qv, p0, p1);
+                    else AccumulatePairsTail<METRIC>(acc, qv, p0, p1, tail);
                 }
             }
         }
 
-        // publish the 64x64 distance tile
+        // publish the 64x64 distance tile: member m of pair pr is row tx + 32 pr + 16 m
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[i][j];
-                if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;   // src/dist.cpp:50-52
-                sD[(ty + 16 * i) * kPT + tx + 16 * j] = v;
-            }
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float v = acc[i][pr][m];
+                    if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;   // src/dist.cpp:50-52
+                    sD[(ty + 16 * i) * kPT + tx + 32 * pr + 16 * m] = v;
+                }
         __syncthreads();
 
         // selection: this wave's 16 queries, lane = row of the tile
@@ -461,7 +536,7 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
         a.d = s->d;
         a.ld = s->ld;
         a.k = k;
-        const size_t lds = (size_t)(kQT * kLdsStride + kPT * kLdsStride + kQT * kPT) * sizeof(float);
+        const size_t lds = (size_t)(kQT * kLdsStride + (kPT / 2) * kPairStride + kQT * kPT) * sizeof(float);
         const dim3 grid((uint32_t)plan.units.size());
         const bool aux = (flags & GPANN_AUX_PASS) != 0;
         if (s->metric == GPANN_METRIC_L2) {
