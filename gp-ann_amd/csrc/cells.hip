@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members,
 
 // bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
 __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
-                                                                 char* planes, uint64_t lo_offset, uint32_t plane_ks) {
+                                                                 char* planes, uint64_t lo_offset, uint32_t plane_ks, const float* mu) {
     const uint32_t g_per_row = 2 * plane_ks;   // groups of 8 dims per row: 16 or 32
     const uint64_t total = plane_rows * g_per_row;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -52,10 +52,18 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
         if (row != kNoRow && 8 * g8 < ld) {
             const float4 x = *reinterpret_cast<const float4*>(points + (size_t)row * ld + 8 * g8);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            if (mu) {
+                const float4 m = *reinterpret_cast<const float4*>(mu + 8 * g8);
+                v[0] -= m.x; v[1] -= m.y; v[2] -= m.z; v[3] -= m.w;
+            }
         }
         if (row != kNoRow && 8 * g8 + 4 < ld) {
             const float4 x = *reinterpret_cast<const float4*>(points + (size_t)row * ld + 8 * g8 + 4);
             v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+            if (mu) {
+                const float4 m = *reinterpret_cast<const float4*>(mu + 8 * g8 + 4);
+                v[4] -= m.x; v[5] -= m.y; v[6] -= m.z; v[7] -= m.w;
+            }
         }
         Frag fh, fl;
 #pragma unroll
@@ -65,6 +73,17 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
         *reinterpret_cast<uint4*>(base) = fh.q;
         *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
     }
+}
+
+// column sums of the rows (double atomics): the store's mean row.  Thread t of a block sums column t % ld over the block's row slab.
+__global__ void __launch_bounds__(256) ColumnSumKernel(const float* points, uint64_t rows, uint32_t ld, uint64_t rows_per_block, double* sums) {
+    const uint32_t col = threadIdx.x % ld, lane_rows = 256 / ld;   // (ld <= 256)
+    const uint32_t r_off = threadIdx.x / ld;
+    if (r_off >= lane_rows) return;
+    const uint64_t r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    double acc = 0.0;
+    for (uint64_t r = r0 + r_off; r < r1; r += lane_rows) acc += (double)points[r * ld + col];
+    atomicAdd(&sums[col], acc);
 }
 
 // norms of the shard-sample rows (padding: -inf)
@@ -109,7 +128,7 @@ __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, con
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.sample_planes, (void*)c.sample_perm, (void*)c.sample_norm})
+                    (void*)c.plane_norm, (void*)c.sample_planes, (void*)c.sample_perm, (void*)c.sample_norm, (void*)c.d_mu})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -237,12 +256,43 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, 2 * tile_bytes) == hipSuccess &&
              hipMemset(s->frag_planes + (2 * C.n_tiles + 2) * tile_bytes, 0, 2 * tile_bytes) == hipSuccess;
     }
+    // squared L2: everything the matrix-core bound touches is taken around the store's mean row (translation leaves the distances alone
+    // and makes |p|, |q| — which the bound's error terms scale with — as small as the data allows; a cloud that sits at +100 in every
+    // coordinate would otherwise have error terms larger than its k-th distances).  GPANN_FILTER_CENTER=0 switches it off.
+    const char* centre_env = std::getenv("GPANN_FILTER_CENTER");
+    if (ok && s->metric == GPANN_METRIC_L2 && !(centre_env && centre_env[0] == '0')) {
+        double* d_sums = nullptr;
+        unsigned long long* d_max_bits = reinterpret_cast<unsigned long long*>(s->d_shard_rmax);
+        uint32_t* d_bad = nullptr;
+        ok = hipMalloc(&C.d_mu, (size_t)ld * 4) == hipSuccess && hipMalloc(&d_sums, (size_t)ld * 8) == hipSuccess && hipMalloc(&d_bad, 4) == hipSuccess &&
+             hipMemset(d_sums, 0, (size_t)ld * 8) == hipSuccess && hipMemset(d_bad, 0, 4) == hipSuccess;
+        if (ok) {
+            const uint64_t rows_per_block = std::max<uint64_t>(256, (s->rows + 8191) / 8192);
+            hipLaunchKernelGGL(ColumnSumKernel, dim3((uint32_t)((s->rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, 0, s->points, s->rows, ld, rows_per_block,
+                               d_sums);
+            std::vector<double> sums(ld);
+            ok = hipMemcpy(sums.data(), d_sums, (size_t)ld * 8, hipMemcpyDeviceToHost) == hipSuccess;
+            std::vector<float> mu(ld, 0.f);
+            for (uint32_t x = 0; x < s->d; ++x) mu[x] = (float)(sums[x] / (double)s->rows);
+            ok = ok && hipMemcpy(C.d_mu, mu.data(), (size_t)ld * 4, hipMemcpyHostToDevice) == hipSuccess;
+            // the rows' norms and the shards' max norms once more, in the centred frame
+            ok = ok && hipMemset(d_max_bits, 0, (size_t)S * 8) == hipSuccess;
+            if (ok) {
+                const int grid = (int)std::min<uint64_t>((s->rows + 3) / 4, 256 * 32);
+                hipLaunchKernelGGL(RowNormKernel, dim3(grid), dim3(256), 0, 0, s->points, s->rows, s->d, ld, s->d_offsets, S, s->neg_half_norm, d_max_bits, d_bad, C.d_mu);
+                uint32_t bad = 0;
+                ok = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+            }
+        }
+        if (d_sums) (void)hipFree(d_sums);
+        if (d_bad) (void)hipFree(d_bad);
+    }
     if (ok) {
         hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
         const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
-                           (uint64_t)(C.n_tiles + 2) * tile_bytes, C.plane_ks);
+                           (uint64_t)(C.n_tiles + 2) * tile_bytes, C.plane_ks, C.d_mu);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }
@@ -275,7 +325,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                 hipLaunchKernelGGL(SampleNormKernel, dim3((uint32_t)((srows + 255) / 256)), dim3(256), 0, 0, C.sample_perm, srows, s->neg_half_norm, C.sample_norm);
                 const int g3 = (int)std::min<uint64_t>((srows * 2 * C.plane_ks + 255) / 256, 256 * 64);
                 hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, C.sample_perm, srows, ld, C.sample_planes,
-                                   (uint64_t)(C.n_sample_tiles + 2) * tile_bytes, C.plane_ks);
+                                   (uint64_t)(C.n_sample_tiles + 2) * tile_bytes, C.plane_ks, C.d_mu);
                 sok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
             }
         }

@@ -52,6 +52,7 @@ struct gpann_router {
     uint32_t* shard_has_cent = nullptr;  // [S] 1 if the shard has at least one centroid (its min_dist cannot stay at FLT_MAX after a full visit)
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
     float* cent_nhn = nullptr;           // [n_centroids + 64] -|c|^2/2
+    float* cent_mu = nullptr;            // squared L2: [ld] mean centroid — planes, norms and query fragments of the bound path live in the frame c - mu, q - mu
     double cent_rmax = 0.0;              // largest centroid norm
     gpann::DeviceBuffer ws_bound, ws_verify;
     uint64_t stat_bound_calls = 0, stat_bound_selfcheck = 0, stat_bound_overflow = 0, stat_verified = 0, stat_verify_failures = 0;
@@ -1232,14 +1233,26 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             TRY_OR_FAIL(hipMalloc(&r->shard_has_cent, (size_t)S * 4));
             TRY_OR_FAIL(hipMemcpy(r->shard_has_cent, has.data(), (size_t)S * 4, hipMemcpyHostToDevice));
         }
-        // matrix-core bound for the visit-everything case (router_bound.h)
+        // matrix-core bound for the visit-everything case (router_bound.h).  Squared L2: in the frame of the mean centroid (translation
+        // leaves the distances alone; the bound's error terms scale with the norms).
         bool finite = true;
+        std::vector<float> mu(r->ld, 0.f);
+        const char* centre_env = std::getenv("GPANN_FILTER_CENTER");
+        const bool centred = metric == GPANN_METRIC_L2 && nc > 0 && !(centre_env && centre_env[0] == '0');
+        if (centred) {
+            std::vector<double> sum(d, 0.0);
+            for (size_t c = 0; c < nc; ++c)
+                for (uint32_t x = 0; x < d; ++x) sum[x] += centroids[c * d + x];
+            for (uint32_t x = 0; x < d; ++x) mu[x] = (float)(sum[x] / (double)nc);
+            for (uint32_t x = 0; x < d; ++x) finite = finite && std::isfinite(mu[x]);
+        }
         double rmax2 = 0.0;
         for (size_t c = 0; c < nc && finite; ++c) {
             double s2 = 0.0;
             for (uint32_t x = 0; x < d; ++x) {
-                const double v = centroids[c * d + x];
-                finite = finite && std::isfinite(v);
+                const float raw = centroids[c * d + x];
+                finite = finite && std::isfinite(raw);
+                const double v = centred ? (double)(raw - mu[x]) : (double)raw;   // (the fp32 difference the planes are split from)
                 s2 += v * v;
             }
             rmax2 = std::max(rmax2, s2);
@@ -1249,8 +1262,12 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             if (hipMalloc(&r->cent_planes, tiles * (size_t)kGTileBytes) == hipSuccess && hipMalloc(&r->cent_nhn, (nc + 64) * 4) == hipSuccess) {
                 TRY_OR_FAIL(hipMemset(r->cent_planes, 0, tiles * (size_t)kGTileBytes));
                 TRY_OR_FAIL(hipMemset(r->cent_nhn, 0, (nc + 64) * 4));
+                if (centred) {
+                    TRY_OR_FAIL(hipMalloc(&r->cent_mu, (size_t)r->ld * 4));
+                    TRY_OR_FAIL(hipMemcpy(r->cent_mu, mu.data(), (size_t)r->ld * 4, hipMemcpyHostToDevice));
+                }
                 hipLaunchKernelGGL(CentroidPlanesKernel, dim3((uint32_t)std::min<uint64_t>((nc * 16 + 255) / 256, 4096)), dim3(256), 0, 0, r->centroids, (uint64_t)nc, d,
-                                   r->ld, r->cent_planes, r->cent_nhn);
+                                   r->ld, r->cent_planes, r->cent_nhn, r->cent_mu);
                 TRY_OR_FAIL(hipGetLastError());
                 TRY_OR_FAIL(hipDeviceSynchronize());
                 r->cent_rmax = std::sqrt(rmax2) * (1.0 + 1e-9);
@@ -1312,7 +1329,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn, (void*)r->cent_mu})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -1495,6 +1512,7 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     ba.C = (uint32_t)C;
     ba.S = S;
     ba.ld = ld;
+    ba.mu = r->cent_mu;
     const uint32_t groups = (nb + 255) / 256;
     const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
     // one round of workgroups: (query groups) x (centroid segments) <= the CUs (a workgroup per CU, 132 KiB of LDS each) — 40 groups x 8
@@ -1516,8 +1534,8 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     void* kargs[] = {&ba};
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[0], st));
     GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
-    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
-    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax);
+    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu);
+    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu);
     GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[1], st));
     const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
@@ -1587,6 +1605,8 @@ gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipS
     GPANN_HIP_TRY(hipMemcpy(cshard.data(), r->cent_shard, C * 4, hipMemcpyDeviceToHost));
     std::vector<float> nhn(C);
     GPANN_HIP_TRY(hipMemcpy(nhn.data(), r->cent_nhn, C * 4, hipMemcpyDeviceToHost));
+    std::vector<float> mu(ld, 0.f);   // the frame of the bound (zero when the router is not centred)
+    if (r->cent_mu) GPANN_HIP_TRY(hipMemcpy(mu.data(), r->cent_mu, (size_t)ld * 4, hipMemcpyDeviceToHost));
 
     auto bits_to_float = [](uint32_t o) { uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; std::memcpy(&f, &b, 4); return f; };
     size_t bad1 = 0, bad2 = 0, unset1 = 0, max_diff = 0, thr_diff = 0, thr_nan1 = 0, max_zero1 = 0, q_diff = 0, q_vs_caller = 0;
@@ -1626,7 +1646,7 @@ gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipS
             ++n_in;
             double dot = 0, dist = 0;
             for (uint32_t x = 0; x < d; ++x) {
-                dot += (double)qv[x] * cents[c * ld + x];
+                dot += (double)(qv[x] - mu[x]) * (double)(cents[c * ld + x] - mu[x]);
                 const double df = (double)qv[x] - cents[c * ld + x];
                 dist += df * df;
             }

@@ -31,6 +31,7 @@ struct BoundArgs {
     uint2* cand;                  // [cand_cap] (query, centroid)
     uint32_t cand_cap;
     uint32_t nq, C, S, ld, n_seg;
+    const float* mu;              // squared L2: the centre the centroid planes were built around ([ld]); nullptr = not centred
 };
 
 __device__ __forceinline__ uint32_t OrderedBitsB(float f) {
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
 
     {   // the query image: wavefront w builds query tile w (zeros for absent queries)
         const uint32_t ql = 32u * wave + c;
-        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)(q_base + min(ql, q_count - 1)) * ld, ql < q_count, ld, lane);
+        BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)(q_base + min(ql, q_count - 1)) * ld, ql < q_count, ld, lane, a.mu);
     }
     __syncthreads();
 
@@ -220,11 +221,14 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
 // thr[q][shard] from the pass-1 maxima; |q|^2 in double per query.  One workgroup (64 threads) per query.
 template <int METRIC>
 __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, const uint32_t* max_bits, float* thr, uint32_t S, uint32_t d, uint32_t ld,
-                                                        double cent_rmax) {
+                                                        double cent_rmax, const float* mu) {
     const uint32_t q = blockIdx.x;
     const float* row = queries + (size_t)q * ld;
     double nq = 0.0;
-    for (uint32_t i = threadIdx.x; i < d; i += 64) nq += (double)row[i] * (double)row[i];
+    for (uint32_t i = threadIdx.x; i < d; i += 64) {
+        const float v = mu ? row[i] - mu[i] : row[i];   // the frame of the planes (BuildQueryTile)
+        nq += (double)v * (double)v;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nq += __shfl_xor(nq, o);
     const double qn = sqrt(nq) * (1.0 + 1e-12), R = cent_rmax, dd = (double)d;
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, co
         double t;
         if (METRIC == GPANN_METRIC_L2) {
             const double g1 = (dd + 32.0) * 0x1p-23;
-            const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20;
+            const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20 + 0x1p-21;   // (+ 2^-21: rounding of the centred coordinates)
             const double e2 = c2 * (R + qn) * (R + qn) + 1e-30;
             const double Dap = fmax(nq - 2.0 * m, 0.0) + e2;
             t = m - 0.5 * (3.0 * g1 * Dap + e2 * (2.0 + 3.0 * g1)) - 1e-30;
@@ -262,7 +266,8 @@ __global__ void ExactCandidatesKernel(const float* centroids, const float* queri
 }
 
 // centroids -> bf16 hi/lo planes in MFMA A-operand order (as SplitFragPlanes of the shard store), and -|c|^2/2
-static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* centroids, uint64_t C, uint32_t d, uint32_t ld, char* planes, float* nhn) {
+static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* centroids, uint64_t C, uint32_t d, uint32_t ld, char* planes, float* nhn,
+                                                                   const float* mu) {
     const uint64_t total = C * 16;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = i >> 4;
@@ -273,10 +278,18 @@ static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* 
         if (8 * g8 < ld) {
             const float4 x = *reinterpret_cast<const float4*>(centroids + r * ld + 8 * g8);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            if (mu) {
+                const float4 m = *reinterpret_cast<const float4*>(mu + 8 * g8);
+                v[0] -= m.x; v[1] -= m.y; v[2] -= m.z; v[3] -= m.w;
+            }
         }
         if (8 * g8 + 4 < ld) {
             const float4 x = *reinterpret_cast<const float4*>(centroids + r * ld + 8 * g8 + 4);
             v[4] = x.x; v[5] = x.y; v[6] = x.z; v[7] = x.w;
+            if (mu) {
+                const float4 m = *reinterpret_cast<const float4*>(mu + 8 * g8 + 4);
+                v[4] -= m.x; v[5] -= m.y; v[6] -= m.z; v[7] -= m.w;
+            }
         }
         Frag fh, fl;
 #pragma unroll
@@ -287,7 +300,10 @@ static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* 
         *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
         if (g8 == 0) {
             double s = 0.0;
-            for (uint32_t x = 0; x < d; ++x) s += (double)centroids[r * ld + x] * (double)centroids[r * ld + x];
+            for (uint32_t x = 0; x < d; ++x) {
+                const float v = mu ? centroids[r * ld + x] - mu[x] : centroids[r * ld + x];
+                s += (double)v * (double)v;
+            }
             nhn[r] = (float)(-0.5 * s);
         }
     }

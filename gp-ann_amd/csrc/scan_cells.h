@@ -113,7 +113,7 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
 // nearest cell (smallest |q - c|^2, first minimum) and |q|^2 of every task
 static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t* task_shard, const uint32_t* shard_cell_begin, const float* queries,
                                          const uint32_t* task_query, uint32_t tasks, uint32_t kmax, uint32_t d, uint32_t ld, uint32_t* nearest,
-                                         double* task_nq) {
+                                         double* task_nq, const float* mu) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tasks) return;
     const uint32_t b = task_shard[t];
@@ -131,7 +131,10 @@ static __global__ void NearestCellKernel(const float* cell_dist, const uint32_t*
     if (task_nq) {
         const float* q = queries + (size_t)task_query[t] * ld;
         double nq = 0.0;
-        for (uint32_t i = 0; i < d; ++i) nq += (double)q[i] * (double)q[i];
+        for (uint32_t i = 0; i < d; ++i) {
+            const float v = mu ? q[i] - mu[i] : q[i];   // the frame of the planes (BuildQueryTile)
+            nq += (double)v * (double)v;
+        }
         task_nq[t] = nq;
     }
 }
@@ -322,14 +325,14 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
 // (group, query tile).  FilterKernelCells copies the tiles it needs into LDS for every work item (LDS-DMA, no registers).
 template <int KS, int QT>
 static __global__ void __launch_bounds__(64) QueryImageKernel(const float* queries, const uint32_t* task_query, const CellGroup* groups, uint32_t ld,
-                                                              char* image) {
+                                                              char* image, const float* mu) {
     const uint32_t g = blockIdx.x / QT, qt = blockIdx.x - g * QT;
     const int lane = threadIdx.x, c = lane & 31;
     const uint32_t task_begin = groups[g].task_begin, task_count = groups[g].task_count;
     const uint32_t tl = 32u * qt + c;
     if (32u * qt >= task_count) return;   // (tiles past the group's tasks are never read)
     const uint32_t task = task_begin + min(tl, task_count - 1);
-    BuildQueryTile<KS>(image + ((size_t)g * QT + qt) * KS * 2048, queries + (size_t)task_query[task] * ld, tl < task_count, ld, lane);
+    BuildQueryTile<KS>(image + ((size_t)g * QT + qt) * KS * 2048, queries + (size_t)task_query[task] * ld, tl < task_count, ld, lane, mu);
 }
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm:

@@ -61,8 +61,10 @@ constexpr int kGTasks = 256;                   // tasks per filter group: 8 quer
 // wavefront: lane (c, h) converts dims 16 ks + 8 h .. + 7 of query row `qrow` (its row c of the tile; zeros if !real).  All
 // global loads are issued before the first conversion: per-k-step load -> convert -> store chains cost ~2 us each and made the
 // image (rebuilt for every work item) the dominant cost of small items.
+// `mu` (optional, [ld], pad entries zero): the centre the store's planes were built around (squared L2 is translation invariant: both
+// sides of the bound live in the frame p - mu, q - mu, whose norms — and with them the bound's error terms — are as small as the data allows)
 template <int KS>
-__device__ __forceinline__ void BuildQueryTile(char* tile_lds, const float* qrow, bool real, uint32_t ld, int lane) {
+__device__ __forceinline__ void BuildQueryTile(char* tile_lds, const float* qrow, bool real, uint32_t ld, int lane, const float* mu = nullptr) {
     const int h = lane >> 5;
     float4 x0[KS], x1[KS];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -70,8 +72,14 @@ __device__ __forceinline__ void BuildQueryTile(char* tile_lds, const float* qrow
     for (int ks = 0; ks < KS; ++ks) {
         const uint32_t k0 = 16u * ks + 8u * h;
         // (addresses are clamped into the row, the values masked afterwards: no branch between the loads)
-        const float4 a0 = *reinterpret_cast<const float4*>(qrow + min(k0, ld - 4));
-        const float4 a1 = *reinterpret_cast<const float4*>(qrow + min(k0 + 4, ld - 4));
+        float4 a0 = *reinterpret_cast<const float4*>(qrow + min(k0, ld - 4));
+        float4 a1 = *reinterpret_cast<const float4*>(qrow + min(k0 + 4, ld - 4));
+        if (mu) {
+            const float4 m0 = *reinterpret_cast<const float4*>(mu + min(k0, ld - 4));
+            const float4 m1 = *reinterpret_cast<const float4*>(mu + min(k0 + 4, ld - 4));
+            a0 = make_float4(a0.x - m0.x, a0.y - m0.y, a0.z - m0.z, a0.w - m0.w);
+            a1 = make_float4(a1.x - m1.x, a1.y - m1.y, a1.z - m1.z, a1.w - m1.w);
+        }
         x0[ks] = (real && k0 < ld) ? a0 : zero4;
         x1[ks] = (real && k0 + 4 < ld) ? a1 : zero4;
     }
@@ -125,7 +133,8 @@ __device__ __forceinline__ float ThresholdOf(double tau, double nq, double R, do
     double U;
     if (METRIC == GPANN_METRIC_L2) {
         const double g1 = (dd + 32.0) * 0x1p-23;
-        const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20;
+        // (+ 2^-21: the rounding of the centred coordinates fl(p - mu), fl(q - mu): |D_centred - D| <= 2^-22 (R + |q|)^2)
+        const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20 + 0x1p-21;
         // hi plane only: |(q_h + q_l).(p_l + r_p) + r_q.p| <= (2^-9 * 1.01 + 2^-17) |q||p| of the dot product is missing, twice that in D
         const double e_hi = hi_only ? 2.0 * 1.02 * 0x1p-9 * qn * R : 0.0;
         const double e2 = c2 * (R + qn) * (R + qn) + e_hi + 1e-30;
@@ -364,14 +373,18 @@ static __global__ void ListOutputKernel(const float* list_dist, const uint32_t* 
 // row norms for the filter: -|p|^2/2 as float (from a double sum), per-shard max |p| via an ordered-bits atomic max, and a
 // finiteness / magnitude check.  One wavefront per row.
 static __global__ void __launch_bounds__(256) RowNormKernel(const float* points, uint64_t rows, uint32_t d, uint32_t ld, const int64_t* shard_offsets,
-                                                     uint32_t S, float* neg_half_norm, unsigned long long* shard_max_bits, uint32_t* bad) {
+                                                     uint32_t S, float* neg_half_norm, unsigned long long* shard_max_bits, uint32_t* bad,
+                                                     const float* mu = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave_id = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave_id; r < rows; r += n_waves) {
         const float* p = points + r * ld;
         double s = 0.0;
-        for (uint32_t i = lane; i < d; i += 64) s += (double)p[i] * (double)p[i];
+        for (uint32_t i = lane; i < d; i += 64) {
+            const float v = mu ? p[i] - mu[i] : p[i];   // (the fp32 value the planes are split from)
+            s += (double)v * (double)v;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) {

@@ -109,6 +109,9 @@ struct gpann_shards {
         char* sample_planes = nullptr;             // hi tiles, then (n_sample_tiles + 2) tiles further the lo tiles
         uint32_t* sample_perm = nullptr;           // [n_sample_tiles*32] sample row -> store row (0xFFFFFFFF: padding)
         float* sample_norm = nullptr;              // [n_sample_tiles*32 + 64]
+        // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
+        // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
+        float* d_mu = nullptr;
     } cells;
     bool filter_ok = false;
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)

@@ -188,3 +188,36 @@ def test_cells_200_dimensions_midsize_inner_product(orc, gp, monkeypatch):
     ivf = orc.ivf_build(pts, clusters)
     wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries[sub], k, probes[sub], S, 1, nthreads=16)
     assert np.array_equal(ids[sub], wi) and np.array_equal(dist[sub].view(np.uint32), wd.view(np.uint32))
+
+
+@pytest.mark.parametrize("d,offset", [(128, 100.0), (96, 1000.0), (30, -250.0)])
+def test_cells_on_data_far_from_the_origin(orc, gp, d, offset):
+    """a cloud that sits far from the origin (SIFT-like, non-negative coordinates): squared L2 is translation invariant and the store builds
+    its planes around its mean row, so the matrix-core bound stays as sharp as on centred data — the filter must still be the path that
+    answers (no fallback to the exact scan), prune, and return the oracle's bits"""
+    rng = np.random.default_rng(int(d))
+    n, S, nq, k = 60000, 2, 300, 10
+    pts = (make_mixture(orc, n, d, n_centers=24) + np.float32(offset)).astype(np.float32)
+    clusters = random_clusters(rng, n, S)
+    queries = (make_mixture(orc, nq, d, seed=556, n_centers=24) + np.float32(offset)).astype(np.float32)
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    st = _check(orc, gp, pts, clusters, queries, probes, 2, k, 0, expect_filtered=True)
+    assert 0 < st["filter_pairs"] < 0.6 * nq * n, st                              # cells still prune
+    assert st["filter_candidates"] < 0.05 * st["filter_pairs"], st                  # and the bound still separates
+
+
+def test_router_bound_path_on_data_far_from_the_origin(orc, gp):
+    """the router's matrix-core bound in the frame of the mean centroid: few candidates per (query, shard), verified minima (conftest arms
+    GPANN_ROUTER_VERIFY), the oracle's probes"""
+    rng = np.random.default_rng(77)
+    n, d, S = 40000, 64, 6
+    pts = (make_mixture(orc, n, d, n_centers=24) + np.float32(100.0)).astype(np.float32)
+    clusters = random_clusters(rng, n, S)
+    queries = (make_mixture(orc, 500, d, seed=556, n_centers=24) + np.float32(100.0)).astype(np.float32)
+    tree = orc.kmtr_train(pts, clusters, 64, 350, 6000, 0, nthreads=4)
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    router = gp.Router(tree.flat(), 0)
+    p, md, _ = router.query_batch(queries, 10 ** 6)
+    assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+    st = router.stats()
+    assert st["bound_calls"] == 1 and st["verified"] == 1 and st["verify_failures"] == 0 and st["bound_overflow"] == 0 and st["bound_selfcheck"] == 0
