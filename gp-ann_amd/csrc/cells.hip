@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, con
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.sample_planes, (void*)c.sample_perm, (void*)c.sample_norm, (void*)c.d_mu})
+                    (void*)c.plane_norm, (void*)c.d_mu})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -230,14 +230,32 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     const uint64_t plane_rows = C.n_tiles * kGTileRows;
     C.plane_ks = s->d <= 128 ? 8u : 16u;
     const size_t tile_bytes = (size_t)C.plane_ks * 1024;   // one plane of one tile
+    // the shard sample: the first rows of every shard (store order = the order of Clusters[b] = a random sample), appended as tiles of their own
+    std::vector<uint32_t> sample_perm_host;
+    {
+        const char* sr = std::getenv("GPANN_FILTER_EXACT_ROWS");   // (historic name: the rows of the first, shard-wide sample)
+        const uint64_t want = sr ? (uint64_t)std::max(64L, std::atol(sr)) : 4096;
+        C.sample_tile_begin.assign(S + 1, 0);
+        for (uint32_t b = 0; b < S; ++b) {
+            const uint64_t n = (uint64_t)(s->offsets[b + 1] - s->offsets[b]), m = std::min(n, want);
+            const uint64_t tiles = (m + kGTileRows - 1) / kGTileRows;
+            C.sample_tile_begin[b + 1] = C.sample_tile_begin[b] + tiles;
+            for (uint64_t i = 0; i < tiles * kGTileRows; ++i) sample_perm_host.push_back(i < m ? (uint32_t)(s->offsets[b] + i) : kNoRow);
+        }
+        C.n_sample_tiles = C.sample_tile_begin[S];
+        C.sample_tile_base = C.n_tiles + 2;
+    }
+    const uint64_t all_tiles = C.sample_tile_base + C.n_sample_tiles;   // cell tiles | 2 zero tiles | sample tiles (| 2 zero tiles)
+    C.lo_offset_tiles = all_tiles + 2;
+    const uint64_t all_rows = all_tiles * kGTileRows;
 
     uint64_t* d_member_begin = nullptr;
     uint32_t* d_cell_size = nullptr;
     bool ok = hipMalloc(&C.d_shard_cell_begin, (S + 1) * 4) == hipSuccess && hipMalloc(&C.d_cell_tile_begin, (C.n_cells + 1) * 8) == hipSuccess &&
               hipMalloc(&C.d_center, (size_t)C.n_cells * ld * 4) == hipSuccess && hipMalloc(&C.d_radius, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
-              hipMalloc(&C.plane_perm, plane_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (plane_rows + 64) * 4) == hipSuccess &&
-              hipMalloc(&s->frag_planes, 2 * (C.n_tiles + 2) * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
+              hipMalloc(&C.plane_perm, all_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (all_rows + 64) * 4) == hipSuccess &&
+              hipMalloc(&s->frag_planes, 2 * C.lo_offset_tiles * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
               hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess;
     std::vector<float> cnorm(C.n_cells);
     for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
@@ -252,9 +270,10 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemcpy(C.d_center, centers.data(), (size_t)C.n_cells * ld * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(d_member_begin, member_begin.data(), C.n_cells * 8, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(d_cell_size, cell_size.data(), C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemset(C.plane_norm + plane_rows, 0, 64 * 4) == hipSuccess &&
-             hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, 2 * tile_bytes) == hipSuccess &&
-             hipMemset(s->frag_planes + (2 * C.n_tiles + 2) * tile_bytes, 0, 2 * tile_bytes) == hipSuccess;
+             hipMemset(C.plane_norm + plane_rows, 0, (all_rows - plane_rows + 64) * 4) == hipSuccess &&
+             hipMemset(C.plane_perm + plane_rows, 0xFF, (all_rows - plane_rows) * 4) == hipSuccess &&   // (kNoRow: the gap tiles and, for now, the sample)
+             hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, (C.lo_offset_tiles - C.n_tiles) * tile_bytes) == hipSuccess &&
+             hipMemset(s->frag_planes + (C.lo_offset_tiles + C.n_tiles) * tile_bytes, 0, (C.lo_offset_tiles - C.n_tiles) * tile_bytes) == hipSuccess;
     }
     // squared L2: everything the matrix-core bound touches is taken around the store's mean row (translation leaves the distances alone
     // and makes |p|, |q| — which the bound's error terms scale with — as small as the data allows; a cloud that sits at +100 in every
@@ -292,7 +311,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
         const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
-                           (uint64_t)(C.n_tiles + 2) * tile_bytes, C.plane_ks, C.d_mu);
+                           (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }
@@ -300,32 +319,19 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     if (d_cell_size) (void)hipFree(d_cell_size);
     if (!ok) return give_up("device");
 
-    // the shard sample: the first kSampleRows store rows of every shard (store order = the order of Clusters[b] = a random sample)
+    // the shard sample's rows, norms and planes behind the cell tiles
     {
-        const char* sr = std::getenv("GPANN_FILTER_EXACT_ROWS");   // (historic name: the rows of the first, shard-wide sample)
-        const uint64_t want = sr ? (uint64_t)std::max(64L, std::atol(sr)) : 4096;
-        C.sample_tile_begin.assign(S + 1, 0);
-        std::vector<uint32_t> perm;
-        for (uint32_t b = 0; b < S; ++b) {
-            const uint64_t n = (uint64_t)(s->offsets[b + 1] - s->offsets[b]), m = std::min(n, want);
-            const uint64_t tiles = (m + kGTileRows - 1) / kGTileRows;
-            C.sample_tile_begin[b + 1] = C.sample_tile_begin[b] + tiles;
-            for (uint64_t i = 0; i < tiles * kGTileRows; ++i) perm.push_back(i < m ? (uint32_t)(s->offsets[b] + i) : kNoRow);
-        }
-        C.n_sample_tiles = C.sample_tile_begin[S];
         const uint64_t srows = C.n_sample_tiles * kGTileRows;
-        bool sok = hipMalloc(&C.sample_perm, std::max<size_t>(srows * 4, 256)) == hipSuccess &&
-                   hipMalloc(&C.sample_norm, (srows + 64) * 4) == hipSuccess &&
-                   hipMalloc(&C.sample_planes, 2 * (C.n_sample_tiles + 2) * tile_bytes) == hipSuccess;
-        if (sok && srows) {
-            sok = hipMemcpy(C.sample_perm, perm.data(), srows * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemset(C.sample_norm + srows, 0, 64 * 4) == hipSuccess &&
-                  hipMemset(C.sample_planes, 0, 2 * (C.n_sample_tiles + 2) * tile_bytes) == hipSuccess;
+        bool sok = true;
+        if (srows) {
+            uint32_t* sperm = C.plane_perm + C.sample_tile_base * kGTileRows;
+            float* snorm = C.plane_norm + C.sample_tile_base * kGTileRows;
+            sok = hipMemcpy(sperm, sample_perm_host.data(), srows * 4, hipMemcpyHostToDevice) == hipSuccess;
             if (sok) {
-                hipLaunchKernelGGL(SampleNormKernel, dim3((uint32_t)((srows + 255) / 256)), dim3(256), 0, 0, C.sample_perm, srows, s->neg_half_norm, C.sample_norm);
+                hipLaunchKernelGGL(SampleNormKernel, dim3((uint32_t)((srows + 255) / 256)), dim3(256), 0, 0, sperm, srows, s->neg_half_norm, snorm);
                 const int g3 = (int)std::min<uint64_t>((srows * 2 * C.plane_ks + 255) / 256, 256 * 64);
-                hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, C.sample_perm, srows, ld, C.sample_planes,
-                                   (uint64_t)(C.n_sample_tiles + 2) * tile_bytes, C.plane_ks, C.d_mu);
+                hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
+                                   (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu);
                 sok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
             }
         }

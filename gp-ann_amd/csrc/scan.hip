@@ -651,6 +651,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (const CellGroup& g : groups)
         for (uint32_t c = C.shard_cell_begin[g.shard]; c < C.shard_cell_begin[g.shard + 1]; ++c)
             items_cap += (C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]) / seg_tiles + 1;
+    const uint32_t sample_items_room = (uint32_t)(G * ((C.n_sample_tiles / std::max<uint32_t>(1, S) + 31) / 32 + 2) + (C.n_sample_tiles + 31) / 32 + 16);
+    items_cap += sample_items_room;   // pass 0 also runs the shard-sample items (they come first in the list)
     GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
     GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
@@ -782,7 +784,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.ld = s->ld;
     fa.frag_planes = s->frag_planes;
     fa.plane_tile_bytes = C.plane_ks * 1024u;
-    fa.plane_lo_offset = (uint64_t)(C.n_tiles + 2) * fa.plane_tile_bytes;
+    fa.plane_lo_offset = (uint64_t)C.lo_offset_tiles * fa.plane_tile_bytes;
     fa.plane_norm = C.plane_norm;
     fa.plane_perm = C.plane_perm;
     fa.groups = d_groups;
@@ -868,16 +870,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
     }
-    // ---- the shard-sample pass (with the seed lists): the first rows of every shard (store order: a random sample of the shard; built
-    //      as planes of their own at store build) go through the matrix cores against the seed thresholds, the candidates are re-scored.
-    //      Afterwards every list's k-th distance is at most the k-th of ~4096 random rows of the shard — what bounds the number of rows
-    //      the later passes can still find below it (and so the bucket fill) WHATEVER the query's position; the nearest-cell seed alone
-    //      gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
+    // ---- the shard-sample items: the first rows of every shard (store order: a random sample of the shard; appended to the cell tiles
+    //      at store build) go through the matrix cores in the SAME launch as the head pass, against the seed thresholds, and are re-scored
+    //      with it.  Afterwards every list's k-th distance is at most the k-th of ~4096 random rows of the shard — what bounds the number
+    //      of rows the later passes can still find below it (and so the bucket fill) WHATEVER the query's position; the nearest-cell seed
+    //      alone gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
+    uint32_t n_sample_items = 0;
     if (seed_rows != 0 && C.n_sample_tiles != 0) {
         const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
         for (uint32_t g = 0; g < G; ++g) {
-            const uint64_t t0 = C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_begin[groups[g].shard + 1];
+            const uint64_t t0 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard + 1];
             const uint32_t qtiles = (groups[g].task_count + 31) / 32, mask = (1u << qtiles) - 1u;
             for (uint64_t t = t0; t < t1; t += piece) {
                 CellItem it;
@@ -891,43 +894,18 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 sitems.push_back(it);
             }
         }
-        if (!sitems.empty()) {
-            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + 64));
-            uint32_t* s_cursor = s->ws_misc.as<uint32_t>();   // [0] cursor, [1] item count
-            CellItem* d_sitems = reinterpret_cast<CellItem*>(s_cursor + 16);
-            const uint32_t head[2] = {0u, (uint32_t)sitems.size()};
-            GPANN_HIP_TRY(UploadAsync(s, s_cursor, head, 8, st));
-            GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
-            GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-            th.hi_only = ks16 ? 1u : 0u;
-            if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            CellFilterArgs fs = fa;
-            fs.frag_planes = C.sample_planes;
-            fs.plane_lo_offset = (uint64_t)(C.n_sample_tiles + 2) * fa.plane_tile_bytes;
-            fs.plane_norm = C.sample_norm;
-            fs.plane_perm = C.sample_perm;
-            fs.items = d_sitems;
-            fs.n_items = s_cursor + 1;
-            fs.next_item = s_cursor;
-            fs.items_cap = (uint32_t)sitems.size();
-            fs.pass = 0;
-            fs.need = nullptr;
-            fs.done0 = fs.done0b = fs.done1 = nullptr;
-            void* sargs[] = {&fs};
-            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
-            hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
-            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
-            GPANN_HIP_TRY(hipGetLastError());
-        }
+        n_sample_items = (uint32_t)sitems.size();
+        if (n_sample_items > sample_items_room) return GPANN_ERR_INTERNAL;   // (items_cap reserved room for them)
+        GPANN_HIP_TRY(UploadAsync(s, d_items, sitems.data(), sitems.size() * sizeof(CellItem), st));
     }
-    for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 0 && head_tiles == 0 && n_sample_items == 0) continue;
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
+        na.items_init = pass == 0 ? n_sample_items : 0u;
         na.need = need_pass[pass];
         if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);

@@ -187,6 +187,7 @@ struct NeedArgs {
     uint32_t* cand_cnt;
     uint32_t* zero2;
     uint32_t hi_only;
+    uint32_t items_init;                // work items already in the list when FilterItemsKernel starts appending (pass 0: the shard-sample items)
 };
 
 // One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
@@ -205,7 +206,10 @@ static __global__ void NeedKernel(NeedArgs a) {
     if (j == 0) {
         a.task_U[t] = ThresholdOf<METRIC>((double)a.list_dist[(size_t)t * a.k + a.k - 1], a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
         a.cand_cnt[t] = 0;
-        if (t == 0) a.zero2[0] = a.zero2[1] = 0;
+        if (t == 0) {
+            a.zero2[0] = 0;
+            a.zero2[1] = a.items_init;
+        }
     }
     if (j >= K) return;
     bool need;

@@ -104,11 +104,12 @@ struct gpann_shards {
         float* plane_norm = nullptr;               // [n_tiles*32 + 64] -|p|^2/2 in plane order (-inf for padding)
         // the shard SAMPLE: the first rows of every shard in store order (a random sample of the shard) once more as planes, so that
         // the filter's first threshold comes from a matrix-core pass over them instead of an exact VALU scan (scan.hip, sample pass)
-        std::vector<uint64_t> sample_tile_begin;   // [S+1] host: first sample tile of every shard
+        // They are appended to the cell tiles — tile sample_tile_base + sample_tile_begin[b] .. of the same plane / perm / norm arrays —
+        // so one filter launch can run items of both kinds.
+        std::vector<uint64_t> sample_tile_begin;   // [S+1] host: first sample tile of every shard, relative to sample_tile_base
         uint64_t n_sample_tiles = 0;
-        char* sample_planes = nullptr;             // hi tiles, then (n_sample_tiles + 2) tiles further the lo tiles
-        uint32_t* sample_perm = nullptr;           // [n_sample_tiles*32] sample row -> store row (0xFFFFFFFF: padding)
-        float* sample_norm = nullptr;              // [n_sample_tiles*32 + 64]
+        uint64_t sample_tile_base = 0;             // = n_tiles + 2 (two zero tiles follow the cell tiles: the kernels' prefetch may run past a range)
+        uint64_t lo_offset_tiles = 0;              // the lo plane of tile T lies lo_offset_tiles tiles after its hi plane (= all tiles + 2)
         // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
         // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
         float* d_mu = nullptr;
