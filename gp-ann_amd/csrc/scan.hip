@@ -651,8 +651,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     for (const CellGroup& g : groups)
         for (uint32_t c = C.shard_cell_begin[g.shard]; c < C.shard_cell_begin[g.shard + 1]; ++c)
             items_cap += (C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]) / seg_tiles + 1;
-    const uint32_t sample_items_room = (uint32_t)(G * ((C.n_sample_tiles / std::max<uint32_t>(1, S) + 31) / 32 + 2) + (C.n_sample_tiles + 31) / 32 + 16);
-    items_cap += sample_items_room;   // pass 0 also runs the shard-sample items (they come first in the list)
     GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
     GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
@@ -721,7 +719,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     //      (rows inside a cell are in store order, i.e. a random sample of the cell): k-th of 64 such rows is as tight a first
     //      threshold as the k-th of 4096 random rows of the whole shard, for 1/64 of the evaluations (0.77 -> 0.1 ms per 10k tasks on
     //      the NS workload).  GPANN_FILTER_SEED_ROWS=0: the earlier exact scan of the first m0 rows of the shard (ScanTileKernel).
-    const uint32_t seed_rows = EnvU32("GPANN_FILTER_SEED_ROWS", 64);
+    // (at least 6 k rows: the k-th of the seed rows has to be a quantile of them, not their maximum)
+    const uint32_t seed_rows_env = EnvU32("GPANN_FILTER_SEED_ROWS", 64);
+    const uint32_t seed_rows = seed_rows_env == 0 ? 0u : std::max<uint32_t>(seed_rows_env, (6 * k + 15) / 16 * 16);
     plan.padded_pairs = 0;
     if (seed_rows == 0) {
         std::vector<int64_t> lo(S), hi(S);
@@ -870,12 +870,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
     }
-    // ---- the shard-sample items: the first rows of every shard (store order: a random sample of the shard; appended to the cell tiles
-    //      at store build) go through the matrix cores in the SAME launch as the head pass, against the seed thresholds, and are re-scored
-    //      with it.  Afterwards every list's k-th distance is at most the k-th of ~4096 random rows of the shard — what bounds the number
-    //      of rows the later passes can still find below it (and so the bucket fill) WHATEVER the query's position; the nearest-cell seed
-    //      alone gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
-    uint32_t n_sample_items = 0;
+    // ---- the shard-sample pass (with the seed lists): the first rows of every shard (store order: a random sample of the shard; appended
+    //      to the cell tiles at store build) go through the matrix cores against the seed thresholds, the candidates are re-scored.
+    //      Afterwards every list's k-th distance is at most the k-th of ~4096 random rows of the shard — what bounds the number of rows
+    //      the later passes can still find below it (and so the bucket fill) WHATEVER the query's position; the nearest-cell seed alone
+    //      gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
+    //      (Run inside the head pass's launch instead — the tiles share the arrays — it saved no kernel time and let 18 % more
+    //      candidates through: the head pass then works with the looser seed threshold.)
     if (seed_rows != 0 && C.n_sample_tiles != 0) {
         const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
@@ -894,18 +895,40 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 sitems.push_back(it);
             }
         }
-        n_sample_items = (uint32_t)sitems.size();
-        if (n_sample_items > sample_items_room) return GPANN_ERR_INTERNAL;   // (items_cap reserved room for them)
-        GPANN_HIP_TRY(UploadAsync(s, d_items, sitems.data(), sitems.size() * sizeof(CellItem), st));
+        if (!sitems.empty()) {
+            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + 64));
+            uint32_t* s_cursor = s->ws_misc.as<uint32_t>();   // [0] cursor, [1] item count
+            CellItem* d_sitems = reinterpret_cast<CellItem*>(s_cursor + 16);
+            const uint32_t head[2] = {0u, (uint32_t)sitems.size()};
+            GPANN_HIP_TRY(UploadAsync(s, s_cursor, head, 8, st));
+            GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
+            GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
+            th.hi_only = ks16 ? 1u : 0u;
+            if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            CellFilterArgs fs = fa;
+            fs.items = d_sitems;
+            fs.n_items = s_cursor + 1;
+            fs.next_item = s_cursor;
+            fs.items_cap = (uint32_t)sitems.size();
+            fs.pass = 0;
+            fs.need = nullptr;
+            fs.done0 = fs.done0b = fs.done1 = nullptr;
+            void* sargs[] = {&fs};
+            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
+            hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
+            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+            GPANN_HIP_TRY(hipGetLastError());
+        }
     }
-    for (int pass = 0; pass < 3; ++pass) {
-        if (pass == 0 && head_tiles == 0 && n_sample_items == 0) continue;
+    for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
-        na.items_init = pass == 0 ? n_sample_items : 0u;
+        na.items_init = 0u;
         na.need = need_pass[pass];
         if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
