@@ -1997,7 +1997,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
 // one wavefront per query, S <= 64: a bitonic sort of (min_dist, shard).  Where all min_dist values of a query differ, every correct
 // sort returns the same permutation as the reference's; a query with two equal values (duplicate centroids, unvisited shards at
 // FLT_MAX) is flagged and the host redoes it with the reference's own unstable std::sort call.
-__global__ void __launch_bounds__(256) ProbeOrderKernel(const float* min_dist, uint32_t nq, uint32_t S, int32_t* probes, uint32_t* tie_flag) {
+__global__ void __launch_bounds__(256) ProbeOrderKernel(const float* min_dist, uint32_t nq, uint32_t S, uint32_t cols, int32_t* probes, uint32_t* tie_flag) {
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -2022,7 +2022,7 @@ __global__ void __launch_bounds__(256) ProbeOrderKernel(const float* min_dist, u
     const float next = __shfl_down(key, 1);
     const bool tie = (uint32_t)lane + 1 < S && next == key;
     const unsigned long long any = __ballot(tie);
-    if ((uint32_t)lane < S) probes[(size_t)q * S + lane] = id;
+    if ((uint32_t)lane < cols) probes[(size_t)q * cols + lane] = id;   // (the first `cols` shards of the order)
     if (lane == 0) tie_flag[q] = any != 0ull ? 1u : 0u;
 }
 
@@ -2031,15 +2031,22 @@ __global__ void __launch_bounds__(256) ProbeOrderKernel(const float* min_dist, u
 gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
                                       float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
     GPANN_REQUIRE(r != nullptr, "router handle is null");
+    return gpann_router_query_batch_top(r, queries, nq, budget, r->S, out_probes, out_min_dist, flags, stream, elapsed_ms);
+}
+
+gpann_status gpann_router_query_batch_top(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
+                                          float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
     GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
+    GPANN_REQUIRE(n_top >= 1 && n_top <= r->S, "n_top must be in [1, S]");
     GPANN_TRY(EnsureDevice(r->device));
     if (elapsed_ms) *elapsed_ms = 0.f;
     if (nq == 0) return GPANN_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint32_t S = r->S;
+    const uint32_t S = r->S, cols = n_top;
     GPANN_TRY(LaunchWalk(r, queries, nq, budget, flags, st, nullptr, nullptr, nullptr, 0));
 
-    const size_t words = (size_t)nq * S;
+    const size_t words = (size_t)nq * S, pwords = (size_t)nq * cols;   // min_dist words, probe words
     auto pinned = [&](void** p, size_t* have, size_t need_words) {
         if (*have >= need_words) return true;
         if (*p) (void)hipHostFree(*p);
@@ -2069,27 +2076,34 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     // kmeans_tree_router.cpp:125-127 — the reference's own call on the GPU-computed min_dist
     auto host_sort = [&](uint32_t q) {
         const float* min_dist = md + (size_t)q * S;
-        int* probes = out_probes + (size_t)q * S;
+        int order[4096];
+        std::vector<int> big;
+        int* probes = order;
+        if (S > 4096) {
+            big.resize(S);
+            probes = big.data();
+        }
         std::iota(probes, probes + S, 0);
         std::sort(probes, probes + S, [&](int l, int rr) { return min_dist[l] < min_dist[rr]; });
+        std::memcpy(out_probes + (size_t)q * cols, probes, (size_t)cols * sizeof(int));
     };
 
-    if (out_probes && S <= 64 && pinned((void**)&r->pinned_probes, &r->pinned_probe_words, words + nq)) {
+    if (out_probes && S <= 64 && pinned((void**)&r->pinned_probes, &r->pinned_probe_words, pwords + nq)) {
         // the order on the device (ProbeOrderKernel); the host only redoes the queries with equal min_dist values
-        GPANN_TRY(r->ws_probes.Reserve((words + nq) * 4));
+        GPANN_TRY(r->ws_probes.Reserve((pwords + nq) * 4));
         int32_t* d_probes = r->ws_probes.as<int32_t>();
-        uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_probes + words);
-        hipLaunchKernelGGL(ProbeOrderKernel, dim3((nq + 3) / 4), dim3(256), 0, st, r->ws_out.as<float>(), nq, S, d_probes, d_flags);
+        uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_probes + pwords);
+        hipLaunchKernelGGL(ProbeOrderKernel, dim3((nq + 3) / 4), dim3(256), 0, st, r->ws_out.as<float>(), nq, S, cols, d_probes, d_flags);
         GPANN_HIP_TRY(hipGetLastError());
         // a caller-provided pinned array receives the lists directly; otherwise they pass through the handle's pinned staging
         hipPointerAttribute_t attr{};
         const bool direct = hipPointerGetAttributes(&attr, out_probes) == hipSuccess && attr.type == hipMemoryTypeHost;
         if (!direct) (void)hipGetLastError();
         if (direct) {
-            GPANN_HIP_TRY(hipMemcpyAsync(out_probes, d_probes, words * 4, hipMemcpyDeviceToHost, st));
-            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes + words, d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(out_probes, d_probes, pwords * 4, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes + pwords, d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
         } else {
-            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes, d_probes, (words + nq) * 4, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_probes, d_probes, (pwords + nq) * 4, hipMemcpyDeviceToHost, st));
         }
         if (out_min_dist) GPANN_TRY(fetch_min_dist());
         else GPANN_HIP_TRY(hipStreamSynchronize(st));
@@ -2098,14 +2112,14 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
             GPANN_TRY(ResolvePendingBound(r, &repeat));
             if (repeat) {   // (rare) the whole call again without the bound path
                 r->canonical_once = true;
-                const gpann_status again = gpann_router_query_batch(r, queries, nq, budget, out_probes, out_min_dist, flags, stream, elapsed_ms);
+                const gpann_status again = gpann_router_query_batch_top(r, queries, nq, budget, n_top, out_probes, out_min_dist, flags, stream, elapsed_ms);
                 r->canonical_once = false;
                 return again;
             }
         }
         if (elapsed_ms) GPANN_HIP_TRY(hipEventElapsedTime(elapsed_ms, r->ev[0], r->ev[1]));
-        if (!direct) std::memcpy(out_probes, r->pinned_probes, words * 4);
-        const uint32_t* flags = reinterpret_cast<const uint32_t*>(r->pinned_probes + words);
+        if (!direct) std::memcpy(out_probes, r->pinned_probes, pwords * 4);
+        const uint32_t* flags = reinterpret_cast<const uint32_t*>(r->pinned_probes + pwords);
         std::vector<uint32_t> redo;
         for (uint32_t q = 0; q < nq; ++q)
             if (flags[q]) redo.push_back(q);
@@ -2126,7 +2140,7 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
         GPANN_TRY(ResolvePendingBound(r, &repeat));
         if (repeat) {
             r->canonical_once = true;
-            const gpann_status again = gpann_router_query_batch(r, queries, nq, budget, out_probes, out_min_dist, flags, stream, elapsed_ms);
+            const gpann_status again = gpann_router_query_batch_top(r, queries, nq, budget, n_top, out_probes, out_min_dist, flags, stream, elapsed_ms);
             r->canonical_once = false;
             return again;
         }

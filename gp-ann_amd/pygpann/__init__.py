@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_build_filter", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_query_batch_top", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -98,6 +98,7 @@ def lib():
     L.gpann_router_get_stats.argtypes = [C.c_void_p, C.POINTER(RouterStats)]
     L.gpann_router_export.argtypes = [C.c_void_p, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p]
     L.gpann_router_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
+    L.gpann_router_query_batch_top.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, _i32p, _f32p, C.c_int, C.c_void_p, _f32p]
     L.gpann_router_frequency_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, _f32p, _f32p, _u32p, _u32p,
                                                      C.c_int, C.c_void_p, _f32p]
     L.gpann_merge_dedup.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, _u32p, _u32p]
@@ -341,9 +342,10 @@ class Router:
         except Exception:
             pass
 
-    def query_batch(self, queries, budget, stream=None, on_device=False, nq=None, out_probes=None, want_min_dist=True):
+    def query_batch(self, queries, budget, stream=None, on_device=False, nq=None, out_probes=None, want_min_dist=True, n_top=None):
         """Batched KMeansTreeRouter::Query.  Returns probes [nq,S] int32, min_dist [nq,S] float32 (None unless want_min_dist), ms.
-        out_probes: a reusable [nq,S] int32 array to fill instead of a fresh one."""
+        out_probes: a reusable [nq,S] int32 array to fill instead of a fresh one.  n_top: only the first n_top shards of every order
+        (probes [nq,n_top]; gpann_router_query_batch_top)."""
         if on_device:
             qp = C.c_void_p(int(queries))
             flags = QUERIES_ON_DEVICE
@@ -352,12 +354,13 @@ class Router:
             nq = queries.shape[0]
             qp = _vp(queries)
             flags = 0
-        probes = out_probes if out_probes is not None else np.empty((nq, self.S), np.int32)
-        assert probes.shape == (nq, self.S) and probes.dtype == np.int32 and probes.flags.c_contiguous
+        cols = self.S if n_top is None else int(n_top)
+        probes = out_probes if out_probes is not None else np.empty((nq, cols), np.int32)
+        assert probes.shape == (nq, cols) and probes.dtype == np.int32 and probes.flags.c_contiguous
         md = np.empty((nq, self.S), np.float32) if want_min_dist else None
         ms = C.c_float(0)
-        _check(lib().gpann_router_query_batch(self.h, qp, nq, budget, probes.ctypes.data_as(_i32p), md.ctypes.data_as(_f32p) if want_min_dist else None,
-                                              flags, C.c_void_p(stream or 0), C.byref(ms)))
+        _check(lib().gpann_router_query_batch_top(self.h, qp, nq, budget, cols, probes.ctypes.data_as(_i32p), md.ctypes.data_as(_f32p) if want_min_dist else None,
+                                                  flags, C.c_void_p(stream or 0), C.byref(ms)))
         return probes, md, ms.value
 
 

@@ -219,6 +219,11 @@ gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* o
 gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int32_t* out_probes,
                                       float* out_min_dist, int flags, void* stream, float* elapsed_ms);
 
+/* The same, returning only the first n_top shards of every query's order: out_probes host [nq][n_top], 1 <= n_top <= S (additive: a caller
+ * that probes nprobe shards does not need — and does not have to copy back — the other S - nprobe columns). */
+gpann_status gpann_router_query_batch_top(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
+                                          float* out_min_dist, int flags, void* stream, float* elapsed_ms);
+
 /* Batched KMeansTreeRouter::FrequencyQuery (kmeans_tree_router.cpp:132-172): the same walk, plus for every query the
  * num_voting lexicographically smallest (distance, shard) pairs over all evaluated centroids, ascending (what
  * FrequencyQueryData holds after Init()).  out_nn_* are host [nq][num_voting]; out_nn_count host [nq]. */
