@@ -134,6 +134,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # multi: the exchange layer is in use.  GPANN_BENCH_FORCE_COMM=1 (debugging aid) runs the N > 1 code path — communicator, RCCL
+    # collectives, owner selection, id maps — with a single rank, which is as far as a 1-GPU box can exercise it on device buffers.
+    multi = world > 1 or os.environ.get("GPANN_BENCH_FORCE_COMM") == "1"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -143,7 +146,7 @@ def main():
         local_rank = int(os.environ["GPANN_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         # the exchange layer is the C-ABI library libgpann_comm.so (include/gpann_comm.h): RCCL collectives on this process's HIP stream.
         # RCCL over xGMI is the measured configuration: if it cannot be initialised the run FAILS — a number taken over host sockets must
         # be asked for explicitly (--backend tcp) and says so in the JSON line ("backend")
@@ -168,7 +171,7 @@ def main():
     sample = torch.empty((n_sample, d), dtype=torch.float32, device=dev)
     synth(sample, POINT_SEED, 0, n_sample)
     shard_cent, sample_assign = lloyd_gpu(torch, pygpann, sample, S, 20, 555, stream)
-    if world > 1:
+    if multi:
         # the device k-means sums with float atomics, so its centroids differ in the last bits from run to run: every rank
         # must cut the cloud with rank 0's centroids or rows would be owned by two ranks / by none
         if on_dev:
@@ -196,7 +199,7 @@ def main():
     # and the hottest shards get replicas while a rank has room (gpann_plan_replicas; the reference models exactly this when it
     # predicts QPS, route_search_combination.cpp:149-183).  A replicated shard's tasks are split over its replicas by query id.
     placement = None
-    if world > 1 and args.replica_capacity > 0:
+    if multi and args.replica_capacity > 0:
         qa = torch.empty(nq, dtype=torch.int32, device=dev)
         pygpann.nearest_centroid_device(queries.data_ptr(), nq, d, 0, shard_cent.data_ptr(), S, qa.data_ptr(), stream)
         est_tasks = np.bincount(qa.cpu().numpy().astype(np.int64), minlength=S).astype(np.float64) + 0.5
@@ -256,7 +259,7 @@ def main():
         of the shards this rank holds; with several ranks every rank trains the subtrees of its own shards and the parts are merged"""
         t_train = time.time()
         rt = pygpann.Router.train(shards, n, args.router_centroids, args.router_min_cluster, index_budget)
-        if world > 1:
+        if multi:
             part = rt
             rt = comm.merge_router(part, owner, local_rank)   # every rank's subtrees -> the router over all shards, replicated
             part.close()
@@ -288,7 +291,7 @@ def main():
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host.
         buf: which of the two pinned host buffer sets receives the results (the timed loop merges batch i on a worker thread while
         batch i + 1 is on the GPU)"""
-        if world == 1:
+        if not multi:
             lp = np.ascontiguousarray(probes[:, :nprobe])
         elif placement:
             lp = gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, rank)
@@ -300,7 +303,7 @@ def main():
         oi, od = dev_out[nprobe]
         ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
         key = (nq, nprobe, buf)
-        if world > 1:
+        if multi:
             # the result exchange (gpann_comm_gather_slots): local row ids -> global ids, ONE all-gather of the per-slot lists over RCCL
             # on this stream, owner selection on the device; the selected lists come back through pinned host buffers
             n_slots = nq * nprobe * k
@@ -343,7 +346,7 @@ def main():
         """KMeansTreeRouter::Query for the whole batch.  n_top: only the first n_top shards of every order come back (the timed steps
         probe nprobe shards; the sweep before them needs the whole order).  N > 1: the router is replicated, every rank routes its slice
         of the queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered."""
-        if world == 1:   # (one reusable host array for the probe lists; min_dist itself is not needed here)
+        if not multi:   # (one reusable host array for the probe lists; min_dist itself is not needed here)
             buf = probes_buf
             if n_top is not None and n_top < S:
                 if n_top not in probes_top:
@@ -368,7 +371,7 @@ def main():
             comm.allgather(route_mine, route_all, route_mine.nbytes)
         return route_all.reshape(-1, S)[:nq], r_ms
 
-    if world > 1:
+    if multi:
         route_mine_t = torch.empty((chunk_q, S), dtype=torch.int32).pin_memory()
         route_all_t = torch.empty((world, chunk_q, S), dtype=torch.int32).pin_memory()
         route_mine, route_all = route_mine_t.numpy(), route_all_t.numpy()
@@ -423,7 +426,7 @@ def main():
         return md, mi, r_ms, s_ms
 
     def barrier():
-        if world > 1:
+        if multi:
             comm.barrier()
         torch.cuda.synchronize()
 
@@ -441,7 +444,7 @@ def main():
             step()
         barrier()
         trial = (time.perf_counter() - t0) / 2
-        if world > 1:
+        if multi:
             trial = comm.max_double(trial)
         candidates.append(dict(index_budget=index_budget, router=router, tree=tree, train_s=router_train_s, nprobe=nprobe, recall_curve=recall_curve,
                                trial_ms=1000.0 * trial, probes=probes.copy()))
@@ -488,7 +491,7 @@ def main():
     elapsed = time.perf_counter() - t0
     merger.shutdown()
     gc.enable()
-    if world > 1:
+    if multi:
         elapsed = comm.max_double(elapsed)
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
     qps = nq * args.steps / elapsed
@@ -551,9 +554,9 @@ def main():
         result["roofline"].update({"router_mfma_ms": 1000.0 * rb_s, "router_mfma_TFLOPs": router_bound_flops / rb_s / 1e12,
                                    "router_mfma_frac": router_bound_flops / rb_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                    "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
-    result["backend"] = comm.name if world > 1 else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
-    result["world_size_seen"] = comm.world if world > 1 else 1
-    if world > 1:
+    result["backend"] = comm.name if multi else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
+    result["world_size_seen"] = comm.world if multi else 1
+    if multi:
         # the work every rank actually did in the last timed step: task rows (pairs) of its scan
         per_rank = comm.allgather_host(np.array([float(stats["pairs"])], np.float64)).reshape(-1)
         result["placement"] = dict(placement or {"replicas": 0}, rank_task_rows=[float(x) for x in per_rank],
@@ -624,7 +627,7 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
-    if world > 1:
+    if multi:
         comm.barrier()
         comm.close()
 

@@ -244,3 +244,24 @@ def test_bound_path_without_verify_defers_its_counter_check(orc, gp, monkeypatch
             assert np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
     st = router.stats()
     assert st["bound_calls"] == 2 and st["verified"] == 0 and st["bound_selfcheck"] == 0 and st["bound_overflow"] == 0 and st["last_bound_ms"] > 0
+
+
+def test_query_batch_top_returns_the_first_columns(orc, gp):
+    """gpann_router_query_batch_top: only the first n_top shards of every order come back — the same shards, in the same order, as the
+    full call returns, including for queries whose order the host has to settle (equal min_dist values: duplicated centroids)"""
+    rng = np.random.default_rng(11)
+    n, d, S = 20000, 32, 9
+    pts = make_mixture(orc, n, d, n_centers=16)
+    pts[::4] = pts[0]                                   # duplicates -> duplicate centroids -> equal min_dist values for some queries
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, 32, 100, 3000, 0, nthreads=4)
+    queries = make_mixture(orc, 400, d, seed=556, n_centers=16)
+    queries[:20] = pts[0]
+    router = gp.Router(tree.flat(), 0)
+    for budget in (10 ** 6, 700):
+        full, md, _ = router.query_batch(queries, budget)
+        want_p, want_md = tree.query_batch(queries, budget, nthreads=4)
+        assert np.array_equal(full, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+        for n_top in (1, 3, S):
+            top, _, _ = router.query_batch(queries, budget, n_top=n_top, want_min_dist=False)
+            assert top.shape == (400, n_top) and np.array_equal(top, full[:, :n_top])
