@@ -359,50 +359,24 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
     // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor; the claim for the
-    // next item is issued while the current one streams
-    // A claim takes TWO consecutive list entries while the launch is far from its end, one near it.  Consecutive entries are usually the
-    // pieces of one (task group, cell) block — FilterItemsKernel writes a block's pieces back to back — and two such pieces stream as ONE
-    // range: one start-up (claim, query image, first tile, pipeline fill) for twice the tiles; the short claims near the end keep the
-    // persistent workgroups balanced.  An entry that does not continue its predecessor is carried into the next round as its own item.
-    __shared__ uint32_t s_item, s_take;
+    // next item is issued while the current one streams.  (Claims of two consecutive entries, streamed as one range when they are pieces
+    // of one block — half the start-ups — measured 3 % SLOWER on the rest pass: 4.21 against 4.08 ms.)
+    __shared__ uint32_t s_item;
     const uint32_t n_items = min(*a.n_items, a.items_cap);
     uint32_t my_products = 0, my_tiles = 0;
-    const uint32_t far = 8u * gridDim.x;   // entries that must remain after a claim for it to take two
-    if (threadIdx.x == 0) {
-        const uint32_t take = far < n_items ? 2u : 1u;
-        s_item = atomicAdd(a.next_item, take);
-        s_take = take;
-    }
-    uint32_t carry = 0xFFFFFFFFu;   // (uniform) the second entry of a claim that could not be merged
+    if (threadIdx.x == 0) s_item = atomicAdd(a.next_item, 1u);
     for (;;) {
-    __syncthreads();   // s_item / s_take are written; everyone is done with the previous item's query image
-    uint32_t item = s_item;
-    bool second = s_take == 2u;   // the entry after `item` is ours as well
-    if (carry != 0xFFFFFFFFu) {
-        item = carry;
-        second = false;
-        carry = 0xFFFFFFFFu;
-    }
+    __syncthreads();   // s_item is written; everyone is done with the previous item's query image
+    const uint32_t item = s_item;
     if (item >= n_items) break;
     // one 32-byte record per item (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended up in
     // vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued before it)
-    const uint32_t t_begin = a.items[item].t_begin, t_a = a.items[item].t_a, t_b = a.items[item].t_b;
-    uint32_t t_end = a.items[item].t_end;
+    const uint32_t t_begin = a.items[item].t_begin, t_end = a.items[item].t_end, t_a = a.items[item].t_a, t_b = a.items[item].t_b;
     const uint32_t task_begin = a.items[item].task_begin, task_count = a.items[item].task_count;
     const uint32_t acts = a.items[item].acts;
     const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
-    if (second && item + 1u < n_items) {
-        if (a.items[item + 1u].group == a.items[item].group && a.items[item + 1u].t_begin == t_end && a.items[item + 1u].acts == acts &&
-            a.items[item + 1u].t_a == t_a && a.items[item + 1u].t_b == t_b)
-            t_end = a.items[item + 1u].t_end;   // the next piece of the same block: one range
-        else carry = item + 1u;
-    }
-    const bool claims = carry == 0xFFFFFFFFu;   // (uniform) this round ends with a fresh claim
-    uint32_t next_claim = 0, next_take = 1;
-    if (threadIdx.x == 0 && claims) {   // lands under the first tile loads
-        next_take = item + far < n_items ? 2u : 1u;
-        next_claim = atomicAdd(a.next_item, next_take);
-    }
+    uint32_t next_claim = 0;
+    if (threadIdx.x == 0) next_claim = atomicAdd(a.next_item, 1u);   // lands under the first tile loads
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -558,10 +532,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             if (T >= t_end) break;
         }
     }
-    if (threadIdx.x == 0 && claims) {
-        s_item = next_claim;
-        s_take = next_take;
-    }
+    if (threadIdx.x == 0) s_item = next_claim;
     }   // next item
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
