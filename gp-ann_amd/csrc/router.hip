@@ -52,6 +52,7 @@ struct gpann_router {
     uint32_t* shard_has_cent = nullptr;  // [S] 1 if the shard has at least one centroid (its min_dist cannot stay at FLT_MAX after a full visit)
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
     float* cent_nhn = nullptr;           // [n_centroids + 64] -|c|^2/2
+    uint32_t plane_ks = 8;               // k-steps per plane of a centroid tile (8: d <= 128, 16: d <= 256)
     float* cent_mu = nullptr;            // squared L2: [ld] mean centroid — planes, norms and query fragments of the bound path live in the frame c - mu, q - mu
     double cent_rmax = 0.0;              // largest centroid norm
     gpann::DeviceBuffer ws_bound, ws_verify;
@@ -1257,17 +1258,19 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             }
             rmax2 = std::max(rmax2, s2);
         }
-        if (finite && d <= 16u * kFKS && nc > 0) {
+        if (finite && d <= 256u && nc > 0) {
             const uint64_t tiles = (nc + kGTileRows - 1) / kGTileRows + 1;
-            if (hipMalloc(&r->cent_planes, tiles * (size_t)kGTileBytes) == hipSuccess && hipMalloc(&r->cent_nhn, (nc + 64) * 4) == hipSuccess) {
-                TRY_OR_FAIL(hipMemset(r->cent_planes, 0, tiles * (size_t)kGTileBytes));
+            r->plane_ks = d <= 128u ? 8u : 16u;
+            const size_t tile_bytes = (size_t)r->plane_ks * 2048;
+            if (hipMalloc(&r->cent_planes, tiles * tile_bytes) == hipSuccess && hipMalloc(&r->cent_nhn, (nc + 64) * 4) == hipSuccess) {
+                TRY_OR_FAIL(hipMemset(r->cent_planes, 0, tiles * tile_bytes));
                 TRY_OR_FAIL(hipMemset(r->cent_nhn, 0, (nc + 64) * 4));
                 if (centred) {
                     TRY_OR_FAIL(hipMalloc(&r->cent_mu, (size_t)r->ld * 4));
                     TRY_OR_FAIL(hipMemcpy(r->cent_mu, mu.data(), (size_t)r->ld * 4, hipMemcpyHostToDevice));
                 }
                 hipLaunchKernelGGL(CentroidPlanesKernel, dim3((uint32_t)std::min<uint64_t>((nc * 16 + 255) / 256, 4096)), dim3(256), 0, 0, r->centroids, (uint64_t)nc, d,
-                                   r->ld, r->cent_planes, r->cent_nhn, r->cent_mu);
+                                   r->ld, r->cent_planes, r->cent_nhn, r->cent_mu, r->plane_ks);
                 TRY_OR_FAIL(hipGetLastError());
                 TRY_OR_FAIL(hipDeviceSynchronize());
                 r->cent_rmax = std::sqrt(rmax2) * (1.0 + 1e-9);
@@ -1495,7 +1498,8 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     const uint64_t C = r->n_centroids;
     const size_t nb_s = (size_t)nb * S;
     // (slots are handed out in chunks of 256 per wavefront: room for every wavefront's last, partly used chunk)
-    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)nb_s * 4 + (uint64_t)((nb + 255) / 256) * 80 * 8 * 256 + 1024);
+    const uint32_t wg_queries = r->d > 128 ? 128u : 256u;   // queries per workgroup of RouterBoundKernel
+    const uint32_t cand_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)nb_s * 4 + (uint64_t)((nb + wg_queries - 1) / wg_queries) * 80 * 8 * 256 + 1024);
     const size_t cand_off = (nb_s * 8 + 15) & ~(size_t)15;   // bytes: max_bits | thr | (pad to 16) | cand | counters
     GPANN_TRY(r->ws_bound.Reserve(cand_off + (size_t)cand_cap * 8 + 64));
     ba.queries = da.queries;
@@ -1513,7 +1517,10 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     ba.S = S;
     ba.ld = ld;
     ba.mu = r->cent_mu;
-    const uint32_t groups = (nb + 255) / 256;
+    ba.plane_ks = r->plane_ks;
+    const bool ks16 = r->d > 128;
+    const uint32_t group_q = ks16 ? 128u : 256u;   // queries per workgroup (4 / 8 query tiles)
+    const uint32_t groups = (nb + group_q - 1) / group_q;
     const uint32_t n_tiles = (uint32_t)((C + kGTileRows - 1) / kGTileRows);
     // one round of workgroups: (query groups) x (centroid segments) <= the CUs (a workgroup per CU, 132 KiB of LDS each) — 40 groups x 8
     // segments = 320 workgroups on 256 CUs ran as 256 + 64, i.e. at the pace of 160
@@ -1522,10 +1529,11 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 16, st));   // candidate counter, the self-check's counter, (verify mode) two more words
     GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
     const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
-    const size_t blds = (size_t)8 * (ks4 ? 4 : 8) * 2048 + 8 * kGTileRows * sizeof(float);
+    const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
     const void *f1, *f2;
-#define GPANN_PICKB(P_) (l2 ? (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, P_>) \
-                            : (ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, P_>))
+#define GPANN_PICKB(P_)                                                                                                                                          \
+    (l2 ? (ks16 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 16, P_> : ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, P_>) \
+        : (ks16 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 16, P_> : ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, P_> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, P_>))
     f1 = GPANN_PICKB(1);
     f2 = GPANN_PICKB(2);
 #undef GPANN_PICKB

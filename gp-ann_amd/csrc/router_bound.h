@@ -31,6 +31,7 @@ struct BoundArgs {
     uint2* cand;                  // [cand_cap] (query, centroid)
     uint32_t cand_cap;
     uint32_t nq, C, S, ld, n_seg;
+    uint32_t plane_ks;            // k-steps (16 dimensions each) per plane of a centroid tile: 8 (d <= 128) or 16 (d <= 256); a tile = 2 planes of plane_ks KiB
     const float* mu;              // squared L2: the centre the centroid planes were built around ([ld]); nullptr = not centred
 };
 
@@ -40,19 +41,20 @@ __device__ __forceinline__ uint32_t OrderedBitsB(float f) {
 }
 __device__ __forceinline__ float FromOrderedBitsB(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
 
-// grid = (n_seg, query groups of 256); one workgroup = 8 wavefronts
-template <int METRIC, int KS, int PASS>
+// grid = (n_seg, query groups of 32 QT); one workgroup = 8 wavefronts.  QT query tiles of 32 queries: 8 up to KS = 8, 4 for KS = 16 (129 - 200
+// dimensions: the query image, QT * KS * 2 KiB, has to fit LDS).
+template <int METRIC, int KS, int PASS, int QT = (KS <= 8 ? 8 : 4)>
 __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
     extern __shared__ uint4 bsm4[];
-    char* lds = reinterpret_cast<char*>(bsm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
-    const uint32_t q_base = blockIdx.y * 256u;
-    const uint32_t q_count = min(256u, a.nq - q_base);
+    char* lds = reinterpret_cast<char*>(bsm4);   // [QT query tiles][KS][2 planes][1 KiB] + per-wave norms
+    const uint32_t q_base = blockIdx.y * (32u * QT);
+    const uint32_t q_count = min(32u * QT, a.nq - q_base);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t ld = a.ld;
     const int nqt = (int)((q_count + 31u) / 32u);
 
-    {   // the query image: wavefront w builds query tile w (zeros for absent queries)
+    if (wave < QT) {   // the query image: wavefront w builds query tile w (zeros for absent queries)
         const uint32_t ql = 32u * wave + c;
         BuildQueryTile<KS>(lds + (size_t)wave * KS * 2048, a.queries + (size_t)(q_base + min(ql, q_count - 1)) * ld, ql < q_count, ld, lane, a.mu);
     }
@@ -68,7 +70,8 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
     const int64_t t_begin = b_begin + (int64_t)wave * wper, t_end = min(b_end, t_begin + wper);
     const char* lane_planes = a.cent_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
-    float* wave_norms = reinterpret_cast<float*>(lds + 8 * KS * 2048) + wave * kGTileRows;
+    float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
+    const size_t plane_bytes = (size_t)a.plane_ks * 1024, tile_bytes = 2 * plane_bytes;
 
     // candidates (pass 2) go to the global list in chunks of 256 slots per wavefront: one atomic on the shared counter per chunk
     // instead of one per candidate (400k same-address atomics were most of this kernel's time); unused slots stay (~0, ~0)
@@ -91,13 +94,13 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
         chunk_used += need;
     };
     uint32_t cur_shard = 0xFFFFFFFFu;
-    float run[8];   // pass 1: running max of the current shard; pass 2: its threshold
+    float run[QT];   // pass 1: running max of the current shard; pass 2: its threshold
 #pragma unroll
-    for (int qt = 0; qt < 8; ++qt) run[qt] = PASS == 1 ? -INFINITY : INFINITY;
+    for (int qt = 0; qt < QT; ++qt) run[qt] = PASS == 1 ? -INFINITY : INFINITY;
     auto flush = [&]() {
         if (PASS != 1 || cur_shard == 0xFFFFFFFFu) return;
 #pragma unroll
-        for (int qt = 0; qt < 8; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const uint32_t ql = 32u * qt + c;
             if (qt < nqt && h == 0 && ql < q_count && run[qt] > -INFINITY)
                 atomicMax(&a.max_bits[(size_t)(q_base + ql) * a.S + cur_shard], OrderedBitsB(run[qt]));
@@ -106,11 +109,11 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
     };
 
     auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, int64_t T) {
-        const char* base = lane_planes + (size_t)T * kGTileBytes;
+        const char* base = lane_planes + (size_t)T * tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             Ah[ks].q = *reinterpret_cast<const uint4*>(base + ks * 1024);
-            Al[ks].q = *reinterpret_cast<const uint4*>(base + kGPlaneBytes + ks * 1024);
+            Al[ks].q = *reinterpret_cast<const uint4*>(base + plane_bytes + ks * 1024);
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.cent_nhn[T * kGTileRows + c];
     };
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
             cur_shard = shard_first;
             if (PASS == 2) {
 #pragma unroll
-                for (int qt = 0; qt < 8; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     const uint32_t ql = 32u * qt + c;
                     run[qt] = (qt < nqt && ql < q_count) ? a.thr[(size_t)(q_base + ql) * a.S + cur_shard] : INFINITY;
                 }
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
         }
         // two query tiles per pass of the k-loop: two independent accumulator chains keep the matrix core busy
 #pragma unroll
-        for (int qp = 0; qp < 4; ++qp) {
+        for (int qp = 0; qp < QT / 2; ++qp) {
             if (2 * qp >= nqt) break;
             f32x16 acc[2];
 #pragma unroll
@@ -267,11 +270,12 @@ __global__ void ExactCandidatesKernel(const float* centroids, const float* queri
 
 // centroids -> bf16 hi/lo planes in MFMA A-operand order (as SplitFragPlanes of the shard store), and -|c|^2/2
 static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* centroids, uint64_t C, uint32_t d, uint32_t ld, char* planes, float* nhn,
-                                                                   const float* mu) {
-    const uint64_t total = C * 16;
+                                                                   const float* mu, uint32_t plane_ks) {
+    const uint32_t g_per_row = 2 * plane_ks;   // groups of 8 dimensions per row
+    const uint64_t total = C * g_per_row;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i >> 4;
-        const uint32_t g8 = (uint32_t)(i & 15);
+        const uint64_t r = i / g_per_row;
+        const uint32_t g8 = (uint32_t)(i - r * g_per_row);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -295,9 +299,9 @@ static __global__ void __launch_bounds__(256) CentroidPlanesKernel(const float* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * (uint64_t)kGTileBytes + ks * 1024 + lane * 16;
+        char* base = planes + (r >> 5) * ((uint64_t)plane_ks * 2048) + ks * 1024 + lane * 16;
         *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + kGPlaneBytes) = fl.q;
+        *reinterpret_cast<uint4*>(base + (uint64_t)plane_ks * 1024) = fl.q;
         if (g8 == 0) {
             double s = 0.0;
             for (uint32_t x = 0; x < d; ++x) {

@@ -265,3 +265,22 @@ def test_query_batch_top_returns_the_first_columns(orc, gp):
         for n_top in (1, 3, S):
             top, _, _ = router.query_batch(queries, budget, n_top=n_top, want_min_dist=False)
             assert top.shape == (400, n_top) and np.array_equal(top, full[:, :n_top])
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [130, 200, 256])
+def test_bound_path_beyond_128_dimensions(orc, gp, metric, d):
+    """129 - 256 dimensions: the router's matrix-core bound with 16 k-step centroid tiles and 4 query tiles per workgroup (C4's
+    200-dimensional inner-product router runs through it); every minimum verified against the canonical evaluation (conftest)"""
+    rng = np.random.default_rng(d + metric)
+    n, S = 24000, 7
+    pts = make_mixture(orc, n, d, n_centers=20)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, 64, 200, 5000, metric, nthreads=4)
+    queries = make_mixture(orc, 333, d, seed=556, n_centers=20)          # 333: partly filled query tiles and groups
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    router = gp.Router(tree.flat(), metric)
+    p, md, _ = router.query_batch(queries, 10 ** 6)
+    assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+    st = router.stats()
+    assert st["bound_calls"] == 1 and st["verified"] == 1 and st["verify_failures"] == 0 and st["bound_overflow"] == 0 and st["bound_selfcheck"] == 0
