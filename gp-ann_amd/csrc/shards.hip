@@ -63,6 +63,16 @@ __global__ void __launch_bounds__(256) GatherRowsKernel(const float* __restrict_
 
 using namespace gpann;
 
+// Target rows per cell (GPANN_CELL_ROWS overrides): about 128 cells per shard, between 2048 and 32768 rows.  Measured on the
+// BASELINE.json shapes: 100M x 128 in 40 shards is flat between 16k and 32k rows (bigger cells stream rows for task groups that do not need
+// them, smaller ones add work items); 10M x 96 in 16 shards and 1M x 128 in 8 shards want 4k / 2k rows (their mixture components are that
+// small: larger cells mix components and their balls prune nothing).
+static uint32_t DefaultCellRows(const gpann_shards* s) {
+    if (const char* cr = std::getenv("GPANN_CELL_ROWS")) return (uint32_t)std::max(64L, std::atol(cr));
+    const uint64_t per_shard = s->rows / std::max<uint32_t>(1, s->S);
+    return (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(2048, per_shard / 128));
+}
+
 extern "C" {
 
 const char* gpann_last_error(void) { return g_last_error.c_str(); }
@@ -195,8 +205,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         // (allocation failure, GPANN_FILTER_PLANES=0, d > 256, non-finite data) the store only offers the plain exact scan.
         // GPANN_CELL_ROWS sets the target cell size.
         const char* want = std::getenv("GPANN_FILTER_PLANES");
-        const char* cr = std::getenv("GPANN_CELL_ROWS");
-        const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
+        const uint32_t cell_rows = DefaultCellRows(s);
         if (s->filter_ok && d <= 256 && !(want && want[0] == '0') && !(flags & GPANN_STORE_PLAIN)) {
             gpann_status cst = BuildCells(s, cell_rows);
             if (cst != GPANN_OK) return fail(cst);
@@ -216,9 +225,7 @@ gpann_status gpann_shards_build_filter(gpann_shards* s) {
         SetLastError("the store's data is not fit for the filter (non-finite values or d > 256)");
         return GPANN_ERR_UNSUPPORTED;
     }
-    const char* cr = std::getenv("GPANN_CELL_ROWS");
-    const uint32_t cell_rows = cr ? (uint32_t)std::max(64L, std::atol(cr)) : 32768u;
-    return BuildCells(s, cell_rows);
+    return BuildCells(s, DefaultCellRows(s));
 }
 
 gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode) {
