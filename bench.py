@@ -204,7 +204,9 @@ def main():
         pygpann.nearest_centroid_device(queries.data_ptr(), nq, d, 0, shard_cent.data_ptr(), S, qa.data_ptr(), stream)
         est_tasks = np.bincount(qa.cpu().numpy().astype(np.int64), minlength=S).astype(np.float64) + 0.5
         cap_rows = int(max(args.replica_capacity * counts.sum() / world, 1.25 * counts.max()))
-        rep_begin, rep_rank, rank_work, load = gcomm.plan_replicas(counts, est_tasks * counts, world, cap_rows, 1.05)
+        # (GPANN_BENCH_REPLICA_IMBALANCE: the heaviest rank's estimated work over the mean at which no more replicas are added; 1.0 fills the room)
+        rep_begin, rep_rank, rank_work, load = gcomm.plan_replicas(counts, est_tasks * counts, world, cap_rows,
+                                                                   float(os.environ.get("GPANN_BENCH_REPLICA_IMBALANCE", 1.05)))
         owner = rep_rank[rep_begin[:-1]].astype(np.int32)          # the primary of every shard (trains its subtree)
         mine = np.array([b for b in range(S) if rank in rep_rank[rep_begin[b]:rep_begin[b + 1]]], np.int64)
         placement = {"replicas": int(rep_begin[S]) - S, "capacity_rows": cap_rows, "rank_rows": [int(x) for x in load],
