@@ -358,35 +358,26 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
-    // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor; the claim for the
-    // next item is issued while the current one streams.  (Claims of two consecutive entries, streamed as one range when they are pieces
-    // of one block — half the start-ups — measured 3 % SLOWER on the rest pass: 4.21 against 4.08 ms.)
-    __shared__ uint32_t s_item;
+    // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor, TWO ahead: while item
+    // i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2 is in flight, and the prefetch that
+    // would run past the end of item i fetches the first row tile of item i + 1 instead.  What is left between two items is the query
+    // image (it cannot be replaced before every wavefront is done with the old one): two barriers and one L2 round trip, instead of
+    // claim -> record -> first tile, three dependent memory latencies with nothing in flight.
+    // (Claims of two consecutive entries, streamed as one range when they are pieces of one block, measured 3 % SLOWER on the rest
+    // pass: 4.21 against 4.08 ms.)
+    __shared__ uint32_t s_claim;
     const uint32_t n_items = min(*a.n_items, a.items_cap);
     uint32_t my_products = 0, my_tiles = 0;
-    if (threadIdx.x == 0) s_item = atomicAdd(a.next_item, 1u);
-    for (;;) {
-    __syncthreads();   // s_item is written; everyone is done with the previous item's query image
-    const uint32_t item = s_item;
-    if (item >= n_items) break;
-    // one 32-byte record per item (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended up in
-    // vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued before it)
-    const uint32_t t_begin = a.items[item].t_begin, t_end = a.items[item].t_end, t_a = a.items[item].t_a, t_b = a.items[item].t_b;
-    const uint32_t task_begin = a.items[item].task_begin, task_count = a.items[item].task_count;
-    const uint32_t acts = a.items[item].acts;
-    const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
-    uint32_t next_claim = 0;
-    if (threadIdx.x == 0) next_claim = atomicAdd(a.next_item, 1u);   // lands under the first tile loads
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t ld = a.ld;
-    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image below)
-
+    (void)ld;
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
 
+    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
+    float nrm[2] = {0.f, 0.f};
     auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
 #pragma unroll
@@ -397,6 +388,35 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
     };
+    // an item's record as wave-uniform scalars (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended
+    // up in vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued
+    // before it)
+    auto uniform = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+
+    if (tid == 0) s_claim = atomicAdd(a.next_item, 2u);
+    __syncthreads();
+    uint32_t item = uniform(s_claim), nxt = item + 1;
+    if (item >= n_items) return;
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_task_count, r_acts, r_group;
+    {
+        const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
+        r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
+        r_task_begin = uniform(hi.x); r_task_count = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+    }
+    load_tile(Ah[0], Al[0], nrm[0], min(r_t_begin + wave, r_t_end - 1));
+    for (;;) {
+    // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or >= n_items)
+    const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
+    const uint32_t task_begin = r_task_begin, task_count = r_task_count;
+    const uint32_t acts = r_acts;
+    const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
+    uint32_t next_claim = 0;
+    if (tid == 0) next_claim = atomicAdd(a.next_item, 1u);
+    const CellItem* rn = a.items + min(nxt, n_items - 1);
+    const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
+
+    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image below)
+
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
@@ -496,43 +516,65 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     };
 
     // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
-    // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it re-reads the last tile — because
-    // a load under a branch leaves the compiler unable to count the loads in flight at the join, and it then drains them all
-    // (s_waitcnt vmcnt(0)) before the first use of the current tile: no overlap at all (measured on the rest pass of the NS
-    // workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for the hi-only passes was measured slower: spills.)
-    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
-    float nrm[2] = {0.f, 0.f};
+    // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it fetches the first tile of the
+    // next item (or, after the last item, re-reads the last tile) — because a load under a branch leaves the compiler unable to count
+    // the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use of the current tile: no
+    // overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for
+    // the hi-only passes was measured slower: spills.)
     if (mask >> wave & 1u) {
-        const char* src = a.image + ((size_t)a.items[item].group * QT + wave) * KS * 2048 + lane * 16;
+        const char* src = a.image + ((size_t)r_group * QT + wave) * KS * 2048 + lane * 16;
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
     }
-    uint32_t T = t_begin + wave;
-    const uint32_t t_last = t_end - 1;
-    load_tile(Ah[0], Al[0], nrm[0], min(T, t_last));   // the item's first tile is on its way while the query image lands
-
     // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const uint32_t tl = 32u * qt + c;
         U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
     }
-    DmaWaitAll();      // this wavefront's part of the image is in LDS (so is its first tile)
+    DmaWaitAll();      // this wavefront's part of the image is in LDS (so are its first tile, the next record and the claim)
+    if (tid == 0) s_claim = next_claim;
     __syncthreads();
+    const uint32_t after = uniform(s_claim);
+    const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
+    const uint32_t t_last = t_end - 1;
+    // this wavefront's first tile of the next item
+    const uint32_t n_first = nxt < n_items ? min(n_t_begin + wave, n_t_end - 1) : t_last;
+    uint32_t T = t_begin + wave;
     if (T < t_end) {
+        const uint32_t steps = (t_end - T + kFWaves - 1) / kFWaves;
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], min(T + kFWaves, t_last));
+            uint32_t Tn = T + kFWaves;
+            uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
             compute_tile(Ah[0], Al[0], nrm[0], T);
-            T += kFWaves;
+            T = Tn;
             if (T >= t_end) break;
-            load_tile(Ah[0], Al[0], nrm[0], min(T + kFWaves, t_last));
+            Tn = T + kFWaves;
+            own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
             compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
-            T += kFWaves;
+            T = Tn;
             if (T >= t_end) break;
         }
+        if (steps & 1u) {   // the next item's first tile went to buffer 1
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Ah[0][ks].v = Ah[1][ks].v;
+                if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
+            }
+            nrm[0] = nrm[1];
+        }
+    } else {
+        load_tile(Ah[0], Al[0], nrm[0], n_first);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
     }
-    if (threadIdx.x == 0) s_item = next_claim;
+    __syncthreads();   // everyone is done with this item's query image (and has read s_claim)
+    if (nxt >= n_items) break;
+    r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
+    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = uniform(n_hi.w);
+    item = nxt;
+    nxt = after;
     }   // next item
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
