@@ -647,26 +647,34 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
     const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
+    // one item list per task group: group_first[g] = where it starts (capacity: every cell of the group's shard cut into pieces)
     uint64_t items_cap = 0;
-    for (const CellGroup& g : groups)
-        for (uint32_t c = C.shard_cell_begin[g.shard]; c < C.shard_cell_begin[g.shard + 1]; ++c)
+    std::vector<uint32_t> group_first(G + 1);
+    for (uint32_t g = 0; g < G; ++g) {
+        GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
+        group_first[g] = (uint32_t)items_cap;
+        for (uint32_t c = C.shard_cell_begin[groups[g].shard]; c < C.shard_cell_begin[groups[g].shard + 1]; ++c)
             items_cap += (C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]) / seg_tiles + 1;
+    }
     GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
-    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + (size_t)items_cap * sizeof(CellItem)));
+    group_first[G] = (uint32_t)items_cap;
+    const size_t gtab_words = ((size_t)3 * G + 1 + 3) / 4 * 4;   // group_first [G+1] | group_count [G] | group_cursor [G], 16-byte multiple
+    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
     need_pass[0] = s->ws_need.as<uint32_t>();
     need_pass[1] = need_pass[0] + need_words;
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
     CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [2] work-stealing cursor + item count, [3] = [1] before the rest pass
-    uint32_t* d_next_item = reinterpret_cast<uint32_t*>(d_work + 2);
-    uint32_t* d_n_items = d_next_item + 1;
-    CellItem* d_items = reinterpret_cast<CellItem*>(d_work + 4);
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [3] = [1] before the rest pass
+    uint32_t* d_group_first = reinterpret_cast<uint32_t*>(d_work + 4);
+    uint32_t* d_group_count = d_group_first + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
+    CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first + gtab_words);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
     GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
     GPANN_HIP_TRY(UploadAsync(s, d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), st));
     GPANN_HIP_TRY(UploadAsync(s, d_groups, groups.data(), (size_t)G * sizeof(CellGroup), st));
+    GPANN_HIP_TRY(UploadAsync(s, d_group_first, group_first.data(), (size_t)(G + 1) * 4, st));
     GPANN_HIP_TRY(UploadAsync(s, d_task_group, task_group.data(), (size_t)T * 4, st));
 
     CellDistArgs cd;
@@ -768,7 +776,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.task_src = d_task_src;
     na.task_U = task_U;
     na.cand_cnt = cand_cnt;
-    na.zero2 = d_next_item;
+    na.group_zero = d_group_count;
+    na.n_groups = G;
     th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
@@ -794,13 +803,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.head_tiles = head_tiles;
     fa.sample_div = sample_div;
     fa.work = d_work;
-    fa.next_item = d_next_item;
     fa.n_groups = G;
     fa.items = d_items;
+    fa.group_first = d_group_first;
+    fa.group_count = d_group_count;
+    fa.group_cursor = d_group_count + G;
     fa.image = s->ws_image.as<char>();
-    fa.n_items = d_n_items;
     fa.seg_tiles = seg_tiles;
-    fa.items_cap = (uint32_t)items_cap;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -880,7 +889,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     if (seed_rows != 0 && C.n_sample_tiles != 0) {
         const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
+        std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of this pass's lists
         for (uint32_t g = 0; g < G; ++g) {
+            stab[g] = (uint32_t)sitems.size();
             const uint64_t t0 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard + 1];
             const uint32_t qtiles = (groups[g].task_count + 31) / 32, mask = (1u << qtiles) - 1u;
             for (uint64_t t = t0; t < t1; t += piece) {
@@ -894,13 +905,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 it.group = g;
                 sitems.push_back(it);
             }
+            stab[G + g] = (uint32_t)sitems.size() - stab[g];
         }
         if (!sitems.empty()) {
-            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + 64));
-            uint32_t* s_cursor = s->ws_misc.as<uint32_t>();   // [0] cursor, [1] item count
-            CellItem* d_sitems = reinterpret_cast<CellItem*>(s_cursor + 16);
-            const uint32_t head[2] = {0u, (uint32_t)sitems.size()};
-            GPANN_HIP_TRY(UploadAsync(s, s_cursor, head, 8, st));
+            const size_t stab_words = ((size_t)3 * G + 3) / 4 * 4;
+            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + stab_words * 4 + 64));
+            uint32_t* d_stab = s->ws_misc.as<uint32_t>();
+            CellItem* d_sitems = reinterpret_cast<CellItem*>(d_stab + stab_words);
+            GPANN_HIP_TRY(UploadAsync(s, d_stab, stab.data(), (size_t)3 * G * 4, st));
             GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
             GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
             th.hi_only = ks16 ? 1u : 0u;
@@ -908,9 +920,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
             CellFilterArgs fs = fa;
             fs.items = d_sitems;
-            fs.n_items = s_cursor + 1;
-            fs.next_item = s_cursor;
-            fs.items_cap = (uint32_t)sitems.size();
+            fs.group_first = d_stab;
+            fs.group_count = d_stab + G;
+            fs.group_cursor = d_stab + 2 * G;
             fs.pass = 0;
             fs.need = nullptr;
             fs.done0 = fs.done0b = fs.done1 = nullptr;
@@ -928,7 +940,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
-        na.items_init = 0u;
         na.need = need_pass[pass];
         if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);

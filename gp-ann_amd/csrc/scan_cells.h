@@ -185,9 +185,9 @@ struct NeedArgs {
     // 0 of the launch zeroes the item cursor / count of the pass
     float* task_U;
     uint32_t* cand_cnt;
-    uint32_t* zero2;
+    uint32_t* group_zero;               // [2 n_groups]: the item counts and claim cursors of the task groups, zeroed here for the pass
+    uint32_t n_groups;
     uint32_t hi_only;
-    uint32_t items_init;                // work items already in the list when FilterItemsKernel starts appending (pass 0: the shard-sample items)
 };
 
 // One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
@@ -206,9 +206,9 @@ static __global__ void NeedKernel(NeedArgs a) {
     if (j == 0) {
         a.task_U[t] = ThresholdOf<METRIC>((double)a.list_dist[(size_t)t * a.k + a.k - 1], a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
         a.cand_cnt[t] = 0;
-        if (t == 0) {
-            a.zero2[0] = 0;
-            a.zero2[1] = a.items_init;
+        if (t < a.n_groups) {   // (every group has a task: tasks >= n_groups)
+            a.group_zero[t] = 0;
+            a.group_zero[a.n_groups + t] = 0;
         }
     }
     if (j >= K) return;
@@ -267,12 +267,15 @@ struct CellFilterArgs {
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
     unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
-    uint32_t* next_item;         // work-stealing cursor over `items` (zeroed before the launch)
     uint32_t n_groups;
-    // the pass's work items, written by FilterItemsKernel: a (task group, cell) block's tile range cut into pieces of <= seg_tiles
+    // the pass's work items, written by FilterItemsKernel: a (task group, cell) block's tile range cut into pieces of <= seg_tiles.
+    // The items of task group g are items[group_first[g] .. + group_count[g]) (group_first: capacities, computed by the host);
+    // group_cursor[g] counts the claims made on them (work stealing, FilterKernelCells).
     CellItem* items;
-    uint32_t* n_items;
-    uint32_t seg_tiles, items_cap;
+    const uint32_t* group_first;
+    uint32_t* group_count;
+    uint32_t* group_cursor;
+    uint32_t seg_tiles;
     const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel)
 };
 
@@ -281,7 +284,7 @@ constexpr int kFWaves = 8;
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
-// blocks without work never reach them).  Order of the list is irrelevant for the result.
+// blocks without work never reach them), one list per task group.  Order of the lists is irrelevant for the result.
 static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a) {
     const uint32_t block = blockIdx.x * 256 + threadIdx.x;
     if (block >= a.n_groups * a.kmax) return;
@@ -307,7 +310,7 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
     // the end of the item for a full memory latency)
     const int64_t per = ((range + n - 1) / n + kFWaves - 1) / kFWaves * kFWaves;
-    const uint32_t base = atomicAdd(a.n_items, n);
+    const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
     CellItem it;
     it.t_a = (uint32_t)t_a;
     it.t_b = (uint32_t)t_b;
@@ -319,7 +322,7 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
         it.t_begin = (uint32_t)b;
         it.t_end = (uint32_t)e;
-        if (base + i < a.items_cap) a.items[base + i] = it;
+        a.items[base + i] = it;   // (group_first reserves tiles / seg_tiles + 1 >= n entries for every cell of the group)
     }
 }
 
@@ -347,6 +350,47 @@ __device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) 
 }
 __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+
+// Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
+// Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
+// Every failed claim coincides with a group running dry, so the loop ends after at most n_groups rounds.
+__device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, const uint32_t* group_count, uint32_t* group_cursor, uint32_t n_groups,
+                                                   int lane, uint32_t& g, uint32_t& first, uint32_t& count) {
+    for (;;) {
+        uint32_t best = 0, best_g = kNoItem;
+        for (uint32_t i = (uint32_t)lane; i < n_groups; i += 64) {
+            const uint32_t cnt = group_count[i];
+            const uint32_t cur = __hip_atomic_load(&group_cursor[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t rem = cur < cnt ? cnt - cur : 0u;
+            if (rem > best) {
+                best = rem;
+                best_g = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t ob = (uint32_t)__shfl_xor((int)best, off), og = (uint32_t)__shfl_xor((int)best_g, off);
+            if (ob > best || (ob == best && og < best_g)) {
+                best = ob;
+                best_g = og;
+            }
+        }
+        best_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
+        if (best_g == kNoItem) return kNoItem;
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&group_cursor[best_g], 1u);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        const uint32_t cnt = group_count[best_g];
+        if (idx < cnt) {
+            g = best_g;
+            first = group_first[best_g];
+            count = cnt;
+            return first + idx;
+        }
+    }
+}
+
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
 // query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
 // tiles do not fit the register file).
@@ -358,15 +402,18 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
-    // persistent workgroups: one per CU, each claims work items (FilterItemsKernel's list) from a shared cursor, TWO ahead: while item
-    // i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2 is in flight, and the prefetch that
-    // would run past the end of item i fetches the first row tile of item i + 1 instead.  What is left between two items is the query
-    // image (it cannot be replaced before every wavefront is done with the old one): two barriers and one L2 round trip, instead of
-    // claim -> record -> first tile, three dependent memory latencies with nothing in flight.
+    // Persistent workgroups, one per CU, claim work items from the task groups' lists.  Two things keep the time between two items short:
+    //  * claims run TWO ahead: while item i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2
+    //    is in flight, and the prefetch that would run past the end of item i fetches the first row tile of item i + 1 instead
+    //    (claim -> record -> first tile were three dependent memory latencies with nothing in flight);
+    //  * a workgroup stays with ONE task group while that group has unclaimed items: its query image (up to 128 KiB, which at the
+    //    workgroup's share of the memory system took about as long to copy as the three latencies together) is copied when the group
+    //    changes — a few times per launch instead of once per item — and consecutive items of a group need no barrier between them
+    //    but the one that hands the next claim to the other wavefronts.  A workgroup whose group runs dry moves to the group with the
+    //    most unclaimed items (ClaimElsewhere).
     // (Claims of two consecutive entries, streamed as one range when they are pieces of one block, measured 3 % SLOWER on the rest
     // pass: 4.21 against 4.08 ms.)
-    __shared__ uint32_t s_claim;
-    const uint32_t n_items = min(*a.n_items, a.items_cap);
+    __shared__ uint32_t s_claim[4];
     uint32_t my_products = 0, my_tiles = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -393,10 +440,34 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // before it)
     auto uniform = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-    if (tid == 0) s_claim = atomicAdd(a.next_item, 2u);
+    // claim state: meaningful in wavefront 0 only (wave-uniform there)
+    uint32_t c_g = 0, c_first = 0, c_count = 0;
+    bool drained = false;
+    // wavefront 0: the item behind cursor value idx of group c_g, or a claim on another group
+    auto claim_for = [&](uint32_t idx) __attribute__((always_inline)) {
+        if (idx < c_count) return c_first + idx;
+        if (drained) return kNoItem;
+        const uint32_t got = ClaimElsewhere(a.group_first, a.group_count, a.group_cursor, a.n_groups, lane, c_g, c_first, c_count);
+        drained = got == kNoItem;
+        return got;
+    };
+    if (wave == 0) {
+        c_g = (uint32_t)((uint64_t)blockIdx.x * a.n_groups / gridDim.x);
+        c_first = a.group_first[c_g];
+        c_count = a.group_count[c_g];
+        for (int j = 0; j < 2; ++j) {
+            uint32_t idx = 0;
+            if (lane == 0 && !drained) idx = atomicAdd(&a.group_cursor[c_g], 1u);
+            const uint32_t got = claim_for(uniform(idx));
+            if (lane == 0) s_claim[j] = got;
+        }
+    }
     __syncthreads();
-    uint32_t item = uniform(s_claim), nxt = item + 1;
-    if (item >= n_items) return;
+    uint32_t item = uniform(s_claim[0]), nxt = uniform(s_claim[1]);
+    if (item == kNoItem) return;
+    uint32_t loaded_group = kNoItem, loaded = 0;   // the query image in LDS: whose, and which of its query tiles
+    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image)
+    uint32_t iter = 0;
     uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_task_count, r_acts, r_group;
     {
         const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
@@ -405,17 +476,15 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     }
     load_tile(Ah[0], Al[0], nrm[0], min(r_t_begin + wave, r_t_end - 1));
     for (;;) {
-    // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or >= n_items)
+    // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
     const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
     const uint32_t task_begin = r_task_begin, task_count = r_task_count;
     const uint32_t acts = r_acts;
     const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
-    uint32_t next_claim = 0;
-    if (tid == 0) next_claim = atomicAdd(a.next_item, 1u);
-    const CellItem* rn = a.items + min(nxt, n_items - 1);
+    uint32_t next_idx = 0;
+    if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
+    const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
-
-    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image below)
 
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
@@ -521,26 +590,38 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use of the current tile: no
     // overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for
     // the hi-only passes was measured slower: spills.)
-    if (mask >> wave & 1u) {
+    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it and it is not there yet
+    //      (a new group's image replaces the old one: the barrier at the end of the previous item made sure nobody reads that any more;
+    //      further tiles of the SAME group go to slots nobody reads yet)
+    const bool same_group = r_group == loaded_group;
+    const uint32_t fetch = same_group ? mask & ~loaded : mask;
+    if (fetch >> wave & 1u) {
         const char* src = a.image + ((size_t)r_group * QT + wave) * KS * 2048 + lane * 16;
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
     }
-    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it
+    if (!same_group) {   // (a query tile outside the item's mask is never multiplied: its thresholds need no masking)
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const uint32_t tl = 32u * qt + c;
-        U[qt] = (tl < task_count && (mask >> qt & 1u)) ? a.task_U[task_begin + tl] : INFINITY;
+        for (int qt = 0; qt < QT; ++qt) {
+            const uint32_t tl = 32u * qt + c;
+            U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
+        }
     }
+    loaded = same_group ? loaded | mask : mask;
+    loaded_group = r_group;
     DmaWaitAll();      // this wavefront's part of the image is in LDS (so are its first tile, the next record and the claim)
-    if (tid == 0) s_claim = next_claim;
+    if (wave == 0) {
+        const uint32_t got = claim_for(uniform(next_idx));
+        if (lane == 0) s_claim[2 + (iter & 1u)] = got;
+    }
     __syncthreads();
-    const uint32_t after = uniform(s_claim);
+    const uint32_t after = uniform(s_claim[2 + (iter & 1u)]);
+    ++iter;
     const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
     const uint32_t t_last = t_end - 1;
     // this wavefront's first tile of the next item
-    const uint32_t n_first = nxt < n_items ? min(n_t_begin + wave, n_t_end - 1) : t_last;
+    const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave, n_t_end - 1) : t_last;
     uint32_t T = t_begin + wave;
     if (T < t_end) {
         const uint32_t steps = (t_end - T + kFWaves - 1) / kFWaves;
@@ -569,10 +650,11 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     } else {
         load_tile(Ah[0], Al[0], nrm[0], n_first);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
     }
-    __syncthreads();   // everyone is done with this item's query image (and has read s_claim)
-    if (nxt >= n_items) break;
+    if (nxt == kNoItem) break;
+    const uint32_t n_group = uniform(n_hi.w);
+    if (n_group != r_group) __syncthreads();   // the next item replaces the query image: everyone has to be done with this one
     r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
-    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = uniform(n_hi.w);
+    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
     item = nxt;
     nxt = after;
     }   // next item
