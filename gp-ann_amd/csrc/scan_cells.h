@@ -279,7 +279,7 @@ struct CellFilterArgs {
     const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel)
 };
 
-// wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
+// wavefronts per workgroup of FilterKernelCells (one workgroup per CU): each of them streams the row tiles of its own work items
 constexpr int kFWaves = 8;
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
@@ -307,9 +307,8 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     if (t_first >= t_pass_end) return;
     const int64_t range = t_pass_end - t_first;
     const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
-    // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
-    // the end of the item for a full memory latency)
-    const int64_t per = ((range + n - 1) / n + kFWaves - 1) / kFWaves * kFWaves;
+    // equal pieces (n = ceil(range / seg_tiles) and per <= seg_tiles: none of them is empty)
+    const int64_t per = (range + n - 1) / n;
     const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
     CellItem it;
     it.t_a = (uint32_t)t_a;
@@ -352,43 +351,29 @@ __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)"
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
-// Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
-// Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
-// Every failed claim coincides with a group running dry, so the loop ends after at most n_groups rounds.
-__device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, const uint32_t* group_count, uint32_t* group_cursor, uint32_t n_groups,
-                                                   int lane, uint32_t& g, uint32_t& first, uint32_t& count) {
-    for (;;) {
-        uint32_t best = 0, best_g = kNoItem;
-        for (uint32_t i = (uint32_t)lane; i < n_groups; i += 64) {
-            const uint32_t cnt = group_count[i];
-            const uint32_t cur = __hip_atomic_load(&group_cursor[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t rem = cur < cnt ? cnt - cur : 0u;
-            if (rem > best) {
-                best = rem;
-                best_g = i;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off; off >>= 1) {
-            const uint32_t ob = (uint32_t)__shfl_xor((int)best, off), og = (uint32_t)__shfl_xor((int)best_g, off);
-            if (ob > best || (ob == best && og < best_g)) {
-                best = ob;
-                best_g = og;
-            }
-        }
-        best_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
-        if (best_g == kNoItem) return kNoItem;
-        uint32_t idx = 0;
-        if (lane == 0) idx = atomicAdd(&group_cursor[best_g], 1u);
-        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-        const uint32_t cnt = group_count[best_g];
-        if (idx < cnt) {
-            g = best_g;
-            first = group_first[best_g];
-            count = cnt;
-            return first + idx;
+// Wavefront 0 of a workgroup (all 64 lanes) picks the task group the workgroup turns to next: `prefer` if it has unclaimed work
+// items, else the group with the most of them; kNoItem once every list is exhausted.
+__device__ __forceinline__ uint32_t PickGroup(const uint32_t* group_count, const uint32_t* group_cursor, uint32_t n_groups, int lane, uint32_t prefer) {
+    uint32_t best = 0, best_g = kNoItem;
+    for (uint32_t i = (uint32_t)lane; i < n_groups; i += 64) {
+        const uint32_t cnt = group_count[i];
+        const uint32_t cur = __hip_atomic_load(&group_cursor[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t rem = cur < cnt ? cnt - cur : 0u;
+        if (rem != 0u && i == prefer) rem = 0xFFFFFFFFu;
+        if (rem > best) {
+            best = rem;
+            best_g = i;
         }
     }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)best, off), og = (uint32_t)__shfl_xor((int)best_g, off);
+        if (ob > best || (ob == best && og < best_g)) {
+            best = ob;
+            best_g = og;
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
 }
 
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
@@ -402,23 +387,19 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
-    // Persistent workgroups, one per CU, claim work items from the task groups' lists.  Two things keep the time between two items short:
-    //  * claims run TWO ahead: while item i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2
-    //    is in flight, and the prefetch that would run past the end of item i fetches the first row tile of item i + 1 instead
-    //    (claim -> record -> first tile were three dependent memory latencies with nothing in flight);
-    //  * a workgroup stays with ONE task group while that group has unclaimed items: its query image (up to 128 KiB, which at the
-    //    workgroup's share of the memory system took about as long to copy as the three latencies together) is copied when the group
-    //    changes — a few times per launch instead of once per item — and consecutive items of a group need no barrier between them
-    //    but the one that hands the next claim to the other wavefronts.  A workgroup whose group runs dry moves to the group with the
-    //    most unclaimed items (ClaimElsewhere).
-    // (Claims of two consecutive entries, streamed as one range when they are pieces of one block, measured 3 % SLOWER on the rest
-    // pass: 4.21 against 4.08 ms.)
-    __shared__ uint32_t s_claim[4];
+    // Persistent workgroups, one per CU.  A workgroup works on ONE task group at a time — the group's query image (up to 128 KiB) sits
+    // in LDS — and each of its WAVEFRONTS claims work items (pieces of at most seg_tiles row tiles) from that group's list on its own:
+    //  * no barrier and no drained load queue between two items (a workgroup-wide item cost a barrier per item — the wavefronts'
+    //    progress differs by microseconds — plus a wait for the claim with nothing else in flight: about 9 us per item, a fifth of
+    //    the rest pass);
+    //  * claims run two ahead: while item i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2
+    //    is in flight, and the prefetch that would run past the end of item i fetches the first row tile of item i + 1 instead;
+    //  * the image is copied when the workgroup changes its group — when the group's list runs dry it moves to the group with the
+    //    most unclaimed items (PickGroup) — a few times per launch.
+    __shared__ uint32_t s_group;
     uint32_t my_products = 0, my_tiles = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const uint32_t ld = a.ld;
-    (void)ld;
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
@@ -440,52 +421,55 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // before it)
     auto uniform = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-    // claim state: meaningful in wavefront 0 only (wave-uniform there)
-    uint32_t c_g = 0, c_first = 0, c_count = 0;
-    bool drained = false;
-    // wavefront 0: the item behind cursor value idx of group c_g, or a claim on another group
-    auto claim_for = [&](uint32_t idx) __attribute__((always_inline)) {
-        if (idx < c_count) return c_first + idx;
-        if (drained) return kNoItem;
-        const uint32_t got = ClaimElsewhere(a.group_first, a.group_count, a.group_cursor, a.n_groups, lane, c_g, c_first, c_count);
-        drained = got == kNoItem;
-        return got;
-    };
     if (wave == 0) {
-        c_g = (uint32_t)((uint64_t)blockIdx.x * a.n_groups / gridDim.x);
-        c_first = a.group_first[c_g];
-        c_count = a.group_count[c_g];
-        for (int j = 0; j < 2; ++j) {
-            uint32_t idx = 0;
-            if (lane == 0 && !drained) idx = atomicAdd(&a.group_cursor[c_g], 1u);
-            const uint32_t got = claim_for(uniform(idx));
-            if (lane == 0) s_claim[j] = got;
-        }
+        const uint32_t g0 = PickGroup(a.group_count, a.group_cursor, a.n_groups, lane, (uint32_t)((uint64_t)blockIdx.x * a.n_groups / gridDim.x));
+        if (lane == 0) s_group = g0;
     }
+    for (;;) {   // the task groups this workgroup works on
+    __syncthreads();   // s_group is written; everyone is done with the previous group's query image
+    const uint32_t group = uniform(s_group);
+    if (group == kNoItem) break;
+    const uint32_t task_begin = a.groups[group].task_begin, task_count = a.groups[group].task_count;
+    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image
+    if ((uint32_t)wave * 32u < task_count && wave < QT) {
+        const char* src = a.image + ((size_t)group * QT + wave) * KS * 2048 + lane * 16;
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
+    }
+    float U[QT];   // thresholds of this lane's task in each query tile (a query tile outside an item's mask is never multiplied)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const uint32_t tl = 32u * qt + c;
+        U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
+    }
+    // this wavefront's first two claims on the group's list
+    const uint32_t g_first = a.group_first[group], g_count = a.group_count[group];
+    uint32_t idx2 = 0;
+    if (lane == 0) idx2 = atomicAdd(&a.group_cursor[group], 2u);
+    DmaWaitAll();      // this wavefront's part of the image is in LDS
     __syncthreads();
-    uint32_t item = uniform(s_claim[0]), nxt = uniform(s_claim[1]);
-    if (item == kNoItem) return;
-    uint32_t loaded_group = kNoItem, loaded = 0;   // the query image in LDS: whose, and which of its query tiles
-    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image)
-    uint32_t iter = 0;
-    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_task_count, r_acts, r_group;
+    idx2 = uniform(idx2);
+    uint32_t item = idx2 < g_count ? g_first + idx2 : kNoItem;
+    uint32_t nxt = idx2 + 1u < g_count ? g_first + idx2 + 1u : kNoItem;
+    bool dry = nxt == kNoItem;   // a claim on this list has come back empty: no further ones
+    if (item != kNoItem) {
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_acts;
     {
         const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
         r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
-        r_task_begin = uniform(hi.x); r_task_count = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+        r_acts = uniform(hi.z);
     }
-    load_tile(Ah[0], Al[0], nrm[0], min(r_t_begin + wave, r_t_end - 1));
-    for (;;) {
+    load_tile(Ah[0], Al[0], nrm[0], r_t_begin);
+    for (;;) {   // this wavefront's items
     // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
     const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
-    const uint32_t task_begin = r_task_begin, task_count = r_task_count;
     const uint32_t acts = r_acts;
     const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
     uint32_t next_idx = 0;
-    if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
+    if (lane == 0 && !dry) next_idx = atomicAdd(&a.group_cursor[group], 1u);
     const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
-
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
@@ -590,74 +574,49 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use of the current tile: no
     // overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for
     // the hi-only passes was measured slower: spills.)
-    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it and it is not there yet
-    //      (a new group's image replaces the old one: the barrier at the end of the previous item made sure nobody reads that any more;
-    //      further tiles of the SAME group go to slots nobody reads yet)
-    const bool same_group = r_group == loaded_group;
-    const uint32_t fetch = same_group ? mask & ~loaded : mask;
-    if (fetch >> wave & 1u) {
-        const char* src = a.image + ((size_t)r_group * QT + wave) * KS * 2048 + lane * 16;
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
-#pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
-    }
-    if (!same_group) {   // (a query tile outside the item's mask is never multiplied: its thresholds need no masking)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const uint32_t tl = 32u * qt + c;
-            U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
-        }
-    }
-    loaded = same_group ? loaded | mask : mask;
-    loaded_group = r_group;
-    DmaWaitAll();      // this wavefront's part of the image is in LDS (so are its first tile, the next record and the claim)
-    if (wave == 0) {
-        const uint32_t got = claim_for(uniform(next_idx));
-        if (lane == 0) s_claim[2 + (iter & 1u)] = got;
-    }
-    __syncthreads();
-    const uint32_t after = uniform(s_claim[2 + (iter & 1u)]);
-    ++iter;
-    const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
+    const uint32_t n_t_begin = uniform(n_lo.x);
     const uint32_t t_last = t_end - 1;
-    // this wavefront's first tile of the next item
-    const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave, n_t_end - 1) : t_last;
-    uint32_t T = t_begin + wave;
-    if (T < t_end) {
-        const uint32_t steps = (t_end - T + kFWaves - 1) / kFWaves;
-        for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
-            uint32_t Tn = T + kFWaves;
-            uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
-            compute_tile(Ah[0], Al[0], nrm[0], T);
-            T = Tn;
-            if (T >= t_end) break;
-            Tn = T + kFWaves;
-            own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
-            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
-            T = Tn;
-            if (T >= t_end) break;
-        }
-        if (steps & 1u) {   // the next item's first tile went to buffer 1
+    const uint32_t n_first = nxt != kNoItem ? n_t_begin : t_last;   // the first tile of the next item
+    uint32_t T = t_begin;
+    const uint32_t steps = t_end - t_begin;
+    for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
+        uint32_t Tn = T + 1;
+        uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+        load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
+        compute_tile(Ah[0], Al[0], nrm[0], T);
+        T = Tn;
+        if (T >= t_end) break;
+        Tn = T + 1;
+        own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+        load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
+        compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
+        T = Tn;
+        if (T >= t_end) break;
+    }
+    if (steps & 1u) {   // the next item's first tile went to buffer 1
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                Ah[0][ks].v = Ah[1][ks].v;
-                if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
-            }
-            nrm[0] = nrm[1];
+        for (int ks = 0; ks < KS; ++ks) {
+            Ah[0][ks].v = Ah[1][ks].v;
+            if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
         }
-    } else {
-        load_tile(Ah[0], Al[0], nrm[0], n_first);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
+        nrm[0] = nrm[1];
     }
     if (nxt == kNoItem) break;
-    const uint32_t n_group = uniform(n_hi.w);
-    if (n_group != r_group) __syncthreads();   // the next item replaces the query image: everyone has to be done with this one
-    r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
-    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
+    next_idx = uniform(next_idx);
+    const uint32_t after = (!dry && next_idx < g_count) ? g_first + next_idx : kNoItem;
+    dry = after == kNoItem;
+    r_t_begin = n_t_begin; r_t_end = uniform(n_lo.y); r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
+    r_acts = uniform(n_hi.z);
     item = nxt;
     nxt = after;
     }   // next item
+    }
+    __syncthreads();   // every wavefront has run out of items of this group
+    if (wave == 0) {
+        const uint32_t g1 = PickGroup(a.group_count, a.group_cursor, a.n_groups, lane, kNoItem);
+        if (lane == 0) s_group = g1;
+    }
+    }   // next group
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
         atomicAdd(&a.work[1], (unsigned long long)my_tiles);
