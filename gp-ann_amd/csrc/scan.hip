@@ -859,7 +859,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere.  Beyond 128 dimensions every pass is a hi-plane pass.
     const bool hi_last = ks16 || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
     const int hi_from_pass = ks16 ? 0 : (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
-    const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
+    const size_t glds = FilterLdsBytes((size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);

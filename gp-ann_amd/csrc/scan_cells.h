@@ -281,6 +281,11 @@ struct CellFilterArgs {
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): each of them streams the row tiles of its own work items
 constexpr int kFWaves = 8;
+// candidates a wavefront of FilterKernelCells collects in LDS before it writes them to the tasks' buckets (what is left of the 160 KiB
+// next to a 128 KiB query image and the norms)
+constexpr uint32_t kFQueue = 448;
+// dynamic LDS of FilterKernelCells
+constexpr size_t FilterLdsBytes(size_t image_bytes) { return image_bytes + kFWaves * kGTileRows * sizeof(float) + (size_t)kFWaves * kFQueue * 8; }
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
@@ -403,10 +408,25 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
+    // Candidates go through a per-wavefront queue in LDS: (task, store row) pairs, written to the tasks' buckets — a returning atomic
+    // per candidate for the slot — when the queue fills up and when the workgroup leaves the task group.  (Written straight from the
+    // tile loop, every row tile with a candidate cost two dependent round trips — row id, slot — during which the wavefront had
+    // nothing else in flight: vmcnt is in-order, the waits also drained the prefetch.)
+    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + kFWaves * kGTileRows * sizeof(float)) + wave * kFQueue;
+    uint32_t q_len = 0;
+    auto flush_queue = [&]() __attribute__((always_inline)) {
+        for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
+            const uint2 e = queue[i];
+            const uint32_t slot = atomicAdd(&a.cand_cnt[e.x], 1u);
+            if (slot < a.cand_cap) a.cand_row[(size_t)e.x * a.cand_cap + slot] = e.y;
+        }
+        q_len = 0;
+    };
 
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
+    uint32_t prm[2] = {0u, 0u};   // the store rows of the tile's 32 rows (lane c: row c)
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t& prm, uint32_t T) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -415,6 +435,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + a.plane_lo_offset + ks * 1024));
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
+        prm = a.plane_perm[(size_t)T * kGTileRows + c];
     };
     // an item's record as wave-uniform scalars (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended
     // up in vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued
@@ -460,7 +481,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
         r_acts = uniform(hi.z);
     }
-    load_tile(Ah[0], Al[0], nrm[0], r_t_begin);
+    load_tile(Ah[0], Al[0], nrm[0], prm[0], r_t_begin);
     for (;;) {   // this wavefront's items
     // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
     const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
@@ -471,7 +492,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
 
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t prm, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
         // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
         // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
@@ -485,83 +506,62 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
         my_products += (uint32_t)__builtin_popcount(act);
         my_tiles += 1;
-        uint32_t cmask[QT / 2];   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
+        uint32_t cmask[QT];   // bit r of cmask[q]: accumulator register r of query tile q passed
 #pragma unroll
-        for (int qp = 0; qp < QT / 2; ++qp) cmask[qp] = 0u;
-        // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
-        auto pass = [&](auto pair_tag, int q0, int qp, int shift) __attribute__((always_inline)) {
-            constexpr bool PAIR = decltype(pair_tag)::value;
-            f32x16 acc0, acc1;
+        for (int q = 0; q < QT; ++q) cmask[q] = 0u;
+        // one pass of the k-loop per query tile: one accumulator chain (the matrix cores accumulate back to back on the same registers;
+        // two interleaved chains — pairs of query tiles — bought nothing but 16 + 8 more live registers)
+        auto pass = [&](int q) __attribute__((always_inline)) {
+            f32x16 acc;
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc0[4 * gg + 0] = n.x; acc0[4 * gg + 1] = n.y; acc0[4 * gg + 2] = n.z; acc0[4 * gg + 3] = n.w;
-                if (PAIR) {
-                    acc1[4 * gg + 0] = n.x; acc1[4 * gg + 1] = n.y; acc1[4 * gg + 2] = n.z; acc1[4 * gg + 3] = n.w;
-                }
+                acc[4 * gg + 0] = n.x; acc[4 * gg + 1] = n.y; acc[4 * gg + 2] = n.z; acc[4 * gg + 3] = n.w;
             }
-            const char* p0 = lane_lds + (q0 * KS) * 2048;
-            const char* p1 = lane_lds + ((q0 + 1) * KS) * 2048;
+            const char* p = lane_lds + (q * KS) * 2048;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag bh0, bl0, bh1, bl1;
-                bh0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048);
-                bl0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048 + 1024);
-                if (PAIR) {
-                    bh1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048);
-                    bl1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048 + 1024);
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
-                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
-                if (!HI_ONLY) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
-                    if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
-                }
+                Frag bh, bl;
+                bh.q = *reinterpret_cast<const uint4*>(p + ks * 2048);
+                bl.q = *reinterpret_cast<const uint4*>(p + ks * 2048 + 1024);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh.v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl.v, acc, 0, 0, 0);
+                if (!HI_ONLY) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh.v, acc, 0, 0, 0);
             }
-            const float u0 = (q0 & 1) ? U[2 * qp + 1] : U[2 * qp];
-            const float u1 = U[2 * qp + 1];
-            float m0 = acc0[0], m1 = PAIR ? acc1[0] : -INFINITY;
+            const float u = U[q];
+            float m = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                m0 = fmaxf(m0, acc0[r]);
-                if (PAIR) m1 = fmaxf(m1, acc1[r]);
-            }
-            if (__any(m0 >= u0 || (PAIR && m1 >= u1))) {
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            if (__any(m >= u)) {
                 uint32_t bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    bits |= acc0[r] >= u0 ? 1u << (r + shift) : 0u;
-                    if (PAIR) bits |= acc1[r] >= u1 ? 0x10000u << r : 0u;
-                }
-                cmask[qp] = bits;
+                for (int r = 0; r < 16; ++r) bits |= acc[r] >= u ? 1u << r : 0u;
+                cmask[q] = bits;
             }
         };
 #pragma unroll
-        for (int qp = 0; qp < QT / 2; ++qp) {
-            const uint32_t two = act >> (2 * qp) & 3u;
-            if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
-            else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
-            else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
-        }
+        for (int q = 0; q < QT; ++q)
+            if (act >> q & 1u) pass(q);
         uint32_t any_bits = 0;
 #pragma unroll
-        for (int qp = 0; qp < QT / 2; ++qp) any_bits |= cmask[qp];
+        for (int q = 0; q < QT; ++q) any_bits |= cmask[q];
         if (__any(any_bits != 0u)) {
 #pragma unroll
-            for (int qp = 0; qp < QT / 2; ++qp) {
-                uint32_t bits = cmask[qp];
-                while (bits) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const int r = b & 15;
-                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
-                    const uint32_t row = a.plane_perm[(size_t)T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
-                    if (row != 0xFFFFFFFFu && tl < task_count) {
-                        const uint32_t task = task_begin + tl;
-                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = row;
+            for (int q = 0; q < QT; ++q) {
+                uint32_t bits = cmask[q];
+                while (__any(bits != 0u)) {   // (wave-uniform: every lane takes its lowest set bit, if it has one)
+                    const bool has = bits != 0u;
+                    const int r = has ? __builtin_ctz(bits) : 0;
+                    bits &= bits - 1u;
+                    const uint32_t row = (uint32_t)__shfl((int)prm, (r & 3) + 8 * (r >> 2) + 4 * h);
+                    const uint32_t tl = 32u * q + c;
+                    const bool ok = has && row != 0xFFFFFFFFu && tl < task_count;
+                    const unsigned long long votes = __ballot(ok);
+                    if (votes != 0ull) {
+                        if (q_len + 64u > kFQueue) flush_queue();
+                        const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
+                        if (ok) queue[pos] = make_uint2(task_begin + tl, row);
+                        q_len += (uint32_t)__builtin_popcountll(votes);
                     }
                 }
             }
@@ -582,14 +582,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
         uint32_t Tn = T + 1;
         uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-        load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
-        compute_tile(Ah[0], Al[0], nrm[0], T);
+        load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], prm[1], (Tn & own) | (n_first & ~own));
+        compute_tile(Ah[0], Al[0], nrm[0], prm[0], T);
         T = Tn;
         if (T >= t_end) break;
         Tn = T + 1;
         own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-        load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
-        compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
+        load_tile(Ah[0], Al[0], nrm[0], prm[0], (Tn & own) | (n_first & ~own));
+        compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], prm[1], T);
         T = Tn;
         if (T >= t_end) break;
     }
@@ -600,6 +600,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
         }
         nrm[0] = nrm[1];
+        prm[0] = prm[1];
     }
     if (nxt == kNoItem) break;
     next_idx = uniform(next_idx);
@@ -611,6 +612,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     nxt = after;
     }   // next item
     }
+    flush_queue();
     __syncthreads();   // every wavefront has run out of items of this group
     if (wave == 0) {
         const uint32_t g1 = PickGroup(a.group_count, a.group_cursor, a.n_groups, lane, kNoItem);
