@@ -647,6 +647,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
     // work items of a pass (one wavefront each): pieces of at most seg_tiles row tiles (small stores: small pieces, so that every wavefront gets some)
     const uint32_t seg_tiles = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, C.n_tiles / 16384))));
+    GPANN_REQUIRE(((uint64_t)C.sample_tile_base + C.n_sample_tiles + 2) * kGTileRows < 0xFFFFFFFFull, "plane rows beyond 32 bits");
     // one item list per task group: group_first[g] = where it starts (capacity: every cell of the group's shard cut into pieces)
     uint64_t items_cap = 0;
     std::vector<uint32_t> group_first(G + 1);

@@ -381,6 +381,15 @@ __device__ __forceinline__ uint32_t PickGroup(const uint32_t* group_count, const
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
 }
 
+// The row tile k places after tile T in a wavefront's stream: its own item's (last tile t_last), then the next item's (tiles n_begin ..
+// n_last) — never further: past the next item (or without one) it is a tile that is in the stream already, loaded a second time.
+__device__ __forceinline__ uint32_t SuccTile(uint32_t T, uint32_t k, uint32_t t_last, bool has_next, uint32_t n_begin, uint32_t n_last) {
+    const uint32_t t = T + k;
+    if (t <= t_last) return t;
+    if (!has_next) return t_last;
+    return min(n_begin + (t - t_last - 1u), n_last);
+}
+
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
 // query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
 // tiles do not fit the register file).
@@ -408,25 +417,29 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
-    // Candidates go through a per-wavefront queue in LDS: (task, store row) pairs, written to the tasks' buckets — a returning atomic
-    // per candidate for the slot — when the queue fills up and when the workgroup leaves the task group.  (Written straight from the
-    // tile loop, every row tile with a candidate cost two dependent round trips — row id, slot — during which the wavefront had
-    // nothing else in flight: vmcnt is in-order, the waits also drained the prefetch.)
+    // Candidates go through a per-wavefront queue in LDS: (task, plane row) pairs, mapped to store rows and written to the tasks'
+    // buckets — a returning atomic per candidate for the slot — when the queue fills up and when the workgroup leaves the task group.
+    // (Written straight from the tile loop, every row tile with a candidate cost two dependent round trips — row id, slot — and
+    // vmcnt is in-order: the waits also drain the prefetch.)
     uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + kFWaves * kGTileRows * sizeof(float)) + wave * kFQueue;
     uint32_t q_len = 0;
     auto flush_queue = [&]() __attribute__((always_inline)) {
         for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
             const uint2 e = queue[i];
+            const uint32_t row = a.plane_perm[e.y];
+            if (row == 0xFFFFFFFFu) continue;   // (padding row of a cell's last tile)
             const uint32_t slot = atomicAdd(&a.cand_cnt[e.x], 1u);
-            if (slot < a.cand_cap) a.cand_row[(size_t)e.x * a.cand_cap + slot] = e.y;
+            if (slot < a.cand_cap) a.cand_row[(size_t)e.x * a.cand_cap + slot] = row;
         }
         q_len = 0;
     };
 
-    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
-    float nrm[2] = {0.f, 0.f};
-    uint32_t prm[2] = {0u, 0u};   // the store rows of the tile's 32 rows (lane c: row c)
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t& prm, uint32_t T) __attribute__((always_inline)) {
+    // NS row tiles per wavefront: the one being multiplied and the next NS - 1 of the wavefront's stream, on their way.  Three where the
+    // register file has room for them (hi plane only, d <= 128: 32 registers per tile), else two.
+    constexpr int NS = (HI_ONLY && KS <= 8) ? 3 : 2;
+    Frag Ah[NS][KS], Al[HI_ONLY ? 1 : NS][KS];   // (the lo set is never touched when HI_ONLY)
+    float nrm[NS] = {};
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -435,7 +448,6 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + a.plane_lo_offset + ks * 1024));
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
-        prm = a.plane_perm[(size_t)T * kGTileRows + c];
     };
     // an item's record as wave-uniform scalars (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended
     // up in vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued
@@ -464,39 +476,56 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         const uint32_t tl = 32u * qt + c;
         U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
     }
-    // this wavefront's first two claims on the group's list
+    // this wavefront's first three claims on the group's list
     const uint32_t g_first = a.group_first[group], g_count = a.group_count[group];
-    uint32_t idx2 = 0;
-    if (lane == 0) idx2 = atomicAdd(&a.group_cursor[group], 2u);
+    uint32_t idx3 = 0;
+    if (lane == 0) idx3 = atomicAdd(&a.group_cursor[group], 3u);
     DmaWaitAll();      // this wavefront's part of the image is in LDS
     __syncthreads();
-    idx2 = uniform(idx2);
-    uint32_t item = idx2 < g_count ? g_first + idx2 : kNoItem;
-    uint32_t nxt = idx2 + 1u < g_count ? g_first + idx2 + 1u : kNoItem;
-    bool dry = nxt == kNoItem;   // a claim on this list has come back empty: no further ones
-    if (item != kNoItem) {
-    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_acts;
+    idx3 = uniform(idx3);
+    uint32_t cur = idx3 < g_count ? g_first + idx3 : kNoItem;
+    uint32_t nxt = idx3 + 1u < g_count ? g_first + idx3 + 1u : kNoItem;
+    uint32_t aft = idx3 + 2u < g_count ? g_first + idx3 + 2u : kNoItem;
+    bool dry = aft == kNoItem;   // a claim on this list has come back empty: no further ones
+    if (cur != kNoItem) {
+    // The items in hand: `cur` (being streamed: t_begin .. t_last, T the tile being multiplied), `nxt` (n_*: record in scalar registers —
+    // the prefetch runs into it), `aft` (its record is on its way, p_*) and the claim after that (p_claim, in flight).
+    uint32_t t_begin, t_last, t_a, t_b, acts;
+    uint32_t n_begin = 0, n_last = 0, n_t_a = 0, n_t_b = 0, n_acts = 0;
     {
-        const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
-        r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
-        r_acts = uniform(hi.z);
+        const uint4 lo = reinterpret_cast<const uint4*>(a.items + cur)[0];
+        const uint32_t ac = a.items[cur].acts;
+        t_begin = uniform(lo.x); t_last = uniform(lo.y) - 1u; t_a = uniform(lo.z); t_b = uniform(lo.w);
+        acts = uniform(ac);
     }
-    load_tile(Ah[0], Al[0], nrm[0], prm[0], r_t_begin);
-    for (;;) {   // this wavefront's items
-    // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
-    const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
-    const uint32_t acts = r_acts;
-    const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
-    uint32_t next_idx = 0;
-    if (lane == 0 && !dry) next_idx = atomicAdd(&a.group_cursor[group], 1u);
-    const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
-    const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
+    if (nxt != kNoItem) {
+        const uint4 lo = reinterpret_cast<const uint4*>(a.items + nxt)[0];
+        const uint32_t ac = a.items[nxt].acts;
+        n_begin = uniform(lo.x); n_last = uniform(lo.y) - 1u; n_t_a = uniform(lo.z); n_t_b = uniform(lo.w);
+        n_acts = uniform(ac);
+    }
+    uint32_t T = t_begin;
+    load_tile(Ah[0], Al[0], nrm[0], T);
+    if (NS == 3) load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], SuccTile(T, 1u, t_last, nxt != kNoItem, n_begin, n_last));
+    uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t p_acts = 0, p_claim = 0;
+    // the record of `aft` and the claim after it: requested a whole item before they are looked at (vmcnt is in-order: by then they
+    // are older than every tile load in flight, and waiting for them waits for nothing else)
+    auto request = [&]() __attribute__((always_inline)) {
+        if (aft != kNoItem) {
+            p_lo = reinterpret_cast<const uint4*>(a.items + aft)[0];
+            p_acts = a.items[aft].acts;
+        }
+        if (lane == 0 && !dry) p_claim = atomicAdd(&a.group_cursor[group], 1u);
+    };
+    request();
 
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t prm, uint32_t T) __attribute__((always_inline)) {
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
         // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
         // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
         // a flat one.)
+        const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
         const uint32_t in_head = T < t_a ? 0xFFu : 0u, in_sample = T < t_b ? 0xFFu & ~in_head : 0u;
         const uint32_t act = (act_head & in_head) | (act_sample & in_sample) | (mask & ~(in_head | in_sample));
         if (act == 0) return;
@@ -553,14 +582,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
                     const bool has = bits != 0u;
                     const int r = has ? __builtin_ctz(bits) : 0;
                     bits &= bits - 1u;
-                    const uint32_t row = (uint32_t)__shfl((int)prm, (r & 3) + 8 * (r >> 2) + 4 * h);
+                    const uint32_t prow = T * kGTileRows + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);   // (plane rows fit 32 bits: the tile index does)
                     const uint32_t tl = 32u * q + c;
-                    const bool ok = has && row != 0xFFFFFFFFu && tl < task_count;
+                    const bool ok = has && tl < task_count;
                     const unsigned long long votes = __ballot(ok);
                     if (votes != 0ull) {
                         if (q_len + 64u > kFQueue) flush_queue();
                         const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
-                        if (ok) queue[pos] = make_uint2(task_begin + tl, row);
+                        if (ok) queue[pos] = make_uint2(task_begin + tl, prow);
                         q_len += (uint32_t)__builtin_popcountll(votes);
                     }
                 }
@@ -568,49 +597,55 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
     };
 
-    // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
-    // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it fetches the first tile of the
-    // next item (or, after the last item, re-reads the last tile) — because a load under a branch leaves the compiler unable to count
-    // the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use of the current tile: no
-    // overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for
-    // the hi-only passes was measured slower: spills.)
-    const uint32_t n_t_begin = uniform(n_lo.x);
-    const uint32_t t_last = t_end - 1;
-    const uint32_t n_first = nxt != kNoItem ? n_t_begin : t_last;   // the first tile of the next item
-    uint32_t T = t_begin;
-    const uint32_t steps = t_end - t_begin;
-    for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
-        uint32_t Tn = T + 1;
-        uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-        load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], prm[1], (Tn & own) | (n_first & ~own));
-        compute_tile(Ah[0], Al[0], nrm[0], prm[0], T);
-        T = Tn;
-        if (T >= t_end) break;
-        Tn = T + 1;
-        own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-        load_tile(Ah[0], Al[0], nrm[0], prm[0], (Tn & own) | (n_first & ~own));
-        compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], prm[1], T);
-        T = Tn;
-        if (T >= t_end) break;
-    }
-    if (steps & 1u) {   // the next item's first tile went to buffer 1
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            Ah[0][ks].v = Ah[1][ks].v;
-            if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
+    // Row tiles stream through registers, TWO tiles ahead of the products: with one 512-thread workgroup per CU it is the bytes in
+    // flight per wavefront, not occupancy, that cover the HBM latency, and one tile (8 KiB) per wavefront was not enough — 16 MiB in
+    // flight on the whole chip, 2.7 us of loaded latency: 6.2 TB/s whatever else the kernel did.  The stream does not stop at the end of
+    // an item: the prefetch runs on into the next item's tiles (SuccTile).
+    // The prefetch is UNCONDITIONAL — without a next item it re-reads the last tile — because a load under a branch leaves the
+    // compiler unable to count the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use
+    // of the current tile: no overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).
+    // One step: slot s0 holds tile T, s1 its successor; the tile two places on goes to s2.  Returns false after the last tile of the
+    // wavefront's last item.
+    auto step = [&](const Frag (&A0h)[KS], const Frag (&A0l)[KS], float nrm0,
+                    Frag (&A1h)[KS], Frag (&A1l)[KS], float& nrm1,
+                    Frag (&A2h)[KS], Frag (&A2l)[KS], float& nrm2) __attribute__((always_inline)) {
+        load_tile(A2h, A2l, nrm2, SuccTile(T, (uint32_t)(NS - 1), t_last, nxt != kNoItem, n_begin, n_last));
+        compute_tile(A0h, A0l, nrm0, T);
+        if (T != t_last) {
+            ++T;
+            return true;
         }
-        nrm[0] = nrm[1];
-        prm[0] = prm[1];
+        if (nxt == kNoItem) return false;
+        // ---- on to the next item
+        const bool one_tile = t_begin == t_last;
+        t_begin = n_begin; t_last = n_last; t_a = n_t_a; t_b = n_t_b; acts = n_acts;
+        T = t_begin;
+        cur = nxt;
+        nxt = aft;
+        if (nxt != kNoItem) {
+            n_begin = uniform(p_lo.x); n_last = uniform(p_lo.y) - 1u; n_t_a = uniform(p_lo.z); n_t_b = uniform(p_lo.w);
+            n_acts = uniform(p_acts);
+        }
+        const uint32_t claimed = uniform(p_claim);
+        aft = (!dry && claimed < g_count) ? g_first + claimed : kNoItem;
+        dry = aft == kNoItem;
+        request();
+        // an item of a single tile cannot aim the prefetch of its predecessor's last step past itself (that would be an item further on
+        // than the records in hand): its successor's first tile has not been requested yet
+        if (NS == 3 && one_tile) load_tile(A1h, A1l, nrm1, T);
+        return true;
+    };
+    constexpr int L1 = HI_ONLY ? 0 : 1, S2 = NS - 1;   // (slot 2 exists only when NS == 3: HI_ONLY)
+    for (;;) {
+        if (NS == 3) {
+            if (!step(Ah[0], Al[0], nrm[0], Ah[1], Al[0], nrm[1], Ah[S2], Al[0], nrm[S2])) break;
+            if (!step(Ah[1], Al[0], nrm[1], Ah[S2], Al[0], nrm[S2], Ah[0], Al[0], nrm[0])) break;
+            if (!step(Ah[S2], Al[0], nrm[S2], Ah[0], Al[0], nrm[0], Ah[1], Al[0], nrm[1])) break;
+        } else {   // two slots: the "next" slot is the one being loaded
+            if (!step(Ah[0], Al[0], nrm[0], Ah[1], Al[L1], nrm[1], Ah[1], Al[L1], nrm[1])) break;
+            if (!step(Ah[1], Al[L1], nrm[1], Ah[0], Al[0], nrm[0], Ah[0], Al[0], nrm[0])) break;
+        }
     }
-    if (nxt == kNoItem) break;
-    next_idx = uniform(next_idx);
-    const uint32_t after = (!dry && next_idx < g_count) ? g_first + next_idx : kNoItem;
-    dry = after == kNoItem;
-    r_t_begin = n_t_begin; r_t_end = uniform(n_lo.y); r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
-    r_acts = uniform(n_hi.z);
-    item = nxt;
-    nxt = after;
-    }   // next item
     }
     flush_queue();
     __syncthreads();   // every wavefront has run out of items of this group
