@@ -645,9 +645,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
     uint32_t* d_task_group = d_nearest + T;
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
-    // work items of a pass (one wavefront each): pieces of at most seg_tiles row tiles (small stores: small pieces, so that every wavefront gets some)
-    const uint32_t seg_tiles = std::max<uint32_t>(1, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, C.n_tiles / 16384))));
-    GPANN_REQUIRE(((uint64_t)C.sample_tile_base + C.n_sample_tiles + 2) * kGTileRows < 0xFFFFFFFFull, "plane rows beyond 32 bits");
+    // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
+    const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
     // one item list per task group: group_first[g] = where it starts (capacity: every cell of the group's shard cut into pieces)
     uint64_t items_cap = 0;
     std::vector<uint32_t> group_first(G + 1);
@@ -860,7 +859,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere.  Beyond 128 dimensions every pass is a hi-plane pass.
     const bool hi_last = ks16 || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
     const int hi_from_pass = ks16 ? 0 : (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
-    const size_t glds = FilterLdsBytes((size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048);
+    const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
@@ -888,7 +887,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     //      (Run inside the head pass's launch instead — the tiles share the arrays — it saved no kernel time and let 18 % more
     //      candidates through: the head pass then works with the looser seed threshold.)
     if (seed_rows != 0 && C.n_sample_tiles != 0) {
-        const uint32_t piece = EnvU32("GPANN_FILTER_SAMPLE_PIECE", 4);   // row tiles per work item
+        const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
         std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of this pass's lists
         for (uint32_t g = 0; g < G; ++g) {

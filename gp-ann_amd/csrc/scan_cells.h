@@ -279,13 +279,8 @@ struct CellFilterArgs {
     const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel)
 };
 
-// wavefronts per workgroup of FilterKernelCells (one workgroup per CU): each of them streams the row tiles of its own work items
+// wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
 constexpr int kFWaves = 8;
-// candidates a wavefront of FilterKernelCells collects in LDS before it writes them to the tasks' buckets (what is left of the 160 KiB
-// next to a 128 KiB query image and the norms)
-constexpr uint32_t kFQueue = 448;
-// dynamic LDS of FilterKernelCells
-constexpr size_t FilterLdsBytes(size_t image_bytes) { return image_bytes + kFWaves * kGTileRows * sizeof(float) + (size_t)kFWaves * kFQueue * 8; }
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
@@ -312,8 +307,9 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     if (t_first >= t_pass_end) return;
     const int64_t range = t_pass_end - t_first;
     const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
-    // equal pieces (n = ceil(range / seg_tiles) and per <= seg_tiles: none of them is empty)
-    const int64_t per = (range + n - 1) / n;
+    // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
+    // the end of the item for a full memory latency)
+    const int64_t per = ((range + n - 1) / n + kFWaves - 1) / kFWaves * kFWaves;
     const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
     CellItem it;
     it.t_a = (uint32_t)t_a;
@@ -356,38 +352,43 @@ __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)"
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 
-// Wavefront 0 of a workgroup (all 64 lanes) picks the task group the workgroup turns to next: `prefer` if it has unclaimed work
-// items, else the group with the most of them; kNoItem once every list is exhausted.
-__device__ __forceinline__ uint32_t PickGroup(const uint32_t* group_count, const uint32_t* group_cursor, uint32_t n_groups, int lane, uint32_t prefer) {
-    uint32_t best = 0, best_g = kNoItem;
-    for (uint32_t i = (uint32_t)lane; i < n_groups; i += 64) {
-        const uint32_t cnt = group_count[i];
-        const uint32_t cur = __hip_atomic_load(&group_cursor[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t rem = cur < cnt ? cnt - cur : 0u;
-        if (rem != 0u && i == prefer) rem = 0xFFFFFFFFu;
-        if (rem > best) {
-            best = rem;
-            best_g = i;
+// Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
+// Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
+// Every failed claim coincides with a group running dry, so the loop ends after at most n_groups rounds.
+__device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, const uint32_t* group_count, uint32_t* group_cursor, uint32_t n_groups,
+                                                   int lane, uint32_t& g, uint32_t& first, uint32_t& count) {
+    for (;;) {
+        uint32_t best = 0, best_g = kNoItem;
+        for (uint32_t i = (uint32_t)lane; i < n_groups; i += 64) {
+            const uint32_t cnt = group_count[i];
+            const uint32_t cur = __hip_atomic_load(&group_cursor[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t rem = cur < cnt ? cnt - cur : 0u;
+            if (rem > best) {
+                best = rem;
+                best_g = i;
+            }
         }
-    }
 #pragma unroll
-    for (int off = 32; off; off >>= 1) {
-        const uint32_t ob = (uint32_t)__shfl_xor((int)best, off), og = (uint32_t)__shfl_xor((int)best_g, off);
-        if (ob > best || (ob == best && og < best_g)) {
-            best = ob;
-            best_g = og;
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t ob = (uint32_t)__shfl_xor((int)best, off), og = (uint32_t)__shfl_xor((int)best_g, off);
+            if (ob > best || (ob == best && og < best_g)) {
+                best = ob;
+                best_g = og;
+            }
+        }
+        best_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
+        if (best_g == kNoItem) return kNoItem;
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&group_cursor[best_g], 1u);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        const uint32_t cnt = group_count[best_g];
+        if (idx < cnt) {
+            g = best_g;
+            first = group_first[best_g];
+            count = cnt;
+            return first + idx;
         }
     }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)best_g);
-}
-
-// The row tile k places after tile T in a wavefront's stream: its own item's (last tile t_last), then the next item's (tiles n_begin ..
-// n_last) — never further: past the next item (or without one) it is a tile that is in the stream already, loaded a second time.
-__device__ __forceinline__ uint32_t SuccTile(uint32_t T, uint32_t k, uint32_t t_last, bool has_next, uint32_t n_begin, uint32_t n_last) {
-    const uint32_t t = T + k;
-    if (t <= t_last) return t;
-    if (!has_next) return t_last;
-    return min(n_begin + (t - t_last - 1u), n_last);
 }
 
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
@@ -401,44 +402,29 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
-    // Persistent workgroups, one per CU.  A workgroup works on ONE task group at a time — the group's query image (up to 128 KiB) sits
-    // in LDS — and each of its WAVEFRONTS claims work items (pieces of at most seg_tiles row tiles) from that group's list on its own:
-    //  * no barrier and no drained load queue between two items (a workgroup-wide item cost a barrier per item — the wavefronts'
-    //    progress differs by microseconds — plus a wait for the claim with nothing else in flight: about 9 us per item, a fifth of
-    //    the rest pass);
-    //  * claims run two ahead: while item i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2
-    //    is in flight, and the prefetch that would run past the end of item i fetches the first row tile of item i + 1 instead;
-    //  * the image is copied when the workgroup changes its group — when the group's list runs dry it moves to the group with the
-    //    most unclaimed items (PickGroup) — a few times per launch.
-    __shared__ uint32_t s_group;
+    // Persistent workgroups, one per CU, claim work items from the task groups' lists.  Two things keep the time between two items short:
+    //  * claims run TWO ahead: while item i streams, the record of item i + 1 is already in scalar registers and the claim for i + 2
+    //    is in flight, and the prefetch that would run past the end of item i fetches the first row tile of item i + 1 instead
+    //    (claim -> record -> first tile were three dependent memory latencies with nothing in flight);
+    //  * a workgroup stays with ONE task group while that group has unclaimed items: its query image (up to 128 KiB, which at the
+    //    workgroup's share of the memory system took about as long to copy as the three latencies together) is copied when the group
+    //    changes — a few times per launch instead of once per item — and consecutive items of a group need no barrier between them
+    //    but the one that hands the next claim to the other wavefronts.  A workgroup whose group runs dry moves to the group with the
+    //    most unclaimed items (ClaimElsewhere).
+    // (Claims of two consecutive entries, streamed as one range when they are pieces of one block, measured 3 % SLOWER on the rest
+    // pass: 4.21 against 4.08 ms.)
+    __shared__ uint32_t s_claim[4];
     uint32_t my_products = 0, my_tiles = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
+    const uint32_t ld = a.ld;
+    (void)ld;
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
-    // Candidates go through a per-wavefront queue in LDS: (task, plane row) pairs, mapped to store rows and written to the tasks'
-    // buckets — a returning atomic per candidate for the slot — when the queue fills up and when the workgroup leaves the task group.
-    // (Written straight from the tile loop, every row tile with a candidate cost two dependent round trips — row id, slot — and
-    // vmcnt is in-order: the waits also drain the prefetch.)
-    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + kFWaves * kGTileRows * sizeof(float)) + wave * kFQueue;
-    uint32_t q_len = 0;
-    auto flush_queue = [&]() __attribute__((always_inline)) {
-        for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
-            const uint2 e = queue[i];
-            const uint32_t row = a.plane_perm[e.y];
-            if (row == 0xFFFFFFFFu) continue;   // (padding row of a cell's last tile)
-            const uint32_t slot = atomicAdd(&a.cand_cnt[e.x], 1u);
-            if (slot < a.cand_cap) a.cand_row[(size_t)e.x * a.cand_cap + slot] = row;
-        }
-        q_len = 0;
-    };
 
-    // NS row tiles per wavefront: the one being multiplied and the next NS - 1 of the wavefront's stream, on their way.  Three where the
-    // register file has room for them (hi plane only, d <= 128: 32 registers per tile), else two.
-    constexpr int NS = (HI_ONLY && KS <= 8) ? 3 : 2;
-    Frag Ah[NS][KS], Al[HI_ONLY ? 1 : NS][KS];   // (the lo set is never touched when HI_ONLY)
-    float nrm[NS] = {};
+    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
+    float nrm[2] = {0.f, 0.f};
     auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
 #pragma unroll
@@ -454,78 +440,58 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // before it)
     auto uniform = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-    if (wave == 0) {
-        const uint32_t g0 = PickGroup(a.group_count, a.group_cursor, a.n_groups, lane, (uint32_t)((uint64_t)blockIdx.x * a.n_groups / gridDim.x));
-        if (lane == 0) s_group = g0;
-    }
-    for (;;) {   // the task groups this workgroup works on
-    __syncthreads();   // s_group is written; everyone is done with the previous group's query image
-    const uint32_t group = uniform(s_group);
-    if (group == kNoItem) break;
-    const uint32_t task_begin = a.groups[group].task_begin, task_count = a.groups[group].task_count;
-    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image
-    if ((uint32_t)wave * 32u < task_count && wave < QT) {
-        const char* src = a.image + ((size_t)group * QT + wave) * KS * 2048 + lane * 16;
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
-#pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
-    }
-    float U[QT];   // thresholds of this lane's task in each query tile (a query tile outside an item's mask is never multiplied)
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const uint32_t tl = 32u * qt + c;
-        U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
-    }
-    // this wavefront's first three claims on the group's list
-    const uint32_t g_first = a.group_first[group], g_count = a.group_count[group];
-    uint32_t idx3 = 0;
-    if (lane == 0) idx3 = atomicAdd(&a.group_cursor[group], 3u);
-    DmaWaitAll();      // this wavefront's part of the image is in LDS
-    __syncthreads();
-    idx3 = uniform(idx3);
-    uint32_t cur = idx3 < g_count ? g_first + idx3 : kNoItem;
-    uint32_t nxt = idx3 + 1u < g_count ? g_first + idx3 + 1u : kNoItem;
-    uint32_t aft = idx3 + 2u < g_count ? g_first + idx3 + 2u : kNoItem;
-    bool dry = aft == kNoItem;   // a claim on this list has come back empty: no further ones
-    if (cur != kNoItem) {
-    // The items in hand: `cur` (being streamed: t_begin .. t_last, T the tile being multiplied), `nxt` (n_*: record in scalar registers —
-    // the prefetch runs into it), `aft` (its record is on its way, p_*) and the claim after that (p_claim, in flight).
-    uint32_t t_begin, t_last, t_a, t_b, acts;
-    uint32_t n_begin = 0, n_last = 0, n_t_a = 0, n_t_b = 0, n_acts = 0;
-    {
-        const uint4 lo = reinterpret_cast<const uint4*>(a.items + cur)[0];
-        const uint32_t ac = a.items[cur].acts;
-        t_begin = uniform(lo.x); t_last = uniform(lo.y) - 1u; t_a = uniform(lo.z); t_b = uniform(lo.w);
-        acts = uniform(ac);
-    }
-    if (nxt != kNoItem) {
-        const uint4 lo = reinterpret_cast<const uint4*>(a.items + nxt)[0];
-        const uint32_t ac = a.items[nxt].acts;
-        n_begin = uniform(lo.x); n_last = uniform(lo.y) - 1u; n_t_a = uniform(lo.z); n_t_b = uniform(lo.w);
-        n_acts = uniform(ac);
-    }
-    uint32_t T = t_begin;
-    load_tile(Ah[0], Al[0], nrm[0], T);
-    if (NS == 3) load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], SuccTile(T, 1u, t_last, nxt != kNoItem, n_begin, n_last));
-    uint4 p_lo = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t p_acts = 0, p_claim = 0;
-    // the record of `aft` and the claim after it: requested a whole item before they are looked at (vmcnt is in-order: by then they
-    // are older than every tile load in flight, and waiting for them waits for nothing else)
-    auto request = [&]() __attribute__((always_inline)) {
-        if (aft != kNoItem) {
-            p_lo = reinterpret_cast<const uint4*>(a.items + aft)[0];
-            p_acts = a.items[aft].acts;
-        }
-        if (lane == 0 && !dry) p_claim = atomicAdd(&a.group_cursor[group], 1u);
+    // claim state: meaningful in wavefront 0 only (wave-uniform there)
+    uint32_t c_g = 0, c_first = 0, c_count = 0;
+    bool drained = false;
+    // wavefront 0: the item behind cursor value idx of group c_g, or a claim on another group
+    auto claim_for = [&](uint32_t idx) __attribute__((always_inline)) {
+        if (idx < c_count) return c_first + idx;
+        if (drained) return kNoItem;
+        const uint32_t got = ClaimElsewhere(a.group_first, a.group_count, a.group_cursor, a.n_groups, lane, c_g, c_first, c_count);
+        drained = got == kNoItem;
+        return got;
     };
-    request();
+    if (wave == 0) {
+        c_g = (uint32_t)((uint64_t)blockIdx.x * a.n_groups / gridDim.x);
+        c_first = a.group_first[c_g];
+        c_count = a.group_count[c_g];
+        for (int j = 0; j < 2; ++j) {
+            uint32_t idx = 0;
+            if (lane == 0 && !drained) idx = atomicAdd(&a.group_cursor[c_g], 1u);
+            const uint32_t got = claim_for(uniform(idx));
+            if (lane == 0) s_claim[j] = got;
+        }
+    }
+    __syncthreads();
+    uint32_t item = uniform(s_claim[0]), nxt = uniform(s_claim[1]);
+    if (item == kNoItem) return;
+    uint32_t loaded_group = kNoItem, loaded = 0;   // the query image in LDS: whose, and which of its query tiles
+    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image)
+    uint32_t iter = 0;
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_task_count, r_acts, r_group;
+    {
+        const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
+        r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
+        r_task_begin = uniform(hi.x); r_task_count = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+    }
+    load_tile(Ah[0], Al[0], nrm[0], min(r_t_begin + wave, r_t_end - 1));
+    for (;;) {
+    // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
+    const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
+    const uint32_t task_begin = r_task_begin, task_count = r_task_count;
+    const uint32_t acts = r_acts;
+    const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
+    uint32_t next_idx = 0;
+    if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
+    const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
+    const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
+
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
         // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
         // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
         // a flat one.)
-        const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
         const uint32_t in_head = T < t_a ? 0xFFu : 0u, in_sample = T < t_b ? 0xFFu & ~in_head : 0u;
         const uint32_t act = (act_head & in_head) | (act_sample & in_sample) | (mask & ~(in_head | in_sample));
         if (act == 0) return;
@@ -535,125 +501,163 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
         my_products += (uint32_t)__builtin_popcount(act);
         my_tiles += 1;
-        uint32_t cmask[QT];   // bit r of cmask[q]: accumulator register r of query tile q passed
+        uint32_t cmask[QT / 2];   // bit r (+16 for the odd query tile) of cmask[qp]: accumulator register r passed
 #pragma unroll
-        for (int q = 0; q < QT; ++q) cmask[q] = 0u;
-        // one pass of the k-loop per query tile: one accumulator chain (the matrix cores accumulate back to back on the same registers;
-        // two interleaved chains — pairs of query tiles — bought nothing but 16 + 8 more live registers)
-        auto pass = [&](int q) __attribute__((always_inline)) {
-            f32x16 acc;
+        for (int qp = 0; qp < QT / 2; ++qp) cmask[qp] = 0u;
+        // one pass of the k-loop: query tiles q0 and (PAIR) q0 + 1, two independent accumulator chains
+        auto pass = [&](auto pair_tag, int q0, int qp, int shift) __attribute__((always_inline)) {
+            constexpr bool PAIR = decltype(pair_tag)::value;
+            f32x16 acc0, acc1;
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc[4 * gg + 0] = n.x; acc[4 * gg + 1] = n.y; acc[4 * gg + 2] = n.z; acc[4 * gg + 3] = n.w;
+                acc0[4 * gg + 0] = n.x; acc0[4 * gg + 1] = n.y; acc0[4 * gg + 2] = n.z; acc0[4 * gg + 3] = n.w;
+                if (PAIR) {
+                    acc1[4 * gg + 0] = n.x; acc1[4 * gg + 1] = n.y; acc1[4 * gg + 2] = n.z; acc1[4 * gg + 3] = n.w;
+                }
             }
-            const char* p = lane_lds + (q * KS) * 2048;
+            const char* p0 = lane_lds + (q0 * KS) * 2048;
+            const char* p1 = lane_lds + ((q0 + 1) * KS) * 2048;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                Frag bh, bl;
-                bh.q = *reinterpret_cast<const uint4*>(p + ks * 2048);
-                bl.q = *reinterpret_cast<const uint4*>(p + ks * 2048 + 1024);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh.v, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl.v, acc, 0, 0, 0);
-                if (!HI_ONLY) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh.v, acc, 0, 0, 0);
+                Frag bh0, bl0, bh1, bl1;
+                bh0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048);
+                bl0.q = *reinterpret_cast<const uint4*>(p0 + ks * 2048 + 1024);
+                if (PAIR) {
+                    bh1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048);
+                    bl1.q = *reinterpret_cast<const uint4*>(p1 + ks * 2048 + 1024);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bh1.v, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl0.v, acc0, 0, 0, 0);
+                if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ks].v, bl1.v, acc1, 0, 0, 0);
+                if (!HI_ONLY) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh0.v, acc0, 0, 0, 0);
+                    if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ks].v, bh1.v, acc1, 0, 0, 0);
+                }
             }
-            const float u = U[q];
-            float m = acc[0];
+            const float u0 = (q0 & 1) ? U[2 * qp + 1] : U[2 * qp];
+            const float u1 = U[2 * qp + 1];
+            float m0 = acc0[0], m1 = PAIR ? acc1[0] : -INFINITY;
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            if (__any(m >= u)) {
+            for (int r = 1; r < 16; ++r) {
+                m0 = fmaxf(m0, acc0[r]);
+                if (PAIR) m1 = fmaxf(m1, acc1[r]);
+            }
+            if (__any(m0 >= u0 || (PAIR && m1 >= u1))) {
                 uint32_t bits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bits |= acc[r] >= u ? 1u << r : 0u;
-                cmask[q] = bits;
+                for (int r = 0; r < 16; ++r) {
+                    bits |= acc0[r] >= u0 ? 1u << (r + shift) : 0u;
+                    if (PAIR) bits |= acc1[r] >= u1 ? 0x10000u << r : 0u;
+                }
+                cmask[qp] = bits;
             }
         };
 #pragma unroll
-        for (int q = 0; q < QT; ++q)
-            if (act >> q & 1u) pass(q);
+        for (int qp = 0; qp < QT / 2; ++qp) {
+            const uint32_t two = act >> (2 * qp) & 3u;
+            if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
+            else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
+            else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
+        }
         uint32_t any_bits = 0;
 #pragma unroll
-        for (int q = 0; q < QT; ++q) any_bits |= cmask[q];
+        for (int qp = 0; qp < QT / 2; ++qp) any_bits |= cmask[qp];
         if (__any(any_bits != 0u)) {
 #pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                uint32_t bits = cmask[q];
-                while (__any(bits != 0u)) {   // (wave-uniform: every lane takes its lowest set bit, if it has one)
-                    const bool has = bits != 0u;
-                    const int r = has ? __builtin_ctz(bits) : 0;
-                    bits &= bits - 1u;
-                    const uint32_t prow = T * kGTileRows + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);   // (plane rows fit 32 bits: the tile index does)
-                    const uint32_t tl = 32u * q + c;
-                    const bool ok = has && tl < task_count;
-                    const unsigned long long votes = __ballot(ok);
-                    if (votes != 0ull) {
-                        if (q_len + 64u > kFQueue) flush_queue();
-                        const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
-                        if (ok) queue[pos] = make_uint2(task_begin + tl, prow);
-                        q_len += (uint32_t)__builtin_popcountll(votes);
+            for (int qp = 0; qp < QT / 2; ++qp) {
+                uint32_t bits = cmask[qp];
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const int r = b & 15;
+                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
+                    const uint32_t row = a.plane_perm[(size_t)T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    if (row != 0xFFFFFFFFu && tl < task_count) {
+                        const uint32_t task = task_begin + tl;
+                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
+                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = row;
                     }
                 }
             }
         }
     };
 
-    // Row tiles stream through registers, TWO tiles ahead of the products: with one 512-thread workgroup per CU it is the bytes in
-    // flight per wavefront, not occupancy, that cover the HBM latency, and one tile (8 KiB) per wavefront was not enough — 16 MiB in
-    // flight on the whole chip, 2.7 us of loaded latency: 6.2 TB/s whatever else the kernel did.  The stream does not stop at the end of
-    // an item: the prefetch runs on into the next item's tiles (SuccTile).
-    // The prefetch is UNCONDITIONAL — without a next item it re-reads the last tile — because a load under a branch leaves the
-    // compiler unable to count the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use
-    // of the current tile: no overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).
-    // One step: slot s0 holds tile T, s1 its successor; the tile two places on goes to s2.  Returns false after the last tile of the
-    // wavefront's last item.
-    auto step = [&](const Frag (&A0h)[KS], const Frag (&A0l)[KS], float nrm0,
-                    Frag (&A1h)[KS], Frag (&A1l)[KS], float& nrm1,
-                    Frag (&A2h)[KS], Frag (&A2l)[KS], float& nrm2) __attribute__((always_inline)) {
-        load_tile(A2h, A2l, nrm2, SuccTile(T, (uint32_t)(NS - 1), t_last, nxt != kNoItem, n_begin, n_last));
-        compute_tile(A0h, A0l, nrm0, T);
-        if (T != t_last) {
-            ++T;
-            return true;
-        }
-        if (nxt == kNoItem) return false;
-        // ---- on to the next item
-        const bool one_tile = t_begin == t_last;
-        t_begin = n_begin; t_last = n_last; t_a = n_t_a; t_b = n_t_b; acts = n_acts;
-        T = t_begin;
-        cur = nxt;
-        nxt = aft;
-        if (nxt != kNoItem) {
-            n_begin = uniform(p_lo.x); n_last = uniform(p_lo.y) - 1u; n_t_a = uniform(p_lo.z); n_t_b = uniform(p_lo.w);
-            n_acts = uniform(p_acts);
-        }
-        const uint32_t claimed = uniform(p_claim);
-        aft = (!dry && claimed < g_count) ? g_first + claimed : kNoItem;
-        dry = aft == kNoItem;
-        request();
-        // an item of a single tile cannot aim the prefetch of its predecessor's last step past itself (that would be an item further on
-        // than the records in hand): its successor's first tile has not been requested yet
-        if (NS == 3 && one_tile) load_tile(A1h, A1l, nrm1, T);
-        return true;
-    };
-    constexpr int L1 = HI_ONLY ? 0 : 1, S2 = NS - 1;   // (slot 2 exists only when NS == 3: HI_ONLY)
-    for (;;) {
-        if (NS == 3) {
-            if (!step(Ah[0], Al[0], nrm[0], Ah[1], Al[0], nrm[1], Ah[S2], Al[0], nrm[S2])) break;
-            if (!step(Ah[1], Al[0], nrm[1], Ah[S2], Al[0], nrm[S2], Ah[0], Al[0], nrm[0])) break;
-            if (!step(Ah[S2], Al[0], nrm[S2], Ah[0], Al[0], nrm[0], Ah[1], Al[0], nrm[1])) break;
-        } else {   // two slots: the "next" slot is the one being loaded
-            if (!step(Ah[0], Al[0], nrm[0], Ah[1], Al[L1], nrm[1], Ah[1], Al[L1], nrm[1])) break;
-            if (!step(Ah[1], Al[L1], nrm[1], Ah[0], Al[0], nrm[0], Ah[0], Al[0], nrm[0])) break;
+    // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
+    // is what covers the HBM latency).  The prefetch is UNCONDITIONAL — past the end of the range it fetches the first tile of the
+    // next item (or, after the last item, re-reads the last tile) — because a load under a branch leaves the compiler unable to count
+    // the loads in flight at the join, and it then drains them all (s_waitcnt vmcnt(0)) before the first use of the current tile: no
+    // overlap at all (measured on the rest pass of the NS workload: 5.33 ms with the branch, 4.86 ms without).  (A third buffer for
+    // the hi-only passes was measured slower: spills.)
+    // ---- the query image: wavefront w copies query tile w of the group's prebuilt image if this item uses it and it is not there yet
+    //      (a new group's image replaces the old one: the barrier at the end of the previous item made sure nobody reads that any more;
+    //      further tiles of the SAME group go to slots nobody reads yet)
+    const bool same_group = r_group == loaded_group;
+    const uint32_t fetch = same_group ? mask & ~loaded : mask;
+    if (fetch >> wave & 1u) {
+        const char* src = a.image + ((size_t)r_group * QT + wave) * KS * 2048 + lane * 16;
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * KS * 2048));
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) DmaToLds16(src + i * 1024, dst + i * 1024);
+    }
+    if (!same_group) {   // (a query tile outside the item's mask is never multiplied: its thresholds need no masking)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const uint32_t tl = 32u * qt + c;
+            U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
         }
     }
-    }
-    flush_queue();
-    __syncthreads();   // every wavefront has run out of items of this group
+    loaded = same_group ? loaded | mask : mask;
+    loaded_group = r_group;
+    DmaWaitAll();      // this wavefront's part of the image is in LDS (so are its first tile, the next record and the claim)
     if (wave == 0) {
-        const uint32_t g1 = PickGroup(a.group_count, a.group_cursor, a.n_groups, lane, kNoItem);
-        if (lane == 0) s_group = g1;
+        const uint32_t got = claim_for(uniform(next_idx));
+        if (lane == 0) s_claim[2 + (iter & 1u)] = got;
     }
-    }   // next group
+    __syncthreads();
+    const uint32_t after = uniform(s_claim[2 + (iter & 1u)]);
+    ++iter;
+    const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
+    const uint32_t t_last = t_end - 1;
+    // this wavefront's first tile of the next item
+    const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave, n_t_end - 1) : t_last;
+    uint32_t T = t_begin + wave;
+    if (T < t_end) {
+        const uint32_t steps = (t_end - T + kFWaves - 1) / kFWaves;
+        for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
+            uint32_t Tn = T + kFWaves;
+            uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
+            compute_tile(Ah[0], Al[0], nrm[0], T);
+            T = Tn;
+            if (T >= t_end) break;
+            Tn = T + kFWaves;
+            own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
+            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
+            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
+            T = Tn;
+            if (T >= t_end) break;
+        }
+        if (steps & 1u) {   // the next item's first tile went to buffer 1
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Ah[0][ks].v = Ah[1][ks].v;
+                if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
+            }
+            nrm[0] = nrm[1];
+        }
+    } else {
+        load_tile(Ah[0], Al[0], nrm[0], n_first);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
+    }
+    if (nxt == kNoItem) break;
+    const uint32_t n_group = uniform(n_hi.w);
+    if (n_group != r_group) __syncthreads();   // the next item replaces the query image: everyone has to be done with this one
+    r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
+    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
+    item = nxt;
+    nxt = after;
+    }   // next item
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
         atomicAdd(&a.work[1], (unsigned long long)my_tiles);
