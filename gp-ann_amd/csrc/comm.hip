@@ -307,7 +307,7 @@ gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out) {
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), device = env_int("LOCAL_RANK", 0);
     const char* addr = std::getenv("MASTER_ADDR");
     const int port = env_int("GPANN_COMM_PORT", env_int("MASTER_PORT", 29500) + 1);
-    return gpann_comm_init(rank, world, addr && *addr ? addr : "127.0.0.1", port, backend, device, env_int("GPANN_COMM_TIMEOUT", 120), out);
+    return gpann_comm_init(rank, world, addr && *addr ? addr : "127.0.0.1", port, backend, device, env_int("GPANN_COMM_TIMEOUT", 600), out);
 }
 
 gpann_status gpann_comm_destroy(gpann_comm* c) {

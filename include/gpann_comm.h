@@ -45,7 +45,8 @@ const char* gpann_comm_last_error(void);
 
 /* device: HIP device of this rank (RCCL backend; ignored by TCP).  timeout_s: how long to wait for the other ranks to show up. */
 gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int port, int backend, int device, int timeout_s, gpann_comm** out);
-/* RANK, WORLD_SIZE, MASTER_ADDR, GPANN_COMM_PORT (default MASTER_PORT + 1), LOCAL_RANK (device) from the environment */
+/* RANK, WORLD_SIZE, MASTER_ADDR, GPANN_COMM_PORT (default MASTER_PORT + 1), LOCAL_RANK (device), GPANN_COMM_TIMEOUT (seconds to wait for
+ * the other ranks, default 600: the first `import torch` of a rank on a fresh machine can take minutes) from the environment */
 gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out);
 gpann_status gpann_comm_destroy(gpann_comm* c);
 gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend);
