@@ -977,6 +977,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
             GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 16, hipMemcpyDeviceToHost, st));
             GPANN_HIP_TRY(hipStreamSynchronize(st));
+            {
+                std::vector<uint32_t> h_cnt(T);
+                GPANN_HIP_TRY(hipMemcpy(h_cnt.data(), cand_cnt, (size_t)T * 4, hipMemcpyDeviceToHost));
+                std::sort(h_cnt.begin(), h_cnt.end());
+                uint64_t sum = 0;
+                for (uint32_t v : h_cnt) sum += v;
+                fprintf(stderr, "[gpann cells] pass %d candidates per task: mean %.1f  median %u  p90 %u  p99 %u  p99.9 %u  max %u\n", pass, (double)sum / T,
+                        h_cnt[T / 2], h_cnt[(size_t)T * 9 / 10], h_cnt[(size_t)T * 99 / 100], h_cnt[(size_t)T * 999 / 1000], h_cnt[T - 1]);
+            }
             fprintf(stderr, "[gpann cells] pass %d: T=%u G=%u kmax=%u cap=%u  pairs so far %.3e (all rows x tasks %.3e)  row tiles so far %llu  candidates so far %llu  overflowed so far %u\n",
                     pass, T, G, kmax, cap, (double)h_work[0] * 1024.0, (double)plan.pairs, (unsigned long long)h_work[1],
                     (unsigned long long)((uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32)), h_words[0]);

@@ -222,8 +222,10 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
 
 // One wavefront per task.  Candidates are taken 16 at a time: their rows are fetched COALESCED (half a wavefront per row: one
 // 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row costs the texture path 64 cache lines per load
-// instruction) and staged through LDS, the next 16 rows being in flight while lanes 0..15 evaluate the canonical distance of the
-// current ones against the query row in LDS; the survivors are inserted into the task's list (one entry per lane).
+// instruction) and staged through LDS, the next 16 rows being in flight while the wavefront evaluates the canonical distance of the
+// current ones against the query row in LDS (four lanes per row for the terms, one for the sum: the kernel is bound by its own
+// instruction stream — with lanes 0..15 doing all of it a round of 16 rows took about 2 500 cycles, a quarter of the lanes busy); the
+// survivors are inserted into the task's list (one entry per lane).
 constexpr int kRescoreSub = 16;                                                   // candidates per round
 constexpr int kRescoreRounds = 64 / kRescoreSub;                                  // rounds per block of 64 row ids
 constexpr int kRescoreTasksPerWG = 1;   // wavefronts (= tasks) per workgroup: candidate counts are long-tailed and a workgroup lasts as long as its
@@ -327,8 +329,57 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         fetch(v, row, 0);                  // the next round's rows are in flight while this one is evaluated
         __builtin_amdgcn_wave_barrier();
         const bool valid = cur_row != kNoId;
+        // The canonical distance of the 16 staged rows, with all 64 lanes.  What the reference's sequence fixes is the ORDER OF THE
+        // ADDITIONS into `result` (src/dist.cpp:17-52); its terms — L2: s_g = ((d0 d0 + d1 d1) + d2 d2) + d3 d3 of a group of four
+        // dimensions, inner product: the products q_i p_i — do not depend on `result`.  Phase A: lane (part = lane / 16, candidate =
+        // lane % 16) computes the terms of groups part, part + 4, ... and leaves them in the row's own LDS words (nobody else reads a
+        // group's words); phase B: lanes 0..15 add them up in the reference's order, then the tail dimensions (d % 4).
+        {
+            const uint32_t full = a.d >> 2;
+            float* my_row = srow + (size_t)(lane & (kRescoreSub - 1)) * stride;
+            const float4* q4 = reinterpret_cast<const float4*>(sq);
+#pragma unroll 8
+            for (uint32_t g = (uint32_t)lane / kRescoreSub; g < full; g += 64 / kRescoreSub) {
+                float4* w = reinterpret_cast<float4*>(my_row) + g;
+                const float4 pv = *w, qv = q4[g];
+                if (METRIC == GPANN_METRIC_L2) {
+                    const float d0 = pv.x - qv.x, d1 = pv.y - qv.y, d2 = pv.z - qv.z, d3 = pv.w - qv.w;
+                    float sg = d0 * d0 + d1 * d1;
+                    sg = sg + d2 * d2;
+                    sg = sg + d3 * d3;
+                    my_row[4 * g] = sg;
+                } else {
+                    *w = make_float4(qv.x * pv.x, qv.y * pv.y, qv.z * pv.z, qv.w * pv.w);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         float e = INFINITY;
-        if (valid) e = ExactDistanceVec4<METRIC>(srow + (size_t)lane * stride, sq, a.d);   // (rows and the query copy are 16-byte aligned)
+        if (valid) {   // (lanes 0..15)
+            const uint32_t full = a.d >> 2;
+            const float* row_terms = srow + (size_t)lane * stride;
+            float result = 0.f;
+            if (METRIC == GPANN_METRIC_L2) {
+#pragma unroll 8
+                for (uint32_t g = 0; g < full; ++g) result = result + row_terms[4 * g];
+                for (uint32_t i = full << 2; i < a.d; ++i) {
+                    const float d0 = row_terms[i] - sq[i];
+                    result = result + d0 * d0;
+                }
+                e = result;
+            } else {
+#pragma unroll 4
+                for (uint32_t g = 0; g < full; ++g) {
+                    const float4 v = reinterpret_cast<const float4*>(row_terms)[g];
+                    result = result + v.x;
+                    result = result + v.y;
+                    result = result + v.z;
+                    result = result + v.w;
+                }
+                for (uint32_t i = full << 2; i < a.d; ++i) result = result + sq[i] * row_terms[i];
+                e = 1.0f - result;
+            }
+        }
         float td = __shfl(ld_, k - 1);
         uint32_t tr = __shfl(lr_, k - 1);
         bool pass = valid && PairLess(e, cur_row, td, tr);
