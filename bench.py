@@ -457,41 +457,74 @@ def main():
     probes = best["probes"]   # the timed configuration's routes (the CPU baseline's sample is chosen from them)
     log(f"timed configuration: index budget {best['index_budget']}, nprobe {nprobe}")
 
-    for _ in range(args.warmup):
-        step()
     scan_ms, router_ms, algo_bytes, filter_ms, rest_ms, step_wall_ms, stats = [], [], [], [], [], [], None
     router_bound_ms, router_bound_flops = [], 0.0
+    import concurrent.futures
+    # The timed loop is a software pipeline over the batches, one step = route + scan + merge of one batch, K of each inside the clock:
+    #  * the host merge of batch i (DedupNeighbors, ~0.1 ms) runs on a worker thread while batch i + 1 is on the GPU; the results land
+    #    in two alternating pinned buffer sets; every merge has finished before the clock stops;
+    #  * (one rank) batch i + 1 is ROUTED on a second HIP stream by a second worker thread while batch i is scanned: the router's
+    #    kernels fill what the scan leaves idle (its host-side planning, the tail of its launches) and the router -> scan hand-over
+    #    (probe lists through pinned host arrays) leaves the critical path.  GPANN_BENCH_ROUTE_AHEAD=0: strictly one batch at a time.
+    merger = concurrent.futures.ThreadPoolExecutor(1)
+    route_ahead = (not multi) and os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0"
+    if route_ahead:
+        r_stream = torch.cuda.Stream(device=dev)
+        r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(2)]
+        router_pool = concurrent.futures.ThreadPoolExecutor(1)
+        def route_job(j):
+            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j & 1],
+                                             want_min_dist=False, n_top=None if nprobe == S else nprobe)
+            return pr, r_ms, router.stats()
+
+    def run_steps(count, record):
+        """count steps back to back; returns the last merged lists"""
+        pending = None
+        md = mi = None
+        nxt = router_pool.submit(route_job, 0) if route_ahead and count else None
+        for it in range(count):
+            t_step = time.perf_counter()
+            if route_ahead:
+                pr, r_ms, rst = nxt.result()
+                nxt = router_pool.submit(route_job, it + 1) if it + 1 < count else None
+                sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=it & 1)
+                fut = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
+            else:
+                fut, _, r_ms, s_ms = step(buf=it & 1, merge_later=merger)
+                rst = router.stats()
+            if pending is not None:
+                md, mi, _ = pending.result()
+            pending = fut
+            if record is not None:
+                nonlocal_stats = shards.stats()
+                step_wall_ms.append(round(1e3 * (time.perf_counter() - t_step), 3))
+                scan_ms.append(nonlocal_stats["scan_ms"])
+                filter_ms.append(nonlocal_stats["filter_ms"])
+                rest_ms.append(nonlocal_stats["filter_rest_ms"])
+                router_ms.append(r_ms)
+                router_bound_ms.append(rst["last_bound_ms"])
+                algo_bytes.append(nonlocal_stats["algorithmic_bytes"])
+                record["stats"] = nonlocal_stats
+                record["router_bound_flops"] = rst["last_bound_flops"]
+        if pending is not None:
+            md, mi, _ = pending.result()
+        return md, mi
+
+    run_steps(args.warmup, None)
     import gc
     gc.collect()
     gc.disable()   # (a generation-2 collection in the middle of a 9 ms step is a visible outlier)
-    # the host merge of batch i (DedupNeighbors, ~0.1 ms) runs on a worker thread while batch i + 1 is routed and scanned; the results
-    # land in two alternating pinned buffer sets; every merge has finished before the clock stops
-    import concurrent.futures
-    merger = concurrent.futures.ThreadPoolExecutor(1)
-    pending = None
+    rec = {}
     barrier()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        t_step = time.perf_counter()
-        fut, _, r_ms, s_ms = step(buf=it & 1, merge_later=merger)
-        if pending is not None:
-            md, mi, _ = pending.result()
-        pending = fut
-        step_wall_ms.append(round(1e3 * (time.perf_counter() - t_step), 3))
-        st = shards.stats()
-        scan_ms.append(st["scan_ms"])
-        filter_ms.append(st["filter_ms"])
-        rest_ms.append(st["filter_rest_ms"])
-        router_ms.append(r_ms)
-        rst = router.stats()
-        router_bound_ms.append(rst["last_bound_ms"])
-        router_bound_flops = rst["last_bound_flops"]
-        algo_bytes.append(st["algorithmic_bytes"])
-        stats = st
-    md, mi, _ = pending.result()
+    md, mi = run_steps(args.steps, rec)
+    stats = rec.get("stats")
+    router_bound_flops = rec.get("router_bound_flops", 0.0)
     barrier()
     elapsed = time.perf_counter() - t0
     merger.shutdown()
+    if route_ahead:
+        router_pool.shutdown()
     gc.enable()
     if multi:
         elapsed = comm.max_double(elapsed)
@@ -565,6 +598,8 @@ def main():
                                    task_rows_max_over_mean=float(per_rank.max() / max(per_rank.mean(), 1.0)))
     result["index_build_s"] = index_build_s
     result["hbm_resident_GB"] = hbm_resident_gb
+    result["config"]["pipeline"] = ("batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned"
+                                    if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
     result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
