@@ -886,6 +886,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     //      gives no such bound for a query whose neighbours live elsewhere (one overflowing bucket costs a whole-shard re-read).
     //      (Run inside the head pass's launch instead — the tiles share the arrays — it saved no kernel time and let 18 % more
     //      candidates through: the head pass then works with the looser seed threshold.)
+    auto debug_candidate_counts = [&](const char* what) {   // GPANN_CELLS_DEBUG: how the candidates of a pass spread over the tasks
+        std::vector<uint32_t> h_cnt(T);
+        if (hipMemcpy(h_cnt.data(), cand_cnt, (size_t)T * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+        std::sort(h_cnt.begin(), h_cnt.end());
+        uint64_t sum = 0;
+        for (uint32_t v : h_cnt) sum += v;
+        fprintf(stderr, "[gpann cells] %s candidates per task: mean %.1f  median %u  p90 %u  p99 %u  p99.9 %u  max %u\n", what, (double)sum / T, h_cnt[T / 2],
+                h_cnt[(size_t)T * 9 / 10], h_cnt[(size_t)T * 99 / 100], h_cnt[(size_t)T * 999 / 1000], h_cnt[T - 1]);
+    };
     if (seed_rows != 0 && C.n_sample_tiles != 0) {
         const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
@@ -932,6 +941,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
             else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
             GPANN_HIP_TRY(hipGetLastError());
+            if (std::getenv("GPANN_CELLS_DEBUG")) debug_candidate_counts("shard-sample pass");
         }
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
@@ -977,15 +987,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
             GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 16, hipMemcpyDeviceToHost, st));
             GPANN_HIP_TRY(hipStreamSynchronize(st));
-            {
-                std::vector<uint32_t> h_cnt(T);
-                GPANN_HIP_TRY(hipMemcpy(h_cnt.data(), cand_cnt, (size_t)T * 4, hipMemcpyDeviceToHost));
-                std::sort(h_cnt.begin(), h_cnt.end());
-                uint64_t sum = 0;
-                for (uint32_t v : h_cnt) sum += v;
-                fprintf(stderr, "[gpann cells] pass %d candidates per task: mean %.1f  median %u  p90 %u  p99 %u  p99.9 %u  max %u\n", pass, (double)sum / T,
-                        h_cnt[T / 2], h_cnt[(size_t)T * 9 / 10], h_cnt[(size_t)T * 99 / 100], h_cnt[(size_t)T * 999 / 1000], h_cnt[T - 1]);
-            }
+            debug_candidate_counts(pass == 0 ? "head pass" : pass == 1 ? "sample pass" : "rest pass");
             fprintf(stderr, "[gpann cells] pass %d: T=%u G=%u kmax=%u cap=%u  pairs so far %.3e (all rows x tasks %.3e)  row tiles so far %llu  candidates so far %llu  overflowed so far %u\n",
                     pass, T, G, kmax, cap, (double)h_work[0] * 1024.0, (double)plan.pairs, (unsigned long long)h_work[1],
                     (unsigned long long)((uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32)), h_words[0]);
