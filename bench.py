@@ -549,7 +549,7 @@ def main():
     filtered = bool(stats["filtered"])
     # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once; the rest pass — the
     # launch that streams (nearly) the whole store once — is the dominant kernel
-    traffic, traffic_src = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<0, 0", {"true>": 1}, largest_launch=True) if filtered
+    traffic, traffic_src = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"true": 1}, largest_launch=True) if filtered
                             else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
         f_s = float(np.mean(filter_ms)) / 1000.0
