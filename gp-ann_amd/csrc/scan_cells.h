@@ -21,7 +21,7 @@
 //       after the tile's MFMA phase, when the prefetch has landed (the atomic's vmcnt wait would otherwise stall on the loads
 //       issued before it); they are mapped from plane rows back to store rows;
 //     * FilterItemsKernel lists a pass's work — every (task group, cell) block with something left to run, cut into pieces of at most
-//       seg_tiles row tiles — and one persistent workgroup per CU claims items from a shared cursor.
+//       seg_tiles row tiles, one list per task group — and one persistent workgroup per CU claims items from its group's list.
 #pragma once
 
 #include "scan_filter.h"
