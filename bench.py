@@ -721,7 +721,7 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
     cores = os.cpu_count() or 1
     S, k, d = args.shards, args.k, args.d
     want_queries = min(len(probes), int(os.environ.get("GPANN_BENCH_CPU_QUERIES", 2560)))
-    # shards in ascending size until the sample holds enough queries (bounded host memory: <= 16 shards / 24 GB of rows)
+    # shards in ascending size until the sample holds enough queries (bounded host memory: <= 20 shards / 24 GB of rows)
     first = probes[:, :nprobe]
     chosen, sel_q, pairs = [], np.zeros(len(first), bool), 0
     for b in np.argsort(counts, kind="stable"):
@@ -729,7 +729,7 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
             break
         chosen.append(int(b))
         sel_q = np.all(np.isin(first, chosen), axis=1)
-        if int(sel_q.sum()) >= want_queries or len(chosen) >= 16:
+        if int(sel_q.sum()) >= want_queries or len(chosen) >= 20:
             break
     qidx = np.flatnonzero(sel_q)[:want_queries]
     if len(qidx) == 0:

@@ -689,7 +689,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     cd.ld = s->ld;
     auto cell_table = [&](bool with_qnorm) -> gpann_status {
         hipLaunchKernelGGL(CellDistKernel, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
-        hipLaunchKernelGGL(NearestCellKernel, dim3((T + 255) / 256), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
+        hipLaunchKernelGGL(NearestCellKernel, dim3((T + 15) / 16), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
                            s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr, C.d_mu);
         GPANN_HIP_TRY(hipGetLastError());
         return GPANN_OK;
