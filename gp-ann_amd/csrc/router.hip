@@ -799,6 +799,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
 // Equal keys make the order libstdc++'s business only if they sit in the cut-off group (two bottlenecks, or equal minima in
 // the group's frontier); those queries are marked in `redo` and replayed by RouterReplayKernel with the real heap.
 constexpr int kPathMax = 6;
+constexpr int kBatch = 4;   // independent loop trips a lane of RouterThresholdReplayKernel keeps in flight
 constexpr uint32_t kFrontCap = 512;
 constexpr uint32_t kNoCent = 0xFFFFFFFFu;
 
@@ -826,15 +827,31 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
         const float* D = a.dense + (size_t)q * C;
         for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
 
-        // ---- 1. pi (order-preserving bits; 0 = root, later also "visited")
-        for (uint32_t u = lane; u < n_nodes && !t.visit_all; u += 64) {
-            uint32_t m = 0;
+        // ---- 1. pi (order-preserving bits; 0 = root, later also "visited").  The loops of this kernel are chains of dependent loads
+        //      (path table -> distance row, pi -> node sizes, centroid -> node -> pi): four nodes per lane and trip are in flight
+        //      together — one at a time the wavefront spent its life waiting, ~1.5 us per trip, 5.7 ms per query.
+        for (uint32_t u0 = lane; u0 < n_nodes && !t.visit_all; u0 += 64 * kBatch) {
+            uint32_t cidx[kBatch][kPathMax];
 #pragma unroll
-            for (int j = 0; j < kPathMax; ++j) {
-                const uint32_t c = t.path_cent[(size_t)u * kPathMax + j];
-                if (c != kNoCent) m = max(m, OrderedBits(D[c]));
+            for (int k = 0; k < kBatch; ++k) {
+                const uint32_t u = u0 + 64u * k;
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j) cidx[k][j] = u < n_nodes ? t.path_cent[(size_t)u * kPathMax + j] : kNoCent;
             }
-            pi[u] = m;
+            float val[kBatch][kPathMax];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j) val[k][j] = D[cidx[k][j] != kNoCent ? cidx[k][j] : 0u];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const uint32_t u = u0 + 64u * k;
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j)
+                    if (cidx[k][j] != kNoCent) m = max(m, OrderedBits(val[k][j]));
+                if (u < n_nodes) pi[u] = m;
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -850,9 +867,17 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
                 const int shift = 24 - 8 * pass;
                 for (int b = lane; b < 256; b += 64) hist[b] = 0;
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t u = lane; u < n_nodes; u += 64) {
-                    const uint32_t p = pi[u];
-                    if (p != 0 && (p & prefix_mask) == prefix) atomicAdd(&hist[(p >> shift) & 255u], a.node_cent_first[u + 1] - a.node_cent_first[u]);
+                for (uint32_t u0 = lane; u0 < n_nodes; u0 += 64 * kBatch) {
+                    uint32_t p[kBatch], sz[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const uint32_t u = min(u0 + 64u * k, n_nodes - 1);
+                        p[k] = u0 + 64u * k < n_nodes ? pi[u] : 0u;
+                        sz[k] = a.node_cent_first[u + 1] - a.node_cent_first[u];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (p[k] != 0 && (p[k] & prefix_mask) == prefix) atomicAdd(&hist[(p[k] >> shift) & 255u], sz[k]);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // lane l owns bins 4l .. 4l+3
@@ -979,7 +1004,35 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
         } else {
             // ---- 4. minima over the centroids of the visited nodes
             uint32_t n_rec = 0;
-            for (uint32_t base = 0; base < C; base += 64) {
+            if (!a.rec_dist) {
+                // a shard's centroids are one contiguous range (its nodes are, gpann_router_create checks it): every lane keeps a private
+                // minimum over its part of the range, one reduction per shard (a reduction per 64 centroids cost 2 172 x 6 shuffles a query)
+                for (uint32_t b = 0; b < S; ++b) {
+                    const uint32_t c0 = a.node_cent_first[a.shard_root[b]];
+                    const uint32_t c1 = b + 1 < S ? a.node_cent_first[a.shard_root[b + 1]] : C;
+                    float mn = FLT_MAX;
+                    for (uint32_t cb = c0 + lane; cb < c1; cb += 64 * kBatch) {
+                        uint32_t node[kBatch];
+                        float dv[kBatch];
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k) {
+                            const uint32_t c = min(cb + 64u * k, c1 - 1);
+                            node[k] = t.cent_node[c];
+                            dv[k] = D[c];
+                        }
+                        uint32_t pv[kBatch];
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k) pv[k] = pi[node[k]];
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k)
+                            if (cb + 64u * k < c1 && (all || pv[k] < xs)) mn = fminf(mn, dv[k]);
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                    if (lane == 0) sMinOrd[b] = min(sMinOrd[b], OrderedBits(mn));
+                }
+            }
+            for (uint32_t base = 0; base < C && a.rec_dist; base += 64) {
                 const uint32_t c = base + lane;
                 bool take = false;
                 uint32_t shard = 0;
@@ -1899,8 +1952,11 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 GPANN_HIP_TRY(hipGetLastError());
                 ra.only_redo = 1;
             } else if (threshold_ok) {
-                const uint32_t t_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / t_lds));
-                const uint32_t t_grid = std::min<uint32_t>((nb + kRWaves - 1) / kRWaves, (uint32_t)prop.multiProcessorCount * t_bpc);
+                // a wavefront per query while the pi scratch (n_nodes words per wavefront) stays below 2 GiB: the kernel lives on wavefronts in flight
+                const uint32_t t_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / t_lds));
+                const uint64_t t_fit = std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)kRWaves * r->n_nodes * 4));
+                const uint32_t t_grid = (uint32_t)std::min<uint64_t>((nb + kRWaves - 1) / kRWaves,
+                                                                     std::max<uint64_t>((uint64_t)prop.multiProcessorCount * t_bpc, std::min<uint64_t>(t_fit, 1u << 20)));
                 GPANN_TRY(r->ws_pi.Reserve((size_t)t_grid * kRWaves * r->n_nodes * 4));
                 ThresholdTree tt;
                 tt.path_cent = r->path_cent;
