@@ -209,4 +209,64 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 // lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
 
+// ---- the same sequence on PAIRS of point rows: packed (two-lane) fp32 instructions ---------------------------------------------
+// The rows of a tile lie in LDS as pairs [pair][dim][member] (one ds_read_b128 = two dimensions of both rows); every operation of the
+// distance sequence is then a packed instruction on a natural register pair, the query operand broadcast by op_sel.  Unpacked, the
+// vector ALUs issue 39.3 T lane-operations/s at most — what DenseDistKernel ran at before it took this layout over from ScanTileKernel.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// one group of 4 dimensions of the reference's sequence (src/dist.cpp:23-31 / :44-46) for a thread's 4 queries x 2 point pairs
+template <int METRIC>
+__device__ __forceinline__ void AccumulatePairs(f32x2_t (&acc)[4][2], const float4 (&qv)[4], const f32x4_t (&p0)[2], const f32x4_t (&p1)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const f32x2_t px = p0[pr].xy, py = p0[pr].zw, pz = p1[pr].xy, pw = p1[pr].zw;
+            const f32x2_t qx = {qv[i].x, qv[i].x}, qy = {qv[i].y, qv[i].y}, qz = {qv[i].z, qv[i].z}, qw = {qv[i].w, qv[i].w};
+            if (METRIC == GPANN_METRIC_L2) {
+                const f32x2_t d0 = px - qx, d1 = py - qy, d2 = pz - qz, d3 = pw - qw;
+                f32x2_t t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                t = t + d3 * d3;
+                acc[i][pr] = acc[i][pr] + t;
+            } else {
+                f32x2_t r = acc[i][pr];
+                r = r + qx * px;
+                r = r + qy * py;
+                r = r + qz * pz;
+                r = r + qw * pw;
+                acc[i][pr] = r;
+            }
+        }
+    }
+}
+
+// the 1..3 trailing dimensions (src/dist.cpp:33-36), one at a time
+template <int METRIC>
+__device__ __forceinline__ void AccumulatePairsTail(f32x2_t (&acc)[4][2], const float4 (&qv)[4], const f32x4_t (&p0)[2], const f32x4_t (&p1)[2], int tail) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            f32x2_t r = acc[i][pr];
+            const f32x2_t pe[3] = {p0[pr].xy, p0[pr].zw, p1[pr].xy};
+            const float qe[3] = {qv[i].x, qv[i].y, qv[i].z};
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                if (x < tail) {
+                    const f32x2_t qb = {qe[x], qe[x]};
+                    if (METRIC == GPANN_METRIC_L2) {
+                        const f32x2_t d0 = pe[x] - qb;
+                        r = r + d0 * d0;
+                    } else {
+                        r = r + qb * pe[x];
+                    }
+                }
+            }
+            acc[i][pr] = r;
+        }
+    }
+}
 }  // namespace gpann

@@ -382,8 +382,9 @@ template <int METRIC, bool MIN_ONLY>
 __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
     extern __shared__ float4 dsm4[];
     constexpr int kStride = kRDC + 4;
+    constexpr int kPairStride = 2 * kRDC + 4;       // centroid rows as pairs (common.h, AccumulatePairs)
     float* sQ = reinterpret_cast<float*>(dsm4);   // [64][36]
-    float* sP = sQ + 64 * kStride;                 // [64][36]
+    float* sP = sQ + 64 * kStride;                 // [32 pairs][68]
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     const uint32_t q0 = blockIdx.y * 64u, c0 = blockIdx.x * 64u;
@@ -392,45 +393,73 @@ __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
     const int tail = (int)(d & 3u);
     const uint32_t nchunks = (ld + kRDC - 1) / kRDC;
     const int st_row0 = tid >> 3, st_row1 = (tid + 256) >> 3, st_c4 = tid & 7;
+    // centroid staging role: pair st_pair = rows st_prow0 and st_prow0 + 16 of the tile, float4 #st_c4 of both
+    const int st_pair = tid >> 3;
+    const int st_prow0 = (st_pair & 15) + 32 * (st_pair >> 4);
     const float* qrow0 = a.queries + (size_t)min(q0 + st_row0, a.nq - 1) * ld;
     const float* qrow1 = a.queries + (size_t)min(q0 + st_row1, a.nq - 1) * ld;
-    const float* prow0 = a.centroids + (size_t)min(c0 + st_row0, a.C - 1) * ld;
-    const float* prow1 = a.centroids + (size_t)min(c0 + st_row1, a.C - 1) * ld;
-    float acc[4][4];
+    const float* prow0 = a.centroids + (size_t)min(c0 + st_prow0, a.C - 1) * ld;
+    const float* prow1 = a.centroids + (size_t)min(c0 + st_prow0 + 16, a.C - 1) * ld;
+    f32x2_t acc2[4][2];   // acc2[i][pr] = query ty + 16 i x centroids (tx + 32 pr, tx + 32 pr + 16)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int pr = 0; pr < 2; ++pr) acc2[i][pr] = (f32x2_t){0.f, 0.f};
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
-        const uint32_t c = ch * kRDC + 4u * st_c4;
+    float4 gq0, gq1, gp0, gp1;
+    {
+        const uint32_t c = 4u * st_c4;
         const bool in = c < ld;
-        const float4 gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
-        const float4 gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
-        const float4 gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
-        const float4 gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+        gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
+        gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
+        gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
+        gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+    }
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
         *reinterpret_cast<float4*>(sQ + st_row0 * kStride + 4 * st_c4) = gq0;
         *reinterpret_cast<float4*>(sQ + st_row1 * kStride + 4 * st_c4) = gq1;
-        *reinterpret_cast<float4*>(sP + st_row0 * kStride + 4 * st_c4) = gp0;
-        *reinterpret_cast<float4*>(sP + st_row1 * kStride + 4 * st_c4) = gp1;
+        // the two rows of the pair, interleaved dimension by dimension
+        *reinterpret_cast<float4*>(sP + st_pair * kPairStride + 8 * st_c4) = make_float4(gp0.x, gp1.x, gp0.y, gp1.y);
+        *reinterpret_cast<float4*>(sP + st_pair * kPairStride + 8 * st_c4 + 4) = make_float4(gp0.z, gp1.z, gp0.w, gp1.w);
         __syncthreads();
+        if (ch + 1 < nchunks) {   // the next chunk's global loads complete under the arithmetic below
+            const uint32_t c = (ch + 1) * kRDC + 4u * st_c4;
+            const bool in = c < ld;
+            gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + c) : zero4;
+            gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + c) : zero4;
+            gp0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4;
+            gp1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
+        }
         const uint32_t g0 = ch * (kRDC / 4);
         const float* q_base = sQ + ty * kStride;
-        const float* p_base = sP + tx * kStride;
+        const float* p_base = sP + tx * kPairStride;   // pairs tx (centroids tx, tx + 16) and tx + 16 (centroids tx + 32, tx + 48)
+        const bool whole = g0 + kRDC / 4 <= full_groups;
 #pragma unroll 2
         for (int g = 0; g < kRDC / 4; ++g) {
             const uint32_t G = g0 + g;
-            if (G > full_groups || (G == full_groups && tail == 0)) break;
-            float4 qv[4], pv[4];
+            if (!whole && (G > full_groups || (G == full_groups && tail == 0))) break;
+            float4 qv[4];
+            f32x4_t p0[2], p1[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q_base + 16 * i * kStride + 4 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const float4*>(p_base + 16 * j * kStride + 4 * g);
-            if (G < full_groups) AccumulateGroup<METRIC>(acc, qv, pv);
-            else AccumulateTail<METRIC>(acc, qv, pv, tail);
+            for (int pr = 0; pr < 2; ++pr) {
+                p0[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g);
+                p1[pr] = *reinterpret_cast<const f32x4_t*>(p_base + 16 * pr * kPairStride + 8 * g + 4);
+            }
+            if (whole || G < full_groups) AccumulatePairs<METRIC>(acc2, qv, p0, p1);
+            else AccumulatePairsTail<METRIC>(acc2, qv, p0, p1, tail);
         }
     }
+    float acc[4][4];   // acc[i][j]: query ty + 16 i x centroid tx + 16 j
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            acc[i][2 * pr] = acc2[i][pr].x;
+            acc[i][2 * pr + 1] = acc2[i][pr].y;
+        }
     if (MIN_ONLY) {
         const uint32_t shard_first = a.cent_shard[c0], shard_last = a.cent_shard[min(c0 + 63u, a.C - 1)];
         if (shard_first == shard_last) {   // (centroids are numbered shard by shard) the usual case: one shard per tile
@@ -466,16 +495,26 @@ __global__ void __launch_bounds__(256, 3) DenseDistKernel(DenseArgs a) {
         }
         return;
     }
+    // the 64 x 64 tile goes out through LDS: one store instruction per table row and wavefront writes 64 consecutive floats (written
+    // from the register tile, an instruction wrote 16 floats of 4 different rows)
+    constexpr int kOutStride = 65;
+    float* sT = reinterpret_cast<float*>(dsm4);   // [64][65] (the staging buffers are done with)
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t q = q0 + ty + 16 * i;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t c = c0 + tx + 16 * j;
             float v = acc[i][j];
             if (METRIC == GPANN_METRIC_MIPS) v = 1.0f - v;
-            if (q < a.nq && c < a.C) a.out[(size_t)q * a.C + c] = v;
+            sT[(ty + 16 * i) * kOutStride + tx + 16 * j] = v;
         }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = c0 + (uint32_t)lane;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t q = q0 + (uint32_t)(16 * wave + r);
+        if (q < a.nq && c < a.C) a.out[(size_t)q * a.C + c] = sT[(16 * wave + r) * kOutStride + lane];
     }
 }
 
@@ -1624,7 +1663,7 @@ gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipS
     dv.out_min_bits = r->ws_verify.as<uint32_t>();
     uint32_t* d_diff = ba.cand_count + 2;   // zeroed by EnqueueBound
     const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
-    const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+    const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);   // (>= the 64 x 65 floats of the output tile)
     const uint32_t fgrid = (uint32_t)((nb_s + 255) / 256);
     hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, dv.out_min_bits, nb_s);
     if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, dv);
@@ -1874,7 +1913,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             da.nq = nb;
             da.C = (uint32_t)C;
             const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
-            const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+            const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);   // (>= the 64 x 65 floats of the output tile)
             da.cent_shard = r->cent_shard;
             da.out_min_bits = reinterpret_cast<uint32_t*>(r->ws_out.as<float>() + (size_t)q0 * S);
             da.S = S;
