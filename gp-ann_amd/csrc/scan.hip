@@ -591,6 +591,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
     const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
+    GPANN_REQUIRE(((uint64_t)C.sample_tile_base + C.n_sample_tiles + 2) * kGTileRows < 0xFFFFFFFFull, "plane rows beyond 32 bits");
     // one item list per task group: group_first[g] = where it starts (capacity: every cell of the group's shard cut into pieces)
     uint64_t items_cap = 0;
     std::vector<uint32_t> group_first(G + 1);
@@ -803,7 +804,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere.  Beyond 128 dimensions every pass is a hi-plane pass.
     const bool hi_last = ks16 || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
     const int hi_from_pass = ks16 ? 0 : (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
-    const size_t glds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + kFWaves * kGTileRows * sizeof(float);
+    const size_t glds = FilterLdsBytes((size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);

@@ -294,6 +294,11 @@ struct CellFilterArgs {
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
 constexpr int kFWaves = 8;
+// candidates a wavefront of FilterKernelCells collects in LDS before it writes them to the tasks' buckets (what is left of the 160 KiB
+// next to a 128 KiB query image and the norms)
+constexpr uint32_t kFQueue = 448;
+// dynamic LDS of FilterKernelCells
+constexpr size_t FilterLdsBytes(size_t image_bytes) { return image_bytes + kFWaves * kGTileRows * sizeof(float) + (size_t)kFWaves * kFQueue * 8; }
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
@@ -435,6 +440,22 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
     float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
+    // Candidates go through a per-wavefront queue in LDS: (task, plane row) pairs, mapped to store rows and written to the tasks'
+    // buckets — a returning atomic per candidate for the slot — when the queue fills up and at the end of the kernel.  (Written
+    // straight from the tile loop, every row tile with a candidate costs two dependent round trips — row id, slot: the head and sample
+    // passes, 15 and 4 candidates per row tile, streamed at two thirds of the rest pass's rate.)
+    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + kFWaves * kGTileRows * sizeof(float)) + wave * kFQueue;
+    uint32_t q_len = 0;
+    auto flush_queue = [&]() __attribute__((always_inline)) {
+        for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
+            const uint2 e = queue[i];
+            const uint32_t row = a.plane_perm[e.y];
+            if (row == 0xFFFFFFFFu) continue;   // (padding row of a cell's last tile)
+            const uint32_t slot = atomicAdd(&a.cand_cnt[e.x], 1u);
+            if (slot < a.cand_cap) a.cand_row[(size_t)e.x * a.cand_cap + slot] = row;
+        }
+        q_len = 0;
+    };
 
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
@@ -581,16 +602,20 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
 #pragma unroll
             for (int qp = 0; qp < QT / 2; ++qp) {
                 uint32_t bits = cmask[qp];
-                while (bits) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1;
+                while (__any(bits != 0u)) {   // (wave-uniform: every lane takes its lowest set bit, if it has one)
+                    const bool has = bits != 0u;
+                    const int b = has ? __builtin_ctz(bits) : 0;
+                    bits &= bits - 1u;
                     const int r = b & 15;
                     const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
-                    const uint32_t row = a.plane_perm[(size_t)T * kGTileRows + (r & 3) + 8 * (r >> 2) + 4 * h];
-                    if (row != 0xFFFFFFFFu && tl < task_count) {
-                        const uint32_t task = task_begin + tl;
-                        const uint32_t slot = atomicAdd(&a.cand_cnt[task], 1u);
-                        if (slot < a.cand_cap) a.cand_row[(size_t)task * a.cand_cap + slot] = row;
+                    const uint32_t prow = T * kGTileRows + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);   // (plane rows fit 32 bits: checked by the host)
+                    const bool ok = has && tl < task_count;
+                    const unsigned long long votes = __ballot(ok);
+                    if (votes != 0ull) {
+                        if (q_len + 64u > kFQueue) flush_queue();
+                        const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
+                        if (ok) queue[pos] = make_uint2(task_begin + tl, prow);
+                        q_len += (uint32_t)__builtin_popcountll(votes);
                     }
                 }
             }
@@ -671,6 +696,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     item = nxt;
     nxt = after;
     }   // next item
+    flush_queue();
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
         atomicAdd(&a.work[1], (unsigned long long)my_tiles);
