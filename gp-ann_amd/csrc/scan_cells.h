@@ -17,9 +17,10 @@
 //       its next tile (unconditionally — see the tile loop) into a second register set while the matrix core works on the current one.  (An earlier design staged
 //       POINT tiles in LDS by LDS-DMA with the queries in registers: a barrier per tile, and the fill landing in LDS and the
 //       ds_read/MFMA stream slowed each other down — its time was fill-only + compute-only.)
-//     * only the query tiles whose bit is set run on a row tile; candidates of a tile are collected as bit masks and written
-//       after the tile's MFMA phase, when the prefetch has landed (the atomic's vmcnt wait would otherwise stall on the loads
-//       issued before it); they are mapped from plane rows back to store rows;
+//     * only the query tiles whose bit is set run on a row tile; candidates of a tile are collected as bit masks and pushed, after
+//       the tile's MFMA phase, into a per-wavefront queue in LDS as (task, plane row) pairs; the queue is emptied — plane rows mapped
+//       back to store rows, a bucket slot per candidate — when it is full and at the end of the kernel (the global round trips of
+//       a candidate, with their in-order vmcnt waits, stay out of the tile loop);
 //     * FilterItemsKernel lists a pass's work — every (task group, cell) block with something left to run, cut into pieces of at most
 //       seg_tiles row tiles, one list per task group — and one persistent workgroup per CU claims items from its group's list.
 #pragma once
