@@ -1,0 +1,35 @@
+"""bench.py's `roofline.traffic` is looked up in the committed PMC summaries (profiles/*/*_pmc_traffic.json) by kernel-name fragments:
+a change of the kernel's template arguments must not silently send the lookup back to an older round's file."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_traffic_of_the_ns_rest_pass_comes_from_the_newest_round():
+    b = _bench()
+    traffic, src = b.lookup_traffic(100_000_000, 128, 40, 1, "FilterKernelCells<", {"true": 1}, largest_launch=True)
+    assert src is not None and src.startswith("profiles/r02/"), src
+    # the rest pass reads about one hi plane + norm word per row of the store: 100M x 260 B, give or take the pruned / repeated cells
+    assert 20e9 < traffic < 30e9, traffic
+
+
+def test_traffic_lookup_knows_the_other_configurations_and_nothing_else():
+    b = _bench()
+    for shape in [(1_000_000, 128, 8, 1), (10_000_000, 96, 16, 4), (100_000_000, 200, 40, 1)]:
+        traffic, src = b.lookup_traffic(*shape, "FilterKernelCells<", {"true": 1}, largest_launch=True)
+        assert src is not None and traffic > 0, shape
+    assert b.lookup_traffic(123, 7, 3, 1, "FilterKernelCells<", {"true": 1}, largest_launch=True) == (None, None)
