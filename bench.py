@@ -91,9 +91,15 @@ def main():
     ap.add_argument("--shards", type=int, default=40)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--target-recall", type=float, default=0.9)
-    ap.add_argument("--config", choices=["ns", "c2", "c3", "c4"], default="ns",
+    ap.add_argument("--config", choices=["ns", "c2", "c3", "c4", "c5"], default="ns",
                     help="BASELINE.json configuration shapes: ns = the metric's own (100M x 128 L2, 40 shards; the default), c2 = 1M x 128, 8 shards, "
-                         "c3 = 10M x 96, 16 shards, nprobe 4, c4 = 100M x 200 inner product, 40 shards (sets --points/--d/--shards/--metric/--nprobe)")
+                         "c3 = 10M x 96, 16 shards, nprobe 4, c4 = 100M x 200 inner product, 40 shards, c5 = 100-dim, 60 OVERLAPPING shards (20 %% of the "
+                         "points in a second shard), nprobe swept, 200M points = the largest size one GPU holds "
+                         "(sets --points/--d/--shards/--metric/--nprobe/--overlap; GPANN_BENCH_N still overrides the size)")
+    ap.add_argument("--overlap", type=float, default=0.0,
+                    help="SPANN-style overlapping shards (reference src/overlapping_partitioning.cpp:143-235): this fraction of the points — those "
+                         "closest to a representative of another shard — is ALSO stored in that shard; the merge drops the copies "
+                         "(small_scale_queries.cpp:15-23)")
     ap.add_argument("--metric", choices=["l2", "ip"], default="l2", help="ip = the reference's MIPS_DISTANCE build: 1 - <p, q>")
     ap.add_argument("--nprobe", type=int, default=0, help="probe exactly this many shards (0: the smallest count that reaches --target-recall)")
     ap.add_argument("--dist", choices=["mixture", "uniform", "offset"], default="mixture",
@@ -118,9 +124,12 @@ def main():
     ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
     preset = {"ns": {}, "c2": dict(n=1_000_000, d=128, shards=8), "c3": dict(n=10_000_000, d=96, shards=16, nprobe=4),
-              "c4": dict(n=100_000_000, d=200, shards=40, metric="ip")}[args.config]
+              "c4": dict(n=100_000_000, d=200, shards=40, metric="ip"),
+              "c5": dict(n=200_000_000, d=100, shards=60, overlap=0.2)}[args.config]
     for key, val in preset.items():
         setattr(args, key, val)
+    if args.config != "ns" and "GPANN_BENCH_N" in os.environ:
+        args.n = int(os.environ["GPANN_BENCH_N"])
     metric = 1 if args.metric == "ip" else 0
     n_centers, sigma = (1, 1.0) if args.dist == "uniform" else (N_CENTERS, SIGMA)
     offset = 100.0 if args.dist == "offset" else 0.0
@@ -188,12 +197,32 @@ def main():
     chunk = 4_000_000
     counts = torch.zeros(S, dtype=torch.int64, device=dev)
     assign_all = torch.empty(n, dtype=torch.int32, device=dev)
+    # --overlap: the reference's MakeOverlappingWithCentroids rates every (point, foreign shard) pair by the distance to that shard's
+    # nearest representative and realises the `overlap * n` best ratings.  Here, at 10^8 points: one representative per shard (its
+    # centroid), the best foreign shard per point, and the rating threshold = the `overlap` quantile of the first chunk's ratings
+    # (points are i.i.d. over the chunks).  second_all[i] = that shard, or -1.
+    second_all = torch.full((n,), -1, dtype=torch.int32, device=dev) if args.overlap > 0 else None
+    overlap_thr = None
+    cent_sq = (shard_cent.double() ** 2).sum(1).float()
     buf = torch.empty((min(chunk, n), d), dtype=torch.float32, device=dev)
     for r0 in range(0, n, chunk):
         m = min(chunk, n - r0)
         synth(buf, POINT_SEED, r0, m)
         pygpann.nearest_centroid_device(buf.data_ptr(), m, d, 0, shard_cent.data_ptr(), S, assign_all[r0:r0 + m].data_ptr(), stream)
-    counts = torch.bincount(assign_all.to(torch.int64), minlength=S).cpu().numpy()
+        if second_all is not None:
+            x = buf[:m]
+            d2 = (x * x).sum(1, keepdim=True) + cent_sq[None, :] - 2.0 * (x @ shard_cent.T)
+            d2.scatter_(1, assign_all[r0:r0 + m].to(torch.int64)[:, None], float("inf"))   # not the shard the point already lives in
+            rating, second = d2.min(dim=1)
+            if overlap_thr is None:
+                overlap_thr = torch.kthvalue(rating, max(1, int(args.overlap * m))).values
+            second_all[r0:r0 + m] = torch.where(rating <= overlap_thr, second.to(torch.int32), torch.full_like(second, -1, dtype=torch.int32))
+            del d2, rating, second
+    counts_t = torch.bincount(assign_all.to(torch.int64), minlength=S)
+    if second_all is not None:
+        counts_t += torch.bincount(second_all[second_all >= 0].to(torch.int64), minlength=S)
+    counts = counts_t.cpu().numpy()
+    store_rows = int(counts.sum())   # rows of the shard store (> n with overlapping shards)
     # Placement.  Rows alone (LPT) balance memory, not work: a shard's work per batch is (queries routed to it) x rows, and the popular
     # shards are also the big ones.  The query load is estimated before anything is built — queries per shard = nearest shard centroid —
     # and the hottest shards get replicas while a rank has room (gpann_plan_replicas; the reference models exactly this when it
@@ -219,6 +248,8 @@ def main():
     mine_mask = torch.zeros(S, dtype=torch.bool, device=dev)
     mine_mask[torch.as_tensor(mine, device=dev)] = True
     keep = mine_mask[assign_all.to(torch.int64)]
+    if second_all is not None:
+        keep |= (second_all >= 0) & mine_mask[second_all.clamp(min=0).to(torch.int64)]
     my_ids = torch.nonzero(keep).squeeze(1)                      # global ids I own, ascending
     n_local = int(my_ids.numel())
     local_points = torch.empty((n_local, d), dtype=torch.float32, device=dev)
@@ -233,13 +264,23 @@ def main():
         local_points[pos:pos + c] = buf[:m][kc]
         pos += c
     del buf, keep
-    my_assign = assign_all[my_ids]
+    # (local row, shard) pairs: every point with its own shard, the overlapping ones once more with their second shard
+    my_assign = assign_all[my_ids].to(torch.int64)
     del assign_all
-    order = torch.sort(my_assign.to(torch.int64), stable=True).indices       # local rows grouped by shard
-    sorted_assign = my_assign[order].cpu().numpy()
-    local_rows_by_shard = order.to(torch.int32).cpu().numpy().astype(np.uint32)
-    global_ids_by_shard = my_ids[order].cpu().numpy().astype(np.uint32)
-    del order, my_assign
+    pair_row = torch.arange(n_local, dtype=torch.int64, device=dev)
+    pair_shard = my_assign
+    if second_all is not None:
+        my_second = second_all[my_ids].to(torch.int64)
+        del second_all
+        prim_ok = mine_mask[my_assign]
+        sec_ok = (my_second >= 0) & mine_mask[my_second.clamp(min=0)]
+        pair_row = torch.cat([pair_row[prim_ok], pair_row[sec_ok]])
+        pair_shard = torch.cat([my_assign[prim_ok], my_second[sec_ok]])
+        del my_second, prim_ok, sec_ok
+    order = torch.sort(pair_shard, stable=True).indices       # grouped by shard: a shard's own points (ascending id), then its extra ones
+    sorted_assign = pair_shard[order].cpu().numpy()
+    local_rows_by_shard = pair_row[order].to(torch.int32).cpu().numpy().astype(np.uint32)
+    del order, my_assign, pair_row, pair_shard
     # Clusters over the LOCAL point array (all S shards; shards of other ranks are empty here)
     bounds = np.searchsorted(sorted_assign, np.arange(S + 1))
     clusters_local = [local_rows_by_shard[bounds[b]:bounds[b + 1]] for b in range(S)]
@@ -270,7 +311,7 @@ def main():
         log(f"router (index budget {index_budget}) trained on the GPU in {train_s:.2f}s: {len(tr['node_shard'])} nodes, {tr['centroids'].shape[0]} centroids")
         return rt, tr, train_s
 
-    log(f"rank {rank}: {n_local} rows in {len(mine)} shards resident; setup {time.time() - t_setup:.1f}s")
+    log(f"rank {rank}: {n_local} points = {len(local_rows_by_shard)} store rows in {len(mine)} shards resident; setup {time.time() - t_setup:.1f}s")
 
     def to_global(ids_local):
         """scan results carry ids of the local point array; map them to the global ids of the synthetic cloud"""
@@ -530,6 +571,10 @@ def main():
         elapsed = comm.max_double(elapsed)
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
     qps = nq * args.steps / elapsed
+    # what the merge of the last step had to drop: ids that came back from more than one probed shard (overlapping shards only)
+    last_ids = np.sort(host_out[(nq, nprobe, (args.steps - 1) & 1)][1].numpy().view(np.uint32).reshape(nq, -1), axis=1)
+    dup_ids = int(np.count_nonzero((last_ids[:, 1:] == last_ids[:, :-1]) & (last_ids[:, 1:] != 0xFFFFFFFF)))
+    slot_entries = int(np.count_nonzero(last_ids != 0xFFFFFFFF))
 
     result = {
         "metric": "QPS @ recall@10=0.9, 10k batched queries" if not args.nprobe else f"QPS @ nprobe={args.nprobe}, 10k batched queries",
@@ -538,10 +583,12 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {n}x{d} f32 {'inner product' if metric else 'L2'}, "
                                + (f"Gaussian mixture ({n_centers} centres, sigma {sigma})" if args.dist != "uniform" else "one Gaussian blob (no clusters)")
-                               + (f" + {offset:g} in every coordinate" if offset else "") + f", {nq} queries, {S} k-means shards, "
+                               + (f" + {offset:g} in every coordinate" if offset else "") + f", {nq} queries, {S} k-means shards"
+                               + (f" overlapping SPANN-style ({store_rows - n} points = {100.0 * (store_rows - n) / n:.1f} % also in a second shard: {store_rows} store rows)" if args.overlap > 0 else "") + ", "
                                f"k={k}, KMeansTreeRouter ({tree['centroids'].shape[0]} centroids in {len(tree['node_shard'])} nodes, search budget {args.search_budget}) + exact "
                                f"shard scan, nprobe={nprobe}",
                    "n": n, "d": d, "metric": args.metric, "dist": args.dist, "queries": nq, "shards": S, "k": k, "nprobe": nprobe, "recall_at_k": recall,
+                   "overlap": args.overlap, "store_rows": store_rows,
                    "parallelism": f"shards over {world} GPU(s), LPT"},
     }
     avg_scan_s = float(np.mean(scan_ms)) / 1000.0
@@ -557,7 +604,7 @@ def main():
         flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only passes run 2 of the 3 products)
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
         # bytes the rest pass has to read: its row tiles x (bf16 hi plane [+ lo plane] + the row's norm word)
-        ks_read = 4 if d <= 64 else (8 if d <= 128 else 16)   # 16-dim k-steps the kernel loads per row and plane (32 B each, zero padded)
+        ks_read = stats["filter_plane_ksteps"]   # 16-dim k-steps a plane row is stored with and the kernel loads (32 B each; ceil(d / 16) rounded up to a kernel instance)
         rest_bytes = stats["filter_rest_rows"] * (32.0 * ks_read * (1.0 if stats["filter_rest_hi_only"] else 2.0) + 4.0)
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": rest_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rest_gbps / HBM_PEAK_GBPS,
@@ -600,7 +647,9 @@ def main():
     result["hbm_resident_GB"] = hbm_resident_gb
     result["config"]["pipeline"] = ("batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned"
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
-    result["detail"] = {"scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
+    result["detail"] = {"merge": {"slot_entries": slot_entries, "duplicate_ids_dropped": dup_ids,
+                                  "note": "DedupNeighbors over the per-slot lists of the last timed step: entries whose id also came back from another probed shard"},
+                        "scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
                         "router_train_s": router_train_s, "router_index_budget": best["index_budget"],

@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members,
 
 // bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
 __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
-                                                                 char* planes, uint64_t lo_offset, uint32_t plane_ks, const float* mu) {
+                                                                 char* planes, uint64_t lo_offset, uint32_t plane_ks, const float* mu,
+                                                                 const uint32_t* tile_lo_index) {
     const uint32_t g_per_row = 2 * plane_ks;   // groups of 8 dims per row: 16 or 32
     const uint64_t total = plane_rows * g_per_row;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -69,9 +70,16 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
 #pragma unroll
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
-        char* base = planes + (r >> 5) * ((uint64_t)plane_ks * 1024) + ks * 1024 + lane * 16;   // all hi tiles first, then all lo tiles
+        const uint64_t tile_bytes = (uint64_t)plane_ks * 1024;
+        char* base = planes + (r >> 5) * tile_bytes + ks * 1024 + lane * 16;   // all hi tiles first, then the lo tiles
         *reinterpret_cast<uint4*>(base) = fh.q;
-        *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
+        // lo tile: at the same index as the hi tile (tile_lo_index == nullptr), or at tile_lo_index[tile] of the lo array if the tile has one
+        if (!tile_lo_index) {
+            *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
+        } else {
+            const uint32_t li = tile_lo_index[r >> 5];
+            if (li != kNoRow) *reinterpret_cast<uint4*>(planes + lo_offset + li * tile_bytes + ks * 1024 + lane * 16) = fl.q;
+        }
     }
 }
 
@@ -128,7 +136,7 @@ __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, con
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.d_mu})
+                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -228,7 +236,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     C.n_tiles = C.cell_tile_begin.back();
     if (C.n_cells == 0) return give_up("no cells");
     const uint64_t plane_rows = C.n_tiles * kGTileRows;
-    C.plane_ks = s->d <= 128 ? 8u : 16u;
+    C.plane_ks = PlaneKSteps(s->d);
     const size_t tile_bytes = (size_t)C.plane_ks * 1024;   // one plane of one tile
     // the shard sample: the first rows of every shard (store order = the order of Clusters[b] = a random sample), appended as tiles of their own
     std::vector<uint32_t> sample_perm_host;
@@ -248,6 +256,32 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     const uint64_t all_tiles = C.sample_tile_base + C.n_sample_tiles;   // cell tiles | 2 zero tiles | sample tiles (| 2 zero tiles)
     C.lo_offset_tiles = all_tiles + 2;
     const uint64_t all_rows = all_tiles * kGTileRows;
+    // which tiles get a lo tile (shards.h): every one (GPANN_FILTER_LO_ROWS=all), or the sample tiles and the first rows of every cell —
+    // the only ones the two-plane passes read.  Beyond 128 dimensions every pass is a hi-plane pass: no lo tiles at all.
+    std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), tile_lo_index;
+    {
+        const char* lr = std::getenv("GPANN_FILTER_LO_ROWS");
+        C.lo_full = lr && std::string(lr) == "all";
+        const uint64_t lo_rows = C.plane_ks > 8 ? 0 : (lr && !C.lo_full ? (uint64_t)std::max(0L, std::atol(lr)) : 512);
+        C.lo_head_tiles = C.lo_full ? 0xFFFFFFFFu : (uint32_t)((lo_rows + kGTileRows - 1) / kGTileRows);
+        if (C.lo_full) {
+            for (uint32_t c = 0; c <= C.n_cells; ++c) cell_lo_begin[c] = (uint32_t)C.cell_tile_begin[c];
+            C.lo_sample_begin = C.sample_tile_base;
+            C.n_lo_tiles = all_tiles;
+        } else {
+            tile_lo_index.assign(C.n_tiles, kNoRow);
+            uint64_t at = 0;
+            for (uint32_t c = 0; c < C.n_cells; ++c) {
+                cell_lo_begin[c] = (uint32_t)at;
+                const uint64_t keep = std::min<uint64_t>(C.lo_head_tiles, C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]);
+                for (uint64_t i = 0; i < keep; ++i) tile_lo_index[C.cell_tile_begin[c] + i] = (uint32_t)(at + i);
+                at += keep;
+            }
+            cell_lo_begin[C.n_cells] = (uint32_t)at;
+            C.lo_sample_begin = at + 2;
+            C.n_lo_tiles = C.lo_sample_begin + (C.plane_ks > 8 ? 0 : C.n_sample_tiles);
+        }
+    }
 
     uint64_t* d_member_begin = nullptr;
     uint32_t* d_cell_size = nullptr;
@@ -255,8 +289,12 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
               hipMalloc(&C.d_center, (size_t)C.n_cells * ld * 4) == hipSuccess && hipMalloc(&C.d_radius, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.plane_perm, all_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (all_rows + 64) * 4) == hipSuccess &&
-              hipMalloc(&s->frag_planes, 2 * C.lo_offset_tiles * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
-              hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess;
+              hipMalloc(&s->frag_planes, (C.lo_offset_tiles + C.n_lo_tiles + 2) * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
+              hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess && hipMalloc(&C.d_cell_lo_begin, (size_t)(C.n_cells + 1) * 4) == hipSuccess;
+    uint32_t* d_tile_lo_index = nullptr;
+    if (ok && !tile_lo_index.empty())
+        ok = hipMalloc(&d_tile_lo_index, tile_lo_index.size() * 4) == hipSuccess &&
+             hipMemcpy(d_tile_lo_index, tile_lo_index.data(), tile_lo_index.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     std::vector<float> cnorm(C.n_cells);
     for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
         double acc = 0.0;
@@ -272,8 +310,11 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemcpy(d_cell_size, cell_size.data(), C.n_cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemset(C.plane_norm + plane_rows, 0, (all_rows - plane_rows + 64) * 4) == hipSuccess &&
              hipMemset(C.plane_perm + plane_rows, 0xFF, (all_rows - plane_rows) * 4) == hipSuccess &&   // (kNoRow: the gap tiles and, for now, the sample)
+             hipMemcpy(C.d_cell_lo_begin, cell_lo_begin.data(), (size_t)(C.n_cells + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, (C.lo_offset_tiles - C.n_tiles) * tile_bytes) == hipSuccess &&
-             hipMemset(s->frag_planes + (C.lo_offset_tiles + C.n_tiles) * tile_bytes, 0, (C.lo_offset_tiles - C.n_tiles) * tile_bytes) == hipSuccess;
+             // the lo array: everything that is not a cell's lo tile (the gaps, the sample's tiles until they are written)
+             (C.lo_full ? hipMemset(s->frag_planes + (C.lo_offset_tiles + C.n_tiles) * tile_bytes, 0, (C.n_lo_tiles + 2 - C.n_tiles) * tile_bytes)
+                        : hipMemset(s->frag_planes + (C.lo_offset_tiles + cell_lo_begin[C.n_cells]) * tile_bytes, 0, (C.n_lo_tiles + 2 - cell_lo_begin[C.n_cells]) * tile_bytes)) == hipSuccess;
     }
     // squared L2: everything the matrix-core bound touches is taken around the store's mean row (translation leaves the distances alone
     // and makes |p|, |q| — which the bound's error terms scale with — as small as the data allows; a cloud that sits at +100 in every
@@ -311,12 +352,13 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
         const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
-                           (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu);
+                           (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu, C.lo_full ? nullptr : d_tile_lo_index);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }
     if (d_member_begin) (void)hipFree(d_member_begin);
     if (d_cell_size) (void)hipFree(d_cell_size);
+    if (d_tile_lo_index) (void)hipFree(d_tile_lo_index);
     if (!ok) return give_up("device");
 
     // the shard sample's rows, norms and planes behind the cell tiles
@@ -330,8 +372,21 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
             if (sok) {
                 hipLaunchKernelGGL(SampleNormKernel, dim3((uint32_t)((srows + 255) / 256)), dim3(256), 0, 0, sperm, srows, s->neg_half_norm, snorm);
                 const int g3 = (int)std::min<uint64_t>((srows * 2 * C.plane_ks + 255) / 256, 256 * 64);
-                hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
-                                   (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu);
+                // (the sample's lo tiles: lo_sample_begin + j of the lo array; beyond 128 dimensions there are none — they land in the two spare tiles' place,
+                // which the allocation covers only for j < 2: write them nowhere instead)
+                if (C.plane_ks > 8) {
+                    // hi planes only: a lo index table that says "none" for every sample tile
+                    uint32_t* d_none = nullptr;
+                    sok = hipMalloc(&d_none, C.n_sample_tiles * 4) == hipSuccess && hipMemset(d_none, 0xFF, C.n_sample_tiles * 4) == hipSuccess;
+                    if (sok)
+                        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
+                                           (uint64_t)0, C.plane_ks, C.d_mu, d_none);
+                    sok = sok && hipDeviceSynchronize() == hipSuccess;
+                    if (d_none) (void)hipFree(d_none);
+                } else {
+                    hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
+                                       (uint64_t)(C.lo_offset_tiles + C.lo_sample_begin - C.sample_tile_base) * tile_bytes, C.plane_ks, C.d_mu, (const uint32_t*)nullptr);
+                }
                 sok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
             }
         }

@@ -541,20 +541,24 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const auto& C = s->cells;
     const uint32_t kmax = C.kmax;
     const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
-    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (1536ull << 20) / (4ull * T))));
+    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (6144ull << 20) / (4ull * T))));
     // Three filter passes keep the candidate buckets small whatever the geometry: rows inside a cell are in store order, i.e.
     // a random sample of the cell, so after a pass over a fraction 1/f of the needed rows only about f * k rows of the rest can
     // still beat the k-th distance.  Pass 0 = the head of each task's nearest cell (at most half a bucket of rows), pass 1 =
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
     // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
-    const uint32_t head_tiles = std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows;
+    // (the head pass multiplies both planes: it cannot reach past the rows that have a lo tile)
+    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows, C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles);
     int64_t max_rows = 1;
     for (uint32_t b = 0; b < S; ++b) max_rows = std::max<int64_t>(max_rows, s->offsets[b + 1] - s->offsets[b]);
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap);
     const uint32_t sample_div = std::max<uint32_t>(2, EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
-    const bool l2 = s->metric == GPANN_METRIC_L2, aux = (flags & GPANN_AUX_PASS) != 0, ks4 = s->d <= 64, ks16 = s->d > 128;
-    const uint32_t group_tasks = ks16 ? 128u : (uint32_t)kGTasks;   // the query image of a group has to fit LDS: 4 query tiles at 16 k-steps
+    const bool l2 = s->metric == GPANN_METRIC_L2;
+    (void)flags;
+    const uint32_t KS = C.plane_ks, QT = (uint32_t)FilterQueryTiles((int)KS);
+    const bool wide = KS > 8;   // beyond 128 dimensions: hi-plane passes only, 4 query tiles per group
+    const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
     GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
@@ -658,13 +662,18 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
 
     // ---- the groups' query images (bf16 fragments in MFMA B-operand order), once per call
-    const uint32_t img_ks = ks16 ? 16u : (ks4 ? 4u : 8u), img_qt = ks16 ? 4u : 8u;
-    GPANN_TRY(s->ws_image.Reserve((size_t)G * img_qt * img_ks * 2048 + 256));
+    GPANN_TRY(s->ws_image.Reserve((size_t)G * QT * KS * 2048 + 256));
     {
         char* img = s->ws_image.as<char>();
-        if (ks16) hipLaunchKernelGGL((QueryImageKernel<16, 4>), dim3(G * 4), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img, C.d_mu);
-        else if (ks4) hipLaunchKernelGGL((QueryImageKernel<4, 8>), dim3(G * 8), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img, C.d_mu);
-        else hipLaunchKernelGGL((QueryImageKernel<8, 8>), dim3(G * 8), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img, C.d_mu);
+        switch (KS) {
+#define GPANN_IMAGE(KS_)                                                                                                                              \
+    case KS_:                                                                                                                                         \
+        hipLaunchKernelGGL((QueryImageKernel<KS_, FilterQueryTiles(KS_)>), dim3(G * QT), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, img, C.d_mu); \
+        break;
+            GPANN_IMAGE(2) GPANN_IMAGE(4) GPANN_IMAGE(6) GPANN_IMAGE(7) GPANN_IMAGE(8) GPANN_IMAGE(10) GPANN_IMAGE(13) GPANN_IMAGE(16)
+#undef GPANN_IMAGE
+            default: GPANN_REQUIRE(false, "no filter kernel for this number of k-steps");
+        }
         GPANN_HIP_TRY(hipGetLastError());
     }
 
@@ -744,6 +753,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.groups = d_groups;
     fa.shard_cell_begin = C.d_shard_cell_begin;
     fa.cell_tile_begin = C.d_cell_tile_begin;
+    fa.cell_lo_begin = C.d_cell_lo_begin;
     fa.kmax = kmax;
     fa.head_tiles = head_tiles;
     fa.sample_div = sample_div;
@@ -782,29 +792,26 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.shard_cell_begin = C.d_shard_cell_begin;
     ra.cell_tile_begin = C.d_cell_tile_begin;
     ra.plane_perm = C.plane_perm;
+    // the kernel for this store's k-steps: both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
     const void *fn = nullptr, *fn_hi = nullptr;
-#define GPANN_PICK(M, TAG_, KS_, HI_) (const void*)FilterKernelCells<M, TAG_, KS_, HI_>
-#define GPANN_PICK2(HI_)                                                                                                   \
-    (l2 ? (aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 1, 4, HI_) : GPANN_PICK(GPANN_METRIC_L2, 1, 8, HI_))                     \
-               : (ks4 ? GPANN_PICK(GPANN_METRIC_L2, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_L2, 0, 8, HI_)))                    \
-        : (aux ? (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 1, 8, HI_))                 \
-               : (ks4 ? GPANN_PICK(GPANN_METRIC_MIPS, 0, 4, HI_) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 8, HI_))))
-    if (ks16) {   // 16 k-steps: hi-plane passes only (two tiles of both planes do not fit the register file)
-        fn_hi = l2 ? (aux ? GPANN_PICK(GPANN_METRIC_L2, 1, 16, true) : GPANN_PICK(GPANN_METRIC_L2, 0, 16, true))
-                   : (aux ? GPANN_PICK(GPANN_METRIC_MIPS, 1, 16, true) : GPANN_PICK(GPANN_METRIC_MIPS, 0, 16, true));
-        fn = fn_hi;
-    } else {
-        fn = GPANN_PICK2(false);
-        fn_hi = GPANN_PICK2(true);
-    }
-#undef GPANN_PICK2
+    switch (KS) {
+#define GPANN_PICK(KS_)                                                                                                                                   \
+    case KS_:                                                                                                                                             \
+        fn_hi = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, true> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, true>;      \
+        if constexpr (KS_ <= 8) fn = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, false> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, false>; \
+        else fn = fn_hi;                                                                                                                                  \
+        break;
+        GPANN_PICK(2) GPANN_PICK(4) GPANN_PICK(6) GPANN_PICK(7) GPANN_PICK(8) GPANN_PICK(10) GPANN_PICK(13) GPANN_PICK(16)
 #undef GPANN_PICK
+        default: GPANN_REQUIRE(false, "no filter kernel for this number of k-steps");
+    }
     // the sample and rest passes (all but the small head pass) read only the hi plane of the points: half the HBM bytes and two of
-    // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates);
-    // GPANN_FILTER_HI_ONLY=0 keeps all three products everywhere.  Beyond 128 dimensions every pass is a hi-plane pass.
-    const bool hi_last = ks16 || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
-    const int hi_from_pass = ks16 ? 0 : (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1);
-    const size_t glds = FilterLdsBytes((size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048);
+    // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates).  A store
+    // built with GPANN_FILTER_LO_ROWS=all has a lo tile for every tile: GPANN_FILTER_HI_ONLY=0 then keeps all three products everywhere,
+    // GPANN_FILTER_HI_FROM_PASS chooses the first hi-plane pass.  Beyond 128 dimensions every pass is a hi-plane pass.
+    const bool hi_last = wide || !C.lo_full || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
+    const int hi_from_pass = wide ? 0 : (C.lo_full ? (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1) : (int)std::min<uint32_t>(1, EnvU32("GPANN_FILTER_HI_FROM_PASS", 1)));
+    const size_t glds = FilterLdsBytes((size_t)QT * KS * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
@@ -855,8 +862,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 it.t_end = (uint32_t)std::min<uint64_t>(t1, t + piece);
                 it.t_a = it.t_b = it.t_begin;   // no head / sample segment: every query tile runs on every row tile
                 it.task_begin = groups[g].task_begin;
-                it.task_count = groups[g].task_count;
-                it.acts = mask | mask << 8 | mask << 16;
+                it.lo_shift = (uint32_t)(C.sample_tile_base - C.lo_sample_begin);   // sample tile j: hi tile sample_tile_base + j, lo tile lo_sample_begin + j
+                it.acts = mask | mask << 8 | mask << 16 | (groups[g].task_count - 1u) << 24;
                 it.group = g;
                 sitems.push_back(it);
             }
@@ -870,7 +877,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(UploadAsync(s, d_stab, stab.data(), (size_t)3 * G * 4, st));
             GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
             GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-            th.hi_only = ks16 ? 1u : 0u;
+            th.hi_only = wide ? 1u : 0u;
             if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
             else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
             CellFilterArgs fs = fa;
@@ -975,6 +982,12 @@ static bool FilterWanted(const gpann_shards* s, uint32_t k) {
 static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
                                  uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
     ScanPlan& plan = s->plan;
+    // The pinned staging area and the plan's host arrays are the sources of the previous call's asynchronous uploads: that call may have
+    // returned with them still queued (device output, no timing — nothing made it synchronise), so wait for its last upload first.
+    if (s->stage_in_flight) {
+        GPANN_HIP_TRY(hipEventSynchronize(s->ev[3]));
+        s->stage_in_flight = false;
+    }
     plan.Clear();
     GPANN_TRY(BuildTasks(s, nq, probes, probe_stride, nprobe, plan));
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
@@ -1029,6 +1042,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
     }
     GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
+    GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));   // every staged upload of this call is queued before this point
+    s->stage_in_flight = true;
 
     s->stats.pairs = plan.pairs;
     s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)T * k * 8ull;
@@ -1040,6 +1055,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.filter_rest_rows = plan.filter_rest_rows;
     s->stats.filter_rest_hi_only = plan.filter_rest_hi_only ? 1u : 0u;
     s->stats.filter_candidates = plan.filter_candidates;
+    s->stats.filter_plane_ksteps = s->stats.filtered ? s->cells.plane_ks : 0u;
     return GPANN_OK;
 }
 

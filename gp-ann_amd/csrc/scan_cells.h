@@ -36,8 +36,9 @@ struct CellGroup {
 struct CellItem {   // everything FilterKernelCells needs to run one piece of a (task group, cell) block: one 32-byte record
     uint32_t t_begin, t_end;   // row tiles of this piece
     uint32_t t_a, t_b;         // the cell's head segment ends at tile t_a, its sample segment at t_b
-    uint32_t task_begin, task_count;
-    uint32_t acts;             // query tiles to run on the head | sample << 8 | rest << 16 segment
+    uint32_t task_begin;
+    uint32_t lo_shift;         // the lo plane of row tile T is tile T - lo_shift of the lo array (two-plane passes only; shards.h)
+    uint32_t acts;             // query tiles to run on the head | sample << 8 | rest << 16 segment | (tasks of the group - 1) << 24
     uint32_t group;            // the task group (its query image)
 };
 
@@ -266,13 +267,14 @@ struct CellFilterArgs {
     uint32_t* cand_row;
     uint32_t cand_cap, ld;
     const char* frag_planes;     // all hi tiles (plane_tile_bytes each), then at +plane_lo_offset all lo tiles
-    uint64_t plane_lo_offset;
-    uint32_t plane_tile_bytes;   // KiB per tile and plane = the store's k-steps (8 for d <= 128, 16 for d <= 256)
+    uint64_t plane_lo_offset;    // where the lo array starts
+    uint32_t plane_tile_bytes;   // KiB per tile and plane = the store's k-steps (PlaneKSteps(d))
     const float* plane_norm;
     const uint32_t* plane_perm;
     const CellGroup* groups;
     const uint32_t* shard_cell_begin;
     const uint64_t* cell_tile_begin;
+    const uint32_t* cell_lo_begin;   // [cells+1] first lo tile of every cell (CellItem::lo_shift)
     const uint32_t* need;        // [groups][kmax] query tiles to run in this pass
     // A cell's tiles form three segments: head [0, head_tiles), sample [head_tiles, max(head_tiles, tiles / sample_div)), rest.
     // Pass p (0 head, 1 sample, 2 rest) covers segments 0..p; done0 / done1 are the query tiles that already ran on segment 0 / 1.
@@ -334,8 +336,8 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     it.t_a = (uint32_t)t_a;
     it.t_b = (uint32_t)t_b;
     it.task_begin = a.groups[g].task_begin;
-    it.task_count = a.groups[g].task_count;
-    it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16;
+    it.lo_shift = (uint32_t)t_cell - a.cell_lo_begin[cell0 + j];
+    it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (a.groups[g].task_count - 1u) << 24;
     it.group = g;
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
@@ -370,6 +372,8 @@ __device__ __forceinline__ void DmaToLds16(const void* gsrc, uint32_t lds_addr) 
 __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+// query tiles (of 32 tasks) per task group: the group's image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS beside the norms and the queues
+constexpr int FilterQueryTiles(int ks) { return ks <= 8 ? 8 : 4; }
 
 // Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
 // Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
@@ -413,10 +417,10 @@ __device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, 
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
 // query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
 // tiles do not fit the register file).
-template <int METRIC, int TAG, int KS, bool HI_ONLY, int QT = (KS <= 8 ? 8 : 4)>
+template <int METRIC, int TAG, int KS, bool HI_ONLY, int QT = FilterQueryTiles(KS)>
 __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
     static_assert(QT == 4 || QT == 8, "query tiles per group");
-    static_assert(KS <= 8 || HI_ONLY, "16 k-steps: hi-plane passes only");
+    static_assert(KS <= 8 || HI_ONLY, "more than 8 k-steps: hi-plane passes only");
     extern __shared__ uint4 csm4[];
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
@@ -460,13 +464,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
 
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T) __attribute__((always_inline)) {
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
+        const char* base_lo = lane_planes + a.plane_lo_offset + (size_t)T_lo * a.plane_tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             // (read-once stream: non-temporal, leaves L2 to the query rows / tables)
             Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
-            if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + a.plane_lo_offset + ks * 1024));
+            if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base_lo + ks * 1024));
         }
         if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
     };
@@ -503,18 +508,21 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     uint32_t loaded_group = kNoItem, loaded = 0;   // the query image in LDS: whose, and which of its query tiles
     float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image)
     uint32_t iter = 0;
-    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_task_count, r_acts, r_group;
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group;
     {
         const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
         r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
-        r_task_begin = uniform(hi.x); r_task_count = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+        r_task_begin = uniform(hi.x); r_lo_shift = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
     }
-    load_tile(Ah[0], Al[0], nrm[0], min(r_t_begin + wave, r_t_end - 1));
+    {
+        const uint32_t T0 = min(r_t_begin + wave, r_t_end - 1);
+        load_tile(Ah[0], Al[0], nrm[0], T0, T0 - r_lo_shift);
+    }
     for (;;) {
     // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
     const uint32_t t_begin = r_t_begin, t_end = r_t_end, t_a = r_t_a, t_b = r_t_b;
-    const uint32_t task_begin = r_task_begin, task_count = r_task_count;
     const uint32_t acts = r_acts;
+    const uint32_t task_begin = r_task_begin, task_count = (acts >> 24) + 1u;
     const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
     uint32_t next_idx = 0;
     if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
@@ -658,6 +666,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const uint32_t after = uniform(s_claim[2 + (iter & 1u)]);
     ++iter;
     const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
+    const uint32_t lo_shift = r_lo_shift, n_lo_shift = HI_ONLY ? 0u : uniform(n_hi.y);   // (n_hi is this item's record after the last item)
     const uint32_t t_last = t_end - 1;
     // this wavefront's first tile of the next item
     const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave, n_t_end - 1) : t_last;
@@ -667,13 +676,13 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
             uint32_t Tn = T + kFWaves;
             uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own));
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
             compute_tile(Ah[0], Al[0], nrm[0], T);
             T = Tn;
             if (T >= t_end) break;
             Tn = T + kFWaves;
             own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own));
+            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
             compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
             T = Tn;
             if (T >= t_end) break;
@@ -687,13 +696,13 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             nrm[0] = nrm[1];
         }
     } else {
-        load_tile(Ah[0], Al[0], nrm[0], n_first);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
+        load_tile(Ah[0], Al[0], nrm[0], n_first, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
     }
     if (nxt == kNoItem) break;
     const uint32_t n_group = uniform(n_hi.w);
     if (n_group != r_group) __syncthreads();   // the next item replaces the query image: everyone has to be done with this one
     r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
-    r_task_begin = uniform(n_hi.x); r_task_count = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
+    r_task_begin = uniform(n_hi.x); r_lo_shift = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
     item = nxt;
     nxt = after;
     }   // next item

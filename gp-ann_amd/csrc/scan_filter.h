@@ -53,6 +53,13 @@ union Frag {   // 8 bf16 = 4 VGPRs, the A/B operand of v_mfma_f32_32x32x16_bf16
 // tiles in one array and all lo tiles in a second one (the big passes stream only the hi array, sequentially); the router's
 // centroid planes keep hi and lo of a tile side by side (kGTileBytes).
 constexpr int kGTileRows = 32;
+// k-steps (16 dimensions each) a row of d dimensions is stored with: ceil(d / 16), rounded up to the next count FilterKernelCells /
+// QueryImageKernel are instantiated for.  A plane row is 32 * k-steps bytes: d = 96 -> 6 (192 B), 100 -> 7, 128 -> 8, 200 -> 13.
+// (Rounds 1-2 knew 4 / 8 / 16 only: every d between paid for the zeros up to the next power of two in HBM bytes and MFMA issue.)
+__host__ __device__ constexpr uint32_t PlaneKSteps(uint32_t d) {
+    const uint32_t need = (d + 15u) / 16u;
+    return need <= 2 ? 2u : need <= 4 ? 4u : need <= 6 ? 6u : need <= 7 ? 7u : need <= 8 ? 8u : need <= 10 ? 10u : need <= 13 ? 13u : 16u;
+}
 constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane][16 B]
 constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
 constexpr int kGTasks = 256;                   // tasks per filter group: 8 query tiles of 32

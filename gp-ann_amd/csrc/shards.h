@@ -42,7 +42,8 @@ struct ScanPlan {
 
 // Pinned host staging area of a handle: the small per-call arrays (task lists, group tables, counters) travel through it, so their
 // hipMemcpyAsync calls are real asynchronous copies — from pageable memory every one of them is a synchronous staging copy of the runtime
-// (12 us of idle GPU each, a dozen per scan call).  Reset at the start of a call; the previous call has synchronised by then.
+// (12 us of idle GPU each, a dozen per scan call).  Reset at the start of a call, after waiting for the previous call's last upload
+// (gpann_shards::stage_in_flight): an untimed call with device output returns without synchronising.
 struct PinnedStage {
     char* base = nullptr;
     size_t cap = 0, used = 0;
@@ -93,7 +94,7 @@ struct gpann_shards {
         uint32_t n_cells = 0, kmax = 0;            // all cells of the store (numbered shard by shard); most cells in one shard
         uint64_t n_tiles = 0;                      // 32-row tiles of the planes
         std::vector<uint32_t> shard_cell_begin;    // [S+1] host
-        uint32_t plane_ks = 8;                     // k-steps (16 dims each) per plane tile: 8 (d <= 128) or 16 (d <= 256); a tile of a plane is plane_ks KiB
+        uint32_t plane_ks = 8;                     // k-steps (16 dims each) per plane tile = PlaneKSteps(d): ceil(d / 16) rounded up to one the kernels exist for; a tile of a plane is plane_ks KiB
         std::vector<uint64_t> cell_tile_begin;     // [n_cells+1] host
         uint32_t* d_shard_cell_begin = nullptr;    // [S+1]
         uint64_t* d_cell_tile_begin = nullptr;     // [n_cells+1]
@@ -109,7 +110,17 @@ struct gpann_shards {
         std::vector<uint64_t> sample_tile_begin;   // [S+1] host: first sample tile of every shard, relative to sample_tile_base
         uint64_t n_sample_tiles = 0;
         uint64_t sample_tile_base = 0;             // = n_tiles + 2 (two zero tiles follow the cell tiles: the kernels' prefetch may run past a range)
-        uint64_t lo_offset_tiles = 0;              // the lo plane of tile T lies lo_offset_tiles tiles after its hi plane (= all tiles + 2)
+        // The lo planes follow the hi tiles (+ 2 zero tiles) as an array of their own, lo_offset_tiles tiles into `frag_planes`.  Only the
+        // passes that multiply both planes read them — the shard-sample pass and the head pass — so by default only the sample tiles and
+        // the first lo_head_tiles tiles of every cell HAVE a lo tile (NS: 0.5 GB instead of 51 GB): lo tile cell_lo_begin[c] + i belongs
+        // to tile i of cell c, lo tile lo_sample_begin + j to sample tile j.  lo_full (GPANN_FILTER_LO_ROWS=all at store build): every
+        // tile has one, at its own index (the layout of rounds 1-2; allows GPANN_FILTER_HI_ONLY=0 / GPANN_FILTER_HI_FROM_PASS=2).
+        uint64_t lo_offset_tiles = 0;
+        uint32_t lo_head_tiles = 0;                // lo tiles kept per cell (its first tiles); 0xFFFFFFFF when lo_full
+        bool lo_full = false;
+        uint64_t n_lo_tiles = 0;                   // tiles of the lo array (cells' heads | 2 zero tiles | sample tiles)
+        uint64_t lo_sample_begin = 0;              // first lo tile of the shard sample
+        uint32_t* d_cell_lo_begin = nullptr;       // [n_cells+1] first lo tile of every cell
         // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
         // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
         float* d_mu = nullptr;
@@ -119,7 +130,8 @@ struct gpann_shards {
 
     // per-call workspace, grown on demand and reused
     gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of a call, [3] its last staged upload
+    bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
     hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
                                                                                           // and of the rest pass's filter launch alone
     int filter_passes_timed = 0;

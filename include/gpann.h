@@ -136,7 +136,7 @@ typedef struct gpann_scan_stats {
     uint64_t filter_pairs;       /* (query, row) pairs evaluated by the MFMA pre-filter (0 in exact mode) */
     uint64_t filter_candidates;  /* rows that passed the pre-filter and were re-scored exactly (all passes) */
     uint32_t filtered;           /* 1 if the MFMA-filtered pipeline produced the result, 0 if the plain exact scan did */
-    uint32_t reserved;
+    uint32_t filter_plane_ksteps;/* 16-dimension k-steps a plane row of the filter is stored with (32 bytes each per row and plane); 0 in exact mode */
     float scan_ms;               /* scan kernels (exact mode: ScanTileKernel; filter mode: every kernel of the pipeline), HIP events */
     float merge_ms;              /* merge kernel(s), HIP events */
     float filter_ms;             /* of scan_ms: the MFMA filter kernels (threshold + filter launches of all passes) */

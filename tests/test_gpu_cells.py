@@ -32,7 +32,9 @@ def _check(orc, gp, pts, clusters, queries, probes, nprobe, k, metric, expect_fi
 
 
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("d", [128, 96, 30, 7, 130, 200, 256])   # > 128: 16 k-steps, 128-task groups, hi-plane passes only
+# every k-step count the kernels exist for (PlaneKSteps: 2, 4, 6, 7, 8, 10, 13, 16) and the dimensions that round up to them;
+# > 128: 128-task groups, hi-plane passes only
+@pytest.mark.parametrize("d", [128, 96, 100, 112, 30, 7, 50, 130, 160, 200, 208, 256])
 def test_cells_match_oracle(orc, gp, metric, d):
     rng = np.random.default_rng(d * 5 + metric)
     n, S, nq, k = 40000, 3, 300, 10
@@ -42,6 +44,26 @@ def test_cells_match_oracle(orc, gp, metric, d):
     probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
     st = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
     assert st["filter_pairs"] > 0
+    want_ks = next(ks for ks in (2, 4, 6, 7, 8, 10, 13, 16) if 16 * ks >= d)
+    assert st["filter_plane_ksteps"] == want_ks, st       # the planes are stored with ceil(d / 16) k-steps, not 4 / 8 / 16
+
+
+@pytest.mark.parametrize("lo_rows", ["all", "0", "64", None])
+def test_cells_lo_plane_layouts(orc, gp, monkeypatch, lo_rows):
+    """The lo planes exist only for the rows the two-plane passes read (default: the shard sample and the first 512 rows of every cell);
+    GPANN_FILTER_LO_ROWS=all keeps one per tile (and allows full-precision later passes), 0 none for the cells: same bits every time."""
+    if lo_rows is not None:
+        monkeypatch.setenv("GPANN_FILTER_LO_ROWS", lo_rows)
+    rng = np.random.default_rng(77)
+    n, d, S, nq, k = 50000, 100, 3, 400, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S, overlap=0.1)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    _check(orc, gp, pts, clusters, queries, probes, 2, k, 0)
+    if lo_rows == "all":
+        monkeypatch.setenv("GPANN_FILTER_HI_ONLY", "0")      # all three products in every pass: needs the full lo array
+        _check(orc, gp, pts, clusters, queries, probes, 2, k, 0)
 
 
 def test_cells_prune_clustered_data(orc, gp):

@@ -142,3 +142,52 @@ def test_larger_segmented_scan(orc, gp):
     queries = make_mixture(orc, nq, d, seed=556)
     probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
     _check_buckets(orc, gp, pts, clusters, queries, probes, S, k, 0)
+
+
+def test_back_to_back_untimed_device_calls_do_not_share_staged_tasks(orc, gp):
+    """Two untimed exact scans with device output return without synchronising; the second call must not overwrite the pinned staging
+    bytes (task arrays, unit lists) the first one is still uploading from (PinnedStage reuse)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")   # the runtime libgpann_hip.so is linked against (device buffers and a stream without torch)
+
+    def ok(rc):
+        assert rc == 0, f"hip error {rc}"
+
+    def dev_alloc(nbytes):
+        p = C.c_void_p()
+        ok(hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)))
+        return p
+
+    rng = np.random.default_rng(21)
+    n, d, S, nq, k = 40000, 64, 6, 2000, 10
+    pts = make_mixture(orc, n, d)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(0)
+    ivf = orc.ivf_build(pts, clusters)
+    q_dev = dev_alloc(queries.nbytes)
+    ok(hip.hipMemcpy(q_dev, queries.ctypes.data_as(C.c_void_p), C.c_size_t(queries.nbytes), 1))
+    st = C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(st)))
+    probes = [np.stack([rng.permutation(S)[:2] for _ in range(nq)]).astype(np.int32) for _ in range(3)]
+    nb = nq * 2 * k * 4
+    outs = [(dev_alloc(nb), dev_alloc(nb)) for _ in range(3)]
+    ok(hip.hipDeviceSynchronize())
+    for pr, (oi, od) in zip(probes, outs):   # no timing, no synchronisation in between
+        shards.scan_buckets_device(q_dev.value, nq, k, pr, 2, oi.value, od.value, st.value, timed=False)
+    ok(hip.hipStreamSynchronize(st))
+    for pr, (oi, od) in zip(probes, outs):
+        ids = np.empty((nq, 2, k), np.uint32)
+        dist = np.empty((nq, 2, k), np.float32)
+        ok(hip.hipMemcpy(ids.ctypes.data_as(C.c_void_p), oi, C.c_size_t(nb), 2))
+        ok(hip.hipMemcpy(dist.ctypes.data_as(C.c_void_p), od, C.c_size_t(nb), 2))
+        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, pr, 2, 0, nthreads=4)
+        assert np.array_equal(ids, wi)
+        assert np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+    shards.close()
+    for a, b in outs:
+        hip.hipFree(a)
+        hip.hipFree(b)
+    hip.hipFree(q_dev)
+    hip.hipStreamDestroy(st)
