@@ -120,6 +120,16 @@ def main():
     ap.add_argument("--replica-capacity", type=float, default=float(os.environ.get("GPANN_BENCH_REPLICA_CAPACITY", 2.0)),
                     help="N > 1: rows a rank may hold, in units of its fair share (rows / N); the room beyond 1.0 is filled with replicas of the "
                          "shards that attract the most query work (0: no replicas, LPT by rows)")
+    ap.add_argument("--no-merge-bound", action="store_true",
+                    help="timed steps: complete per-slot lists instead of GPANN_SCAN_FOR_MERGE (lists cut at the query's merge bound — the merged "
+                         "neighbours are bit-identical either way; only matters for nprobe > 1)")
+    ap.add_argument("--emulate-world", type=str, default="",
+                    help="one GPU only, e.g. 2,4,8: after the timed run, for every listed world size W and every rank r < W build ONLY rank r's "
+                         "shards of the W-way placement (LPT + replica plan, exactly what --gpus W would place) from the same points, run its "
+                         "steps alone on this GPU — routing of its query slice, scan of the slots it owns for all queries, D2H, host merge — and "
+                         "report per-rank ms/step and the implied W-GPU QPS = nq / (max over ranks + exchange); the exchange is timed on this GPU "
+                         "through the real RCCL calls with one rank, its wire time is an estimate.  A hardware-free strong-scaling prediction, "
+                         "not a measurement of W GPUs (`scale_emulated` in the JSON line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-compare", action="store_true", help="skip the extra steps in exact (VALU) scan mode")
     args = ap.parse_args()
@@ -289,6 +299,8 @@ def main():
     # two steps: the rows (InvertedIndex gather) while the generated point array still exists, the filter's planes / cells after it is gone
     # (100M x 200: 80 GB + 80 GB + 102 GB would not fit)
     shards = pygpann.Shards(local_points.data_ptr(), clusters_local, metric, local_rank, n=n_local, d=d, plain=True)
+    emulate_worlds = [int(x) for x in args.emulate_world.split(",") if x] if world == 1 else []
+    points_kept = local_points if emulate_worlds else None   # (--emulate-world builds the emulated ranks' stores from the same point array)
     del local_points
     torch.cuda.empty_cache()
     if args.scan_mode == "filter":
@@ -330,7 +342,7 @@ def main():
     host_out = {}   # pinned result buffers per (nq, nprobe)
     dev_out = {}    # device result buffers per nprobe
 
-    def scan_slots(probes, nprobe, timed=False, aux=False, buf=0):
+    def scan_slots(probes, nprobe, timed=False, aux=False, buf=0, for_merge=False):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host.
         buf: which of the two pinned host buffer sets receives the results (the timed loop merges batch i on a worker thread while
         batch i + 1 is on the GPU)"""
@@ -344,7 +356,7 @@ def main():
             dev_out[nprobe] = ((out_ids, out_dist) if nprobe == S else
                                (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)))
         oi, od = dev_out[nprobe]
-        ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux)
+        ms = shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=timed, aux=aux, for_merge=for_merge)
         key = (nq, nprobe, buf)
         if multi:
             # the result exchange (gpann_comm_gather_slots): local row ids -> global ids, ONE all-gather of the per-slot lists over RCCL
@@ -451,13 +463,14 @@ def main():
 
     # ---------------------------------------------------------------- the timed hot path
     trace = os.environ.get("GPANN_BENCH_TRACE") == "1"
+    merge_bound = not args.no_merge_bound   # the step's product is the MERGED list: slots may be cut at the query's merge bound (include/gpann.h)
     def step(buf=0, merge_later=None):
         """one batch: route -> scan -> merge.  merge_later (the timed loop): the merge is handed to a worker thread and runs while the
         next batch is on the GPU; its future is returned instead of the merged lists."""
         t_a = time.perf_counter()
         pr, r_ms = route(n_top=nprobe)
         t_b = time.perf_counter()
-        sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=buf)
+        sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=buf, for_merge=merge_bound)
         if merge_later is not None:
             return merge_later.submit(pygpann.merge_dedup, sd, si, nprobe, k), None, r_ms, s_ms
         t_c = time.perf_counter()
@@ -528,7 +541,7 @@ def main():
             if route_ahead:
                 pr, r_ms, rst = nxt.result()
                 nxt = router_pool.submit(route_job, it + 1) if it + 1 < count else None
-                sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=it & 1)
+                sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=it & 1, for_merge=merge_bound)
                 fut = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
             else:
                 fut, _, r_ms, s_ms = step(buf=it & 1, merge_later=merger)
@@ -563,6 +576,18 @@ def main():
     router_bound_flops = rec.get("router_bound_flops", 0.0)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the same step strictly one batch at a time (route -> scan -> D2H -> merge, nothing of another batch in flight): the per-batch wall
+    # time the metric's "10k batched queries" literally describes; `value` above is the pipelined throughput
+    lat = []
+    for _ in range(2):
+        step()
+    barrier()
+    for _ in range(max(5, min(20, args.steps))):
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t1))
+    latency_ms_one_batch = float(np.mean(lat))
     merger.shutdown()
     if route_ahead:
         router_pool.shutdown()
@@ -579,7 +604,8 @@ def main():
     result = {
         "metric": "QPS @ recall@10=0.9, 10k batched queries" if not args.nprobe else f"QPS @ nprobe={args.nprobe}, 10k batched queries",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "latency_ms_one_batch": latency_ms_one_batch, "qps_one_batch_at_a_time": 1000.0 * nq / latency_ms_one_batch,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {n}x{d} f32 {'inner product' if metric else 'L2'}, "
                                + (f"Gaussian mixture ({n_centers} centres, sigma {sigma})" if args.dist != "uniform" else "one Gaussian blob (no clusters)")
@@ -596,8 +622,6 @@ def main():
     filtered = bool(stats["filtered"])
     # per step: the cells filter kernel is launched three times (head, sample, rest), the exact kernel once; the rest pass — the
     # launch that streams (nearly) the whole store once — is the dominant kernel
-    traffic, traffic_src = (lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"true": 1}, largest_launch=True) if filtered
-                            else lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1}))
     if filtered:
         f_s = float(np.mean(filter_ms)) / 1000.0
         r_s = float(np.mean(rest_ms)) / 1000.0
@@ -607,8 +631,20 @@ def main():
         ks_read = stats["filter_plane_ksteps"]   # 16-dim k-steps a plane row is stored with and the kernel loads (32 B each; ceil(d / 16) rounded up to a kernel instance)
         rest_bytes = stats["filter_rest_rows"] * (32.0 * ks_read * (1.0 if stats["filter_rest_hi_only"] else 2.0) + 4.0)
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
+        traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"true": 1}, largest_launch=True, kernel_bytes=rest_bytes)
+        # step level: the bytes every launch of the step has to read — plane rows of all filter launches (two-plane launches twice the plane
+        # bytes), the rows re-scored exactly (candidates + seed rows, d x 4 each), the router's centroid planes (both passes, both planes)
+        row_hi = 32.0 * ks_read + 4.0
+        hi_rows = stats["filter_rows"] - stats["filter_two_plane_rows"]
+        step_bytes = (hi_rows * row_hi + stats["filter_two_plane_rows"] * (64.0 * ks_read + 4.0)
+                      + (stats["filter_candidates"] + stats["filter_seed_rows"]) * d * 4.0
+                      + 2.0 * tree["centroids"].shape[0] * 64.0 * ks_read)
+        step_s = elapsed / args.steps
         result["roofline"] = {"bound": "hbm", "achieved": rest_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rest_gbps / HBM_PEAK_GBPS,
                               "traffic": traffic, "traffic_source": traffic_src,
+                              "frac_step": step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, "step_bytes": step_bytes,
+                              "frac_step_note": "bytes ALL launches of a step have to read (plane rows of every filter pass, exactly re-scored rows, the router's "
+                                                "centroid planes) / ms_per_step / 8 TB/s: what the step as a whole makes of the memory system",
                               "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s, "kernel_bytes": rest_bytes,
                               "note": "achieved = the bytes the dominant launch (the rest pass of FilterKernelCells) HAS TO read — its row tiles x (bf16 hi "
                                       "plane + norm word) — / its own HIP-event time on the scan's stream; frac = achieved / 8 TB/s.  traffic = the PMC "
@@ -622,6 +658,7 @@ def main():
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
                               "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
+        traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1})
         lane_ops = stats["padded_pairs"] * d * ops_per_dim / avg_scan_s if avg_scan_s > 0 else 0.0
         result["roofline"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": VALU_F32_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                               "frac": lane_ops / 1e12 / VALU_F32_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -645,6 +682,8 @@ def main():
                                    task_rows_max_over_mean=float(per_rank.max() / max(per_rank.mean(), 1.0)))
     result["index_build_s"] = index_build_s
     result["hbm_resident_GB"] = hbm_resident_gb
+    result["config"]["slot_lists"] = ("cut at the query's merge bound (GPANN_SCAN_FOR_MERGE): the merged neighbours are bit-identical to the merge of the "
+                                      "complete QueryBucket lists" if merge_bound else "complete QueryBucket lists")
     result["config"]["pipeline"] = ("batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned"
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
     result["detail"] = {"merge": {"slot_entries": slot_entries, "duplicate_ids_dropped": dup_ids,
@@ -702,6 +741,13 @@ def main():
         if not same:
             raise SystemExit("bench: the filtered scan's ids / distances differ from the exact scan's on the same step — no result")
 
+    # ---------------------------------------------------------------- --emulate-world: every rank of a W-GPU run, alone on this GPU
+    if emulate_worlds:
+        result["scale_emulated"] = emulate_worlds_on_one_gpu(
+            args, emulate_worlds, torch, pygpann, gcomm, dev, local_rank, stream, points_kept, clusters_local, counts, queries, probes, nprobe, router, merge_bound,
+            one_gpu_ms=1000.0 * elapsed / args.steps)
+        del points_kept
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -718,13 +764,140 @@ def main():
         comm.close()
 
 
-def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=False):
+def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_index, stream, points, clusters, counts, queries, probes, nprobe, router,
+                              merge_bound, one_gpu_ms):
+    """--emulate-world (see its help).  Per world size W and rank r: the shards the W-GPU run would give rank r (same calls: plan_replicas /
+    lpt_owner, mask_probes[_replicated]) as a store of their own, then the rank's share of a step, timed like the real loop (merge of batch
+    i on a worker thread under batch i + 1).  Returns the `scale_emulated` object."""
+    import concurrent.futures
+    nq, d, S, k = args.nq, args.d, args.shards, args.k
+    metric = args.metric_id
+    out = {"note": "per-rank steps of a W-GPU run executed one rank at a time on ONE GPU (same placement, same kernels, same host code); "
+                   "predicted_qps = nq / (max over ranks of ms_per_step + exchange_ms); exchange_ms = the step's three collectives timed through "
+                   "RCCL with ONE rank on this GPU (launch + kernel cost, no wire) + wire_ms_estimate (bytes / 50 GB/s per xGMI link direction, "
+                   "ring of W - 1 steps); NOT a measurement on W GPUs",
+           "one_gpu_ms_per_step": one_gpu_ms, "worlds": []}
+    # the exchange, through the real calls with one rank (RCCL needs one process per device: a single-rank communicator is what one GPU can run)
+    exch_ms = None
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        c1 = gcomm.Comm(gcomm.RCCL, rank=0, world=1, addr="127.0.0.1", port=int(os.environ.get("GPANN_COMM_PORT", int(os.environ["MASTER_PORT"]) + 1)), device=device_index)
+        n_slots = nq * nprobe * k
+        sd = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+        si = torch.zeros(n_slots, dtype=torch.int32, device=dev)
+        gd, gi = torch.empty_like(sd), torch.empty_like(si)
+        scratch = torch.empty(c1.gather_slots_scratch(n_slots), dtype=torch.uint8, device=dev)
+        idm = torch.arange(max(args.n, 1), dtype=torch.int32, device=dev)
+        pr_mine = torch.zeros((nq, S), dtype=torch.int32, device=dev)
+        pr_all = torch.empty_like(pr_mine)
+        def exchange():
+            c1.broadcast(queries.data_ptr(), queries.numel() * 4, 0, stream)
+            c1.allgather(pr_mine.data_ptr(), pr_all.data_ptr(), pr_mine.numel() * 4, stream)
+            c1.gather_slots(sd.data_ptr(), si.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=idm.data_ptr(), stream=stream)
+        for _ in range(3):
+            exchange()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            exchange()
+        torch.cuda.synchronize()
+        exch_ms = 1000.0 * (time.perf_counter() - t0) / 20
+        out["exchange_backend"] = c1.name
+        c1.close()
+        del sd, si, gd, gi, scratch, idm, pr_mine, pr_all
+    except Exception as e:   # the prediction then carries no exchange term and says so
+        out["exchange_error"] = str(e)
+    out["exchange_ms_one_rank_rccl"] = exch_ms
+    est_tasks = np.bincount(probes[:, 0].astype(np.int64), minlength=S).astype(np.float64) + 0.5   # (the real run estimates before routing: nearest shard centroid)
+    for W in worlds:
+        if args.replica_capacity > 0:
+            cap_rows = int(max(args.replica_capacity * counts.sum() / W, 1.25 * counts.max()))
+            rep_begin, rep_rank, rank_work, load = gcomm.plan_replicas(counts, est_tasks * counts, W, cap_rows, float(os.environ.get("GPANN_BENCH_REPLICA_IMBALANCE", 1.05)))
+            holders = [set(int(x) for x in rep_rank[rep_begin[b]:rep_begin[b + 1]]) for b in range(S)]
+        else:
+            owner, load = gcomm.lpt_owner(counts, W)
+            holders = [{int(owner[b])} for b in range(S)]
+        chunk_q = (nq + W - 1) // W
+        ranks = []
+        for r in range(W):
+            mine = [b for b in range(S) if r in holders[b]]
+            cl = [clusters[b] if b in mine else np.zeros(0, np.uint32) for b in range(S)]
+            t_b = time.time()
+            sh = pygpann.Shards(points.data_ptr(), cl, metric, device_index, n=points.shape[0], d=d, plain=True)
+            if args.scan_mode == "filter":
+                sh.build_filter()
+            sh.set_scan_mode(1 if args.scan_mode == "filter" else 0)
+            build_s = time.time() - t_b
+            oi = torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev)
+            od = torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)
+            hbuf = [(torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory()) for _ in range(2)]
+            lo, hi = min(nq, r * chunk_q), min(nq, (r + 1) * chunk_q)
+            route_buf = torch.empty((max(hi - lo, 1), S), dtype=torch.int32).pin_memory().numpy()
+            merger = concurrent.futures.ThreadPoolExecutor(1)
+            tasks_rows = [0.0]
+
+            def one(i):
+                if hi > lo:   # this rank's share of the routing
+                    router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo, out_probes=route_buf[:hi - lo], want_min_dist=False)
+                lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
+                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=True, for_merge=merge_bound)
+                hd, hi_ = hbuf[i & 1]
+                hd.copy_(od, non_blocking=True)
+                hi_.copy_(oi, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                tasks_rows[0] = float(sh.stats()["pairs"])
+                return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k)
+
+            pending = None
+            for i in range(max(2, args.warmup)):
+                f = one(i)
+                if pending is not None:
+                    pending.result()
+                pending = f
+            pending.result()
+            torch.cuda.synchronize()
+            steps = max(5, args.steps // 2)
+            t0 = time.perf_counter()
+            pending = None
+            for i in range(steps):
+                f = one(i)
+                if pending is not None:
+                    pending.result()
+                pending = f
+            pending.result()
+            torch.cuda.synchronize()
+            ms = 1000.0 * (time.perf_counter() - t0) / steps
+            st = sh.stats()
+            ranks.append({"rank": r, "shards": len(mine), "rows": int(sum(int(counts[b]) for b in mine)), "ms_per_step": ms, "scan_kernels_ms": st["scan_ms"],
+                          "rest_pass_ms": st["filter_rest_ms"], "task_rows": tasks_rows[0], "store_build_s": build_s})
+            log(f"emulated world {W} rank {r}: {len(mine)} shards, {ranks[-1]['rows']} rows, {ms:.3f} ms/step (scan kernels {st['scan_ms']:.3f})")
+            merger.shutdown()
+            sh.close()
+            del oi, od, hbuf
+            torch.cuda.empty_cache()
+        worst = max(x["ms_per_step"] for x in ranks)
+        # wire time of the collectives on W GPUs: ring all-gather, (W - 1) steps of one rank's block over one xGMI link direction (~50 GB/s achievable)
+        wire_bytes = (W - 1) * (chunk_q * S * 4 + 2 * nq * nprobe * k * 4) + queries.numel() * 4
+        wire_ms = 1000.0 * wire_bytes / 50e9
+        total = worst + (exch_ms or 0.0) + wire_ms
+        out["worlds"].append({"world": W, "ranks": ranks, "max_ms_per_step": worst, "mean_ms_per_step": float(np.mean([x["ms_per_step"] for x in ranks])),
+                              "wire_ms_estimate": wire_ms, "predicted_ms_per_step": total, "predicted_qps": 1000.0 * nq / total,
+                              "predicted_speedup_over_one_gpu": one_gpu_ms / total,
+                              "replicas": int(sum(len(h) for h in holders) - S)})
+        log(f"emulated world {W}: max {worst:.3f} ms/step -> predicted {1000.0 * nq / total:.0f} QPS ({one_gpu_ms / total:.2f}x one GPU)")
+    return out
+
+
+def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=False, kernel_bytes=None):
     """HBM bytes per STEP of the dominant kernel from the committed PMC pass (profiles/*/…_pmc_traffic.json, FETCH_SIZE doubled per
     the gfx950 correction + WRITE_SIZE), if one exists for exactly this workload; else None.  `launches_per_step` maps a kernel
     name fragment to its launches per step (the cells filter runs as one full-precision launch and two hi-plane launches);
-    largest_launch: the biggest single launch of the matching kernels instead (the rest pass among the hi-plane launches)."""
+    largest_launch: the biggest single launch of the matching kernels instead (the rest pass among the hi-plane launches).
+    kernel_bytes: the bytes this run's dominant launch had to read — a committed pass whose own run (its `dominant_kernel_bytes`) differs
+    from that by more than 2 % was taken from another kernel / layout and is NOT reported (None + a note naming the stale file)."""
     import glob
-    best = None
+    best, stale = None, None
     import re
     natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", p)]   # ... v9 < v10: the newest pass wins
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*_pmc_traffic.json")), key=natural):
@@ -733,6 +906,11 @@ def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=Fa
             w = j["workload"]
             if (w["n"], w["d"], w["shards"], w["nprobe"]) != (n, d, S, nprobe):
                 continue
+            if kernel_bytes is not None:
+                have = j.get("dominant_kernel_bytes")
+                if not have or abs(float(have) / kernel_bytes - 1.0) > 0.02:
+                    stale = os.path.relpath(path, ROOT)
+                    continue
             total, found = 0.0, False
             for name, v in j["kernels"].items():
                 for frag, per_step in launches_per_step.items():
@@ -746,7 +924,9 @@ def lookup_traffic(n, d, S, nprobe, kernel, launches_per_step, largest_launch=Fa
                 best = (total, os.path.relpath(path, ROOT))
         except Exception:
             continue
-    return best if best else (None, None)
+    if best:
+        return best
+    return (None, f"stale: {stale} was measured on a launch whose bytes differ by more than 2 % from this run's" if stale else None)
 
 
 def cpu_model():

@@ -146,8 +146,11 @@ void ReleaseCells(gpann_shards* s) {
 gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     const uint32_t S = s->S, ld = s->ld;
     auto give_up = [&](const char* why) {
-        (void)why;
-        (void)hipGetLastError();
+        // not silent: a store without filter data answers every scan with the (40x slower) exact kernel
+        const hipError_t last = hipGetLastError();
+        fprintf(stderr, "[gpann] filter support data (cells, bf16 planes) could not be built — step '%s'%s%s; scans on this store run in exact mode\n", why,
+                last != hipSuccess ? ", last HIP error: " : "", last != hipSuccess ? hipGetErrorString(last) : "");
+        SetLastError("filter support data could not be built (step '%s'%s%s)", why, last != hipSuccess ? ": " : "", last != hipSuccess ? hipGetErrorString(last) : "");
         ReleaseCells(s);
         if (s->frag_planes) (void)hipFree(s->frag_planes);
         s->frag_planes = nullptr;

@@ -425,6 +425,44 @@ gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uin
     return GPANN_OK;
 }
 
+gpann_status gpann_comm_debug_select_slots(int world, size_t n, const float* rank_dist, const uint32_t* rank_ids, const uint32_t* id_maps,
+                                           const uint64_t* id_map_begin, float* out_dist, uint32_t* out_ids, int device) {
+    COMM_REQUIRE(world >= 1 && (n == 0 || (rank_dist && rank_ids && out_dist && out_ids)) && (!id_maps || id_map_begin), "argument");
+    if (n == 0) return GPANN_OK;
+    COMM_HIP(hipSetDevice(device));
+    const size_t W = (size_t)world;
+    float *g_dist = nullptr, *d_out_dist = nullptr;
+    uint32_t *g_ids = nullptr, *d_local = nullptr, *d_maps = nullptr, *d_out_ids = nullptr;
+    const size_t map_words = id_maps ? (size_t)id_map_begin[world] : 0;
+    gpann_status rc = GPANN_OK;
+    auto fail = [&](hipError_t e) {
+        if (e == hipSuccess) return false;
+        SetErr("debug_select_slots: %s", hipGetErrorString(e));
+        rc = GPANN_ERR_HIP;
+        return true;
+    };
+    do {
+        if (fail(hipMalloc(&g_dist, W * n * 4)) || fail(hipMalloc(&g_ids, W * n * 4)) || fail(hipMalloc(&d_local, W * n * 4)) ||
+            fail(hipMalloc(&d_out_dist, n * 4)) || fail(hipMalloc(&d_out_ids, n * 4)) || (map_words && fail(hipMalloc(&d_maps, map_words * 4))))
+            break;
+        if (fail(hipMemcpy(g_dist, rank_dist, W * n * 4, hipMemcpyHostToDevice)) || fail(hipMemcpy(d_local, rank_ids, W * n * 4, hipMemcpyHostToDevice)) ||
+            (map_words && fail(hipMemcpy(d_maps, id_maps, map_words * 4, hipMemcpyHostToDevice))))
+            break;
+        for (size_t r = 0; r < W; ++r) {   // every rank maps its own list before the all-gather
+            if (id_maps) hipLaunchKernelGGL(MapIdsKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, d_local + r * n, d_maps + id_map_begin[r], n, g_ids + r * n);
+            else if (fail(hipMemcpy(g_ids + r * n, d_local + r * n, n * 4, hipMemcpyDeviceToDevice))) break;
+        }
+        if (rc != GPANN_OK) break;
+        hipLaunchKernelGGL(SelectSlotsKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, g_dist, g_ids, world, n, d_out_dist, d_out_ids);
+        if (fail(hipGetLastError()) || fail(hipMemcpy(out_dist, d_out_dist, n * 4, hipMemcpyDeviceToHost)) ||
+            fail(hipMemcpy(out_ids, d_out_ids, n * 4, hipMemcpyDeviceToHost)))
+            break;
+    } while (false);
+    for (void* p : {(void*)g_dist, (void*)g_ids, (void*)d_local, (void*)d_maps, (void*)d_out_dist, (void*)d_out_ids})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 // ---- placement ------------------------------------------------------------------------------------------------------------------
 gpann_status gpann_lpt_owner(const uint64_t* shard_rows, uint32_t S, uint32_t world, int32_t* owner, uint64_t* load_out) {
     COMM_REQUIRE(world >= 1 && (S == 0 || (shard_rows && owner)), "argument");

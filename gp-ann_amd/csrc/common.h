@@ -208,6 +208,13 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 
 // lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
+// float <-> uint32 whose unsigned order is the float order (negative inner-product "distances" included): atomicMin on the keys
+__device__ __forceinline__ uint32_t OrderedKey(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float OrderedKeyToFloat(uint32_t key) { return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key); }
+constexpr uint32_t kOrderedKeyInf = 0xFF800000u;   // OrderedKey(+inf)
 
 // ---- the same sequence on PAIRS of point rows: packed (two-lane) fp32 instructions ---------------------------------------------
 // The rows of a tile lie in LDS as pairs [pair][dim][member] (one ds_read_b128 = two dimensions of both rows); every operation of the

@@ -1634,8 +1634,9 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     void* kargs[] = {&ba};
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[0], st));
     GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
-    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu);
-    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu);
+    // (cand_count + 1: the self-check counter — pass 1's maxima / thresholds here, the unset minima after pass 2 below)
+    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 1);
+    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 1);
     GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[1], st));
     const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
@@ -2137,8 +2138,19 @@ gpann_status gpann_router_query_batch(gpann_router* r, const float* queries, uin
     return gpann_router_query_batch_top(r, queries, nq, budget, r->S, out_probes, out_min_dist, flags, stream, elapsed_ms);
 }
 
+static gpann_status QueryBatchTopImpl(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
+                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms);
+
 gpann_status gpann_router_query_batch_top(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
                                           float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
+    const gpann_status st = QueryBatchTopImpl(r, queries, nq, budget, n_top, out_probes, out_min_dist, flags, stream, elapsed_ms);
+    // a call that failed between the launch of a bound block and the look at its counters must not leave them to the next call
+    if (st != GPANN_OK && r) r->pending_bound.active = false;
+    return st;
+}
+
+static gpann_status QueryBatchTopImpl(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
+                                      float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
     GPANN_REQUIRE(r != nullptr, "router handle is null");
     GPANN_REQUIRE(nq == 0 || queries != nullptr, "queries is null");
     GPANN_REQUIRE(n_top >= 1 && n_top <= r->S, "n_top must be in [1, S]");

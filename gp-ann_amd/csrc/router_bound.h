@@ -222,9 +222,13 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
 }
 
 // thr[q][shard] from the pass-1 maxima; |q|^2 in double per query.  One workgroup (64 threads) per query.
+// Always-on check of pass 1 (no extra launch): every shard that has centroids must have received a maximum (max_bits != 0: the array
+// is zeroed before pass 1 and OrderedBits of any float is non-zero) and its threshold must be finite — otherwise pass 2 would let
+// nothing (NaN) or everything through.  Violations are counted into *bad_pairs, the same counter the unset-minima check after pass 2
+// feeds: the caller then evaluates every pair canonically (or fails under GPANN_ROUTER_STRICT).
 template <int METRIC>
 __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, const uint32_t* max_bits, float* thr, uint32_t S, uint32_t d, uint32_t ld,
-                                                        double cent_rmax, const float* mu) {
+                                                        double cent_rmax, const float* mu, const uint32_t* shard_has_cent, uint32_t* bad_pairs) {
     const uint32_t q = blockIdx.x;
     const float* row = queries + (size_t)q * ld;
     double nq = 0.0;
@@ -236,7 +240,8 @@ __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, co
     for (int o = 32; o > 0; o >>= 1) nq += __shfl_xor(nq, o);
     const double qn = sqrt(nq) * (1.0 + 1e-12), R = cent_rmax, dd = (double)d;
     for (uint32_t b = threadIdx.x; b < S; b += 64) {
-        const double m = (double)FromOrderedBitsB(max_bits[(size_t)q * S + b]);
+        const uint32_t mb = max_bits[(size_t)q * S + b];
+        const double m = (double)FromOrderedBitsB(mb);
         double t;
         if (METRIC == GPANN_METRIC_L2) {
             const double g1 = (dd + 32.0) * 0x1p-23;
@@ -252,6 +257,7 @@ __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, co
         float tf = (float)t;
         if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
         thr[(size_t)q * S + b] = tf;
+        if (shard_has_cent[b] != 0u && (mb == 0u || !(fabsf(tf) < INFINITY))) atomicAdd(bad_pairs, 1u);
     }
 }
 

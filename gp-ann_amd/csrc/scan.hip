@@ -308,6 +308,22 @@ __global__ void FillKernel(float* dist, uint32_t* ids, uint32_t* rows, size_t n)
     }
 }
 
+// GPANN_SCAN_FOR_MERGE on complete per-slot lists [nq][nprobe][k]: tau_q = min over the slots of the slot's k-th distance (+inf where the
+// list is short or the slot unused); entries beyond it become (+inf, NO_ID).  One thread per query.  `dist` must not be null.
+__global__ void TruncateForMergeKernel(float* dist, uint32_t* ids, uint32_t* rows, uint32_t nq, uint32_t nprobe, uint32_t k) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const size_t base = (size_t)q * nprobe * k;
+    float tau = INFINITY;
+    for (uint32_t j = 0; j < nprobe; ++j) tau = fminf(tau, dist[base + (size_t)j * k + k - 1]);
+    for (size_t i = base; i < base + (size_t)nprobe * k; ++i)
+        if (!(dist[i] <= tau)) {
+            dist[i] = INFINITY;
+            if (ids) ids[i] = kNoId;
+            if (rows) rows[i] = kNoId;
+        }
+}
+
 // RunInShardSearches hit lists: from per-(q, shard) ascending lists keep entries with dist <= kth[q], emit ids descending.
 __global__ void ShardHitsKernel(const float* dist, const uint32_t* ids, const float* kth, uint32_t nq, uint32_t S, uint32_t k,
                                 uint32_t* out_ids, uint32_t* out_count) {
@@ -532,7 +548,7 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
-static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags,
+static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t nq, uint32_t k, int flags,
                                         hipStream_t st, DeviceLists out, bool* overflow) {
     *overflow = false;
     s->filter_passes_timed = 0;
@@ -561,12 +577,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64));
+    const bool for_merge = (flags & GPANN_SCAN_FOR_MERGE) != 0;
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4));
     float* list_dist = s->ws_lists.as<float>();
     uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
     float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T + ((T & 1) ? 1 : 0));   // [0] overflow count, [2..3] candidate total (u64)
     unsigned long long* d_cand_total = reinterpret_cast<unsigned long long*>(d_overflow + 2);
+    // GPANN_SCAN_FOR_MERGE: per query the smallest k-th distance any of its tasks has reached (OrderedKey; RescoreKernel lowers it, the
+    // next pass's thresholds and cell tests of ALL the query's tasks read it)
+    uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
+    if (for_merge) GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_query_tau), (int)kOrderedKeyInf, nq, st));
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
@@ -615,7 +636,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
     CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..1] work counters, [3] = [1] before the rest pass
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..2] work counters (scan_cells.h), [3] = [1] before the rest pass
     uint32_t* d_group_first = reinterpret_cast<uint32_t*>(d_work + 4);
     uint32_t* d_group_count = d_group_first + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
     CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first + gtab_words);
@@ -714,6 +735,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     th.ld = s->ld;
     th.hi_only = 0;
     th.task_nq = d_task_nq;
+    th.query_tau = d_query_tau;
     th.task_src = nullptr;   // (set once the tasks are reordered)
     NeedArgs na;
     na.cell_dist = cell_dist;
@@ -732,6 +754,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.cand_cnt = cand_cnt;
     na.group_zero = d_group_count;
     na.n_groups = G;
+    na.query_tau = d_query_tau;
+    na.task_query = ta.query;
     th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
@@ -792,6 +816,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.shard_cell_begin = C.d_shard_cell_begin;
     ra.cell_tile_begin = C.d_cell_tile_begin;
     ra.plane_perm = C.plane_perm;
+    ra.query_tau = d_query_tau;
     // the kernel for this store's k-steps: both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
     const void *fn = nullptr, *fn_hi = nullptr;
     switch (KS) {
@@ -959,13 +984,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
         const size_t n = (size_t)T * k;
         hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k,
-                           out.dist, out.ids, out.rows);
+                           out.dist, out.ids, out.rows, (const uint32_t*)d_query_tau, (const uint32_t*)ta.query);
         GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipStreamSynchronize(st));
         plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
         plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
         plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
-        plan.filter_rows = (uint64_t)h_work[1] * kGTileRows;
+        plan.filter_rows = (uint64_t)(h_work[1] + h_work[2]) * kGTileRows;
+        plan.filter_two_plane_rows = (uint64_t)h_work[2] * kGTileRows;
         if (h_words[0] > overflow_limit) *overflow = true;
     }
     return GPANN_OK;
@@ -1025,7 +1051,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, k, flags, st, out, &overflow));
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, nq, k, flags, st, out, &overflow));
         done = !overflow;
         s->stats.filtered = done ? 1 : 0;
     }
@@ -1040,6 +1066,9 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         m.out_ids = out.ids;
         m.out_rows = out.rows;
         GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
+        // GPANN_SCAN_FOR_MERGE in exact mode: the full lists are there — cut them at the query's merge bound, as the filtered pipeline does
+        if ((flags & GPANN_SCAN_FOR_MERGE) && nq && nprobe)
+            hipLaunchKernelGGL(TruncateForMergeKernel, dim3((nq + 255) / 256), dim3(256), 0, st, out.dist, out.ids, out.rows, nq, nprobe, k);
     }
     GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
     GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));   // every staged upload of this call is queued before this point
@@ -1056,6 +1085,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.filter_rest_hi_only = plan.filter_rest_hi_only ? 1u : 0u;
     s->stats.filter_candidates = plan.filter_candidates;
     s->stats.filter_plane_ksteps = s->stats.filtered ? s->cells.plane_ks : 0u;
+    s->stats.filter_two_plane_rows = plan.filter_two_plane_rows;
+    s->stats.filter_seed_rows = s->stats.filtered ? plan.padded_pairs : 0;
     return GPANN_OK;
 }
 
@@ -1106,6 +1137,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
                                 float* elapsed_ms) {
     GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
     GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
+    GPANN_REQUIRE(!(flags & GPANN_SCAN_FOR_MERGE) || !(flags & GPANN_OUTPUT_ON_DEVICE) || out_dist != nullptr, "GPANN_SCAN_FOR_MERGE with device output needs out_dist");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)nq * nprobe * k;
     if (n == 0) {
@@ -1160,7 +1192,8 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
         hipLaunchKernelGGL(FillKernel, dim3(64), dim3(256), 0, st, dev_out ? out_dist : d_out_dist, dev_out ? out_ids : d_out_ids,
                            (uint32_t*)nullptr, n);
     } else {
-        GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags, st, slot));
+        // (one TopN over the slots: entries beyond the smallest k-th distance of the query's slots cannot be in it — GPANN_SCAN_FOR_MERGE)
+        GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags | GPANN_SCAN_FOR_MERGE, st, slot));
         MergeArgs m{};
         m.in_dist = slot.dist;
         m.in_row = slot.rows;

@@ -203,6 +203,9 @@ struct NeedArgs {
     uint32_t* group_zero;               // [2 n_groups]: the item counts and claim cursors of the task groups, zeroed here for the pass
     uint32_t n_groups;
     uint32_t hi_only;
+    // GPANN_SCAN_FOR_MERGE: the query's merge bound (OrderedKey, [nq]) caps the tau of each of its tasks
+    const uint32_t* query_tau;
+    const uint32_t* task_query;
 };
 
 // One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
@@ -218,8 +221,11 @@ static __global__ void NeedKernel(NeedArgs a) {
     const uint32_t src = a.task_src[t];
     const uint32_t b = a.task_shard[t];
     const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
+    // the task's k-th distance so far — or, if smaller, the bound the query's other tasks have already reached
+    double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
+    if (a.query_tau) tau = fmin(tau, (double)OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
     if (j == 0) {
-        a.task_U[t] = ThresholdOf<METRIC>((double)a.list_dist[(size_t)t * a.k + a.k - 1], a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
+        a.task_U[t] = ThresholdOf<METRIC>(tau, a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
         a.cand_cnt[t] = 0;
         if (t < a.n_groups) {   // (every group has a task: tasks >= n_groups)
             a.group_zero[t] = 0;
@@ -231,7 +237,6 @@ static __global__ void NeedKernel(NeedArgs a) {
     if (a.head) {
         need = a.nearest[src] == j;
     } else {
-        const double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
         if (!(tau < (double)INFINITY)) {
             need = true;
         } else {
@@ -282,7 +287,7 @@ struct CellFilterArgs {
     const uint32_t* done0b;      // (optional) OR-ed into done0
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
-    unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] += row tiles streamed
+    unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] / [2] += row tiles streamed by hi-plane / two-plane launches
     uint32_t n_groups;
     // the pass's work items, written by FilterItemsKernel: a (task group, cell) block's tile range cut into pieces of <= seg_tiles.
     // The items of task group g are items[group_first[g] .. + group_count[g]) (group_first: capacities, computed by the host);
@@ -709,7 +714,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     flush_queue();
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
-        atomicAdd(&a.work[1], (unsigned long long)my_tiles);
+        atomicAdd(&a.work[HI_ONLY ? 1 : 2], (unsigned long long)my_tiles);   // (row tiles of hi-plane launches / of two-plane launches)
     }
 }
 

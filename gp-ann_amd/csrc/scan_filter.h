@@ -130,6 +130,7 @@ struct ThresholdArgs {
     uint32_t hi_only;             // the filter pass reads only the hi plane of the points: the dropped q.p_lo term joins the error bound
     const double* task_nq;        // optional [tasks]: |q|^2 of every task (NearestCellKernel), indexed through task_src; else summed here
     const uint32_t* task_src;
+    const uint32_t* query_tau;    // optional [nq] (GPANN_SCAN_FOR_MERGE): OrderedKey of the query's merge bound, which caps every task's tau
 };
 
 // nq = |q|^2 (double, summed in the query's dimension order), R = max |p| over the shard
@@ -161,7 +162,8 @@ template <int METRIC>
 __global__ void ThresholdKernel(ThresholdArgs a) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.tasks) return;
-    const double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
+    double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
+    if (a.query_tau) tau = fmin(tau, (double)OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
     double nq;
     if (a.task_nq) {
         nq = a.task_nq[a.task_src ? a.task_src[t] : t];
@@ -197,6 +199,7 @@ struct RescoreArgs {
     const uint32_t* shard_cell_begin;   // [S+1]
     const uint64_t* cell_tile_begin;    // [cells+1] first 32-row plane tile of every cell
     const uint32_t* plane_perm;         // [tiles*32] plane row -> store row (0xFFFFFFFF: padding)
+    uint32_t* query_tau;                // optional [nq] (GPANN_SCAN_FOR_MERGE): atomicMin of OrderedKey(k-th distance) over the query's tasks
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
@@ -413,17 +416,27 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         a.list_dist[(size_t)t * k + lane] = ld_;
         a.list_row[(size_t)t * k + lane] = lr_;
     }
+    // the query's merge bound: the smallest k-th distance among its tasks' lists (a list that is not full yet has +inf there)
+    if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
 }
 
 // final lists -> caller arrays: out[task_out[t]][i] = (dist, permutation[row], row)
+// query_tau / task_query (GPANN_SCAN_FOR_MERGE): entries beyond the query's merge bound are cut — what is left is a prefix of the
+// reference's per-slot list (an entry of OUR list beyond the bound need not be one of the reference's: rows beyond the bound were never looked at)
 static __global__ void ListOutputKernel(const float* list_dist, const uint32_t* list_row, const uint32_t* task_out, const uint32_t* permutation,
-                                 uint32_t tasks, uint32_t k, float* out_dist, uint32_t* out_ids, uint32_t* out_rows) {
+                                 uint32_t tasks, uint32_t k, float* out_dist, uint32_t* out_ids, uint32_t* out_rows, const uint32_t* query_tau,
+                                 const uint32_t* task_query) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= (size_t)tasks * k) return;
     const uint32_t t = (uint32_t)(i / k), e = (uint32_t)(i % k);
     const size_t dst = (size_t)task_out[t] * k + e;
-    const uint32_t row = list_row[i];
-    if (out_dist) out_dist[dst] = list_dist[i];
+    uint32_t row = list_row[i];
+    float dist = list_dist[i];
+    if (query_tau && !(dist <= OrderedKeyToFloat(query_tau[task_query[t]]))) {
+        dist = INFINITY;
+        row = kNoId;
+    }
+    if (out_dist) out_dist[dst] = dist;
     if (out_rows) out_rows[dst] = row;
     if (out_ids) out_ids[dst] = row == kNoId ? kNoId : permutation[row];
 }

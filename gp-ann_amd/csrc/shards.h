@@ -24,7 +24,7 @@ struct ScanUnit {
 struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
-    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0;
+    uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0, filter_two_plane_rows = 0;
     bool filter_rest_hi_only = false;
     uint32_t filter_launches = 0;
     void Clear() {
@@ -35,7 +35,7 @@ struct ScanPlan {
         task_shard.clear();
         shard_task_begin.clear();
         units.clear();
-        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = 0;
+        n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = filter_two_plane_rows = 0;
         filter_launches = 0;
     }
 };

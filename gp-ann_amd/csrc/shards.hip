@@ -225,7 +225,10 @@ gpann_status gpann_shards_build_filter(gpann_shards* s) {
         SetLastError("the store's data is not fit for the filter (non-finite values or d > 256)");
         return GPANN_ERR_UNSUPPORTED;
     }
-    return BuildCells(s, DefaultCellRows(s));
+    GPANN_TRY(BuildCells(s, DefaultCellRows(s)));
+    // asked for explicitly: a store that still has no filter data is an error here (gpann_last_error() names the step that failed)
+    if (s->cells.n_cells == 0 || s->frag_planes == nullptr) return GPANN_ERR_OOM;
+    return GPANN_OK;
 }
 
 gpann_status gpann_shards_set_scan_mode(gpann_shards* s, int mode) {

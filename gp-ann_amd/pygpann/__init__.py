@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1
-QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN = 1, 2, 4, 8, 16
+QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN, SCAN_FOR_MERGE = 1, 2, 4, 8, 16, 32
 MAX_K = 64
 NO_ID = np.uint32(0xFFFFFFFF)
 
@@ -43,7 +43,8 @@ class ScanStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("tasks", C.c_uint64), ("units", C.c_uint64),
                 ("padded_pairs", C.c_uint64), ("filter_pairs", C.c_uint64), ("filter_candidates", C.c_uint64), ("filtered", C.c_uint32), ("filter_plane_ksteps", C.c_uint32),
                 ("scan_ms", C.c_float), ("merge_ms", C.c_float), ("filter_ms", C.c_float), ("reserved2", C.c_float),
-                ("filter_rows", C.c_uint64), ("filter_rest_rows", C.c_uint64), ("filter_rest_ms", C.c_float), ("filter_rest_hi_only", C.c_uint32)]
+                ("filter_rows", C.c_uint64), ("filter_rest_rows", C.c_uint64), ("filter_rest_ms", C.c_float), ("filter_rest_hi_only", C.c_uint32),
+                ("filter_two_plane_rows", C.c_uint64), ("filter_seed_rows", C.c_uint64)]
 
 
 class RouterStats(C.Structure):
@@ -209,8 +210,9 @@ class Shards:
         _check(lib().gpann_shards_export_range(self.h, row_begin, row_count, perm.ctypes.data_as(_u32p), pts.ctypes.data_as(_f32p)))
         return perm, pts
 
-    def scan_buckets(self, queries, k, probes, nprobe=None, stream=None, want_rows=False):
-        """Batched QueryBucket.  queries [nq,d]; probes [nq,stride] int32.  Returns ids, dist [nq,nprobe,k] (+rows), ms."""
+    def scan_buckets(self, queries, k, probes, nprobe=None, stream=None, want_rows=False, for_merge=False):
+        """Batched QueryBucket.  queries [nq,d]; probes [nq,stride] int32.  Returns ids, dist [nq,nprobe,k] (+rows), ms.
+        for_merge: GPANN_SCAN_FOR_MERGE — per-slot lists cut at the query's merge bound (include/gpann.h)."""
         queries = _np(queries, np.float32)
         probes = _np(probes, np.int32)
         if probes.ndim == 1:
@@ -223,19 +225,19 @@ class Shards:
         rows = np.empty((nq, nprobe, k), np.uint32) if want_rows else None
         ms = C.c_float(0)
         _check(lib().gpann_scan_buckets(self.h, _vp(queries), nq, k, probes.ctypes.data_as(_i32p), stride, nprobe, _vp(ids), _vp(dist),
-                                        _vp(rows), 0, C.c_void_p(stream or 0), C.byref(ms)))
+                                        _vp(rows), SCAN_FOR_MERGE if for_merge else 0, C.c_void_p(stream or 0), C.byref(ms)))
         if want_rows:
             return ids, dist, rows, ms.value
         return ids, dist, ms.value
 
-    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False):
+    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False, for_merge=False):
         """Same with queries and outputs resident on the device (raw pointers); asynchronous unless timed."""
         probes = _np(probes, np.int32)
         stride = probes.shape[1]
         ms = C.c_float(0)
         _check(lib().gpann_scan_buckets(self.h, C.c_void_p(int(queries_ptr)), nq, k, probes.ctypes.data_as(_i32p), stride, nprobe,
                                         C.c_void_p(int(out_ids_ptr)), C.c_void_p(int(out_dist_ptr)) if out_dist_ptr else None, None,
-                                        QUERIES_ON_DEVICE | OUTPUT_ON_DEVICE | (AUX_PASS if aux else 0), C.c_void_p(stream or 0),
+                                        QUERIES_ON_DEVICE | OUTPUT_ON_DEVICE | (AUX_PASS if aux else 0) | (SCAN_FOR_MERGE if for_merge else 0), C.c_void_p(stream or 0),
                                         C.byref(ms) if timed else None))
         return ms.value
 

@@ -12,7 +12,7 @@ COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_comm.so")
 RCCL, TCP = 0, 1
 EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_destroy", "gpann_comm_info", "gpann_comm_backend_name",
            "gpann_comm_barrier", "gpann_comm_max_double", "gpann_comm_allgather_host", "gpann_comm_broadcast_host", "gpann_comm_broadcast",
-           "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
+           "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_comm_debug_select_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
            "gpann_comm_merge_router"]
 _lib = None
 
@@ -61,6 +61,22 @@ def _ptr(a):
     if isinstance(a, (int, np.integer)):
         return C.c_void_p(int(a))
     return a.ctypes.data_as(C.c_void_p)
+
+
+def debug_select_slots(rank_dist, rank_ids, id_maps=None, device=0):
+    """the device half of gather_slots on a fabricated world (gpann_comm_debug_select_slots): rank_dist / rank_ids [world][n] host arrays,
+    id_maps: list of the ranks' local-row -> global-id maps (or None).  Returns (dist[n], ids[n])."""
+    rank_dist = np.ascontiguousarray(rank_dist, np.float32)
+    rank_ids = np.ascontiguousarray(rank_ids, np.uint32)
+    world, n = rank_ids.shape
+    out_d, out_i = np.empty(n, np.float32), np.empty(n, np.uint32)
+    maps = begin = None
+    if id_maps is not None:
+        begin = np.concatenate([[0], np.cumsum([len(m) for m in id_maps])]).astype(np.uint64)
+        maps = np.ascontiguousarray(np.concatenate([np.asarray(m, np.uint32) for m in id_maps]), np.uint32)
+    _check(lib().gpann_comm_debug_select_slots(C.c_int(world), C.c_size_t(n), _ptr(rank_dist), _ptr(rank_ids), _ptr(maps) if maps is not None else None,
+                                               _ptr(begin) if begin is not None else None, _ptr(out_d), _ptr(out_i), C.c_int(device)))
+    return out_d, out_i
 
 
 def lpt_owner(shard_rows, world):

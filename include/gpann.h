@@ -58,8 +58,17 @@ enum {
     GPANN_POINTS_ON_DEVICE = 1 << 2,   /* `points` is a device pointer (gpann_shards_create) */
     GPANN_STORE_PLAIN = 1 << 4,        /* gpann_shards_create: rows, offsets and permutation only — no filter support data (cells,
                                           bf16 planes); for stores that only feed training / partitioning.  Scans on it are exact-mode */
-    GPANN_AUX_PASS = 1 << 3            /* profiling label: run the identical scan kernel under a second symbol name so that
+    GPANN_AUX_PASS = 1 << 3,           /* profiling label: run the identical scan kernel under a second symbol name so that
                                           auxiliary passes (ground truth) stay out of the hot path's per-kernel statistics */
+    GPANN_SCAN_FOR_MERGE = 1 << 5      /* gpann_scan_buckets: the caller only merges the slots of a query (DedupNeighbors,
+                                          small_scale_queries.cpp:15-23, or one TopN over them, inverted_index.h:43-60).  Slot j of query q then
+                                          holds the reference's per-slot list TRUNCATED after its last entry with distance <= tau_q, where
+                                          tau_q = min over the query's slots of the slot's k-th distance (+inf for a slot with < k rows);
+                                          the cut entries read (+inf, GPANN_NO_ID).  Every list of q has k distinct ids (ids are unique within a
+                                          shard) at distance <= its own k-th, so the merged k-th distance is <= tau_q and no cut entry can be
+                                          among the first k of the merge: the merged result is bit-identical to the one over the full lists.
+                                          In filter mode tau_q bounds every shard of the query, not only the one that produced it — rows and
+                                          cells beyond it are never evaluated. */
 };
 
 #define GPANN_MAX_K 64u                 /* top-k lists are held one entry per wavefront lane */
@@ -145,6 +154,8 @@ typedef struct gpann_scan_stats {
     uint64_t filter_rest_rows;   /* of filter_rows: the last ("rest") pass, the launch that streams nearly the whole store once */
     float filter_rest_ms;        /* that one FilterKernelCells launch alone, HIP events */
     uint32_t filter_rest_hi_only;/* 1 if it read only the hi plane (d * 2 bytes per row), 0 if hi + lo (d * 4) */
+    uint64_t filter_two_plane_rows; /* of filter_rows: rows streamed by the launches that read both planes (shard-sample and head passes) */
+    uint64_t filter_seed_rows;   /* rows evaluated exactly for the first lists (filter mode: tasks x seed rows) */
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 

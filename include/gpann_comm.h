@@ -73,6 +73,13 @@ size_t gpann_comm_gather_slots_scratch(int world, size_t n);
 gpann_status gpann_comm_gather_slots(gpann_comm* c, const float* dist, const uint32_t* ids, size_t n, float* out_dist, uint32_t* out_ids, void* scratch,
                                      const uint32_t* id_map, void* stream);
 
+/* Testing hook: the DEVICE half of gpann_comm_gather_slots for a fabricated world, without a communicator — what a 1-GPU box can check of the
+ * RCCL path with more than one rank.  rank_dist / rank_ids [world][n] (host): what each rank would contribute, ids still LOCAL when id_maps is
+ * given; id_maps (host, may be NULL): the ranks' id maps back to back, rank r's at id_maps[id_map_begin[r] .. id_map_begin[r + 1]).  Runs
+ * MapIdsKernel on every rank's block and SelectSlotsKernel over the gathered buffer on `device`; out_dist / out_ids [n] (host). */
+gpann_status gpann_comm_debug_select_slots(int world, size_t n, const float* rank_dist, const uint32_t* rank_ids, const uint32_t* id_maps,
+                                           const uint64_t* id_map_begin, float* out_dist, uint32_t* out_ids, int device);
+
 /* ---- placement helpers (host) ---- */
 /* Longest-processing-time bin packing of S shards onto `world` ranks by descending size (ties: lower shard id first; the lighter
  * rank, then the lower rank, takes the shard).  owner[S], load[world] (rows per rank; may be NULL). */

@@ -33,3 +33,13 @@ def test_traffic_lookup_knows_the_other_configurations_and_nothing_else():
         traffic, src = b.lookup_traffic(*shape, "FilterKernelCells<", {"true": 1}, largest_launch=True)
         assert src is not None and traffic > 0, shape
     assert b.lookup_traffic(123, 7, 3, 1, "FilterKernelCells<", {"true": 1}, largest_launch=True) == (None, None)
+
+
+def test_a_pass_taken_on_other_bytes_is_not_reported():
+    """with the run's own dominant-launch bytes given, a committed pass is only used if ITS run read the same bytes (within 2 %): the
+    round-2 files carry no such figure (taken before the guard existed, on a layout with different bytes per row) and must not be used"""
+    b = _bench()
+    traffic, src = b.lookup_traffic(10_000_000, 96, 16, 4, "FilterKernelCells<", {"true": 1}, largest_launch=True, kernel_bytes=15.9e9)
+    assert traffic is None or src.startswith("profiles/r03/"), (traffic, src)
+    if traffic is None:
+        assert src is None or src.startswith("stale: "), src

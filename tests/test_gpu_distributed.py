@@ -101,3 +101,46 @@ def test_ranks_sharing_one_gpu_over_tcp(data, world):
     single = str(data["tmp"] / "router_r1.tree")
     if os.path.exists(single):
         assert a == open(single, "rb").read()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_owner_selection_kernels_on_a_fabricated_world(gp, world):
+    """SelectSlotsKernel / MapIdsKernel (csrc/comm.hip) with world > 1 on device buffers — the part of the RCCL path a 1-GPU box can
+    run: a fabricated all-gather result for `world` ranks incl. replicated shards (a replicated shard's tasks are split by query id, so
+    a slot is still non-empty on exactly one rank), every rank reporting LOCAL row ids with its own id map."""
+    from pygpann import comm as gcomm
+    rng = np.random.default_rng(world)
+    nq, nprobe, k, S = 700, 3, 10, 24
+    shard_rows = rng.integers(1000, 50000, S).astype(np.uint64)
+    work = shard_rows.astype(np.float64) * rng.integers(1, 200, S)
+    rep_begin, rep_rank, _, _ = gcomm.plan_replicas(shard_rows, work, world, int(2.5 * shard_rows.sum() / world), 1.0)
+    assert int(rep_begin[S]) > S or world == 2            # replicas exist (8 ranks always have room)
+    probes = np.stack([rng.permutation(S)[:nprobe] for _ in range(nq)]).astype(np.int32)
+    probes[::11, 1] = -1                                  # skipped slots: empty on every rank
+    n = nq * nprobe * k
+    # every rank: its local rows are a random subset of the global ids, in ascending order (bench.py: my_ids)
+    n_global = 1_000_000
+    id_maps = [np.sort(rng.choice(n_global, 30000, replace=False)).astype(np.uint32) for _ in range(world)]
+    rank_dist = np.full((world, nq, nprobe, k), np.inf, np.float32)
+    rank_ids = np.full((world, nq, nprobe, k), 0xFFFFFFFF, np.uint32)
+    want_dist = np.full((nq, nprobe, k), np.inf, np.float32)
+    want_ids = np.full((nq, nprobe, k), 0xFFFFFFFF, np.uint32)
+    owned = np.zeros((nq, nprobe), bool)
+    for r in range(world):
+        mine = gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r)
+        for q, j in zip(*np.nonzero(mine >= 0)):
+            cnt = int(rng.integers(0, k + 1))             # short lists (cut at the merge bound / small shards) are part of the contract
+            local = rng.choice(len(id_maps[r]), cnt, replace=False).astype(np.uint32)
+            d = np.sort(rng.random(cnt).astype(np.float32))
+            assert not owned[q, j]                        # one owner per slot, replicas included
+            owned[q, j] = True
+            rank_dist[r, q, j, :cnt], rank_ids[r, q, j, :cnt] = d, local
+            want_dist[q, j, :cnt], want_ids[q, j, :cnt] = d, id_maps[r][local]
+    assert np.array_equal(owned, probes >= 0)             # every valid slot has its owner
+    got_d, got_i = gcomm.debug_select_slots(rank_dist.reshape(world, n), rank_ids.reshape(world, n), id_maps)
+    assert np.array_equal(got_i, want_ids.reshape(-1))
+    assert np.array_equal(got_d.view(np.uint32), want_dist.reshape(-1).view(np.uint32))
+    # without id maps: ids pass through
+    got_d2, got_i2 = gcomm.debug_select_slots(rank_dist.reshape(world, n), rank_ids.reshape(world, n))
+    sel = rank_ids.reshape(world, n)
+    assert np.array_equal(got_i2, np.where((sel != 0xFFFFFFFF).any(axis=0), sel.min(axis=0), 0xFFFFFFFF).astype(np.uint32))

@@ -284,3 +284,25 @@ def test_bound_path_beyond_128_dimensions(orc, gp, metric, d):
     assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
     st = router.stats()
     assert st["bound_calls"] == 1 and st["verified"] == 1 and st["verify_failures"] == 0 and st["bound_overflow"] == 0 and st["bound_selfcheck"] == 0
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d,S,num_centroids", [(32, 5, 16), (100, 60, 8), (128, 40, 64), (200, 7, 32)])
+def test_shipping_configuration_of_the_bound_path(orc, gp, metric, d, S, num_centroids, monkeypatch):
+    """What ships is the bound path WITHOUT GPANN_ROUTER_VERIFY (the session arms it, conftest.py): only the always-on checks run — pass 1
+    left a maximum and a finite threshold for every (query, shard-with-centroids), pass 2 a minimum — and must stay silent (STRICT stays
+    armed: a fired check would fail the call).  Same parity bar as the verified runs, first call of a fresh handle included."""
+    monkeypatch.delenv("GPANN_ROUTER_VERIFY", raising=False)
+    pts, clusters, tree = _tree(orc, 30000, d, S, metric, num_centroids, 40, 6000, seed=d + metric)
+    queries = make_mixture(orc, 700, d, seed=556, n_centers=24)
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    for fresh in range(2):
+        router = gp.Router(tree.flat(), metric, 0)
+        for _ in range(2):
+            p, md, _ = router.query_batch(queries, 10 ** 6)          # budget covers the tree: the matrix-core bound path
+            assert np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
+            assert np.array_equal(p, want_p)
+        st = router.stats()
+        assert st["bound_calls"] == 2 and st["verified"] == 0, st
+        assert st["bound_selfcheck"] == 0 and st["bound_overflow"] == 0 and st["verify_failures"] == 0, st
+        router.close()
