@@ -557,18 +557,21 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const auto& C = s->cells;
     const uint32_t kmax = C.kmax;
     const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
-    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1024, (6144ull << 20) / (4ull * T))));
+    // candidate bucket per task: what its rows cost is the candidates actually written, so the size is only bounded by memory (6 GiB);
+    // the pass structure below is laid out for a fill of about a quarter of min(cap, 4096)
+    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1024, (6144ull << 20) / (4ull * T))));
+    const uint32_t cap_plan = std::min<uint32_t>(cap, 4096);
     // Three filter passes keep the candidate buckets small whatever the geometry: rows inside a cell are in store order, i.e.
     // a random sample of the cell, so after a pass over a fraction 1/f of the needed rows only about f * k rows of the rest can
     // still beat the k-th distance.  Pass 0 = the head of each task's nearest cell (at most half a bucket of rows), pass 1 =
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
     // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
     // (the head pass multiplies both planes: it cannot reach past the rows that have a lo tile)
-    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap / 2) / kGTileRows, C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles);
+    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows, C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles);
     int64_t max_rows = 1;
     for (uint32_t b = 0; b < S; ++b) max_rows = std::max<int64_t>(max_rows, s->offsets[b + 1] - s->offsets[b]);
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
-    const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap);
+    const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap_plan - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap_plan);
     const uint32_t sample_div = std::max<uint32_t>(2, EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
     const bool l2 = s->metric == GPANN_METRIC_L2;
     (void)flags;
@@ -578,7 +581,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 
     // ---- workspace
     const bool for_merge = (flags & GPANN_SCAN_FOR_MERGE) != 0;
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4));
+    // dirty tasks (bucket overflow): at most dirty_cap of them are redone exactly on the device; more than that = the data defeats the
+    // filter (masses of equal distances) and the whole call falls back to the plain exact scan
+    const uint32_t dirty_cap = std::max<uint32_t>(16, std::min<uint32_t>(256, T / 100));
+    const uint32_t range_segs = 512;
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 4 + (size_t)dirty_cap * 8 + 64));
+    GPANN_TRY(s->ws_partials.Reserve((size_t)dirty_cap * range_segs * k * 8 + 256));
     float* list_dist = s->ws_lists.as<float>();
     uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
     float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
@@ -588,6 +596,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // next pass's thresholds and cell tests of ALL the query's tasks read it)
     uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
     if (for_merge) GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_query_tau), (int)kOrderedKeyInf, nq, st));
+    uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
+    uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + T) & 4) ? 1 : 0));
+    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 4, st));
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
@@ -799,17 +810,19 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.list_row = list_row;
     ra.task_shard = ta.shard;
     ra.shard_offsets = s->d_offsets;
-    ra.range_lo = 0;               // an overflowed bucket re-reads the whole shard (duplicates are dropped)
-    ra.range_hi = INT64_MAX;
     ra.tasks = T;
     ra.k = k;
     ra.d = s->d;
     ra.ld = s->ld;
     ra.cand_cap = cap;
     ra.dedupe = 1;
-    const uint32_t overflow_limit = std::max<uint32_t>(8, T / 1000);
-    ra.overflow_count = d_overflow;
-    ra.overflow_limit = overflow_limit;
+    ra.dirty_flag = d_dirty_flag;
+    ra.dirty_list = d_dirty_list;
+    ra.dirty_count = d_overflow + 1;
+    ra.dirty_cap = dirty_cap;
+    ra.range_segs = 0;
+    ra.part_dist = s->ws_partials.as<float>();
+    ra.part_row = reinterpret_cast<uint32_t*>(ra.part_dist + (size_t)dirty_cap * range_segs * k);
     ra.seed_rows = 0;
     ra.nearest = d_nearest;
     ra.task_src = d_task_src;
@@ -971,6 +984,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                     (unsigned long long)((uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32)), h_words[0]);
         }
     }
+    {   // the dirty tasks: their whole shards exactly, range_segs segments each on a wavefront of its own, merged into their lists
+        // (launched whatever the count — no host round trip: without dirty tasks both launches end at once)
+        RescoreArgs rr = ra;
+        rr.range_segs = range_segs;
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(4096), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(4096), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        hipLaunchKernelGGL(DirtyMergeKernel, dim3(dirty_cap), dim3(64), 0, st, rr);
+        GPANN_HIP_TRY(hipGetLastError());
+    }
     {
         // the lists go out before the overflow words are looked at (one host round trip less on the way; an overflowed call rewrites
         // them in the plain exact scan)
@@ -992,7 +1014,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
         plan.filter_rows = (uint64_t)(h_work[1] + h_work[2]) * kGTileRows;
         plan.filter_two_plane_rows = (uint64_t)h_work[2] * kGTileRows;
-        if (h_words[0] > overflow_limit) *overflow = true;
+        plan.filter_dirty_tasks = h_words[1];
+        if (h_words[1] > dirty_cap) *overflow = true;
+        if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] buckets overflowed (task x pass) %u, dirty tasks redone exactly %u (cap %u)\n", h_words[0], h_words[1], dirty_cap);
     }
     return GPANN_OK;
 }
@@ -1086,6 +1110,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.filter_candidates = plan.filter_candidates;
     s->stats.filter_plane_ksteps = s->stats.filtered ? s->cells.plane_ks : 0u;
     s->stats.filter_two_plane_rows = plan.filter_two_plane_rows;
+    s->stats.filter_dirty_tasks = plan.filter_dirty_tasks;
     s->stats.filter_seed_rows = s->stats.filtered ? plan.padded_pairs : 0;
     return GPANN_OK;
 }

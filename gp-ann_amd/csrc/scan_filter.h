@@ -184,13 +184,22 @@ struct RescoreArgs {
     const uint32_t* cand_row;
     float* list_dist;             // [tasks][k] in/out, ascending (dist, row)
     uint32_t* list_row;
-    const uint32_t* task_shard;   // for the rare overflowed bucket: the task's shard ...
-    const int64_t* shard_offsets; // ... and the pass's row range inside it, [offset + range_lo, min(end, offset + range_hi))
-    int64_t range_lo, range_hi;
+    const uint32_t* task_shard;
+    const int64_t* shard_offsets;
     uint32_t tasks, k, d, ld, cand_cap;
     uint32_t dedupe;              // 1: skip candidates already in the list (cell passes)
-    const uint32_t* overflow_count;   // buckets overflowed so far in this call (device counter) ...
-    uint32_t overflow_limit;          // ... beyond this many the call falls back to the exact scan: no more in-kernel re-reads
+    // A task whose bucket overflows in some pass is DIRTY: its bucket is not re-scored (its list, made of real rows, stays a valid if
+    // looser bound for the later passes) and after the last pass its whole shard is evaluated exactly by many wavefronts (RANGE mode
+    // below + DirtyMergeKernel).  (Until round 3 the one wavefront of the task re-read the shard inside this kernel: 1.6 s for a 7.5M-row shard.)
+    uint32_t* dirty_flag;         // [tasks] zeroed per call
+    uint2* dirty_list;            // [dirty_cap] (task, unused)
+    uint32_t* dirty_count;        // dirty tasks so far (may exceed dirty_cap: the call then falls back to the plain exact scan)
+    uint32_t dirty_cap;
+    // RANGE mode (range_segs > 0): work item w = (dirty task w / range_segs, segment w % range_segs) of the task's shard, evaluated from
+    // an EMPTY list into part_dist / part_row [w][k]; the workgroups of the launch take items round robin
+    uint32_t range_segs;
+    float* part_dist;
+    uint32_t* part_row;
     // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
     // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
     uint32_t seed_rows;
@@ -246,8 +255,22 @@ template <int METRIC>
 __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * kRescoreTasksPerWG + wave;
-    if (t >= a.tasks) return;
+    const bool ranged = a.range_segs != 0;
+    for (uint32_t item = blockIdx.x * kRescoreTasksPerWG + wave;; item += gridDim.x * kRescoreTasksPerWG) {   // (one pass unless RANGE mode)
+    uint32_t t = item;
+    int64_t scan_lo = 0, scan_hi = 0;
+    if (ranged) {
+        const uint32_t n_dirty = min(*a.dirty_count, a.dirty_cap);
+        if (item >= n_dirty * a.range_segs) return;
+        t = a.dirty_list[item / a.range_segs].x;
+        const uint32_t seg = item % a.range_segs, b = a.task_shard[t];
+        const int64_t r0 = a.shard_offsets[b], rows = a.shard_offsets[b + 1] - r0;
+        const int64_t per = (rows + a.range_segs - 1) / a.range_segs;
+        scan_lo = min(r0 + rows, r0 + (int64_t)seg * per);
+        scan_hi = min(r0 + rows, scan_lo + per);
+    } else if (t >= a.tasks) {
+        return;
+    }
     const bool seed = a.seed_rows != 0;
     uint64_t seed_first = 0;   // first plane row of the task's nearest cell
     uint32_t cnt;
@@ -260,12 +283,20 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         seed_first = a.cell_tile_begin[a.shard_cell_begin[b] + a.nearest[a.task_src[t]]] * kGTileRows;
         if (seed_first + a.seed_rows > p1) seed_first = p1 - p0 > a.seed_rows ? p1 - a.seed_rows : p0;
         cnt = (uint32_t)min((uint64_t)a.seed_rows, p1 - seed_first);
+    } else if (ranged) {
+        cnt = 0;
     } else {
         cnt = a.cand_cnt[t];
         if (cnt == 0) return;
+        if (cnt > a.cand_cap) {   // the bucket overflowed: the task is dirty from now on
+            if (lane == 0 && atomicExch(&a.dirty_flag[t], 1u) == 0u) {
+                const uint32_t slot = atomicAdd(a.dirty_count, 1u);
+                if (slot < a.dirty_cap) a.dirty_list[slot] = make_uint2(t, 0u);
+            }
+            return;
+        }
     }
-    const bool overflowed = !seed && cnt > a.cand_cap;   // rare: this wave then evaluates the pass's whole row range of the shard itself
-    if (overflowed && *a.overflow_count > a.overflow_limit) return;   // wide-spread overflow: the caller discards these lists
+    const bool overflowed = ranged;   // the "candidates" are the rows [scan_lo, scan_hi) of the shard
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
     float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
     float* srow = sq + ld;   // [16][ld + 4]
@@ -274,15 +305,9 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     const uint32_t k = a.k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
-    if (lane < (int)k && !seed) {
+    if (lane < (int)k && !seed && !ranged) {
         ld_ = a.list_dist[(size_t)t * k + lane];
         lr_ = a.list_row[(size_t)t * k + lane];
-    }
-    int64_t scan_lo = 0, scan_hi = 0;
-    if (overflowed) {
-        const uint32_t b = a.task_shard[t];
-        scan_lo = min(a.shard_offsets[b + 1], a.shard_offsets[b] + a.range_lo);
-        scan_hi = a.range_hi == INT64_MAX ? a.shard_offsets[b + 1] : min(a.shard_offsets[b + 1], a.shard_offsets[b] + a.range_hi);
     }
     const uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
     const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 float4 (128 dimensions) of a row per load instruction and half wavefront
@@ -412,11 +437,54 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
             mask = __ballot(pass);
         }
     }
+    if (ranged) {
+        if (lane < (int)k) {
+            a.part_dist[(size_t)item * k + lane] = ld_;
+            a.part_row[(size_t)item * k + lane] = lr_;
+        }
+        __builtin_amdgcn_wave_barrier();   // (the next item re-uses this wavefront's LDS)
+        continue;
+    }
     if (lane < (int)k) {
         a.list_dist[(size_t)t * k + lane] = ld_;
         a.list_row[(size_t)t * k + lane] = lr_;
     }
     // the query's merge bound: the smallest k-th distance among its tasks' lists (a list that is not full yet has +inf there)
+    if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
+    return;
+    }   // items
+}
+
+// The dirty tasks' lists: one wavefront per dirty task merges the range_segs partial lists RescoreKernel's RANGE mode left (ascending
+// (dist, row), disjoint row ranges) into the task's list — which then is the exact top-k of the whole shard, whatever the passes did.
+static __global__ void __launch_bounds__(64) DirtyMergeKernel(RescoreArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t n_dirty = min(*a.dirty_count, a.dirty_cap);
+    if (blockIdx.x >= n_dirty) return;
+    const uint32_t t = a.dirty_list[blockIdx.x].x, k = a.k;
+    float ld_ = INFINITY;
+    uint32_t lr_ = kNoId;
+    for (uint32_t sg = 0; sg < a.range_segs; ++sg) {
+        const size_t base = ((size_t)blockIdx.x * a.range_segs + sg) * k;
+        float cd_l = INFINITY;
+        uint32_t cr_l = kNoId;
+        if (lane < (int)k) {
+            cd_l = a.part_dist[base + lane];
+            cr_l = a.part_row[base + lane];
+        }
+        for (uint32_t e = 0; e < k; ++e) {
+            const float cd = __shfl(cd_l, e);
+            const uint32_t cr = __shfl(cr_l, e);
+            const float td = __shfl(ld_, k - 1);
+            const uint32_t tr = __shfl(lr_, k - 1);
+            if (!PairLess(cd, cr, td, tr)) break;
+            ListInsertF(ld_, lr_, cd, cr, k, lane);
+        }
+    }
+    if (lane < (int)k) {
+        a.list_dist[(size_t)t * k + lane] = ld_;
+        a.list_row[(size_t)t * k + lane] = lr_;
+    }
     if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
 }
 

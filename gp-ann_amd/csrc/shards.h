@@ -26,7 +26,7 @@ struct ScanPlan {
     std::vector<ScanUnit> units;
     uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0, filter_two_plane_rows = 0;
     bool filter_rest_hi_only = false;
-    uint32_t filter_launches = 0;
+    uint32_t filter_launches = 0, filter_dirty_tasks = 0;
     void Clear() {
         task_query.clear();
         task_out.clear();
@@ -36,7 +36,7 @@ struct ScanPlan {
         shard_task_begin.clear();
         units.clear();
         n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = filter_two_plane_rows = 0;
-        filter_launches = 0;
+        filter_launches = filter_dirty_tasks = 0;
     }
 };
 

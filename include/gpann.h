@@ -149,7 +149,7 @@ typedef struct gpann_scan_stats {
     float scan_ms;               /* scan kernels (exact mode: ScanTileKernel; filter mode: every kernel of the pipeline), HIP events */
     float merge_ms;              /* merge kernel(s), HIP events */
     float filter_ms;             /* of scan_ms: the MFMA filter kernels (threshold + filter launches of all passes) */
-    float reserved2;
+    uint32_t filter_dirty_tasks; /* tasks whose candidate bucket overflowed in some pass and whose shard was therefore evaluated exactly, row by row */
     uint64_t filter_rows;        /* rows streamed by the filter kernels: sum over their workgroups of the row segment (all passes) */
     uint64_t filter_rest_rows;   /* of filter_rows: the last ("rest") pass, the launch that streams nearly the whole store once */
     float filter_rest_ms;        /* that one FilterKernelCells launch alone, HIP events */

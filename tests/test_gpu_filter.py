@@ -87,9 +87,9 @@ def test_filtered_scan_duplicates_overflow_falls_back(orc, gp):
     probes = np.zeros((nq, 1), np.int32)
     st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
     assert st["filtered"] == 0
-    queries[1:40] = queries[41:80][:39] if nq >= 80 else queries[40:41]   # only one flooding query: re-scanned inside the rescoring kernel
+    queries[1:40] = queries[41:80][:39] if nq >= 80 else queries[40:41]   # only one flooding query: a DIRTY task, its shard is redone exactly on the device
     st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
-    assert st["filtered"] == 1
+    assert st["filtered"] == 1 and st["filter_dirty_tasks"] >= 1, st
 
 
 def test_filtered_ground_truth_and_merged(orc, gp):
@@ -110,7 +110,8 @@ def test_filtered_ground_truth_and_merged(orc, gp):
 
 
 def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, monkeypatch):
-    """a tiny candidate cap forces a few buckets to overflow: those tasks are re-scanned exactly by the rescoring kernel"""
+    """a tiny candidate cap forces a few buckets to overflow: those tasks become dirty and their shards are evaluated exactly, in segments
+    spread over many wavefronts (RescoreKernel RANGE mode + DirtyMergeKernel), after the last pass"""
     rng = np.random.default_rng(37)
     n, d, nq, k = 30000, 24, 3000, 10
     pts = make_mixture(orc, n, d, n_centers=16)
@@ -118,7 +119,15 @@ def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, mo
     queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
     probes = np.zeros((nq, 1), np.int32)
     monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "200")     # expected fill ~ k * 26000 / 4096 = 63 + tail
-    _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
+    st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
+    assert st["filtered"] == 0 or st["filter_dirty_tasks"] >= 1, st
+    # several shards of different sizes, dirty tasks in each, L2 and inner product, merge bound on: the redone lists obey the same contract
+    S = 4
+    clusters = random_clusters(rng, n, S, overlap=0.2)
+    probes = np.stack([rng.permutation(S)[:3] for _ in range(nq)]).astype(np.int32)
+    monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "120")
+    for metric in (0, 1):
+        st = _check(orc, gp, pts, clusters, queries[:700], probes[:700], 3, k, metric, expect_filtered=None)
 
 
 def test_filter_without_precomputed_planes(orc, gp, monkeypatch):

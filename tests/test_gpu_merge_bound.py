@@ -19,7 +19,7 @@ def _truncate(wd, wi):
     td, ti = wd.copy(), wi.copy()
     td[cut] = np.inf
     ti[cut] = NO_ID
-    return td, ti, int(cut.sum() - (wi == NO_ID).sum())
+    return td, ti, int((cut & (wi != NO_ID)).sum())
 
 
 def _merged(orc, dist, ids, k):
