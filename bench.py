@@ -629,14 +629,15 @@ def main():
         tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
         # bytes the rest pass has to read: its row tiles x (bf16 hi plane [+ lo plane] + the row's norm word)
         ks_read = stats["filter_plane_ksteps"]   # 16-dim k-steps a plane row is stored with and the kernel loads (32 B each; ceil(d / 16) rounded up to a kernel instance)
-        rest_bytes = stats["filter_rest_rows"] * (32.0 * ks_read * (1.0 if stats["filter_rest_hi_only"] else 2.0) + 4.0)
+        # (bf16 hi plane: 32 B per k-step of 16 dimensions; 8-bit plane: 32 B per k-step of 32 dimensions — the library reports which)
+        rest_bytes = stats["filter_rest_rows"] * float(stats["filter_rest_row_bytes"])
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
         traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"true": 1}, largest_launch=True, kernel_bytes=rest_bytes)
         # step level: the bytes every launch of the step has to read — plane rows of all filter launches (two-plane launches twice the plane
         # bytes), the rows re-scored exactly (candidates + seed rows, d x 4 each), the router's centroid planes (both passes, both planes)
         row_hi = 32.0 * ks_read + 4.0
-        hi_rows = stats["filter_rows"] - stats["filter_two_plane_rows"]
-        step_bytes = (hi_rows * row_hi + stats["filter_two_plane_rows"] * (64.0 * ks_read + 4.0)
+        hi_rows = stats["filter_rows"] - stats["filter_two_plane_rows"] - stats["filter_rest_rows"]
+        step_bytes = (rest_bytes + hi_rows * row_hi + stats["filter_two_plane_rows"] * (64.0 * ks_read + 4.0)
                       + (stats["filter_candidates"] + stats["filter_seed_rows"]) * d * 4.0
                       + 2.0 * tree["centroids"].shape[0] * 64.0 * ks_read)
         step_s = elapsed / args.steps
@@ -646,6 +647,8 @@ def main():
                               "frac_step_note": "bytes ALL launches of a step have to read (plane rows of every filter pass, exactly re-scored rows, the router's "
                                                 "centroid planes) / ms_per_step / 8 TB/s: what the step as a whole makes of the memory system",
                               "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s, "kernel_bytes": rest_bytes,
+                              "kernel_row_bytes": stats["filter_rest_row_bytes"],
+                              "kernel_plane": "int8 (per-cell scaled residuals)" if stats["filter_rest_row_bytes"] < 32 * ks_read + 4 else "bf16 hi",
                               "note": "achieved = the bytes the dominant launch (the rest pass of FilterKernelCells) HAS TO read — its row tiles x (bf16 hi "
                                       "plane + norm word) — / its own HIP-event time on the scan's stream; frac = achieved / 8 TB/s.  traffic = the PMC "
                                       "figure (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) of that launch from the committed pass named in "

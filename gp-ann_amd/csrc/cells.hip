@@ -133,10 +133,99 @@ __global__ void __launch_bounds__(256) CellRadiusKernel(const float* points, con
     }
 }
 
+// ---- the 8-bit plane of the rest pass (scan_q8.h) ----------------------------------------------------------------------------------
+// per cell: max over its rows and dimensions of |p~_i - c^_i| (p~ = fl(p - mu), c^ = fl(c - mu); mu absent: the values themselves) -> the
+// cell's quantisation step, and |c^|^2.  One workgroup per cell.
+__global__ void __launch_bounds__(256) CellQ8ScaleKernel(const float* points, const uint32_t* plane_perm, const uint64_t* cell_tile_begin, const float* center,
+                                                         const float* mu, uint32_t d, uint32_t ld, float* scale, double* cnorm) {
+    __shared__ float s_max[256];
+    const uint32_t cell = blockIdx.x;
+    const uint64_t begin = cell_tile_begin[cell] * kGTileRows, end = cell_tile_begin[cell + 1] * kGTileRows;
+    const float* c = center + (size_t)cell * ld;
+    float mx = 0.f;
+    // thread t handles dimension t % ld4 * 4 .. + 3 of rows t / ld4, + 256 / ld4, ...: coalesced over a row
+    const uint32_t ld4 = ld / 4, rows_per_iter = max(1u, 256u / ld4);
+    const uint32_t my_c4 = threadIdx.x % ld4, my_r = threadIdx.x / ld4;
+    if (my_r < rows_per_iter) {
+        float4 cc = *reinterpret_cast<const float4*>(c + 4 * my_c4);
+        float4 mm = mu ? *reinterpret_cast<const float4*>(mu + 4 * my_c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mu) cc = make_float4(cc.x - mm.x, cc.y - mm.y, cc.z - mm.z, cc.w - mm.w);
+        for (uint64_t i = begin + my_r; i < end; i += rows_per_iter) {
+            const uint32_t row = plane_perm[i];
+            if (row == kNoRow) continue;
+            float4 p = *reinterpret_cast<const float4*>(points + (size_t)row * ld + 4 * my_c4);
+            if (mu) p = make_float4(p.x - mm.x, p.y - mm.y, p.z - mm.z, p.w - mm.w);
+            // (float differences of floats: within one rounding of the exact residual — the factor below covers it)
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(p.x - cc.x), fabsf(p.y - cc.y)), fmaxf(fabsf(p.z - cc.z), fabsf(p.w - cc.w))));
+        }
+    }
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double st = fmax((double)s_max[0] * (1.0 + 1e-6) / 127.0, 1e-30);
+        float sf = (float)st;
+        if ((double)sf < st) sf = nextafterf(sf, INFINITY);
+        scale[cell] = sf;
+        double acc = 0.0;
+        for (uint32_t x = 0; x < d; ++x) {
+            const float v = mu ? c[x] - mu[x] : c[x];
+            acc += (double)v * (double)v;
+        }
+        cnorm[cell] = acc;
+    }
+}
+
+// the int8 plane of one cell: P' = round((p~ - c^) / scale) in [-127, 127], v_mfma_i32_32x32x32_i8 A-operand order.  One workgroup per cell;
+// a thread converts 16 dimensions of a row (one 16-byte store).
+__global__ void __launch_bounds__(256) CellQ8PlaneKernel(const float* points, const uint32_t* plane_perm, const uint64_t* cell_tile_begin, const float* center,
+                                                         const float* mu, const float* scale, uint32_t ld, uint32_t q8_ks, char* planes) {
+    const uint32_t cell = blockIdx.x;
+    const uint64_t begin = cell_tile_begin[cell] * kGTileRows, end = cell_tile_begin[cell + 1] * kGTileRows;
+    const float* c = center + (size_t)cell * ld;
+    const double inv = 1.0 / (double)scale[cell];
+    const uint32_t g_per_row = 2 * q8_ks;   // groups of 16 dimensions
+    const uint64_t total = (end - begin) * g_per_row;
+    for (uint64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint64_t r = begin + i / g_per_row;
+        const uint32_t g16 = (uint32_t)(i % g_per_row);
+        const uint32_t row = plane_perm[r];
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (row != kNoRow) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t x = 16 * g16 + j;
+                int v = 0;
+                if (x < ld) {   // (pad columns of a row are zero on both sides: residual 0)
+                    const float pv = mu ? points[(size_t)row * ld + x] - mu[x] : points[(size_t)row * ld + x];
+                    const float cv = mu ? c[x] - mu[x] : c[x];
+                    v = (int)rint(((double)pv - (double)cv) * inv);
+                    v = max(-127, min(127, v));
+                }
+                w[j >> 2] |= ((uint32_t)v & 0xFFu) << (8 * (j & 3));
+            }
+        }
+        const uint32_t ks = g16 >> 1, h = g16 & 1, lane = (uint32_t)(r & 31) + 32 * h;
+        *reinterpret_cast<uint4*>(planes + (r >> 5) * ((uint64_t)q8_ks * 1024) + ks * 1024 + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// max of plane_norm over every 32-row tile (-inf rows: padding)
+__global__ void TileNormMaxKernel(const float* plane_norm, uint64_t tiles, float* tile_nmax) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    float m = -INFINITY;
+    for (int i = 0; i < kGTileRows; ++i) m = fmaxf(m, plane_norm[t * kGTileRows + i]);
+    tile_nmax[t] = m;
+}
+
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin})
+                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_nmax})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -363,6 +452,36 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     if (d_cell_size) (void)hipFree(d_cell_size);
     if (d_tile_lo_index) (void)hipFree(d_tile_lo_index);
     if (!ok) return give_up("device");
+
+    // the 8-bit plane of the rest pass (optional: without it the rest pass streams the bf16 hi plane)
+    {
+        const char* q8_env = std::getenv("GPANN_FILTER_Q8");
+        if (!(q8_env && q8_env[0] == '0')) {
+            C.q8_ks = (s->d + 31) / 32;
+            bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
+                       hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_nmax, (C.n_tiles + 2) * 4) == hipSuccess &&
+                       hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess;
+            if (qok) {
+                hipLaunchKernelGGL(CellQ8ScaleKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, s->d, ld,
+                                   C.d_q8_scale, C.d_q8_cnorm);
+                hipLaunchKernelGGL(CellQ8PlaneKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, C.d_q8_scale, ld,
+                                   C.q8_ks, C.q8_planes);
+                hipLaunchKernelGGL(TileNormMaxKernel, dim3((uint32_t)((C.n_tiles + 2 + 255) / 256)), dim3(256), 0, 0, C.plane_norm, C.n_tiles + 2, C.d_tile_nmax);
+                qok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            }
+            if (!qok) {   // the store works without it
+                (void)hipGetLastError();
+                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_nmax})
+                    if (p) (void)hipFree(p);
+                C.q8_planes = nullptr;
+                C.d_q8_scale = nullptr;
+                C.d_q8_cnorm = nullptr;
+                C.d_tile_nmax = nullptr;
+                C.q8_ks = 0;
+                fprintf(stderr, "[gpann] the 8-bit plane of the filter's rest pass could not be built; the rest pass streams the bf16 plane\n");
+            }
+        }
+    }
 
     // the shard sample's rows, norms and planes behind the cell tiles
     {

@@ -577,6 +577,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     (void)flags;
     const uint32_t KS = C.plane_ks, QT = (uint32_t)FilterQueryTiles((int)KS);
     const bool wide = KS > 8;   // beyond 128 dimensions: hi-plane passes only, 4 query tiles per group
+    // the rest pass on the 8-bit plane (scan_cells.h MODE 2) when the store has one: a quarter of the fp32 bytes per row instead of half
+    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && EnvU32("GPANN_FILTER_Q8", 1) != 0;
+    const uint32_t KS8 = C.q8_ks, QT8 = 8;
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
@@ -619,9 +622,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 8 + (size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     double* d_task_nq = s->ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
-    float* cell_dist = reinterpret_cast<float*>(d_task_nq + T);
+    double* d_task_q1 = d_task_nq + T;              // |q~|_1 (old order) ...
+    float* d_task_tscale = reinterpret_cast<float*>(d_task_q1 + T);   // ... the 8-bit query step (old order) ...
+    float* d_task_qscale = d_task_tscale + T;                          // ... and step / 254 in the NEW order (QueryImageQ8Kernel)
+    float* cell_dist = d_task_qscale + T;
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
     uint32_t* d_task_group = d_nearest + T;
     CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
@@ -671,7 +677,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     auto cell_table = [&](bool with_qnorm) -> gpann_status {
         hipLaunchKernelGGL(CellDistKernel, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
         hipLaunchKernelGGL(NearestCellKernel, dim3((T + 15) / 16), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
-                           s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr, C.d_mu);
+                           s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr, C.d_mu, use_q8 ? d_task_q1 : nullptr, use_q8 ? d_task_tscale : nullptr);
         GPANN_HIP_TRY(hipGetLastError());
         return GPANN_OK;
     };
@@ -705,6 +711,27 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_IMAGE(2) GPANN_IMAGE(4) GPANN_IMAGE(6) GPANN_IMAGE(7) GPANN_IMAGE(8) GPANN_IMAGE(10) GPANN_IMAGE(13) GPANN_IMAGE(16)
 #undef GPANN_IMAGE
             default: GPANN_REQUIRE(false, "no filter kernel for this number of k-steps");
+        }
+        GPANN_HIP_TRY(hipGetLastError());
+    }
+    // the 8-bit images and the (task, cell) threshold table of the rest pass
+    char* q8_image = nullptr;
+    float* q8_B = nullptr;
+    if (use_q8) {
+        const size_t img8 = (size_t)G * QT8 * KS8 * 2048, b_words = (size_t)G * kmax * 32u * QT8;
+        GPANN_TRY(s->ws_q8.Reserve(img8 + b_words * 4 + 256));
+        q8_image = s->ws_q8.as<char>();
+        q8_B = reinterpret_cast<float*>(q8_image + img8);
+        GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, b_words, st));   // +inf: "this task does not need this cell"
+        switch (KS8) {
+#define GPANN_IMAGE8(KS_)                                                                                                                                   \
+    case KS_:                                                                                                                                               \
+        hipLaunchKernelGGL((QueryImageQ8Kernel<KS_, 8>), dim3(G * QT8), dim3(64), 0, st, d_queries, ta.query, d_groups, s->ld, q8_image, C.d_mu, d_task_tscale, \
+                           d_task_src, d_task_qscale);                                                                                                      \
+        break;
+            GPANN_IMAGE8(1) GPANN_IMAGE8(2) GPANN_IMAGE8(3) GPANN_IMAGE8(4) GPANN_IMAGE8(5) GPANN_IMAGE8(6) GPANN_IMAGE8(7) GPANN_IMAGE8(8)
+#undef GPANN_IMAGE8
+            default: GPANN_REQUIRE(false, "no 8-bit filter kernel for this number of k-steps");
         }
         GPANN_HIP_TRY(hipGetLastError());
     }
@@ -767,6 +794,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.n_groups = G;
     na.query_tau = d_query_tau;
     na.task_query = ta.query;
+    na.q8_B = nullptr;   // (set for the pass that runs on the 8-bit plane)
+    na.q8_scale = C.d_q8_scale;
+    na.q8_cnorm = C.d_q8_cnorm;
+    na.task_q1 = d_task_q1;
+    na.task_tscale = d_task_tscale;
+    na.group_tasks = 32u * QT8;
     th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
@@ -800,6 +833,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.group_cursor = d_group_count + G;
     fa.image = s->ws_image.as<char>();
     fa.seg_tiles = seg_tiles;
+    fa.q8_planes = C.q8_planes;
+    fa.tile_nmax = C.d_tile_nmax;
+    fa.q8_B = q8_B;
+    fa.task_qscale = d_task_qscale;
+    fa.q8_scale = C.d_q8_scale;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -835,8 +873,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     switch (KS) {
 #define GPANN_PICK(KS_)                                                                                                                                   \
     case KS_:                                                                                                                                             \
-        fn_hi = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, true> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, true>;      \
-        if constexpr (KS_ <= 8) fn = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, false> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, false>; \
+        fn_hi = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 1>;      \
+        if constexpr (KS_ <= 8) fn = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 0> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 0>; \
         else fn = fn_hi;                                                                                                                                  \
         break;
         GPANN_PICK(2) GPANN_PICK(4) GPANN_PICK(6) GPANN_PICK(7) GPANN_PICK(8) GPANN_PICK(10) GPANN_PICK(13) GPANN_PICK(16)
@@ -852,6 +890,20 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = FilterLdsBytes((size_t)QT * KS * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    const void* fn_q8 = nullptr;
+    const size_t glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048);
+    if (use_q8) {
+        switch (KS8) {
+#define GPANN_PICK8(KS_)                                                                                                                       \
+    case KS_:                                                                                                                                  \
+        fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 2, 8>; \
+        break;
+            GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
+#undef GPANN_PICK8
+            default: break;
+        }
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
+    }
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
     if (rlds > (48u << 10)) {
         if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
@@ -939,9 +991,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
+        const bool q8_pass = use_q8 && pass == 2;   // the rest pass on the 8-bit plane (its thresholds come from Q8Threshold, not from task_U)
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];
+        na.q8_B = q8_pass ? q8_B : nullptr;
         if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         fa.need = na.need;
@@ -956,7 +1010,16 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(hipEventRecord(s->ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
         }
-        GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
+        if (q8_pass) {
+            CellFilterArgs f8 = fa;
+            f8.image = q8_image;
+            void* kargs8[] = {&f8};
+            GPANN_HIP_TRY(hipLaunchKernel(fn_q8, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs8, glds8, st));
+            plan.filter_rest_row_bytes = 32u * KS8 + 4u;
+        } else {
+            GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
+            if (pass == 2) plan.filter_rest_row_bytes = (hi_pass ? 32u : 64u) * KS + 4u;
+        }
         GPANN_HIP_TRY(hipGetLastError());
         if (pass == 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[5], st));
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
@@ -988,8 +1051,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // (launched whatever the count — no host round trip: without dirty tasks both launches end at once)
         RescoreArgs rr = ra;
         rr.range_segs = range_segs;
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(4096), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(4096), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        if (l2) hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_L2, true>), dim3(2048), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        else hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_MIPS, true>), dim3(2048), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
         hipLaunchKernelGGL(DirtyMergeKernel, dim3(dirty_cap), dim3(64), 0, st, rr);
         GPANN_HIP_TRY(hipGetLastError());
     }
@@ -1111,6 +1174,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.filter_plane_ksteps = s->stats.filtered ? s->cells.plane_ks : 0u;
     s->stats.filter_two_plane_rows = plan.filter_two_plane_rows;
     s->stats.filter_dirty_tasks = plan.filter_dirty_tasks;
+    s->stats.filter_rest_row_bytes = s->stats.filtered ? plan.filter_rest_row_bytes : 0u;
     s->stats.filter_seed_rows = s->stats.filtered ? plan.padded_pairs : 0;
     return GPANN_OK;
 }

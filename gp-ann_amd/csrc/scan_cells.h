@@ -40,6 +40,10 @@ struct CellItem {   // everything FilterKernelCells needs to run one piece of a 
     uint32_t lo_shift;         // the lo plane of row tile T is tile T - lo_shift of the lo array (two-plane passes only; shards.h)
     uint32_t acts;             // query tiles to run on the head | sample << 8 | rest << 16 segment | (tasks of the group - 1) << 24
     uint32_t group;            // the task group (its query image)
+    // 8-bit passes (MODE 2): the (task group, cell) block — row of the threshold table q8_B — and the cell's quantisation step
+    uint32_t block;
+    float cell_scale;
+    uint32_t pad0, pad1;       // (48 bytes: three 16-byte loads)
 };
 
 struct CellTileRef {
@@ -116,7 +120,7 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
 // row and its query row alone: 84 us for 10k tasks)
 static __global__ void __launch_bounds__(256) NearestCellKernel(const float* cell_dist, const uint32_t* task_shard, const uint32_t* shard_cell_begin,
                                                                 const float* queries, const uint32_t* task_query, uint32_t tasks, uint32_t kmax, uint32_t d,
-                                                                uint32_t ld, uint32_t* nearest, double* task_nq, const float* mu) {
+                                                                uint32_t ld, uint32_t* nearest, double* task_nq, const float* mu, double* task_q1, float* task_tscale) {
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t sub = threadIdx.x & 15u;
     if (t >= tasks) return;   // (whole groups of 16 lanes leave together: the shuffles below stay inside a group)
@@ -143,14 +147,31 @@ static __global__ void __launch_bounds__(256) NearestCellKernel(const float* cel
     if (sub == 0) nearest[t] = best == 0xFFFFFFFFu ? 0u : best;   // (no finite entry: cell 0, as the serial loop had it)
     if (task_nq) {
         const float* q = queries + (size_t)task_query[t] * ld;
-        double nq = 0.0;
+        double nq = 0.0, q1 = 0.0;
+        float qmax = 0.f;
         for (uint32_t i = sub; i < d; i += 16) {
             const float v = mu ? q[i] - mu[i] : q[i];   // the frame of the planes (BuildQueryTile)
             nq += (double)v * (double)v;
+            q1 += fabs((double)v);
+            qmax = fmaxf(qmax, fabsf(v));
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) nq += __shfl_xor(nq, o, 16);   // (a fixed tree: the same bits in every run)
-        if (sub == 0) task_nq[t] = nq;
+        for (int o = 8; o > 0; o >>= 1) {
+            nq += __shfl_xor(nq, o, 16);   // (a fixed tree: the same bits in every run)
+            q1 += __shfl_xor(q1, o, 16);
+            qmax = fmaxf(qmax, __shfl_xor(qmax, o, 16));
+        }
+        if (sub == 0) {
+            task_nq[t] = nq;
+            // the 8-bit query planes (QueryImageQ8Kernel): |q~|_1 and the quantisation step max |q~_i| / 127 (rounded up, never zero)
+            if (task_q1) task_q1[t] = q1;
+            if (task_tscale) {
+                const double st = fmax((double)qmax * (1.0 + 1e-6) / 127.0, 1e-30);
+                float sf = (float)st;
+                if ((double)sf < st) sf = nextafterf(sf, INFINITY);
+                task_tscale[t] = sf;
+            }
+        }
     }
 }
 
@@ -206,7 +227,52 @@ struct NeedArgs {
     // GPANN_SCAN_FOR_MERGE: the query's merge bound (OrderedKey, [nq]) caps the tau of each of its tasks
     const uint32_t* query_tau;
     const uint32_t* task_query;
+    // 8-bit pass (q8_B != nullptr): the per-(task, cell) thresholds of FilterKernelCells MODE 2, [groups][kmax][group_tasks] floats — +inf
+    // where the task does not need the cell (the array is filled with +inf before the launch)
+    float* q8_B;
+    const float* q8_scale;              // [cells] quantisation step s_c
+    const double* q8_cnorm;             // [cells] |c^|^2
+    const double* task_q1;              // [tasks] |q~|_1 (through task_src)
+    const float* task_tscale;           // [tasks] query quantisation step (through task_src)
+    uint32_t group_tasks;
 };
+
+// The threshold of the 8-bit pass for task t and cell j (derivation in DESIGN.md §3.1c).  With p~ = c^ + s P' + e (|e_i| <= s/2) and
+// q~ = t_q (H + L / 254) + f (|f_i| <= t_q / 508), I = 254 H.P' + L.P' (exact integers):
+//     q~.p~ = q~.c^ + (s t_q / 254) I + E,   |E| <= (s / 2) |q~|_1 + (t_q / 508) (sqrt(d) r + d s / 2)  =: E_tc
+// (r = the cell's radius: s |P'|_1 <= |p~ - c^|_1 + d s / 2 <= sqrt(d) r + d s / 2).  A row whose canonical distance is within tau has
+// true acc* = q~.p~ - |p~|^2/2 >= U_base (ThresholdOf without the bf16 terms), so it passes   (s t_q / 254) I + nhn_p >= B  with
+//     B = U_base - q~.c^ - E_tc - (table error) - (fp32 evaluation slack),   q~.c^ = (|q~|^2 + |c^|^2 - |q~ - c^|^2) / 2  from the cell table.
+template <int METRIC>
+__device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, double tscale, double R, double dd, double D_table, double nc, double s_c,
+                                             double radius) {
+    if (!(tau < (double)INFINITY)) return -INFINITY;
+    const double qn = sqrt(nq) * (1.0 + 1e-12);
+    double Ub;
+    if (METRIC == GPANN_METRIC_L2) {
+        const double g1 = (dd + 32.0) * 0x1p-23;
+        // 2^-21: rounding of the centred coordinates; 2^-20: the stored norm word and slack (as ThresholdOf)
+        const double e2 = (0x1p-20 + 0x1p-21) * (R + qn) * (R + qn) + 1e-30;
+        Ub = -(tau * (1.0 + 2.0 * g1) - nq * (1.0 - 0x1p-40) + e2) * 0.5;
+    } else {
+        const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
+        Ub = 1.0 - tau - e1 - 1e-30;
+    }
+    const double qc = 0.5 * (nq + nc - D_table);
+    // the table entry is a plain fp32 sum of d squared fp32 differences of the ORIGINAL coordinates: relative error (d + 2) 2^-24, plus the
+    // difference between |q - c|^2 and |q~ - c^|^2 (roundings of the centred coordinates: <= 2^-22 (|q~| + |c^|) sqrt(D))
+    const double cn = sqrt(nc);
+    const double e_tab = 0.5 * ((dd + 8.0) * 0x1p-23 * fabs(D_table) + 0x1p-21 * (qn + cn) * sqrt(fabs(D_table)) + 0x1p-40 * (nq + nc));
+    const double E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * radius + 0.5 * dd * s_c);
+    // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2
+    const double e_fp = 0x1p-21 * (qn * (radius + sqrt(dd) * s_c) + 0.5 * R * R + 1.0);
+    const double B = Ub - qc - E - e_tab - e_fp;
+    float Bf = (float)B;
+    if ((double)Bf > B) Bf = nextafterf(Bf, -INFINITY);
+    return Bf;
+}
+
+// One thread per (task, cell).
 
 // One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
 //   L2   canonical E <= tau  =>  D <= tau (1 + 2 g1), g1 = (d + 32) 2^-23 (ThresholdKernel);  D >= (|q - c| - r)^2.
@@ -261,6 +327,10 @@ static __global__ void NeedKernel(NeedArgs a) {
     if (need) {
         const uint32_t g = a.task_group[t];
         atomicOr(&a.need[(size_t)g * a.kmax + j], 1u << ((t - a.groups[g].task_begin) >> 5));
+        if (a.q8_B)
+            a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + (t - a.groups[g].task_begin)] =
+                Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
+                                    (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j]);
     }
 }
 
@@ -297,7 +367,14 @@ struct CellFilterArgs {
     uint32_t* group_count;
     uint32_t* group_cursor;
     uint32_t seg_tiles;
-    const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel)
+    const char* image;           // [groups][QT query tiles][KS][hi | lo][1 KiB]: the groups' query fragments (QueryImageKernel / QueryImageQ8Kernel)
+    // 8-bit pass (MODE 2): the int8 plane (KS KiB per tile, KS = k-steps of 32 dimensions), the tiles' largest norm words, the per-(task,
+    // cell) thresholds written by NeedKernel, the tasks' query quantisation steps / 254, the cells' steps (FilterItemsKernel copies them into the items)
+    const char* q8_planes;
+    const float* tile_nmax;
+    const float* q8_B;           // [groups][kmax][32 QT]
+    const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
+    const float* q8_scale;       // [cells]
 };
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
@@ -344,6 +421,9 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     it.lo_shift = (uint32_t)t_cell - a.cell_lo_begin[cell0 + j];
     it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (a.groups[g].task_count - 1u) << 24;
     it.group = g;
+    it.block = block;
+    it.cell_scale = a.q8_scale ? a.q8_scale[cell0 + j] : 0.f;
+    it.pad0 = it.pad1 = 0u;
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
         it.t_begin = (uint32_t)b;
@@ -366,6 +446,46 @@ static __global__ void __launch_bounds__(64) QueryImageKernel(const float* queri
     if (32u * qt >= task_count) return;   // (tiles past the group's tasks are never read)
     const uint32_t task = task_begin + min(tl, task_count - 1);
     BuildQueryTile<KS>(image + ((size_t)g * QT + qt) * KS * 2048, queries + (size_t)task_query[task] * ld, tl < task_count, ld, lane, mu);
+}
+
+// The 8-bit query image of the rest pass: per 32-task query tile and k-step of 32 dimensions two KiB — the planes H and L of
+//     q~_i = t_q (H_i + L_i / 254) + f_i,   H = round(q~_i / t_q) in [-127, 127],  L = round((q~_i / t_q - H) * 254) in [-127, 127],  |f_i| <= t_q / 508
+// in the B-operand order of v_mfma_i32_32x32x32_i8 (lane (c, h): task c of the tile, dimensions 32 ks + 16 h .. + 15).  t_q = task_tscale
+// (NearestCellKernel, old task order: through task_src); task_qscale[t] = t_q / 254 in the new order for the kernel.  One wavefront per (group, query tile).
+template <int KS, int QT>
+static __global__ void __launch_bounds__(64) QueryImageQ8Kernel(const float* queries, const uint32_t* task_query, const CellGroup* groups, uint32_t ld, char* image,
+                                                                const float* mu, const float* task_tscale, const uint32_t* task_src, float* task_qscale) {
+    const uint32_t g = blockIdx.x / QT, qt = blockIdx.x - g * QT;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const uint32_t task_begin = groups[g].task_begin, task_count = groups[g].task_count;
+    const uint32_t tl = 32u * qt + c;
+    if (32u * qt >= task_count) return;
+    const bool real = tl < task_count;
+    const uint32_t task = task_begin + min(tl, task_count - 1);
+    const float* qrow = queries + (size_t)task_query[task] * ld;
+    const float tq = task_tscale[task_src[task]];
+    if (real && h == 0) task_qscale[task] = tq / 254.0f;   // (exact to one rounding; the threshold's fp32 slack covers it)
+    const double inv = 1.0 / (double)tq;
+    char* tile = image + ((size_t)g * QT + qt) * KS * 2048;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint32_t wh[4] = {0u, 0u, 0u, 0u}, wl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t x = 32u * ks + 16u * h + j;
+            int H = 0, L = 0;
+            if (real && x < ld) {
+                const float v = mu ? qrow[x] - mu[x] : qrow[x];
+                const double u = (double)v * inv;
+                H = max(-127, min(127, (int)rint(u)));
+                L = max(-127, min(127, (int)rint((u - (double)H) * 254.0)));
+            }
+            wh[j >> 2] |= ((uint32_t)H & 0xFFu) << (8 * (j & 3));
+            wl[j >> 2] |= ((uint32_t)L & 0xFFu) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint4*>(tile + (ks * 2 + 0) * 1024 + lane * 16) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+        *reinterpret_cast<uint4*>(tile + (ks * 2 + 1) * 1024 + lane * 16) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    }
 }
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm:
@@ -422,10 +542,15 @@ __device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, 
 // KS k-steps of 16 dimensions; QT query tiles of 32 tasks per task group — 8 (256 tasks) up to KS = 8, 4 (128 tasks) for KS = 16: the
 // query image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS.  KS = 16 exists for hi-only passes only (both planes of two 16-step
 // tiles do not fit the register file).
-template <int METRIC, int TAG, int KS, bool HI_ONLY, int QT = FilterQueryTiles(KS)>
+// MODE 0: both bf16 planes of the points (three products); 1: their hi plane only (two products); 2: the 8-bit plane (scan_q8 notes above
+// Q8Threshold; KS then counts k-steps of 32 dimensions and the image holds the int8 planes H, L of the queries).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS)>
 __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
+    constexpr bool HI_ONLY = MODE >= 1, Q8 = MODE == 2;
     static_assert(QT == 4 || QT == 8, "query tiles per group");
-    static_assert(KS <= 8 || HI_ONLY, "more than 8 k-steps: hi-plane passes only");
+    static_assert(KS <= 8 || MODE == 1, "more than 8 k-steps: bf16 hi-plane passes only");
     extern __shared__ uint4 csm4[];
     char* lds = reinterpret_cast<char*>(csm4);   // [8 query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
@@ -469,7 +594,19 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
 
     Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2] = {0.f, 0.f};
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
+    float nmax[2] = {0.f, 0.f};   // (MODE 2) the tile's largest norm word
+    const char* lane_q8 = Q8 ? a.q8_planes + lane * 16 : nullptr;
+    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, float& nmax, uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
+        if (Q8) {
+            const char* base = lane_q8 + (size_t)T * (KS * 1024);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
+            if (METRIC == GPANN_METRIC_L2) {
+                nrm = a.plane_norm[(size_t)T * kGTileRows + c];
+                nmax = a.tile_nmax[T];
+            }
+            return;
+        }
         const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
         const char* base_lo = lane_planes + a.plane_lo_offset + (size_t)T_lo * a.plane_tile_bytes;
 #pragma unroll
@@ -511,17 +648,25 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     uint32_t item = uniform(s_claim[0]), nxt = uniform(s_claim[1]);
     if (item == kNoItem) return;
     uint32_t loaded_group = kNoItem, loaded = 0;   // the query image in LDS: whose, and which of its query tiles
-    float U[QT];   // thresholds of this lane's task in each query tile (filled with the query image)
+    // thresholds of this lane's task in each query tile: U (bf16 modes; filled with the query image) — MODE 2: the task's query step / 254
+    // (with the image) and, per ITEM, the (task, cell) threshold Bq and the cell's step
+    float U[QT];
+    float Bq[Q8 ? QT : 1];
+    float cell_scale = 0.f;
     uint32_t iter = 0;
-    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group;
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0;
     {
         const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
         r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
         r_task_begin = uniform(hi.x); r_lo_shift = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+        if (Q8) {
+            const uint4 x = reinterpret_cast<const uint4*>(a.items + item)[2];
+            r_block = uniform(x.x); r_scale_bits = uniform(x.y);
+        }
     }
     {
         const uint32_t T0 = min(r_t_begin + wave, r_t_end - 1);
-        load_tile(Ah[0], Al[0], nrm[0], T0, T0 - r_lo_shift);
+        load_tile(Ah[0], Al[0], nrm[0], nmax[0], T0, T0 - r_lo_shift);
     }
     for (;;) {
     // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
@@ -533,9 +678,10 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
     const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
+    const uint4 n_x = Q8 ? reinterpret_cast<const uint4*>(rn)[2] : make_uint4(0u, 0u, 0u, 0u);
 
 
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, uint32_t T) __attribute__((always_inline)) {
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float nmax, uint32_t T) __attribute__((always_inline)) {
         // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
         // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
         // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
@@ -602,12 +748,57 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
                 cmask[qp] = bits;
             }
         };
+        // MODE 2: the same for the 8-bit planes.  Per query tile two integer accumulator chains, H.P' and L.P'; V = 254 H.P' + L.P' is
+        // the exact integer dot product of the quantised vectors; a row passes iff  (float)V * sc + nhn_row >= Bq  (Q8Threshold).  The
+        // quick test uses the largest V of the lane's 16 rows and the tile's largest norm word — both monotone in the exact test's
+        // operands, so it passes whenever some row does.
+        auto pass8 = [&](int q0) __attribute__((always_inline)) {   // (one query tile: its two chains already keep the matrix core busy)
+            i32x16 h0, l0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h0[r] = 0;
+                l0[r] = 0;
+            }
+            const char* p0 = lane_lds + (q0 * KS) * 2048;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i32 av = __builtin_bit_cast(v4i32, Ah[ks].q);
+                const v4i32 bh0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048), bl0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
+                h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bh0, h0, 0, 0, 0);
+                l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bl0, l0, 0, 0, 0);
+            }
+            const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h0[r] = 254 * h0[r] + l0[r];   // V
+            int m0 = h0[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m0 = max(m0, h0[r]);
+            if (__any(__builtin_fmaf((float)m0, s0, nmax) >= b0)) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float nn[4] = {n.x, n.y, n.z, n.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * gg + i;
+                        bits |= __builtin_fmaf((float)h0[r], s0, nn[i]) >= b0 ? 1u << (r + 16 * (q0 & 1)) : 0u;
+                    }
+                }
+                cmask[q0 >> 1] |= bits;
+            }
+        };
 #pragma unroll
         for (int qp = 0; qp < QT / 2; ++qp) {
             const uint32_t two = act >> (2 * qp) & 3u;
-            if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
-            else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
-            else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
+            if constexpr (Q8) {
+                if (two & 1u) pass8(2 * qp);
+                if (two & 2u) pass8(2 * qp + 1);
+            } else {
+                if (two == 3u) pass(std::true_type{}, 2 * qp, qp, 0);
+                else if (two == 1u) pass(std::false_type{}, 2 * qp, qp, 0);
+                else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
+            }
         }
         uint32_t any_bits = 0;
 #pragma unroll
@@ -657,8 +848,15 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const uint32_t tl = 32u * qt + c;
-            U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
+            if (Q8) U[qt] = tl < task_count ? a.task_qscale[task_begin + tl] : 0.f;
+            else U[qt] = tl < task_count ? a.task_U[task_begin + tl] : INFINITY;
         }
+    }
+    if (Q8) {   // this item's cell: the (task, cell) thresholds (+inf: the task does not need the cell / no such task) and step products
+        cell_scale = __uint_as_float(r_scale_bits);
+        const float* brow = a.q8_B + (size_t)r_block * (32u * QT) + c;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) Bq[Q8 ? qt : 0] = brow[32 * qt];
     }
     loaded = same_group ? loaded | mask : mask;
     loaded_group = r_group;
@@ -681,14 +879,14 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
             uint32_t Tn = T + kFWaves;
             uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
-            compute_tile(Ah[0], Al[0], nrm[0], T);
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
+            compute_tile(Ah[0], Al[0], nrm[0], nmax[0], T);
             T = Tn;
             if (T >= t_end) break;
             Tn = T + kFWaves;
             own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[0], Al[0], nrm[0], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
-            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], T);
+            load_tile(Ah[0], Al[0], nrm[0], nmax[0], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
+            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], T);
             T = Tn;
             if (T >= t_end) break;
         }
@@ -699,15 +897,20 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
                 if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
             }
             nrm[0] = nrm[1];
+            nmax[0] = nmax[1];
         }
     } else {
-        load_tile(Ah[0], Al[0], nrm[0], n_first, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
+        load_tile(Ah[0], Al[0], nrm[0], nmax[0], n_first, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
     }
     if (nxt == kNoItem) break;
     const uint32_t n_group = uniform(n_hi.w);
     if (n_group != r_group) __syncthreads();   // the next item replaces the query image: everyone has to be done with this one
     r_t_begin = n_t_begin; r_t_end = n_t_end; r_t_a = uniform(n_lo.z); r_t_b = uniform(n_lo.w);
     r_task_begin = uniform(n_hi.x); r_lo_shift = uniform(n_hi.y); r_acts = uniform(n_hi.z); r_group = n_group;
+    if (Q8) {
+        r_block = uniform(n_x.x);
+        r_scale_bits = uniform(n_x.y);
+    }
     item = nxt;
     nxt = after;
     }   // next item

@@ -251,12 +251,14 @@ constexpr int kRescoreTasksPerWG = 1;   // wavefronts (= tasks) per workgroup: c
                                         // slowest task, so single-wavefront workgroups pack the CUs best
 __host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
 
-template <int METRIC>
+// RANGED (a template argument: the loop over work items must not cost the one-task-per-wavefront instance its registers) = RANGE mode.
+template <int METRIC, bool RANGED = false>
 __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool ranged = a.range_segs != 0;
-    for (uint32_t item = blockIdx.x * kRescoreTasksPerWG + wave;; item += gridDim.x * kRescoreTasksPerWG) {   // (one pass unless RANGE mode)
+    constexpr bool ranged = RANGED;
+    uint32_t item = blockIdx.x * kRescoreTasksPerWG + wave;
+    do {
     uint32_t t = item;
     int64_t scan_lo = 0, scan_hi = 0;
     if (ranged) {
@@ -443,6 +445,7 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
             a.part_row[(size_t)item * k + lane] = lr_;
         }
         __builtin_amdgcn_wave_barrier();   // (the next item re-uses this wavefront's LDS)
+        item += gridDim.x * kRescoreTasksPerWG;
         continue;
     }
     if (lane < (int)k) {
@@ -452,7 +455,7 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     // the query's merge bound: the smallest k-th distance among its tasks' lists (a list that is not full yet has +inf there)
     if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
     return;
-    }   // items
+    } while (RANGED);   // items
 }
 
 // The dirty tasks' lists: one wavefront per dirty task merges the range_segs partial lists RescoreKernel's RANGE mode left (ascending

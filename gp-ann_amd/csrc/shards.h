@@ -26,7 +26,7 @@ struct ScanPlan {
     std::vector<ScanUnit> units;
     uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0, filter_two_plane_rows = 0;
     bool filter_rest_hi_only = false;
-    uint32_t filter_launches = 0, filter_dirty_tasks = 0;
+    uint32_t filter_launches = 0, filter_dirty_tasks = 0, filter_rest_row_bytes = 0;
     void Clear() {
         task_query.clear();
         task_out.clear();
@@ -36,7 +36,7 @@ struct ScanPlan {
         shard_task_begin.clear();
         units.clear();
         n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = filter_two_plane_rows = 0;
-        filter_launches = filter_dirty_tasks = 0;
+        filter_launches = filter_dirty_tasks = filter_rest_row_bytes = 0;
     }
 };
 
@@ -121,6 +121,14 @@ struct gpann_shards {
         uint64_t n_lo_tiles = 0;                   // tiles of the lo array (cells' heads | 2 zero tiles | sample tiles)
         uint64_t lo_sample_begin = 0;              // first lo tile of the shard sample
         uint32_t* d_cell_lo_begin = nullptr;       // [n_cells+1] first lo tile of every cell
+        // The 8-bit plane of the rest pass (scan_q8.h; absent when GPANN_FILTER_Q8=0 or the allocation failed): per 32-row tile and k-step of 32
+        // dimensions one KiB in the A-operand order of v_mfma_i32_32x32x32_i8 — lane (c, h) holds row c, dimensions 32 ks + 16 h .. + 15 as int8
+        // P' = round((p~ - c^) / q8_scale[cell]) (p~, c^: the row and its cell's centre in the frame of the bf16 planes).  q8_ks KiB per tile.
+        char* q8_planes = nullptr;
+        uint32_t q8_ks = 0;                        // k-steps of 32 dimensions = ceil(d / 32)
+        float* d_q8_scale = nullptr;               // [n_cells] quantisation step of the cell: max |p~_i - c^_i| / 127, rounded up
+        double* d_q8_cnorm = nullptr;              // [n_cells] |c^|^2
+        float* d_tile_nmax = nullptr;              // [tiles incl. the sample's] max over the tile's rows of plane_norm (= -min |p~|^2 / 2)
         // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
         // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
         float* d_mu = nullptr;
@@ -129,7 +137,7 @@ struct gpann_shards {
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
     // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image;
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of a call, [3] its last staged upload
     bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
     hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,

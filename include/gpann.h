@@ -156,6 +156,8 @@ typedef struct gpann_scan_stats {
     uint32_t filter_rest_hi_only;/* 1 if it read only the hi plane (d * 2 bytes per row), 0 if hi + lo (d * 4) */
     uint64_t filter_two_plane_rows; /* of filter_rows: rows streamed by the launches that read both planes (shard-sample and head passes) */
     uint64_t filter_seed_rows;   /* rows evaluated exactly for the first lists (filter mode: tasks x seed rows) */
+    uint32_t filter_rest_row_bytes; /* bytes the rest pass reads per row: 32 x k-steps (bf16 hi plane) or 32 x ceil(d / 32) (8-bit plane) + the norm word */
+    uint32_t reserved3;
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 

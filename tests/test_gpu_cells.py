@@ -243,3 +243,46 @@ def test_router_bound_path_on_data_far_from_the_origin(orc, gp):
     assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
     st = router.stats()
     assert st["bound_calls"] == 1 and st["verified"] == 1 and st["verify_failures"] == 0 and st["bound_overflow"] == 0 and st["bound_selfcheck"] == 0
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [128, 100, 40, 200])
+def test_cells_rest_pass_on_the_8_bit_plane(orc, gp, metric, d, monkeypatch):
+    """The rest pass streams the int8 plane (per-cell scaled residuals, integer matrix-core products against the queries' two int8 planes,
+    thresholds per (task, cell): scan_cells.h Q8Threshold) — by default; GPANN_FILTER_Q8=0 at scan time sends it back to the bf16 hi plane.
+    Both return the oracle's bits; the 8-bit pass reads fewer bytes per row and may pass more candidates."""
+    rng = np.random.default_rng(d * 3 + metric)
+    n, S, nq, k = 60000, 3, 500, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    if metric == 0:
+        pts += np.float32(3.0)                       # not centred: the planes live in the frame of the store's mean row
+    clusters = random_clusters(rng, n, S, overlap=0.1)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24) + (np.float32(3.0) if metric == 0 else np.float32(0.0))
+    probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
+    st8 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    assert st8["filter_rest_row_bytes"] == 32 * ((d + 31) // 32) + 4, st8
+    monkeypatch.setenv("GPANN_FILTER_Q8", "0")
+    st16 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    ks = next(x for x in (2, 4, 6, 7, 8, 10, 13, 16) if 16 * x >= d)
+    assert st16["filter_rest_row_bytes"] == 32 * ks + 4, st16
+    assert st8["filter_rest_rows"] == st16["filter_rest_rows"]          # the same cells are needed either way
+    assert st8["filter_candidates"] < 6 * st16["filter_candidates"] + 1000, (st8, st16)
+
+
+def test_cells_8_bit_plane_extreme_values(orc, gp):
+    """rows / queries with a few huge coordinates (a cell's quantisation step is set by its largest residual), duplicated rows (ties at the
+    threshold), a constant dimension (zero residuals), tiny clusters: the bound must hold whatever the scale"""
+    rng = np.random.default_rng(99)
+    n, d, nq, k = 50000, 64, 300, 10
+    pts = make_mixture(orc, n, d, n_centers=12)
+    pts[:, 5] = 1.25                                  # a constant column
+    pts[rng.integers(0, n, 40), rng.integers(0, d, 40)] += np.float32(500.0)   # outliers: huge residuals in their cells
+    pts[1000:1400] = pts[1000]                        # duplicates
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=12)
+    queries[:, 5] = 1.25
+    queries[0] = pts[1000]
+    queries[1, 3] += np.float32(400.0)
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
