@@ -588,7 +588,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // filter (masses of equal distances) and the whole call falls back to the plain exact scan
     const uint32_t dirty_cap = std::max<uint32_t>(16, std::min<uint32_t>(256, T / 100));
     const uint32_t range_segs = 512;
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 4 + (size_t)dirty_cap * 8 + 64));
+    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 8 + (size_t)dirty_cap * 8 + 64));
     GPANN_TRY(s->ws_partials.Reserve((size_t)dirty_cap * range_segs * k * 8 + 256));
     float* list_dist = s->ws_lists.as<float>();
     uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
@@ -599,9 +599,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // next pass's thresholds and cell tests of ALL the query's tasks read it)
     uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
     if (for_merge) GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_query_tau), (int)kOrderedKeyInf, nq, st));
-    uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
-    uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + T) & 4) ? 1 : 0));
-    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 4, st));
+    uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | split_done [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
+    uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + 2 * (size_t)T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + 2 * (size_t)T) & 4) ? 1 : 0));
+    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 8, st));
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
@@ -859,6 +859,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.dirty_count = d_overflow + 1;
     ra.dirty_cap = dirty_cap;
     ra.range_segs = 0;
+    ra.parts = 1;
     ra.part_dist = s->ws_partials.as<float>();
     ra.part_row = reinterpret_cast<uint32_t*>(ra.part_dist + (size_t)dirty_cap * range_segs * k);
     ra.seed_rows = 0;
@@ -909,14 +910,26 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
         else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     }
+    // re-scoring launches: `parts` wavefronts per task (heavy buckets are split, RescoreArgs::parts)
+    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", 4)));
+    GPANN_TRY(s->ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
+    ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 192));
+    ra.split_dist = s->ws_split.as<float>();
+    ra.split_row = reinterpret_cast<uint32_t*>(ra.split_dist + (size_t)T * split_parts * k);
+    ra.split_done = d_dirty_flag + T;   // (zeroed with the dirty flags; the merging wavefront resets its task's counter)
+    auto launch_rescore = [&](uint32_t parts) {
+        ra.parts = parts;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)parts * T);
+        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
+        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
+    };
     const uint64_t need_threads = (uint64_t)T * kmax;
     int n_cus = 256;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
 
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+        launch_rescore(1);   // (seed mode: a fixed number of rows per task)
         GPANN_HIP_TRY(hipGetLastError());
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
@@ -981,8 +994,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             void* sargs[] = {&fs};
             GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
             hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-            if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
-            else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+            launch_rescore(split_parts);
             GPANN_HIP_TRY(hipGetLastError());
             if (std::getenv("GPANN_CELLS_DEBUG")) debug_candidate_counts("shard-sample pass");
         }
@@ -1031,8 +1043,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
         // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
         hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3((T + kRescoreTasksPerWG - 1) / kRescoreTasksPerWG), dim3(64 * kRescoreTasksPerWG), rlds, st, ra);
+        launch_rescore(split_parts);
         GPANN_HIP_TRY(hipGetLastError());
         plan.filter_launches++;
         if (std::getenv("GPANN_CELLS_DEBUG")) {

@@ -200,6 +200,15 @@ struct RescoreArgs {
     uint32_t range_segs;
     float* part_dist;
     uint32_t* part_row;
+    // Heavy buckets are SPLIT (parts > 1: the launch has parts x tasks wavefronts, wavefront w * tasks + t = part w of task t): a bucket
+    // of more than split_min candidates is cut into up to `parts` pieces, each re-scored by a wavefront of its own from the task's
+    // current list; the pieces' lists go to split_dist / split_row [task][part][k] and the LAST piece to finish (split_done[task], an
+    // arrival counter that it also resets) merges them.  The candidate counts are long-tailed (mean 22, maximum 1 283 in the
+    // shard-sample pass of the NS workload) and a launch lasts as long as its heaviest task.
+    uint32_t parts, split_min;
+    float* split_dist;
+    uint32_t* split_row;
+    uint32_t* split_done;
     // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
     // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
     uint32_t seed_rows;
@@ -261,6 +270,12 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     do {
     uint32_t t = item;
     int64_t scan_lo = 0, scan_hi = 0;
+    uint32_t part = 0, n_parts = 1, c_lo = 0;
+    if (!ranged && a.parts > 1) {
+        part = item / a.tasks;
+        t = item - part * a.tasks;
+        if (part >= a.parts) return;
+    }
     if (ranged) {
         const uint32_t n_dirty = min(*a.dirty_count, a.dirty_cap);
         if (item >= n_dirty * a.range_segs) return;
@@ -297,6 +312,13 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
             }
             return;
         }
+        if (a.parts > 1) {   // this wavefront's piece of the bucket
+            n_parts = min(a.parts, (cnt + a.split_min - 1) / a.split_min);
+            if (part >= n_parts) return;
+            const uint32_t per = ((cnt + n_parts - 1) / n_parts + 15u) / 16u * 16u;
+            c_lo = part * per;
+            cnt = min(cnt, c_lo + per) - min(cnt, c_lo);   // (never empty: split_min >> 16 parts)
+        }
     }
     const bool overflowed = ranged;   // the "candidates" are the rows [scan_lo, scan_hi) of the shard
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
@@ -320,7 +342,7 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         const uint64_t idx = first + lane;
         if (idx >= n_items) return kNoId;
         if (seed) return a.plane_perm[seed_first + idx];   // (kNoId on the padding of a cell's last tile: skipped like an absent candidate)
-        return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + idx];
+        return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + c_lo + idx];
     };
     auto round_rows = [&](uint32_t block_rows, uint32_t sub) -> uint32_t {
         const uint32_t r = __shfl(block_rows, (int)(kRescoreSub * sub + (lane & (kRescoreSub - 1))));
@@ -447,6 +469,41 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         __builtin_amdgcn_wave_barrier();   // (the next item re-uses this wavefront's LDS)
         item += gridDim.x * kRescoreTasksPerWG;
         continue;
+    }
+    if (n_parts > 1) {
+        // a piece of a split bucket: publish its list; the last piece to arrive merges all of them (they grew from the same list, so an
+        // entry of that list can be in several: duplicates are dropped by row)
+        float* pd = a.split_dist + ((size_t)t * a.parts) * k;
+        uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
+        if (lane < (int)k) {
+            __hip_atomic_store(&pd[(size_t)part * k + lane], ld_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pr[(size_t)part * k + lane], lr_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&a.split_done[t], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived != n_parts - 1) return;
+        __threadfence();
+        for (uint32_t p = 0; p < n_parts; ++p) {
+            if (p == part) continue;
+            float cd_l = INFINITY;
+            uint32_t cr_l = kNoId;
+            if (lane < (int)k) {
+                cd_l = __hip_atomic_load(&pd[(size_t)p * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cr_l = __hip_atomic_load(&pr[(size_t)p * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (uint32_t e = 0; e < k; ++e) {
+                const float cd = __shfl(cd_l, e);
+                const uint32_t cr = __shfl(cr_l, e);
+                const float td = __shfl(ld_, k - 1);
+                const uint32_t tr = __shfl(lr_, k - 1);
+                if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
+                if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+                ListInsertF(ld_, lr_, cd, cr, k, lane);
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&a.split_done[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next pass)
     }
     if (lane < (int)k) {
         a.list_dist[(size_t)t * k + lane] = ld_;

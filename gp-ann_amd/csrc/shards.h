@@ -137,7 +137,7 @@ struct gpann_shards {
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
     // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8;
+    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8, ws_split;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of a call, [3] its last staged upload
     bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
     hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,

@@ -143,3 +143,24 @@ def test_filter_without_precomputed_planes(orc, gp, monkeypatch):
     for metric in (0, 1):
         st = _check(orc, gp, pts, clusters, queries, probes, S, k, metric, expect_filtered=False)
         assert st["filter_pairs"] == 0
+
+
+@pytest.mark.parametrize("parts,split_min", [("1", "192"), ("8", "64"), ("3", "100")])
+def test_split_buckets_give_the_same_lists(orc, gp, monkeypatch, parts, split_min):
+    """heavy candidate buckets are re-scored by several wavefronts whose lists the last one merges (RescoreArgs::parts): whatever the
+    split, the lists are the oracle's — one blob (no pruning: hundreds of candidates per task), duplicates of the query's neighbours
+    (equal distances across the pieces), L2 and inner product"""
+    monkeypatch.setenv("GPANN_RESCORE_PARTS", parts)
+    monkeypatch.setenv("GPANN_RESCORE_SPLIT_MIN", split_min)
+    monkeypatch.setenv("GPANN_CELL_ROWS", "2000")
+    rng = np.random.default_rng(53)
+    n, d, nq, k = 60000, 32, 400, 10
+    pts = rng.standard_normal((n, d)).astype(np.float32)
+    pts[100:130] = pts[100]
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    queries[0] = pts[100]
+    clusters = [rng.permutation(n).astype(np.uint32)]
+    probes = np.zeros((nq, 1), np.int32)
+    for metric in (0, 1):
+        st = _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
+        assert st["filtered"] == 1 and st["filter_candidates"] > 64 * nq, st   # buckets heavy enough to be split
