@@ -599,9 +599,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // next pass's thresholds and cell tests of ALL the query's tasks read it)
     uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
     if (for_merge) GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_query_tau), (int)kOrderedKeyInf, nq, st));
-    uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | split_done [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
-    uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + 2 * (size_t)T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + 2 * (size_t)T) & 4) ? 1 : 0));
-    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 8, st));
+    uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
+    uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + (size_t)T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + (size_t)T) & 4) ? 1 : 0));
+    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 4, st));
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
@@ -838,6 +838,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.q8_B = q8_B;
     fa.task_qscale = d_task_qscale;
     fa.q8_scale = C.d_q8_scale;
+    fa.unit_tiles = 1;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -892,6 +893,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const void* fn_q8 = nullptr;
+    uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8);
     const size_t glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048);
     if (use_q8) {
         switch (KS8) {
@@ -902,6 +904,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
 #undef GPANN_PICK8
             default: break;
+        }
+        // (measurement aid: GPANN_Q8_UNIT_TILES=1 runs the 128-dimension kernel with one row tile per unit of prefetch)
+        if (KS8 == 4 && EnvU32("GPANN_Q8_UNIT_TILES", 2) == 1) {
+            fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 1>;
+            q8_unit_tiles = 1;
         }
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }
@@ -916,12 +923,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 192));
     ra.split_dist = s->ws_split.as<float>();
     ra.split_row = reinterpret_cast<uint32_t*>(ra.split_dist + (size_t)T * split_parts * k);
-    ra.split_done = d_dirty_flag + T;   // (zeroed with the dirty flags; the merging wavefront resets its task's counter)
     auto launch_rescore = [&](uint32_t parts) {
         ra.parts = parts;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)parts * T);
         if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
         else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
+        if (parts > 1) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 3) / 4), dim3(256), 0, st, ra);
     };
     const uint64_t need_threads = (uint64_t)T * kmax;
     int n_cus = 256;
@@ -1012,6 +1019,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
+        fa.unit_tiles = q8_pass ? q8_unit_tiles : 1u;
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;

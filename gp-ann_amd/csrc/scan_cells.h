@@ -375,6 +375,7 @@ struct CellFilterArgs {
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
+    uint32_t unit_tiles;         // FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of units)
 };
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
@@ -412,7 +413,8 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
     // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
     // the end of the item for a full memory latency)
-    const int64_t per = ((range + n - 1) / n + kFWaves - 1) / kFWaves * kFWaves;
+    const int64_t round = (int64_t)kFWaves * a.unit_tiles;
+    const int64_t per = ((range + n - 1) / n + round - 1) / round * round;
     const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
     CellItem it;
     it.t_a = (uint32_t)t_a;
@@ -499,6 +501,8 @@ __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)"
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 // query tiles (of 32 tasks) per task group: the group's image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS beside the norms and the queues
 constexpr int FilterQueryTiles(int ks) { return ks <= 8 ? 8 : 4; }
+// consecutive row tiles a wavefront of FilterKernelCells takes at a time (its unit of prefetch): two 4 KiB tiles of the 8-bit plane up to 128 dimensions
+constexpr int FilterUnitTiles(int mode, int ks) { return mode == 2 && ks <= 4 ? 2 : 1; }
 
 // Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
 // Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
@@ -546,7 +550,7 @@ __device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, 
 // Q8Threshold; KS then counts k-steps of 32 dimensions and the image holds the int8 planes H, L of the queries).
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS)>
+template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS), int TW_ = FilterUnitTiles(MODE, KS)>
 __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
     constexpr bool HI_ONLY = MODE >= 1, Q8 = MODE == 2;
     static_assert(QT == 4 || QT == 8, "query tiles per group");
@@ -592,18 +596,28 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         q_len = 0;
     };
 
-    Frag Ah[2][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
-    float nrm[2] = {0.f, 0.f};
-    float nmax[2] = {0.f, 0.f};   // (MODE 2) the tile's largest norm word
-    const char* lane_q8 = Q8 ? a.q8_planes + lane * 16 : nullptr;
-    auto load_tile = [&](Frag (&Ah)[KS], Frag (&Al)[KS], float& nrm, float& nmax, uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
-        if (Q8) {
-            const char* base = lane_q8 + (size_t)T * (KS * 1024);
+    // A wavefront's unit of work is TW consecutive row tiles: 1, or 2 for the 8-bit plane up to 128 dimensions — what covers the HBM latency
+    // is the bytes a wavefront has in flight (one unit of prefetch), and a 4 KiB int8 tile alone left the launch at 5.0 TB/s.
+    constexpr int TW = TW_;
+    Frag Ah[2][TW][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
+    float nrm[2][TW], nmax[2][TW];   // (nmax, MODE 2: the tile's largest norm word)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
-            if (METRIC == GPANN_METRIC_L2) {
-                nrm = a.plane_norm[(size_t)T * kGTileRows + c];
-                nmax = a.tile_nmax[T];
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) nrm[b][tw] = nmax[b][tw] = 0.f;
+    const char* lane_q8 = Q8 ? a.q8_planes + lane * 16 : nullptr;
+    // (tiles T .. T + TW - 1: the tile after a range is the next cell's or the zero padding behind the planes — loaded, never multiplied)
+    auto load_tile = [&](Frag (&Ah)[TW][KS], Frag (&Al)[KS], float (&nrm)[TW], float (&nmax)[TW], uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
+        if (Q8) {
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) {
+                const char* base = lane_q8 + (size_t)(T + tw) * (KS * 1024);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) Ah[tw][ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
+                if (METRIC == GPANN_METRIC_L2) {
+                    nrm[tw] = a.plane_norm[(size_t)(T + tw) * kGTileRows + c];
+                    nmax[tw] = a.tile_nmax[T + tw];
+                }
             }
             return;
         }
@@ -612,10 +626,10 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             // (read-once stream: non-temporal, leaves L2 to the query rows / tables)
-            Ah[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
+            Ah[0][ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
             if (!HI_ONLY) Al[ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base_lo + ks * 1024));
         }
-        if (METRIC == GPANN_METRIC_L2) nrm = a.plane_norm[(size_t)T * kGTileRows + c];
+        if (METRIC == GPANN_METRIC_L2) nrm[0] = a.plane_norm[(size_t)T * kGTileRows + c];
     };
     // an item's record as wave-uniform scalars (tile indices are 32-bit all the way: 64-bit copies of these wave-uniform values ended
     // up in vector registers and were spilled — and a scratch reload inside the tile loop has to wait for the tile prefetch issued
@@ -665,7 +679,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
         }
     }
     {
-        const uint32_t T0 = min(r_t_begin + wave, r_t_end - 1);
+        const uint32_t T0 = min(r_t_begin + wave * TW, r_t_end - 1);
         load_tile(Ah[0], Al[0], nrm[0], nmax[0], T0, T0 - r_lo_shift);
     }
     for (;;) {
@@ -872,32 +886,43 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const uint32_t lo_shift = r_lo_shift, n_lo_shift = HI_ONLY ? 0u : uniform(n_hi.y);   // (n_hi is this item's record after the last item)
     const uint32_t t_last = t_end - 1;
     // this wavefront's first tile of the next item
-    const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave, n_t_end - 1) : t_last;
-    uint32_t T = t_begin + wave;
+    const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave * TW, n_t_end - 1) : t_last;
+    constexpr uint32_t kStride = kFWaves * TW;   // tiles between two units of a wavefront
+    // the tiles of the unit that begins at tile T0, from buffer b
+    auto compute_unit = [&](int b, uint32_t T0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw)
+            if (tw == 0 || T0 + tw < t_end) compute_tile(Ah[b][tw], Al[HI_ONLY ? 0 : b], nrm[b][tw], nmax[b][tw], T0 + tw);
+    };
+    uint32_t T = t_begin + wave * TW;
     if (T < t_end) {
-        const uint32_t steps = (t_end - T + kFWaves - 1) / kFWaves;
+        const uint32_t steps = (t_end - T + kStride - 1) / kStride;
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
-            uint32_t Tn = T + kFWaves;
+            uint32_t Tn = T + kStride;
             uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
             load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
-            compute_tile(Ah[0], Al[0], nrm[0], nmax[0], T);
+            compute_unit(0, T);
             T = Tn;
             if (T >= t_end) break;
-            Tn = T + kFWaves;
+            Tn = T + kStride;
             own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
             load_tile(Ah[0], Al[0], nrm[0], nmax[0], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
-            compute_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], T);
+            compute_unit(1, T);
             T = Tn;
             if (T >= t_end) break;
         }
-        if (steps & 1u) {   // the next item's first tile went to buffer 1
+        if (steps & 1u) {   // the next item's first unit went to buffer 1
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                Ah[0][ks].v = Ah[1][ks].v;
-                if (!HI_ONLY) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
+            for (int tw = 0; tw < TW; ++tw) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) Ah[0][tw][ks].v = Ah[1][tw][ks].v;
+                nrm[0][tw] = nrm[1][tw];
+                nmax[0][tw] = nmax[1][tw];
             }
-            nrm[0] = nrm[1];
-            nmax[0] = nmax[1];
+            if (!HI_ONLY) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) Al[0][ks].v = Al[HI_ONLY ? 0 : 1][ks].v;
+            }
         }
     } else {
         load_tile(Ah[0], Al[0], nrm[0], nmax[0], n_first, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)

@@ -202,13 +202,11 @@ struct RescoreArgs {
     uint32_t* part_row;
     // Heavy buckets are SPLIT (parts > 1: the launch has parts x tasks wavefronts, wavefront w * tasks + t = part w of task t): a bucket
     // of more than split_min candidates is cut into up to `parts` pieces, each re-scored by a wavefront of its own from the task's
-    // current list; the pieces' lists go to split_dist / split_row [task][part][k] and the LAST piece to finish (split_done[task], an
-    // arrival counter that it also resets) merges them.  The candidate counts are long-tailed (mean 22, maximum 1 283 in the
+    // current list; the pieces' lists go to split_dist / split_row [task][part][k] and SplitMergeKernel, the next launch, merges them.  The candidate counts are long-tailed (mean 22, maximum 1 283 in the
     // shard-sample pass of the NS workload) and a launch lasts as long as its heaviest task.
     uint32_t parts, split_min;
     float* split_dist;
     uint32_t* split_row;
-    uint32_t* split_done;
     // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
     // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
     uint32_t seed_rows;
@@ -471,39 +469,14 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         continue;
     }
     if (n_parts > 1) {
-        // a piece of a split bucket: publish its list; the last piece to arrive merges all of them (they grew from the same list, so an
-        // entry of that list can be in several: duplicates are dropped by row)
-        float* pd = a.split_dist + ((size_t)t * a.parts) * k;
-        uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
+        // a piece of a split bucket: its list goes to the scratch lists, SplitMergeKernel (the next launch) merges the pieces.  (Merging
+        // inside this kernel — last piece to arrive, agent-scope fences — was measured 10x SLOWER than the whole unsplit launch: on this
+        // multi-XCD part every agent-scope release / acquire writes back and invalidates an XCD's L2.)
         if (lane < (int)k) {
-            __hip_atomic_store(&pd[(size_t)part * k + lane], ld_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pr[(size_t)part * k + lane], lr_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.split_dist[((size_t)t * a.parts + part) * k + lane] = ld_;
+            a.split_row[((size_t)t * a.parts + part) * k + lane] = lr_;
         }
-        __threadfence();
-        uint32_t arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&a.split_done[t], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-        if (arrived != n_parts - 1) return;
-        __threadfence();
-        for (uint32_t p = 0; p < n_parts; ++p) {
-            if (p == part) continue;
-            float cd_l = INFINITY;
-            uint32_t cr_l = kNoId;
-            if (lane < (int)k) {
-                cd_l = __hip_atomic_load(&pd[(size_t)p * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cr_l = __hip_atomic_load(&pr[(size_t)p * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (uint32_t e = 0; e < k; ++e) {
-                const float cd = __shfl(cd_l, e);
-                const uint32_t cr = __shfl(cr_l, e);
-                const float td = __shfl(ld_, k - 1);
-                const uint32_t tr = __shfl(lr_, k - 1);
-                if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
-                if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
-                ListInsertF(ld_, lr_, cd, cr, k, lane);
-            }
-        }
-        if (lane == 0) __hip_atomic_store(&a.split_done[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next pass)
+        return;
     }
     if (lane < (int)k) {
         a.list_dist[(size_t)t * k + lane] = ld_;
@@ -513,6 +486,48 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
     return;
     } while (RANGED);   // items
+}
+
+// The lists of the tasks whose bucket RescoreKernel split (same rule: cand_cnt, split_min, parts): one wavefront per task merges the pieces'
+// lists — all grown from the task's list, so an entry of that list can be in several: duplicates are dropped by row — into the task's list.
+static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.tasks) return;
+    const uint32_t cnt = a.cand_cnt[t];
+    if (cnt == 0 || cnt > a.cand_cap) return;
+    const uint32_t n_parts = min(a.parts, (cnt + a.split_min - 1) / a.split_min), k = a.k;
+    if (n_parts <= 1) return;
+    const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
+    const uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
+    float ld_ = INFINITY;
+    uint32_t lr_ = kNoId;
+    if (lane < (int)k) {
+        ld_ = pd[lane];
+        lr_ = pr[lane];
+    }
+    for (uint32_t p = 1; p < n_parts; ++p) {
+        float cd_l = INFINITY;
+        uint32_t cr_l = kNoId;
+        if (lane < (int)k) {
+            cd_l = pd[(size_t)p * k + lane];
+            cr_l = pr[(size_t)p * k + lane];
+        }
+        for (uint32_t e = 0; e < k; ++e) {
+            const float cd = __shfl(cd_l, e);
+            const uint32_t cr = __shfl(cr_l, e);
+            const float td = __shfl(ld_, k - 1);
+            const uint32_t tr = __shfl(lr_, k - 1);
+            if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
+            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+            ListInsertF(ld_, lr_, cd, cr, k, lane);
+        }
+    }
+    if (lane < (int)k) {
+        a.list_dist[(size_t)t * k + lane] = ld_;
+        a.list_row[(size_t)t * k + lane] = lr_;
+    }
+    if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
 }
 
 // The dirty tasks' lists: one wavefront per dirty task merges the range_segs partial lists RescoreKernel's RANGE mode left (ascending
