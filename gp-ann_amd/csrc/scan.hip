@@ -838,7 +838,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.q8_B = q8_B;
     fa.task_qscale = d_task_qscale;
     fa.q8_scale = C.d_q8_scale;
-    fa.unit_tiles = 1;
+    fa.round_tiles = kFWaves;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -893,8 +893,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     const void* fn_q8 = nullptr;
-    uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8);
-    const size_t glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048);
+    uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8), q8_waves = (uint32_t)FilterWaves(2, (int)KS8);
+    size_t glds8 = 0;
     if (use_q8) {
         switch (KS8) {
 #define GPANN_PICK8(KS_)                                                                                                                       \
@@ -905,11 +905,18 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #undef GPANN_PICK8
             default: break;
         }
-        // (measurement aid: GPANN_Q8_UNIT_TILES=1 runs the 128-dimension kernel with one row tile per unit of prefetch)
-        if (KS8 == 4 && EnvU32("GPANN_Q8_UNIT_TILES", 2) == 1) {
-            fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 1>;
-            q8_unit_tiles = 1;
+        // (measurement aids: GPANN_Q8_WAVES=8 runs the 128-dimension kernel with 8 wavefronts per workgroup, GPANN_Q8_UNIT_TILES=2 on top of
+        // that with two row tiles per unit of prefetch)
+        if (KS8 == 4 && EnvU32("GPANN_Q8_WAVES", 16) == 8) {
+            q8_waves = 8;
+            if (EnvU32("GPANN_Q8_UNIT_TILES", 1) == 2) {
+                fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 2, 8>;
+                q8_unit_tiles = 2;
+            } else {
+                fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 1, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 1, 8>;
+            }
         }
+        glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
@@ -1019,7 +1026,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
-        fa.unit_tiles = q8_pass ? q8_unit_tiles : 1u;
+        fa.round_tiles = q8_pass ? q8_waves * q8_unit_tiles : (uint32_t)kFWaves;
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
@@ -1034,7 +1041,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             void* kargs8[] = {&f8};
-            GPANN_HIP_TRY(hipLaunchKernel(fn_q8, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs8, glds8, st));
+            GPANN_HIP_TRY(hipLaunchKernel(fn_q8, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
             plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));

@@ -375,7 +375,7 @@ struct CellFilterArgs {
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
-    uint32_t unit_tiles;         // FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of units)
+    uint32_t round_tiles;        // wavefronts x FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of the workgroup)
 };
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
@@ -384,7 +384,7 @@ constexpr int kFWaves = 8;
 // next to a 128 KiB query image and the norms)
 constexpr uint32_t kFQueue = 448;
 // dynamic LDS of FilterKernelCells
-constexpr size_t FilterLdsBytes(size_t image_bytes) { return image_bytes + kFWaves * kGTileRows * sizeof(float) + (size_t)kFWaves * kFQueue * 8; }
+constexpr size_t FilterLdsBytes(size_t image_bytes, int waves = kFWaves) { return image_bytes + waves * kGTileRows * sizeof(float) + (size_t)waves * kFQueue * 8; }
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
@@ -413,7 +413,7 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
     // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
     // the end of the item for a full memory latency)
-    const int64_t round = (int64_t)kFWaves * a.unit_tiles;
+    const int64_t round = (int64_t)a.round_tiles;
     const int64_t per = ((range + n - 1) / n + round - 1) / round * round;
     const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
     CellItem it;
@@ -502,7 +502,7 @@ constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 // query tiles (of 32 tasks) per task group: the group's image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS beside the norms and the queues
 constexpr int FilterQueryTiles(int ks) { return ks <= 8 ? 8 : 4; }
 // consecutive row tiles a wavefront of FilterKernelCells takes at a time (its unit of prefetch): two 4 KiB tiles of the 8-bit plane up to 128 dimensions
-constexpr int FilterUnitTiles(int mode, int ks) { return mode == 2 && ks <= 4 ? 2 : 1; }
+constexpr int FilterUnitTiles(int mode, int ks) { return 1; }
 
 // Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
 // Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
@@ -550,8 +550,11 @@ __device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, 
 // Q8Threshold; KS then counts k-steps of 32 dimensions and the image holds the int8 planes H, L of the queries).
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS), int TW_ = FilterUnitTiles(MODE, KS)>
-__global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterArgs a) {
+// NW: wavefronts per workgroup (one workgroup per CU): 8, or 16 for the 8-bit plane up to 128 dimensions, whose small register footprint
+// allows four wavefronts per SIMD — with two, half of a wavefront's time was spent waiting on its own chain tile -> products -> candidates.
+constexpr int FilterWaves(int mode, int ks) { return mode == 2 && ks <= 4 ? 16 : kFWaves; }
+template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS), int TW_ = FilterUnitTiles(MODE, KS), int NW = FilterWaves(MODE, KS)>
+__global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a) {
     constexpr bool HI_ONLY = MODE >= 1, Q8 = MODE == 2;
     static_assert(QT == 4 || QT == 8, "query tiles per group");
     static_assert(KS <= 8 || MODE == 1, "more than 8 k-steps: bf16 hi-plane passes only");
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     // buckets — a returning atomic per candidate for the slot — when the queue fills up and at the end of the kernel.  (Written
     // straight from the tile loop, every row tile with a candidate costs two dependent round trips — row id, slot: the head and sample
     // passes, 15 and 4 candidates per row tile, streamed at two thirds of the rest pass's rate.)
-    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + kFWaves * kGTileRows * sizeof(float)) + wave * kFQueue;
+    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + NW * kGTileRows * sizeof(float)) + wave * kFQueue;
     uint32_t q_len = 0;
     auto flush_queue = [&]() __attribute__((always_inline)) {
         for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
@@ -763,9 +766,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
             }
         };
         // MODE 2: the same for the 8-bit planes.  Per query tile two integer accumulator chains, H.P' and L.P'; V = 254 H.P' + L.P' is
-        // the exact integer dot product of the quantised vectors; a row passes iff  (float)V * sc + nhn_row >= Bq  (Q8Threshold).  The
-        // quick test uses the largest V of the lane's 16 rows and the tile's largest norm word — both monotone in the exact test's
-        // operands, so it passes whenever some row does.
+        // the exact integer dot product of the quantised vectors; a row passes iff  fl(V) * s0 + nhn_row >= Bq  (Q8Threshold).
         auto pass8 = [&](int q0) __attribute__((always_inline)) {   // (one query tile: its two chains already keep the matrix core busy)
             i32x16 h0, l0;
 #pragma unroll
@@ -781,26 +782,27 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
                 h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bh0, h0, 0, 0, 0);
                 l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bl0, l0, 0, 0, 0);
             }
+            // Every row of the tile is tested (no quick test: in the rest pass a product has a candidate more often than not):
+            //   x = fl(fl(fl(254 h + l)) * s0 + nhn_row) - b0 >= 0,   s0 = the cell's step x the task's step / 254,
+            // with 254 h + l formed in fp32 (|h|, |l| < 2^24 are exact, the sum is rounded once: Q8Threshold's fp32 slack).  The sign
+            // bits of the 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies,
+            // compares and selects the same test took 165 vector instructions per product against 8 matrix instructions.)
             const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+            uint32_t neg = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h0[r] = 254 * h0[r] + l0[r];   // V
-            int m0 = h0[0];
+            for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
+                const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float nn[4] = {n.x, n.y, n.z, n.w};
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m0 = max(m0, h0[r]);
-            if (__any(__builtin_fmaf((float)m0, s0, nmax) >= b0)) {
-                uint32_t bits = 0;
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float nn[4] = {n.x, n.y, n.z, n.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 4 * gg + i;
-                        bits |= __builtin_fmaf((float)h0[r], s0, nn[i]) >= b0 ? 1u << (r + 16 * (q0 & 1)) : 0u;
-                    }
+                for (int i = 3; i >= 0; --i) {
+                    const int r = 4 * gg + i;
+                    const float fv = __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
+                    const float x = __builtin_fmaf(fv, s0, nn[i]) - b0;
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x), 31);   // neg = neg << 1 | sign(x)
                 }
-                cmask[q0 >> 1] |= bits;
             }
+            // (a NaN — a padding row's -inf norm against a -inf threshold — may read as a candidate: padding rows are dropped at the flush)
+            cmask[q0 >> 1] |= (~neg & 0xFFFFu) << (16 * (q0 & 1));
         };
 #pragma unroll
         for (int qp = 0; qp < QT / 2; ++qp) {
@@ -887,7 +889,7 @@ __global__ void __launch_bounds__(64 * kFWaves, 1) FilterKernelCells(CellFilterA
     const uint32_t t_last = t_end - 1;
     // this wavefront's first tile of the next item
     const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave * TW, n_t_end - 1) : t_last;
-    constexpr uint32_t kStride = kFWaves * TW;   // tiles between two units of a wavefront
+    constexpr uint32_t kStride = NW * TW;   // tiles between two units of a wavefront
     // the tiles of the unit that begins at tile T0, from buffer b
     auto compute_unit = [&](int b, uint32_t T0) __attribute__((always_inline)) {
 #pragma unroll
