@@ -905,17 +905,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #undef GPANN_PICK8
             default: break;
         }
-        // (measurement aids: GPANN_Q8_WAVES=8 runs the 128-dimension kernel with 8 wavefronts per workgroup, GPANN_Q8_UNIT_TILES=2 on top of
-        // that with two row tiles per unit of prefetch)
-        if (KS8 == 4 && EnvU32("GPANN_Q8_WAVES", 16) == 8) {
-            q8_waves = 8;
-            if (EnvU32("GPANN_Q8_UNIT_TILES", 1) == 2) {
-                fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 2, 8>;
-                q8_unit_tiles = 2;
-            } else {
-                fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 1, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 1, 8>;
-            }
-        }
         glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }

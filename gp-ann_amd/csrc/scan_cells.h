@@ -501,7 +501,7 @@ __device__ __forceinline__ void DmaWaitAll() { asm volatile("s_waitcnt vmcnt(0)"
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 // query tiles (of 32 tasks) per task group: the group's image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS beside the norms and the queues
 constexpr int FilterQueryTiles(int ks) { return ks <= 8 ? 8 : 4; }
-// consecutive row tiles a wavefront of FilterKernelCells takes at a time (its unit of prefetch): two 4 KiB tiles of the 8-bit plane up to 128 dimensions
+// consecutive row tiles a wavefront of FilterKernelCells takes at a time (its unit of prefetch)
 constexpr int FilterUnitTiles(int mode, int ks) { return 1; }
 
 // Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
@@ -550,9 +550,9 @@ __device__ __forceinline__ uint32_t ClaimElsewhere(const uint32_t* group_first, 
 // Q8Threshold; KS then counts k-steps of 32 dimensions and the image holds the int8 planes H, L of the queries).
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-// NW: wavefronts per workgroup (one workgroup per CU): 8, or 16 for the 8-bit plane up to 128 dimensions, whose small register footprint
-// allows four wavefronts per SIMD — with two, half of a wavefront's time was spent waiting on its own chain tile -> products -> candidates.
-constexpr int FilterWaves(int mode, int ks) { return mode == 2 && ks <= 4 ? 16 : kFWaves; }
+// NW: wavefronts per workgroup (one workgroup per CU).  (Measured on the 8-bit rest pass of the NS workload, profiles/r03/q8_kernel_variants.md:
+// 16 wavefronts of 128 registers 2.41 ms, 8 wavefronts 2.20 ms, 8 wavefronts taking two row tiles at a time 2.24 ms.)
+constexpr int FilterWaves(int mode, int ks) { return kFWaves; }
 template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS), int TW_ = FilterUnitTiles(MODE, KS), int NW = FilterWaves(MODE, KS)>
 __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a) {
     constexpr bool HI_ONLY = MODE >= 1, Q8 = MODE == 2;
@@ -599,8 +599,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         q_len = 0;
     };
 
-    // A wavefront's unit of work is TW consecutive row tiles: 1, or 2 for the 8-bit plane up to 128 dimensions — what covers the HBM latency
-    // is the bytes a wavefront has in flight (one unit of prefetch), and a 4 KiB int8 tile alone left the launch at 5.0 TB/s.
+    // A wavefront's unit of work is TW consecutive row tiles (1: two 4 KiB tiles of the 8-bit plane per unit were measured no faster).
     constexpr int TW = TW_;
     Frag Ah[2][TW][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
     float nrm[2][TW], nmax[2][TW];   // (nmax, MODE 2: the tile's largest norm word)
