@@ -169,7 +169,7 @@ def main():
         # the exchange layer is the C-ABI library libgpann_comm.so (include/gpann_comm.h): RCCL collectives on this process's HIP stream.
         # RCCL over xGMI is the measured configuration: if it cannot be initialised the run FAILS — a number taken over host sockets must
         # be asked for explicitly (--backend tcp) and says so in the JSON line ("backend")
-        comm = gcomm.Comm(gcomm.RCCL if args.backend == "rccl" else gcomm.TCP)   # RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK from the environment
+        comm = gcomm.Comm(gcomm.RCCL if args.backend == "rccl" else gcomm.TCP, device=local_rank)   # RANK / WORLD_SIZE / MASTER_* from the environment; the device the buffers are on
         if comm.world != args.gpus or comm.rank != rank:
             raise SystemExit(f"communicator has {comm.world} ranks (this is rank {comm.rank}), --gpus {args.gpus}")
     else:

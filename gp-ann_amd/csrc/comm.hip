@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -234,20 +235,32 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
                 SetErr("rank 0 cannot listen on port %d: %s", port, strerror(errno));
                 return fail(GPANN_ERR_HIP);
             }
+            // the deadline covers accept() and the 4-byte hello only: accepted sockets inherit SO_RCVTIMEO on Linux, and a collective that
+            // waits longer than that for a slow peer (uneven store builds at 10^8 rows) must not read as "connection lost"
             timeval tv{timeout_s, 0};
             setsockopt(c->listen_fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
             c->peers.assign(world, -1);
-            for (int i = 1; i < world; ++i) {
+            for (int arrived = 1; arrived < world;) {
                 const int fd = ::accept(c->listen_fd, nullptr, nullptr);
-                int32_t r = -1;
-                if (fd < 0 || !RecvAll(fd, &r, 4) || r <= 0 || r >= world || c->peers[r] != -1) {
-                    SetErr("rendezvous: %d of %d ranks arrived within %d s", i, world, timeout_s);
-                    if (fd >= 0) ::close(fd);
+                if (fd < 0) {
+                    if ((errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) && std::chrono::steady_clock::now() < deadline) continue;
+                    SetErr("rendezvous: %d of %d ranks arrived within %d s", arrived, world, timeout_s);
                     return fail(GPANN_ERR_HIP);
                 }
+                int32_t r = -1;
+                if (!RecvAll(fd, &r, 4) || r <= 0 || r >= world || c->peers[r] != -1) {
+                    ::close(fd);   // a stray connection / a wrong first word: drop it and keep waiting for the ranks
+                    if (std::chrono::steady_clock::now() < deadline) continue;
+                    SetErr("rendezvous: %d of %d ranks arrived within %d s", arrived, world, timeout_s);
+                    return fail(GPANN_ERR_HIP);
+                }
+                const timeval none{0, 0};
+                setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
                 int one2 = 1;
                 setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one2, sizeof one2);
                 c->peers[r] = fd;
+                ++arrived;
             }
         } else {
             const int fd = ConnectTo(master_addr, port, timeout_s);
@@ -267,6 +280,16 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
             SetErr("RCCL backend: HIP device %d is not available (%d devices)", device, n_dev);
             return fail(GPANN_ERR_NO_DEVICE);
         }
+        // the communicator is bound to `device`; the calling thread's current device is put back afterwards (a caller that chose another
+        // device for its buffers — GPANN_DIST_DEVICE, GPANN_BENCH_FORCE_DEVICE — must pass THAT device here)
+        int prev_device = -1;
+        (void)hipGetDevice(&prev_device);
+        struct Restore {
+            int dev;
+            ~Restore() {
+                if (dev >= 0) (void)hipSetDevice(dev);
+            }
+        } restore{prev_device};
         if (hipSetDevice(device) != hipSuccess) {
             SetErr("hipSetDevice(%d) failed", device);
             return fail(GPANN_ERR_HIP);
@@ -299,12 +322,14 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
     return GPANN_OK;
 }
 
-gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out) {
+gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out) { return gpann_comm_init_from_env_on(backend, -1, out); }
+
+gpann_status gpann_comm_init_from_env_on(int backend, int device_arg, gpann_comm** out) {
     auto env_int = [](const char* k, int dflt) {
         const char* v = std::getenv(k);
         return v && *v ? std::atoi(v) : dflt;
     };
-    const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), device = env_int("LOCAL_RANK", 0);
+    const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), device = device_arg >= 0 ? device_arg : env_int("LOCAL_RANK", 0);
     const char* addr = std::getenv("MASTER_ADDR");
     const int port = env_int("GPANN_COMM_PORT", env_int("MASTER_PORT", 29500) + 1);
     return gpann_comm_init(rank, world, addr && *addr ? addr : "127.0.0.1", port, backend, device, env_int("GPANN_COMM_TIMEOUT", 600), out);

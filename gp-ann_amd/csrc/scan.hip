@@ -914,9 +914,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     }
     // re-scoring launches: `parts` wavefronts per task (heavy buckets are split, RescoreArgs::parts)
-    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", 4)));
+    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", 8)));
     GPANN_TRY(s->ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
-    ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 192));
+    ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 128));
     ra.split_dist = s->ws_split.as<float>();
     ra.split_row = reinterpret_cast<uint32_t*>(ra.split_dist + (size_t)T * split_parts * k);
     auto launch_rescore = [&](uint32_t parts) {

@@ -40,7 +40,7 @@ int main(int argc, const char* argv[]) {
     const int backend = be && std::string(be) == "tcp" ? GPANN_COMM_TCP : GPANN_COMM_RCCL;
     const int device = EnvInt("GPANN_DIST_DEVICE", EnvInt("LOCAL_RANK", 0));
     gpann_comm* comm = nullptr;
-    if (gpann_comm_init_from_env(backend, &comm) != GPANN_OK) {   // (MPI_Init)
+    if (gpann_comm_init_from_env_on(backend, device, &comm) != GPANN_OK) {   // (MPI_Init; the communicator lives on the device the buffers will)
         std::cerr << "communicator: " << gpann_comm_last_error() << std::endl;
         return 2;
     }

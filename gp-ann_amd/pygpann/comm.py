@@ -10,7 +10,7 @@ from . import LIB_PATH, GpannError, OK
 
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_comm.so")
 RCCL, TCP = 0, 1
-EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_destroy", "gpann_comm_info", "gpann_comm_backend_name",
+EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_init_from_env_on", "gpann_comm_destroy", "gpann_comm_info", "gpann_comm_backend_name",
            "gpann_comm_barrier", "gpann_comm_max_double", "gpann_comm_allgather_host", "gpann_comm_broadcast_host", "gpann_comm_broadcast",
            "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_comm_debug_select_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
            "gpann_comm_merge_router"]
@@ -28,6 +28,7 @@ def lib():
         L.gpann_comm_backend_name.argtypes = [C.c_void_p]
         L.gpann_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gpann_comm_init_from_env.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.gpann_comm_init_from_env_on.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gpann_comm_destroy.argtypes = [C.c_void_p]
         L.gpann_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpann_comm_barrier.argtypes = [C.c_void_p]
@@ -131,13 +132,14 @@ def mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, rank, out=None):
 
 
 class Comm:
-    def __init__(self, backend, rank=None, world=None, addr="127.0.0.1", port=None, device=0, timeout_s=120):
-        """rank=None: RANK / WORLD_SIZE / MASTER_ADDR / GPANN_COMM_PORT (default MASTER_PORT + 1) / LOCAL_RANK from the environment"""
+    def __init__(self, backend, rank=None, world=None, addr="127.0.0.1", port=None, device=None, timeout_s=120):
+        """rank=None: RANK / WORLD_SIZE / MASTER_ADDR / GPANN_COMM_PORT (default MASTER_PORT + 1) from the environment; device=None: LOCAL_RANK
+        (pass the device the caller's buffers live on if that is another one)"""
         self.h = C.c_void_p()
         if rank is None:
-            _check(lib().gpann_comm_init_from_env(backend, C.byref(self.h)))
+            _check(lib().gpann_comm_init_from_env_on(backend, -1 if device is None else int(device), C.byref(self.h)))
         else:
-            _check(lib().gpann_comm_init(rank, world, addr.encode(), int(port or 0), backend, device, timeout_s, C.byref(self.h)))
+            _check(lib().gpann_comm_init(rank, world, addr.encode(), int(port or 0), backend, int(device or 0), timeout_s, C.byref(self.h)))
         r, w, b = C.c_int(), C.c_int(), C.c_int()
         _check(lib().gpann_comm_info(self.h, C.byref(r), C.byref(w), C.byref(b)))
         self.rank, self.world, self.backend = r.value, w.value, b.value

@@ -48,6 +48,9 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
 /* RANK, WORLD_SIZE, MASTER_ADDR, GPANN_COMM_PORT (default MASTER_PORT + 1), LOCAL_RANK (device), GPANN_COMM_TIMEOUT (seconds to wait for
  * the other ranks, default 600: the first `import torch` of a rank on a fresh machine can take minutes) from the environment */
 gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out);
+/* the same with the HIP device given by the caller (device < 0: LOCAL_RANK) — for callers that place their buffers on another device than
+ * LOCAL_RANK names (GPANN_DIST_DEVICE, GPANN_BENCH_FORCE_DEVICE): the communicator has to live where the buffers do */
+gpann_status gpann_comm_init_from_env_on(int backend, int device, gpann_comm** out);
 gpann_status gpann_comm_destroy(gpann_comm* c);
 gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend);
 /* "rccl <version>" / "tcp": what the JSON line of bench.py reports as the backend that actually ran */

@@ -1,8 +1,5 @@
-"""Shard-parallel execution over several GPUs (one process per GPU, torch.distributed; backend nccl = RCCL on ROCm).
-
-The path shards naturally: a shard lives on exactly one rank, every rank scans the (query, probe) tasks whose
-shard it owns, and the only exchange is an all-gather of the fixed-shape per-slot results followed by a host-side selection.
-These helpers are backend-agnostic (the CPU tests drive them over gloo)."""
+"""Test helpers: Python restatements of host-side pieces of the multi-rank path, used as expected values — the product's versions are
+gpann_lpt_owner / gpann_mask_probes / gpann_comm_merge_router (csrc/comm.hip, include/gpann_comm.h)."""
 import numpy as np
 
 NO_ID = np.uint32(0xFFFFFFFF)
@@ -29,39 +26,6 @@ def mask_probes(probes, owner, rank):
     p[theirs] = -1
     return p
 
-
-def combine_slots(gathered_dist, gathered_ids, probes, owner):
-    """gathered_*: [world][nq][nprobe][k] (every rank's slot arrays, +inf / NO_ID where it does not own the shard).
-    Picks each slot from the rank that owns its shard -> ([nq][nprobe][k] dist, ids)."""
-    gd = np.asarray(gathered_dist)
-    gi = np.asarray(gathered_ids)
-    p = np.asarray(probes)[:, :gd.shape[2]]
-    sel = np.where(p >= 0, owner[np.clip(p, 0, len(owner) - 1)], 0).astype(np.int64)
-    dist = np.take_along_axis(gd, sel[None, :, :, None], axis=0)[0]
-    ids = np.take_along_axis(gi, sel[None, :, :, None], axis=0)[0]
-    skipped = p < 0
-    dist[skipped] = np.inf
-    ids[skipped] = NO_ID
-    return dist, ids
-
-
-def all_gather_slots(dist_t, ids_t, torch_dist, world):
-    """all_gather of this rank's slot tensors (torch tensors on the backend's device); returns numpy [world, ...] arrays."""
-    import torch
-    gd = [torch.empty_like(dist_t) for _ in range(world)]
-    gi = [torch.empty_like(ids_t) for _ in range(world)]
-    torch_dist.all_gather(gd, dist_t)
-    torch_dist.all_gather(gi, ids_t)
-    return torch.stack(gd).cpu().numpy(), torch.stack(gi).cpu().numpy().view(np.uint32)
-
-
-def reduce_slots(dist_t, gids_t, torch_dist):
-    """The same exchange as all_gather_slots + combine_slots in one collective per array: a slot is scanned by exactly one rank
-    (the owner of its shard) and reads (+inf, -1) everywhere else, so the element-wise MIN of the distances and MAX of the
-    global ids (int64, -1 = no id) over the ranks is the owner's result.  In place, on whatever device the backend uses."""
-    torch_dist.all_reduce(dist_t, op=torch_dist.ReduceOp.MIN)
-    torch_dist.all_reduce(gids_t, op=torch_dist.ReduceOp.MAX)
-    return dist_t, gids_t
 
 
 def merge_trees(flats, owner):

@@ -1,6 +1,6 @@
 """CPU, world size 2 and 3 over the TCP backend of libgpann_comm.so (include/gpann_comm.h): the exchange logic of the multi-GPU path —
 rendezvous, barrier, max over ranks, broadcast, all-gather, the owner selection of the per-slot result lists — and the placement
-helpers against the Python restatements in pygpann.multigpu.  The CPU oracle stands in for the GPU scan; the outcome must equal the
+helpers against the Python restatements in tests/multirank_ref.py.  The CPU oracle stands in for the GPU scan; the outcome must equal the
 single-process result.  (The RCCL backend runs the same calls on device buffers; it needs one GPU per rank.)"""
 import os
 import socket
@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
             sys.path.insert(0, p)
     import pyoracle
     from pygpann import comm as gc
-    from pygpann import multigpu
+    import multirank_ref as multigpu
     c = gc.Comm(gc.TCP, rank=rank, world=world, addr="127.0.0.1", port=port, timeout_s=60)
     assert (c.rank, c.world, c.name) == (rank, world, "tcp")
     c.barrier()

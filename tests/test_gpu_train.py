@@ -98,16 +98,17 @@ def test_device_trainer_beyond_reference_block_size(orc, gp, metric):
 def test_device_trainer_per_rank_parts_merge_to_full_tree(orc, gp):
     """shard-parallel training: every 'rank' trains over a store holding only its own shards (the others are empty and get
     a root without centroids); merging the parts gives the tree trained over all shards"""
-    from pygpann import multigpu
+    import multirank_ref
+    from pygpann import comm as gcomm
     rng = np.random.default_rng(21)
     n, d, S = 16000, 20, 5
     pts = make_mixture(orc, n, d, n_centers=25)
     clusters = random_clusters(rng, n, S)
     o = orc.kmtr_train(pts, clusters, 16, 60, 1000, 0, nthreads=8).flat()
-    owner, _ = multigpu.lpt_owner(np.asarray([len(c) for c in clusters]), 2)
+    owner, _ = gcomm.lpt_owner(np.asarray([len(c) for c in clusters]), 2)
     parts = []
     for rank in range(2):
         mine = [c if owner[b] == rank else np.zeros(0, np.uint32) for b, c in enumerate(clusters)]
         shards = gp.Shards(pts, mine, metric=0)
         parts.append(gp.Router.train(shards, n, 16, 60, 1000).export())
-    _same_tree(multigpu.merge_trees(parts, owner), o)
+    _same_tree(multirank_ref.merge_trees(parts, owner), o)

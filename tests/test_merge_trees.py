@@ -1,4 +1,4 @@
-"""CPU: multigpu.merge_trees — per-rank router parts (own shards trained, other shards empty roots) merge into the tree
+"""CPU: multirank_ref.merge_trees (tests/multirank_ref.py) — per-rank router parts (own shards trained, other shards empty roots) merge into the tree
 KMeansTreeRouter::Train builds over all shards."""
 import numpy as np
 
@@ -30,7 +30,8 @@ def _part(full, owner, rank):
 
 
 def test_merge_trees_roundtrip(orc):
-    from pygpann import multigpu
+    import multirank_ref
+    from pygpann import comm as gcomm
     rng = np.random.default_rng(2)
     n, d, S = 8000, 10, 6
     pts = make_mixture(orc, n, d, n_centers=12)
@@ -38,9 +39,9 @@ def test_merge_trees_roundtrip(orc):
     full = orc.kmtr_train(pts, clusters, 8, 30, 900, 0, nthreads=4).flat()
     assert (full["node_child_count"] > 0).any()
     for world in (1, 2, 3):
-        owner, _ = multigpu.lpt_owner(np.asarray([len(c) for c in clusters]), world)
+        owner, _ = gcomm.lpt_owner(np.asarray([len(c) for c in clusters]), world)
         parts = [_part(full, owner, r) for r in range(world)]
-        merged = multigpu.merge_trees(parts, owner)
+        merged = multirank_ref.merge_trees(parts, owner)
         for key in ("node_shard", "node_cent_first", "node_child_first", "node_child_count", "shard_root"):
             assert np.array_equal(merged[key], full[key]), (world, key)
         assert np.array_equal(merged["centroids"].view(np.uint32), np.asarray(full["centroids"], np.float32).view(np.uint32))

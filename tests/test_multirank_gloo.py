@@ -1,6 +1,10 @@
-"""CPU, world_size 2 over gloo: the shard-parallel exchange used by bench.py --gpus N (pygpann.multigpu).
-Each rank scans only the shards it owns (the CPU oracle stands in for the GPU scan here), the per-slot results are
-all-gathered and combined by owner; the outcome must equal the single-process result."""
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py / DistributedBench with the PRODUCT's exchange library (libgpann_comm.so,
+include/gpann_comm.h) — placement (gpann_lpt_owner, gpann_plan_replicas), probe masks (gpann_mask_probes[_replicated]), the result exchange
+(gpann_comm_gather_slots, TCP backend on host buffers) and the host merge (gpann_merge_dedup) — cross-checked against the same exchange done
+with torch.distributed (gloo all_gather + a numpy owner selection) and against the single-process oracle.  Each rank scans only the slots it
+owns (the CPU oracle stands in for the GPU scan), with complete per-slot lists and with lists cut at the rank's merge bound
+(GPANN_SCAN_FOR_MERGE: a rank only sees its own slots of a query, so its bound is looser than the single-process one — the merged
+neighbours must still be the reference's)."""
 import os
 import socket
 import sys
@@ -8,7 +12,9 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, make_mixture, random_clusters
+from conftest import ROOT, random_clusters
+
+NO_ID = 0xFFFFFFFF
 
 
 def _free_port():
@@ -19,64 +25,106 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _cut_at_merge_bound(d, i):
+    """GPANN_SCAN_FOR_MERGE on [nq][nprobe][k] lists (include/gpann.h)"""
+    tau = d[:, :, -1].min(axis=1)
+    cut = ~(d <= tau[:, None, None])
+    d, i = d.copy(), i.copy()
+    d[cut] = np.inf
+    i[cut] = NO_ID
+    return d, i
+
+
+def _worker(rank, world, port, comm_port, out_dir, replicas):
     for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch
     import torch.distributed as dist
+    import pygpann
     import pyoracle
-    from pygpann import multigpu
+    from pygpann import comm as gcomm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = gcomm.Comm(gcomm.TCP, rank=rank, world=world, addr="127.0.0.1", port=comm_port)
     orc = pyoracle.Oracle("strict")
     rng = np.random.default_rng(21)
     n, d, S, nq, k, nprobe = 4000, 16, 7, 60, 5, 3
     pts = orc.synth_rows(555, 7, 16, 0.35, 0, n, d)
     queries = orc.synth_rows(556, 7, 16, 0.35, 0, nq, d)
-    clusters = random_clusters(rng, n, S, overlap=0.2)
+    clusters = random_clusters(rng, n, S, overlap=0.2)            # ids repeat across shards: the merge drops copies
     probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
-    probes[5, 1] = -1                                     # a skipped slot
-    owner, load = multigpu.lpt_owner([len(c) for c in clusters], world)
-    assert load.sum() == sum(len(c) for c in clusters) and set(owner) == set(range(world))
+    probes[5, 1] = -1                                             # a skipped slot
+    sizes = np.asarray([len(c) for c in clusters], np.uint64)
+    if replicas:
+        work = sizes.astype(np.float64) * (1.0 + np.arange(S))
+        rep_begin, rep_rank, _, _ = gcomm.plan_replicas(sizes, work, world, int(1.6 * sizes.sum() / world), 1.0)
+        held = [b for b in range(S) if rank in rep_rank[rep_begin[b]:rep_begin[b + 1]]]
+        lp = gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, rank)
+    else:
+        owner, load = gcomm.lpt_owner(sizes, world)
+        assert load.sum() == sizes.sum() and set(owner.tolist()) == set(range(world))
+        held = [b for b in range(S) if owner[b] == rank]
+        lp = gcomm.mask_probes(probes, nprobe, owner, rank)
+    assert ((lp == -1) | np.isin(lp, held)).all()
     # this rank's store holds only its shards (others empty), like bench.py
-    mine = [c if owner[b] == rank else np.zeros(0, np.uint32) for b, c in enumerate(clusters)]
-    ivf = orc.ivf_build(pts, mine)
-    lp = multigpu.mask_probes(probes[:, :nprobe], owner, rank)
-    assert ((lp == -1) | (owner[np.clip(lp, 0, S - 1)] == rank)).all()
+    ivf = orc.ivf_build(pts, [c if b in held else np.zeros(0, np.uint32) for b, c in enumerate(clusters)])
     od, oi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, lp, nprobe, 0)
-    gd, gi = multigpu.all_gather_slots(torch.from_numpy(od), torch.from_numpy(oi.view(np.int32)), dist, world)
-    cd, ci = multigpu.combine_slots(gd, gi, probes, owner)
-    # the one-collective form of the same exchange (what bench.py runs): MIN over distances, MAX over int64 ids (-1 = none)
-    rd = torch.from_numpy(od.copy())
-    ri = torch.from_numpy(np.where(oi == 0xFFFFFFFF, -1, oi.astype(np.int64)))
-    multigpu.reduce_slots(rd, ri, dist)
-    assert np.array_equal(rd.numpy().view(np.uint32), cd.view(np.uint32)) and np.array_equal(ri.numpy().astype(np.uint32), ci)
-    # max-over-ranks timing reduction used by bench.py
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert t.item() == world
-    if rank == 0:
+    ok = True
+    for cut in (False, True):
+        sd, si = _cut_at_merge_bound(od, oi) if cut else (od, oi)
+        # the product's exchange ...
+        n_slots = sd.size
+        out_d, out_i = np.empty_like(sd), np.empty_like(si)
+        comm.gather_slots(np.ascontiguousarray(sd), np.ascontiguousarray(si), n_slots, out_d, out_i, np.empty(comm.gather_slots_scratch(n_slots), np.uint8))
+        # ... against torch.distributed: all_gather of every rank's lists, each slot from the one rank where it is not empty
+        gd = [torch.empty((nq, nprobe, k), dtype=torch.float32) for _ in range(world)]
+        gi = [torch.empty((nq, nprobe, k), dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(gd, torch.from_numpy(np.ascontiguousarray(sd)))
+        dist.all_gather(gi, torch.from_numpy(np.ascontiguousarray(si).view(np.int32)))
+        gd = torch.stack(gd).numpy()
+        gi = torch.stack(gi).numpy().view(np.uint32)
+        has = gi != NO_ID
+        assert (has.sum(axis=0) <= 1).all()                       # a slot entry is non-empty on at most one rank
+        want_i = np.where(has.any(axis=0), gi.min(axis=0), NO_ID).astype(np.uint32)
+        want_d = gd.min(axis=0)
+        ok = ok and np.array_equal(out_i, want_i) and np.array_equal(out_d.view(np.uint32), want_d.view(np.uint32))
+        # the host merge over the exchanged lists = the reference's merge over the single-process lists
+        md, mi, mc = pygpann.merge_dedup(out_d, out_i, nprobe, k)
         full = orc.ivf_build(pts, clusters)
         wd, wi, _ = orc.ivf_query_bucket_batch(full, queries, k, probes, nprobe, 0)
-        np.savez(os.path.join(out_dir, "result.npz"), ok=np.array([np.array_equal(ci, wi) and np.array_equal(cd.view(np.uint32), wd.view(np.uint32))]))
+        if not cut:
+            ok = ok and np.array_equal(out_i, wi) and np.array_equal(out_d.view(np.uint32), wd.view(np.uint32))
+        fd, fi, fc = pygpann.merge_dedup(wd, wi, nprobe, k)
+        ok = ok and np.array_equal(mi, fi) and np.array_equal(md.view(np.uint32), fd.view(np.uint32)) and np.array_equal(mc, fc)
+    # max-over-ranks timing reduction: the library's and torch.distributed's
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and t.item() == world and comm.max_double(float(rank + 1)) == world
+    flags = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([1 if ok else 0], dtype=torch.int32))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "result.npz"), ok=np.array([all(int(f.item()) == 1 for f in flags)]))
+    comm.barrier()
+    comm.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_parallel_exchange(tmp_path):
+@pytest.mark.parametrize("replicas", [False, True])
+def test_two_rank_shard_parallel_exchange(tmp_path, replicas):
     import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), _free_port(), str(tmp_path), replicas), nprocs=2, join=True)
     assert bool(np.load(tmp_path / "result.npz")["ok"][0])
 
 
 def test_lpt_and_masks():
-    from pygpann import multigpu
-    owner, load = multigpu.lpt_owner([10, 9, 8, 1, 1, 1], 3)
+    sys.path.insert(0, os.path.join(ROOT, "gp-ann_amd"))
+    from pygpann import comm as gcomm
+    owner, load = gcomm.lpt_owner([10, 9, 8, 1, 1, 1], 3)
     assert sorted(load.tolist()) == [10, 10, 10]
     p = np.array([[0, 3, -1], [5, 1, 2]], np.int32)
-    m = multigpu.mask_probes(p, owner, int(owner[0]))
+    m = gcomm.mask_probes(p, 3, owner, int(owner[0]))
     assert m[0, 0] == 0 and m[0, 2] == -1
     assert all(m[i, j] == -1 or owner[m[i, j]] == owner[0] for i in range(2) for j in range(3))
