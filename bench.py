@@ -632,7 +632,7 @@ def main():
         # (bf16 hi plane: 32 B per k-step of 16 dimensions; 8-bit plane: 32 B per k-step of 32 dimensions — the library reports which)
         rest_bytes = stats["filter_rest_rows"] * float(stats["filter_rest_row_bytes"])
         rest_gbps = rest_bytes / r_s / 1e9 if r_s > 0 else 0.0
-        traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"true": 1}, largest_launch=True, kernel_bytes=rest_bytes)
+        traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"": 1}, largest_launch=True, kernel_bytes=rest_bytes)
         # step level: the bytes every launch of the step has to read — plane rows of all filter launches (two-plane launches twice the plane
         # bytes), the rows re-scored exactly (candidates + seed rows, d x 4 each), the router's centroid planes (both passes, both planes)
         row_hi = 32.0 * ks_read + 4.0

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members,
 // bf16 hi/lo planes in MFMA A-operand order, rows taken through plane_perm (padding rows are zero)
 __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* points, const uint32_t* plane_perm, uint64_t plane_rows, uint32_t ld,
                                                                  char* planes, uint64_t lo_offset, uint32_t plane_ks, const float* mu,
-                                                                 const uint32_t* tile_lo_index) {
+                                                                 const uint32_t* tile_hi_index, const uint32_t* tile_lo_index) {
     const uint32_t g_per_row = 2 * plane_ks;   // groups of 8 dims per row: 16 or 32
     const uint64_t total = plane_rows * g_per_row;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -71,8 +71,10 @@ __global__ void __launch_bounds__(256) SplitFragPlanesPermKernel(const float* po
         for (int j = 0; j < 4; ++j) SplitBf16(v[2 * j], v[2 * j + 1], fh.u[j], fl.u[j]);
         const uint32_t ks = g8 >> 1, h = g8 & 1, lane = (uint32_t)(r & 31) + 32 * h;
         const uint64_t tile_bytes = (uint64_t)plane_ks * 1024;
-        char* base = planes + (r >> 5) * tile_bytes + ks * 1024 + lane * 16;   // all hi tiles first, then the lo tiles
-        *reinterpret_cast<uint4*>(base) = fh.q;
+        // hi tile: at the row's own tile index (tile_hi_index == nullptr), or at tile_hi_index[tile] of the hi array if the tile has one
+        const uint64_t hi = tile_hi_index ? tile_hi_index[r >> 5] : (r >> 5);
+        char* base = planes + hi * tile_bytes + ks * 1024 + lane * 16;   // all hi tiles first, then the lo tiles
+        if (!tile_hi_index || tile_hi_index[r >> 5] != kNoRow) *reinterpret_cast<uint4*>(base) = fh.q;
         // lo tile: at the same index as the hi tile (tile_lo_index == nullptr), or at tile_lo_index[tile] of the lo array if the tile has one
         if (!tile_lo_index) {
             *reinterpret_cast<uint4*>(base + lo_offset) = fl.q;
@@ -225,7 +227,7 @@ __global__ void TileNormMaxKernel(const float* plane_norm, uint64_t tiles, float
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_nmax})
+                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.d_cell_hi_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_nmax})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -345,34 +347,71 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
         C.n_sample_tiles = C.sample_tile_begin[S];
         C.sample_tile_base = C.n_tiles + 2;
     }
-    const uint64_t all_tiles = C.sample_tile_base + C.n_sample_tiles;   // cell tiles | 2 zero tiles | sample tiles (| 2 zero tiles)
-    C.lo_offset_tiles = all_tiles + 2;
+    const uint64_t all_tiles = C.sample_tile_base + C.n_sample_tiles;   // tile numbering of plane_perm / plane_norm / the 8-bit plane: cell tiles | 2 zero tiles | sample tiles
     const uint64_t all_rows = all_tiles * kGTileRows;
-    // which tiles get a lo tile (shards.h): every one (GPANN_FILTER_LO_ROWS=all), or the sample tiles and the first rows of every cell —
-    // the only ones the two-plane passes read.  Beyond 128 dimensions every pass is a hi-plane pass: no lo tiles at all.
-    std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), tile_lo_index;
+    // The 8-bit plane comes first: when the store has one, the rest pass never reads the bf16 planes, and only the tiles the earlier
+    // passes can reach keep a bf16 hi tile (below).
+    {
+        const char* q8_env = std::getenv("GPANN_FILTER_Q8");
+        if (!(q8_env && q8_env[0] == '0')) {
+            C.q8_ks = (s->d + 31) / 32;
+            const bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
+                             hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_nmax, (C.n_tiles + 2) * 4) == hipSuccess &&
+                             hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess;
+            if (!qok) {   // the store works without it
+                (void)hipGetLastError();
+                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_nmax})
+                    if (p) (void)hipFree(p);
+                C.q8_planes = nullptr;
+                C.d_q8_scale = nullptr;
+                C.d_q8_cnorm = nullptr;
+                C.d_tile_nmax = nullptr;
+                C.q8_ks = 0;
+                fprintf(stderr, "[gpann] the 8-bit plane of the filter's rest pass could not be allocated; the rest pass streams the bf16 plane\n");
+            }
+        }
+    }
+    // Which tiles keep a bf16 hi / lo tile (shards.h).  lo: every one (GPANN_FILTER_LO_ROWS=all), or the sample tiles and the first rows of every
+    // cell — the only ones the two-plane passes read (beyond 128 dimensions every pass is a hi-plane pass: no lo tiles at all).  hi: every one, or —
+    // when the rest pass has the 8-bit plane — the sample tiles and the first max(head, 1 / kHiKeepDiv) of every cell: the head and sample passes
+    // never reach further (the sample pass covers at most 1 / 8 of a cell).  GPANN_FILTER_HI_ROWS=all keeps all (then GPANN_FILTER_Q8=0 works at scan time).
+    constexpr uint32_t kHiKeepDiv = 8;
+    std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), cell_hi_begin(C.n_cells + 1, 0), tile_lo_index, tile_hi_index;
     {
         const char* lr = std::getenv("GPANN_FILTER_LO_ROWS");
+        const char* hr = std::getenv("GPANN_FILTER_HI_ROWS");
         C.lo_full = lr && std::string(lr) == "all";
+        C.hi_compact = C.q8_planes != nullptr && !C.lo_full && !(hr && std::string(hr) == "all");
         const uint64_t lo_rows = C.plane_ks > 8 ? 0 : (lr && !C.lo_full ? (uint64_t)std::max(0L, std::atol(lr)) : 512);
         C.lo_head_tiles = C.lo_full ? 0xFFFFFFFFu : (uint32_t)((lo_rows + kGTileRows - 1) / kGTileRows);
-        if (C.lo_full) {
-            for (uint32_t c = 0; c <= C.n_cells; ++c) cell_lo_begin[c] = (uint32_t)C.cell_tile_begin[c];
-            C.lo_sample_begin = C.sample_tile_base;
-            C.n_lo_tiles = all_tiles;
-        } else {
-            tile_lo_index.assign(C.n_tiles, kNoRow);
-            uint64_t at = 0;
-            for (uint32_t c = 0; c < C.n_cells; ++c) {
-                cell_lo_begin[c] = (uint32_t)at;
-                const uint64_t keep = std::min<uint64_t>(C.lo_head_tiles, C.cell_tile_begin[c + 1] - C.cell_tile_begin[c]);
-                for (uint64_t i = 0; i < keep; ++i) tile_lo_index[C.cell_tile_begin[c] + i] = (uint32_t)(at + i);
-                at += keep;
+        C.hi_keep_div = C.hi_compact ? kHiKeepDiv : 1u;
+        uint64_t at_lo = 0, at_hi = 0;
+        if (!C.lo_full) tile_lo_index.assign(C.n_tiles, kNoRow);
+        if (C.hi_compact) tile_hi_index.assign(C.n_tiles, kNoRow);
+        for (uint32_t c = 0; c < C.n_cells; ++c) {
+            const uint64_t t0 = C.cell_tile_begin[c], tiles = C.cell_tile_begin[c + 1] - t0;
+            cell_lo_begin[c] = (uint32_t)(C.lo_full ? t0 : at_lo);
+            cell_hi_begin[c] = (uint32_t)(C.hi_compact ? at_hi : t0);
+            if (!C.lo_full) {
+                const uint64_t keep = std::min<uint64_t>(C.lo_head_tiles, tiles);
+                for (uint64_t i = 0; i < keep; ++i) tile_lo_index[t0 + i] = (uint32_t)(at_lo + i);
+                at_lo += keep;
             }
-            cell_lo_begin[C.n_cells] = (uint32_t)at;
-            C.lo_sample_begin = at + 2;
-            C.n_lo_tiles = C.lo_sample_begin + (C.plane_ks > 8 ? 0 : C.n_sample_tiles);
+            if (C.hi_compact) {
+                // (head: 512 rows, the scan's default and upper limit here; + 1: the sample segment's end is a rounded-up quotient)
+                const uint64_t keep = std::min<uint64_t>(tiles, std::max<uint64_t>(16, (tiles + kHiKeepDiv - 1) / kHiKeepDiv + 1));
+                for (uint64_t i = 0; i < keep; ++i) tile_hi_index[t0 + i] = (uint32_t)(at_hi + i);
+                at_hi += keep;
+            }
         }
+        cell_lo_begin[C.n_cells] = (uint32_t)(C.lo_full ? C.n_tiles : at_lo);
+        cell_hi_begin[C.n_cells] = (uint32_t)(C.hi_compact ? at_hi : C.n_tiles);
+        // hi array: the cells' tiles | 2 zero tiles | the sample's tiles | 2 zero tiles;  lo array behind it, laid out the same way
+        C.n_hi_cell_tiles = cell_hi_begin[C.n_cells];
+        C.hi_sample_begin = C.n_hi_cell_tiles + 2;
+        C.lo_offset_tiles = C.hi_sample_begin + C.n_sample_tiles + 2;
+        C.lo_sample_begin = (uint64_t)cell_lo_begin[C.n_cells] + 2;
+        C.n_lo_tiles = C.lo_sample_begin + (C.plane_ks > 8 ? 0 : C.n_sample_tiles);
     }
 
     uint64_t* d_member_begin = nullptr;
@@ -382,11 +421,15 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
               hipMalloc(&C.d_cnorm, (size_t)C.n_cells * 4) == hipSuccess &&
               hipMalloc(&C.plane_perm, all_rows * 4) == hipSuccess && hipMalloc(&C.plane_norm, (all_rows + 64) * 4) == hipSuccess &&
               hipMalloc(&s->frag_planes, (C.lo_offset_tiles + C.n_lo_tiles + 2) * tile_bytes) == hipSuccess && hipMalloc(&d_member_begin, C.n_cells * 8) == hipSuccess &&
-              hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess && hipMalloc(&C.d_cell_lo_begin, (size_t)(C.n_cells + 1) * 4) == hipSuccess;
-    uint32_t* d_tile_lo_index = nullptr;
+              hipMalloc(&d_cell_size, C.n_cells * 4) == hipSuccess && hipMalloc(&C.d_cell_lo_begin, (size_t)(C.n_cells + 1) * 4) == hipSuccess &&
+              hipMalloc(&C.d_cell_hi_begin, (size_t)(C.n_cells + 1) * 4) == hipSuccess;
+    uint32_t *d_tile_lo_index = nullptr, *d_tile_hi_index = nullptr;
     if (ok && !tile_lo_index.empty())
         ok = hipMalloc(&d_tile_lo_index, tile_lo_index.size() * 4) == hipSuccess &&
              hipMemcpy(d_tile_lo_index, tile_lo_index.data(), tile_lo_index.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && !tile_hi_index.empty())
+        ok = hipMalloc(&d_tile_hi_index, tile_hi_index.size() * 4) == hipSuccess &&
+             hipMemcpy(d_tile_hi_index, tile_hi_index.data(), tile_hi_index.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     std::vector<float> cnorm(C.n_cells);
     for (uint32_t cidx = 0; cidx < C.n_cells; ++cidx) {
         double acc = 0.0;
@@ -403,10 +446,10 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
              hipMemset(C.plane_norm + plane_rows, 0, (all_rows - plane_rows + 64) * 4) == hipSuccess &&
              hipMemset(C.plane_perm + plane_rows, 0xFF, (all_rows - plane_rows) * 4) == hipSuccess &&   // (kNoRow: the gap tiles and, for now, the sample)
              hipMemcpy(C.d_cell_lo_begin, cell_lo_begin.data(), (size_t)(C.n_cells + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemset(s->frag_planes + C.n_tiles * tile_bytes, 0, (C.lo_offset_tiles - C.n_tiles) * tile_bytes) == hipSuccess &&
-             // the lo array: everything that is not a cell's lo tile (the gaps, the sample's tiles until they are written)
-             (C.lo_full ? hipMemset(s->frag_planes + (C.lo_offset_tiles + C.n_tiles) * tile_bytes, 0, (C.n_lo_tiles + 2 - C.n_tiles) * tile_bytes)
-                        : hipMemset(s->frag_planes + (C.lo_offset_tiles + cell_lo_begin[C.n_cells]) * tile_bytes, 0, (C.n_lo_tiles + 2 - cell_lo_begin[C.n_cells]) * tile_bytes)) == hipSuccess;
+             hipMemcpy(C.d_cell_hi_begin, cell_hi_begin.data(), (size_t)(C.n_cells + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             // everything of both arrays that is not a cell's tile: the gaps, the sample's tiles until they are written
+             hipMemset(s->frag_planes + C.n_hi_cell_tiles * tile_bytes, 0, (C.lo_offset_tiles - C.n_hi_cell_tiles) * tile_bytes) == hipSuccess &&
+             hipMemset(s->frag_planes + (C.lo_offset_tiles + cell_lo_begin[C.n_cells]) * tile_bytes, 0, (C.n_lo_tiles + 2 - cell_lo_begin[C.n_cells]) * tile_bytes) == hipSuccess;
     }
     // squared L2: everything the matrix-core bound touches is taken around the store's mean row (translation leaves the distances alone
     // and makes |p|, |q| — which the bound's error terms scale with — as small as the data allows; a cloud that sits at +100 in every
@@ -444,43 +487,24 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
         const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
-                           (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu, C.lo_full ? nullptr : d_tile_lo_index);
+                           (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu, d_tile_hi_index, d_tile_lo_index);
         hipLaunchKernelGGL(CellRadiusKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, s->d, ld, C.d_radius);
         ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }
     if (d_member_begin) (void)hipFree(d_member_begin);
     if (d_cell_size) (void)hipFree(d_cell_size);
     if (d_tile_lo_index) (void)hipFree(d_tile_lo_index);
+    if (d_tile_hi_index) (void)hipFree(d_tile_hi_index);
     if (!ok) return give_up("device");
 
-    // the 8-bit plane of the rest pass (optional: without it the rest pass streams the bf16 hi plane)
-    {
-        const char* q8_env = std::getenv("GPANN_FILTER_Q8");
-        if (!(q8_env && q8_env[0] == '0')) {
-            C.q8_ks = (s->d + 31) / 32;
-            bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
-                       hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_nmax, (C.n_tiles + 2) * 4) == hipSuccess &&
-                       hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess;
-            if (qok) {
-                hipLaunchKernelGGL(CellQ8ScaleKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, s->d, ld,
-                                   C.d_q8_scale, C.d_q8_cnorm);
-                hipLaunchKernelGGL(CellQ8PlaneKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, C.d_q8_scale, ld,
-                                   C.q8_ks, C.q8_planes);
-                hipLaunchKernelGGL(TileNormMaxKernel, dim3((uint32_t)((C.n_tiles + 2 + 255) / 256)), dim3(256), 0, 0, C.plane_norm, C.n_tiles + 2, C.d_tile_nmax);
-                qok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-            }
-            if (!qok) {   // the store works without it
-                (void)hipGetLastError();
-                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_nmax})
-                    if (p) (void)hipFree(p);
-                C.q8_planes = nullptr;
-                C.d_q8_scale = nullptr;
-                C.d_q8_cnorm = nullptr;
-                C.d_tile_nmax = nullptr;
-                C.q8_ks = 0;
-                fprintf(stderr, "[gpann] the 8-bit plane of the filter's rest pass could not be built; the rest pass streams the bf16 plane\n");
-            }
-        }
+    // the 8-bit plane of the rest pass (allocated above)
+    if (C.q8_planes) {
+        hipLaunchKernelGGL(CellQ8ScaleKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, s->d, ld, C.d_q8_scale,
+                           C.d_q8_cnorm);
+        hipLaunchKernelGGL(CellQ8PlaneKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, C.d_q8_scale, ld, C.q8_ks,
+                           C.q8_planes);
+        hipLaunchKernelGGL(TileNormMaxKernel, dim3((uint32_t)((C.n_tiles + 2 + 255) / 256)), dim3(256), 0, 0, C.plane_norm, C.n_tiles + 2, C.d_tile_nmax);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return give_up("8-bit plane");
     }
 
     // the shard sample's rows, norms and planes behind the cell tiles
@@ -501,13 +525,14 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                     uint32_t* d_none = nullptr;
                     sok = hipMalloc(&d_none, C.n_sample_tiles * 4) == hipSuccess && hipMemset(d_none, 0xFF, C.n_sample_tiles * 4) == hipSuccess;
                     if (sok)
-                        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
-                                           (uint64_t)0, C.plane_ks, C.d_mu, d_none);
+                        hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.hi_sample_begin * tile_bytes,
+                                           (uint64_t)0, C.plane_ks, C.d_mu, (const uint32_t*)nullptr, d_none);
                     sok = sok && hipDeviceSynchronize() == hipSuccess;
                     if (d_none) (void)hipFree(d_none);
                 } else {
-                    hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.sample_tile_base * tile_bytes,
-                                       (uint64_t)(C.lo_offset_tiles + C.lo_sample_begin - C.sample_tile_base) * tile_bytes, C.plane_ks, C.d_mu, (const uint32_t*)nullptr);
+                    hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g3), dim3(256), 0, 0, s->points, sperm, srows, ld, s->frag_planes + C.hi_sample_begin * tile_bytes,
+                                       (uint64_t)(C.lo_offset_tiles + C.lo_sample_begin - C.hi_sample_begin) * tile_bytes, C.plane_ks, C.d_mu, (const uint32_t*)nullptr,
+                                       (const uint32_t*)nullptr);
                 }
                 sok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
             }

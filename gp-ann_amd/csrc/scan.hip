@@ -567,18 +567,22 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
     // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
     // (the head pass multiplies both planes: it cannot reach past the rows that have a lo tile)
-    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows, C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles);
+    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows,
+                                                                      C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles),
+                                                   C.hi_compact ? 16u : 0xFFFFFFFFu);   // (compact hi planes keep 16 tiles of every cell at least)
     int64_t max_rows = 1;
     for (uint32_t b = 0; b < S; ++b) max_rows = std::max<int64_t>(max_rows, s->offsets[b + 1] - s->offsets[b]);
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap_plan - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap_plan);
-    const uint32_t sample_div = std::max<uint32_t>(2, EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
+    // (compact hi planes: the sample segment has to stay inside the tiles that kept a bf16 hi tile)
+    const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
     const bool l2 = s->metric == GPANN_METRIC_L2;
     (void)flags;
     const uint32_t KS = C.plane_ks, QT = (uint32_t)FilterQueryTiles((int)KS);
     const bool wide = KS > 8;   // beyond 128 dimensions: hi-plane passes only, 4 query tiles per group
     // the rest pass on the 8-bit plane (scan_cells.h MODE 2) when the store has one: a quarter of the fp32 bytes per row instead of half
-    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && EnvU32("GPANN_FILTER_Q8", 1) != 0;
+    // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
+    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || EnvU32("GPANN_FILTER_Q8", 1) != 0);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
@@ -822,6 +826,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.shard_cell_begin = C.d_shard_cell_begin;
     fa.cell_tile_begin = C.d_cell_tile_begin;
     fa.cell_lo_begin = C.d_cell_lo_begin;
+    fa.cell_hi_begin = C.d_cell_hi_begin;
     fa.kmax = kmax;
     fa.head_tiles = head_tiles;
     fa.sample_div = sample_div;
@@ -968,7 +973,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 it.t_end = (uint32_t)std::min<uint64_t>(t1, t + piece);
                 it.t_a = it.t_b = it.t_begin;   // no head / sample segment: every query tile runs on every row tile
                 it.task_begin = groups[g].task_begin;
-                it.lo_shift = (uint32_t)(C.sample_tile_base - C.lo_sample_begin);   // sample tile j: hi tile sample_tile_base + j, lo tile lo_sample_begin + j
+                it.lo_shift = (uint32_t)(C.sample_tile_base - C.lo_sample_begin);   // sample tile j: row tile sample_tile_base + j, lo tile lo_sample_begin + j ...
+                it.hi_shift = (uint32_t)(C.sample_tile_base - C.hi_sample_begin);   // ... hi tile hi_sample_begin + j
+                it.block = 0;
+                it.cell_scale = 0.f;
+                it.pad1 = 0;
                 it.acts = mask | mask << 8 | mask << 16 | (groups[g].task_count - 1u) << 24;
                 it.group = g;
                 sitems.push_back(it);

@@ -43,7 +43,8 @@ struct CellItem {   // everything FilterKernelCells needs to run one piece of a 
     // 8-bit passes (MODE 2): the (task group, cell) block — row of the threshold table q8_B — and the cell's quantisation step
     uint32_t block;
     float cell_scale;
-    uint32_t pad0, pad1;       // (48 bytes: three 16-byte loads)
+    uint32_t hi_shift;         // bf16 passes: the hi plane of row tile T is tile T - hi_shift of the hi array (shards.h: compact hi planes)
+    uint32_t pad1;             // (48 bytes: three 16-byte loads)
 };
 
 struct CellTileRef {
@@ -350,6 +351,7 @@ struct CellFilterArgs {
     const uint32_t* shard_cell_begin;
     const uint64_t* cell_tile_begin;
     const uint32_t* cell_lo_begin;   // [cells+1] first lo tile of every cell (CellItem::lo_shift)
+    const uint32_t* cell_hi_begin;   // [cells+1] first hi tile of every cell (CellItem::hi_shift)
     const uint32_t* need;        // [groups][kmax] query tiles to run in this pass
     // A cell's tiles form three segments: head [0, head_tiles), sample [head_tiles, max(head_tiles, tiles / sample_div)), rest.
     // Pass p (0 head, 1 sample, 2 rest) covers segments 0..p; done0 / done1 are the query tiles that already ran on segment 0 / 1.
@@ -425,7 +427,8 @@ static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a
     it.group = g;
     it.block = block;
     it.cell_scale = a.q8_scale ? a.q8_scale[cell0 + j] : 0.f;
-    it.pad0 = it.pad1 = 0u;
+    it.hi_shift = (uint32_t)t_cell - a.cell_hi_begin[cell0 + j];
+    it.pad1 = 0u;
     for (uint32_t i = 0; i < n; ++i) {
         const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
         it.t_begin = (uint32_t)b;
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         for (int tw = 0; tw < TW; ++tw) nrm[b][tw] = nmax[b][tw] = 0.f;
     const char* lane_q8 = Q8 ? a.q8_planes + lane * 16 : nullptr;
     // (tiles T .. T + TW - 1: the tile after a range is the next cell's or the zero padding behind the planes — loaded, never multiplied)
-    auto load_tile = [&](Frag (&Ah)[TW][KS], Frag (&Al)[KS], float (&nrm)[TW], float (&nmax)[TW], uint32_t T, uint32_t T_lo) __attribute__((always_inline)) {
+    auto load_tile = [&](Frag (&Ah)[TW][KS], Frag (&Al)[KS], float (&nrm)[TW], float (&nmax)[TW], uint32_t T, uint32_t T_hi, uint32_t T_lo) __attribute__((always_inline)) {
         if (Q8) {
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
@@ -623,7 +626,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
             }
             return;
         }
-        const char* base = lane_planes + (size_t)T * a.plane_tile_bytes;
+        const char* base = lane_planes + (size_t)T_hi * a.plane_tile_bytes;
         const char* base_lo = lane_planes + a.plane_lo_offset + (size_t)T_lo * a.plane_tile_bytes;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -670,19 +673,21 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     float Bq[Q8 ? QT : 1];
     float cell_scale = 0.f;
     uint32_t iter = 0;
-    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0;
+    uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0, r_hi_shift = 0;
     {
         const uint4 lo = reinterpret_cast<const uint4*>(a.items + item)[0], hi = reinterpret_cast<const uint4*>(a.items + item)[1];
         r_t_begin = uniform(lo.x); r_t_end = uniform(lo.y); r_t_a = uniform(lo.z); r_t_b = uniform(lo.w);
         r_task_begin = uniform(hi.x); r_lo_shift = uniform(hi.y); r_acts = uniform(hi.z); r_group = uniform(hi.w);
+        const uint4 x = reinterpret_cast<const uint4*>(a.items + item)[2];
         if (Q8) {
-            const uint4 x = reinterpret_cast<const uint4*>(a.items + item)[2];
             r_block = uniform(x.x); r_scale_bits = uniform(x.y);
+        } else {
+            r_hi_shift = uniform(x.z);
         }
     }
     {
         const uint32_t T0 = min(r_t_begin + wave * TW, r_t_end - 1);
-        load_tile(Ah[0], Al[0], nrm[0], nmax[0], T0, T0 - r_lo_shift);
+        load_tile(Ah[0], Al[0], nrm[0], nmax[0], T0, T0 - r_hi_shift, T0 - r_lo_shift);
     }
     for (;;) {
     // here: r_* is this item's record, its first row tile is on its way to buffer 0, nxt is the item after it (or kNoItem)
@@ -694,7 +699,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
     const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
-    const uint4 n_x = Q8 ? reinterpret_cast<const uint4*>(rn)[2] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 n_x = reinterpret_cast<const uint4*>(rn)[2];
 
 
     auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float nmax, uint32_t T) __attribute__((always_inline)) {
@@ -885,6 +890,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     ++iter;
     const uint32_t n_t_begin = uniform(n_lo.x), n_t_end = uniform(n_lo.y);
     const uint32_t lo_shift = r_lo_shift, n_lo_shift = HI_ONLY ? 0u : uniform(n_hi.y);   // (n_hi is this item's record after the last item)
+    const uint32_t hi_shift = r_hi_shift, n_hi_shift = Q8 ? 0u : uniform(n_x.z);
     const uint32_t t_last = t_end - 1;
     // this wavefront's first tile of the next item
     const uint32_t n_first = nxt != kNoItem ? min(n_t_begin + wave * TW, n_t_end - 1) : t_last;
@@ -901,13 +907,15 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         for (;;) {   // (written out: every exit is a plain break, so the compiler keeps an exact count of the loads in flight)
             uint32_t Tn = T + kStride;
             uint32_t own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
+            load_tile(Ah[1], Al[HI_ONLY ? 0 : 1], nrm[1], nmax[1], (Tn & own) | (n_first & ~own), ((Tn - hi_shift) & own) | ((n_first - n_hi_shift) & ~own),
+                      ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
             compute_unit(0, T);
             T = Tn;
             if (T >= t_end) break;
             Tn = T + kStride;
             own = Tn <= t_last ? 0xFFFFFFFFu : 0u;
-            load_tile(Ah[0], Al[0], nrm[0], nmax[0], (Tn & own) | (n_first & ~own), ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
+            load_tile(Ah[0], Al[0], nrm[0], nmax[0], (Tn & own) | (n_first & ~own), ((Tn - hi_shift) & own) | ((n_first - n_hi_shift) & ~own),
+                      ((Tn - lo_shift) & own) | ((n_first - n_lo_shift) & ~own));
             compute_unit(1, T);
             T = Tn;
             if (T >= t_end) break;
@@ -926,7 +934,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
             }
         }
     } else {
-        load_tile(Ah[0], Al[0], nrm[0], nmax[0], n_first, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
+        load_tile(Ah[0], Al[0], nrm[0], nmax[0], n_first, n_first - n_hi_shift, n_first - n_lo_shift);   // (buffer 0 holds a tile of this item that this wavefront had no use for)
     }
     if (nxt == kNoItem) break;
     const uint32_t n_group = uniform(n_hi.w);
@@ -936,6 +944,8 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     if (Q8) {
         r_block = uniform(n_x.x);
         r_scale_bits = uniform(n_x.y);
+    } else {
+        r_hi_shift = n_hi_shift;
     }
     item = nxt;
     nxt = after;

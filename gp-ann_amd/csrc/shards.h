@@ -121,6 +121,13 @@ struct gpann_shards {
         uint64_t n_lo_tiles = 0;                   // tiles of the lo array (cells' heads | 2 zero tiles | sample tiles)
         uint64_t lo_sample_begin = 0;              // first lo tile of the shard sample
         uint32_t* d_cell_lo_begin = nullptr;       // [n_cells+1] first lo tile of every cell
+        // The hi array likewise holds only the tiles a bf16 pass can reach when the store has the 8-bit plane for the rest pass (hi_compact):
+        // the sample tiles and the first max(16, tiles / hi_keep_div + 1) tiles of every cell — hi tile cell_hi_begin[c] + i belongs to tile i of
+        // cell c, hi tile hi_sample_begin + j to sample tile j (NS: 3.2 GB instead of 25.6 GB).  Not compact: every tile at its own index.
+        bool hi_compact = false;
+        uint32_t hi_keep_div = 1;                  // the sample pass must not cover more than 1 / hi_keep_div of a cell
+        uint64_t n_hi_cell_tiles = 0, hi_sample_begin = 0;
+        uint32_t* d_cell_hi_begin = nullptr;       // [n_cells+1] first hi tile of every cell
         // The 8-bit plane of the rest pass (scan_q8.h; absent when GPANN_FILTER_Q8=0 or the allocation failed): per 32-row tile and k-step of 32
         // dimensions one KiB in the A-operand order of v_mfma_i32_32x32x32_i8 — lane (c, h) holds row c, dimensions 32 ks + 16 h .. + 15 as int8
         // P' = round((p~ - c^) / q8_scale[cell]) (p~, c^: the row and its cell's centre in the frame of the bf16 planes).  q8_ks KiB per tile.

@@ -249,7 +249,8 @@ def test_router_bound_path_on_data_far_from_the_origin(orc, gp):
 @pytest.mark.parametrize("d", [128, 100, 40, 200])
 def test_cells_rest_pass_on_the_8_bit_plane(orc, gp, metric, d, monkeypatch):
     """The rest pass streams the int8 plane (per-cell scaled residuals, integer matrix-core products against the queries' two int8 planes,
-    thresholds per (task, cell): scan_cells.h Q8Threshold) — by default; GPANN_FILTER_Q8=0 at scan time sends it back to the bf16 hi plane.
+    thresholds per (task, cell): scan_cells.h Q8Threshold) — by default; a store built with GPANN_FILTER_Q8=0 has no such plane (and all of its
+    bf16 hi tiles) and streams the bf16 hi plane.
     Both return the oracle's bits; the 8-bit pass reads fewer bytes per row and may pass more candidates."""
     rng = np.random.default_rng(d * 3 + metric)
     n, S, nq, k = 60000, 3, 500, 10
@@ -261,6 +262,7 @@ def test_cells_rest_pass_on_the_8_bit_plane(orc, gp, metric, d, monkeypatch):
     probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
     st8 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
     assert st8["filter_rest_row_bytes"] == 32 * ((d + 31) // 32) + 4, st8
+    # (a store built with the 8-bit plane keeps bf16 hi tiles only where the head / sample passes reach: without the plane, all of them)
     monkeypatch.setenv("GPANN_FILTER_Q8", "0")
     st16 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
     ks = next(x for x in (2, 4, 6, 7, 8, 10, 13, 16) if 16 * x >= d)
@@ -286,3 +288,25 @@ def test_cells_8_bit_plane_extreme_values(orc, gp):
     probes = np.zeros((nq, 1), np.int32)
     for metric in (0, 1):
         _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
+
+
+def test_cells_all_hi_tiles_kept_allows_switching_the_rest_pass(orc, gp, monkeypatch):
+    """GPANN_FILTER_HI_ROWS=all at store build keeps every bf16 hi tile beside the 8-bit plane: GPANN_FILTER_Q8 then chooses per scan"""
+    monkeypatch.setenv("GPANN_FILTER_HI_ROWS", "all")
+    rng = np.random.default_rng(123)
+    n, d, S, nq, k = 50000, 128, 2, 300, 10
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=24)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(1)
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, S, 0, nthreads=4)
+    for q8, row_bytes in (("1", 132), ("0", 260)):
+        monkeypatch.setenv("GPANN_FILTER_Q8", q8)
+        ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
+        st = shards.stats()
+        assert st["filtered"] == 1 and st["filter_rest_row_bytes"] == row_bytes, st
+        assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+    shards.close()
