@@ -548,8 +548,8 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
-static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t nq, uint32_t k, int flags,
-                                        hipStream_t st, DeviceLists out, bool* overflow) {
+static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call, uint32_t k,
+                                        int flags, hipStream_t st, DeviceLists out, bool* overflow) {
     *overflow = false;
     s->filter_passes_timed = 0;
     const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
@@ -584,6 +584,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
     const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || EnvU32("GPANN_FILTER_Q8", 1) != 0);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
+    const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, EnvU32("GPANN_FILTER_Q8_FROM_PASS", 2)));
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
@@ -875,6 +876,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.cell_tile_begin = C.d_cell_tile_begin;
     ra.plane_perm = C.plane_perm;
     ra.query_tau = d_query_tau;
+    ra.seed_first_slot_of = 0;
+    ra.seed_catch_up = 0;
+    ra.task_out = ta.out;
     // the kernel for this store's k-steps: both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
     const void *fn = nullptr, *fn_hi = nullptr;
     switch (KS) {
@@ -937,7 +941,16 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
+        // (under the merge bound only the first slot of a query is seeded: RescoreArgs::seed_first_slot_of)
+        ra.seed_first_slot_of = for_merge && nprobe_of_call > 1 && EnvU32("GPANN_FILTER_SEED_ALL", 0) == 0 ? nprobe_of_call : 0u;
+        ra.seed_catch_up = 0;
         launch_rescore(1);   // (seed mode: a fixed number of rows per task)
+        if (ra.seed_first_slot_of != 0) {
+            ra.seed_catch_up = 1;
+            launch_rescore(1);
+            ra.seed_catch_up = 0;
+        }
+        ra.seed_first_slot_of = 0;
         GPANN_HIP_TRY(hipGetLastError());
         ra.seed_rows = 0;
         plan.padded_pairs = (uint64_t)T * seed_rows;
@@ -1015,7 +1028,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
-        const bool q8_pass = use_q8 && pass == 2;   // the rest pass on the 8-bit plane (its thresholds come from Q8Threshold, not from task_U)
+        // the rest pass (GPANN_FILTER_Q8_FROM_PASS=1: the sample pass too) on the 8-bit plane; its thresholds come from Q8Threshold, not from task_U
+        const bool q8_pass = use_q8 && pass >= q8_from_pass;
+        if (q8_pass && pass != q8_from_pass)   // (the table of the earlier 8-bit pass: back to "not needed")
+            GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];
@@ -1040,7 +1056,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             f8.image = q8_image;
             void* kargs8[] = {&f8};
             GPANN_HIP_TRY(hipLaunchKernel(fn_q8, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
-            plan.filter_rest_row_bytes = 32u * KS8 + 4u;
+            if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
             if (pass == 2) plan.filter_rest_row_bytes = (hi_pass ? 32u : 64u) * KS + 4u;
@@ -1162,7 +1178,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, nq, k, flags, st, out, &overflow));
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, nq, nprobe, k, flags, st, out, &overflow));
         done = !overflow;
         s->stats.filtered = done ? 1 : 0;
     }

@@ -301,9 +301,9 @@ static __global__ void NeedKernel(NeedArgs a) {
     }
     if (j >= K) return;
     bool need;
-    if (a.head) {
-        need = a.nearest[src] == j;
-    } else {
+    if (a.head && a.nearest[src] != j) {
+        need = false;
+    } else {   // (head pass: the nearest cell — unless even its ball cannot reach tau, e.g. a far shard under the query's merge bound)
         if (!(tau < (double)INFINITY)) {
             need = true;
         } else {

@@ -216,6 +216,12 @@ struct RescoreArgs {
     const uint64_t* cell_tile_begin;    // [cells+1] first 32-row plane tile of every cell
     const uint32_t* plane_perm;         // [tiles*32] plane row -> store row (0xFFFFFFFF: padding)
     uint32_t* query_tau;                // optional [nq] (GPANN_SCAN_FOR_MERGE): atomicMin of OrderedKey(k-th distance) over the query's tasks
+    // SEED mode under GPANN_SCAN_FOR_MERGE with several probes per query (seed_first_slot_of != 0 = nprobe): only the task of a query's
+    // FIRST slot — the shard the router ranks nearest — gets seed rows; the other tasks start with an empty list and live on the query's
+    // merge bound, which that first list sets (three quarters of the seed evaluations at nprobe 4 bought lists the bound made irrelevant)
+    uint32_t seed_first_slot_of;
+    uint32_t seed_catch_up;             // second seed launch: the tasks of queries that still have no bound are seeded after all
+    const uint32_t* task_out;           // [tasks] slot index q * nprobe + j of every task
 };
 
 // number of tasks whose candidate bucket overflowed in this pass
@@ -289,6 +295,20 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     const bool seed = a.seed_rows != 0;
     uint64_t seed_first = 0;   // first plane row of the task's nearest cell
     uint32_t cnt;
+    if (seed && a.seed_first_slot_of != 0) {
+        const bool first_slot = a.task_out[t] % a.seed_first_slot_of == 0;
+        if (!a.seed_catch_up) {
+            if (!first_slot) {
+                if (lane < (int)a.k) {   // (an empty list: the pass's thresholds take the query's merge bound instead)
+                    a.list_dist[(size_t)t * a.k + lane] = INFINITY;
+                    a.list_row[(size_t)t * a.k + lane] = kNoId;
+                }
+                return;
+            }
+        } else if (first_slot || a.query_tau[a.task_query[t]] != kOrderedKeyInf) {
+            return;   // (catch-up launch: only tasks of queries whose first slot gave no bound — skipped probe, shard with fewer than k rows)
+        }
+    }
     if (seed) {
         // plane rows [seed_first, seed_first + cnt): from the nearest cell's first row onwards, inside the shard's plane range (the
         // following cells are its neighbours along the cell chain).  (A workgroup of four wavefronts per task with merged private lists
