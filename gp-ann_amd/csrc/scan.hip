@@ -610,7 +610,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
-    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 16, st));
+    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 64, st));
 
     // groups of <= 256 tasks per shard; distance-table tiles of <= 64 tasks
     std::vector<CellGroup> groups;
@@ -845,6 +845,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.task_qscale = d_task_qscale;
     fa.q8_scale = C.d_q8_scale;
     fa.round_tiles = kFWaves;
+    fa.q8_quick = d_overflow + 8;       // (a word of the per-call counter block, zeroed with it)
+    fa.cand_total = d_cand_total;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;

@@ -377,6 +377,11 @@ struct CellFilterArgs {
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
+    // 8-bit passes: q8_quick[0] != 0 = "test the largest accumulators of a product first" — set by FilterItemsKernel when the passes so far
+    // found fewer than one candidate per four products (data without structure: uniform clouds), where most products have no candidate
+    // and the 16 full tests per lane are wasted; the NS rest pass, with more than one candidate per product, runs without it
+    uint32_t* q8_quick;
+    const unsigned long long* cand_total;   // candidates of the passes so far (OverflowCountKernel)
     uint32_t round_tiles;        // wavefronts x FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of the workgroup)
 };
 
@@ -393,6 +398,7 @@ constexpr size_t FilterLdsBytes(size_t image_bytes, int waves = kFWaves) { retur
 // blocks without work never reach them), one list per task group.  Order of the lists is irrelevant for the result.
 static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a) {
     const uint32_t block = blockIdx.x * 256 + threadIdx.x;
+    if (block == 0 && a.q8_quick) a.q8_quick[0] = (a.work && a.cand_total && a.cand_total[0] * 4ull < a.work[0]) ? 1u : 0u;
     if (block >= a.n_groups * a.kmax) return;
     const uint32_t mask = a.need[block];
     if (mask == 0) return;
@@ -672,6 +678,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     float U[QT];
     float Bq[Q8 ? QT : 1];
     float cell_scale = 0.f;
+    const bool q8_quick = Q8 && a.q8_quick && uniform(a.q8_quick[0]) != 0u;
     uint32_t iter = 0;
     uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0, r_hi_shift = 0;
     {
@@ -792,6 +799,18 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
             // bits of the 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies,
             // compares and selects the same test took 165 vector instructions per product against 8 matrix instructions.)
             const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+            if (q8_quick) {
+                // an upper bound of every row's test value: the largest H.P' and the largest L.P' of the lane's 16 rows (they need not be the
+                // same row's) with the tile's largest norm word — monotone in each operand of the exact test below
+                int hm = h0[0], lm = l0[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) {
+                    hm = max(hm, h0[r]);
+                    lm = max(lm, l0[r]);
+                }
+                const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, (float)lm), s0, nmax) - b0;
+                if (!__any(!(xub < 0.f))) return;
+            }
             uint32_t neg = 0;
 #pragma unroll
             for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)

@@ -73,6 +73,19 @@ def _run_config(orc, gp, n, d, nq, S, k, nprobe, metric, index_budget, search_bu
     for a, b in zip(got, exact):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
     _check_properties(*got[2:], k)
+    if overlap > 0:
+        # overlapping shards: the same id does come back from several probes, and the merge keeps one copy — per query the merged count is
+        # the number of DISTINCT ids among its slots (capped at k), which is smaller than the number of slot entries where ids repeat
+        ids_all = got[2].reshape(nq, -1)
+        srt = np.sort(ids_all, axis=1)
+        valid = srt != 0xFFFFFFFF
+        distinct = valid[:, 0].astype(np.int64) + np.count_nonzero((srt[:, 1:] != srt[:, :-1]) & valid[:, 1:], axis=1)
+        entries = np.count_nonzero(valid, axis=1)
+        assert np.array_equal(got[6].astype(np.int64), np.minimum(distinct, k))
+        repeated = distinct < entries
+        assert repeated.mean() > 0.2, repeated.mean()          # ids repeat for a good share of the queries (20 % of the points live in two shards)
+        few = repeated & (distinct < k)
+        assert np.all(got[6][few] < np.minimum(entries[few], k))   # ... and where fewer than k distinct ids came back the merged list is SHORTER than the slot entries
     # recall against the exact ground truth (recall.h:139-150 arithmetic: hits = merged distances <= k-th ground-truth distance)
     gt_ids, gt_dist, _ = gp.ground_truth(pts, queries, k, metric)
     kth = gt_dist[:, k - 1]
