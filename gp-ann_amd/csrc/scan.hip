@@ -548,9 +548,10 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
-static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call, uint32_t k,
+static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call, uint32_t k,
                                         int flags, hipStream_t st, DeviceLists out, bool* overflow) {
     *overflow = false;
+    TaskArrays ta = ta_in;   // (query / out point to the re-ordered copies once the tasks are grouped by nearest cell; the caller's arrays keep the host's order)
     s->filter_passes_timed = 0;
     const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
     if (T == 0) return GPANN_OK;
@@ -576,6 +577,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap_plan - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap_plan);
     // (compact hi planes: the sample segment has to stay inside the tiles that kept a bf16 hi tile)
     const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
+    if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] sample_div %u (auto %llu)\n", sample_div, (unsigned long long)div_auto);
     const bool l2 = s->metric == GPANN_METRIC_L2;
     (void)flags;
     const uint32_t KS = C.plane_ks, QT = (uint32_t)FilterQueryTiles((int)KS);
@@ -700,8 +702,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         hipLaunchKernelGGL(TaskReorderKernel, dim3(S), dim3(256), (size_t)(kmax + 1) * 4, st, d_stb, d_nearest, C.d_shard_cell_begin, ta.query, ta.out, tmp_q, tmp_o,
                            d_task_src);
         GPANN_HIP_TRY(hipGetLastError());
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.query, tmp_q, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(ta.out, tmp_o, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+        ta.query = tmp_q;
+        ta.out = tmp_o;
     }
 
     // ---- the groups' query images (bf16 fragments in MFMA B-operand order), once per call
@@ -845,8 +847,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.task_qscale = d_task_qscale;
     fa.q8_scale = C.d_q8_scale;
     fa.round_tiles = kFWaves;
-    fa.q8_quick = d_overflow + 8;       // (a word of the per-call counter block, zeroed with it)
-    fa.cand_total = d_cand_total;
     RescoreArgs ra;
     ra.points = s->points;
     ra.queries = d_queries;
@@ -1048,8 +1048,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
         hipLaunchKernelGGL(FilterItemsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, fa);
-        if (pass == 2) {   // the big launch on its own: row tiles streamed before it, and its begin / end
-            GPANN_HIP_TRY(hipMemcpyAsync(d_work + 3, d_work + 1, 8, hipMemcpyDeviceToDevice, st));
+        if (pass == 2) {   // the big launch on its own: row tiles streamed before it (FilterItemsKernel keeps the count, work[3]), and its begin / end
             GPANN_HIP_TRY(hipEventRecord(s->ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
         }

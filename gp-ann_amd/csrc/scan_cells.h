@@ -377,11 +377,6 @@ struct CellFilterArgs {
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
-    // 8-bit passes: q8_quick[0] != 0 = "test the largest accumulators of a product first" — set by FilterItemsKernel when the passes so far
-    // found fewer than one candidate per four products (data without structure: uniform clouds), where most products have no candidate
-    // and the 16 full tests per lane are wasted; the NS rest pass, with more than one candidate per product, runs without it
-    uint32_t* q8_quick;
-    const unsigned long long* cand_total;   // candidates of the passes so far (OverflowCountKernel)
     uint32_t round_tiles;        // wavefronts x FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of the workgroup)
 };
 
@@ -391,14 +386,14 @@ constexpr int kFWaves = 8;
 // next to a 128 KiB query image and the norms)
 constexpr uint32_t kFQueue = 448;
 // dynamic LDS of FilterKernelCells
-constexpr size_t FilterLdsBytes(size_t image_bytes, int waves = kFWaves) { return image_bytes + waves * kGTileRows * sizeof(float) + (size_t)waves * kFQueue * 8; }
+constexpr size_t FilterLdsBytes(size_t image_bytes, int waves = kFWaves) { return image_bytes + waves * 2 * kGTileRows * sizeof(float) + (size_t)waves * kFQueue * 8; }
 
 // The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
 // most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
 // blocks without work never reach them), one list per task group.  Order of the lists is irrelevant for the result.
 static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a) {
     const uint32_t block = blockIdx.x * 256 + threadIdx.x;
-    if (block == 0 && a.q8_quick) a.q8_quick[0] = (a.work && a.cand_total && a.cand_total[0] * 4ull < a.work[0]) ? 1u : 0u;
+    if (block == 0 && a.pass == 2 && a.work) a.work[3] = a.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
     if (block >= a.n_groups * a.kmax) return;
     const uint32_t mask = a.need[block];
     if (mask == 0) return;
@@ -511,7 +506,7 @@ constexpr uint32_t kNoItem = 0xFFFFFFFFu;
 // query tiles (of 32 tasks) per task group: the group's image, QT * KS * 2 KiB, has to fit the 160 KiB of LDS beside the norms and the queues
 constexpr int FilterQueryTiles(int ks) { return ks <= 8 ? 8 : 4; }
 // consecutive row tiles a wavefront of FilterKernelCells takes at a time (its unit of prefetch)
-constexpr int FilterUnitTiles(int mode, int ks) { return 1; }
+constexpr int FilterUnitTiles(int mode, int ks) { return mode == 2 && ks <= 4 ? 2 : 1; }
 
 // Wavefront 0 of a workgroup (all 64 lanes) looks for the task group with the most unclaimed work items and claims one there.
 // Returns the item, or kNoItem once every list is exhausted; g / first / count become the group the claim was made on.
@@ -590,12 +585,12 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     (void)ld;
     const char* lane_planes = a.frag_planes + lane * 16;
     const char* lane_lds = lds + lane * 16;
-    float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * kGTileRows;
+    float* wave_norms = reinterpret_cast<float*>(lds + QT * KS * 2048) + wave * 2 * kGTileRows;   // (the norm words of up to two row tiles)
     // Candidates go through a per-wavefront queue in LDS: (task, plane row) pairs, mapped to store rows and written to the tasks'
     // buckets — a returning atomic per candidate for the slot — when the queue fills up and at the end of the kernel.  (Written
     // straight from the tile loop, every row tile with a candidate costs two dependent round trips — row id, slot: the head and sample
     // passes, 15 and 4 candidates per row tile, streamed at two thirds of the rest pass's rate.)
-    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + NW * kGTileRows * sizeof(float)) + wave * kFQueue;
+    uint2* queue = reinterpret_cast<uint2*>(lds + QT * KS * 2048 + NW * 2 * kGTileRows * sizeof(float)) + wave * kFQueue;
     uint32_t q_len = 0;
     auto flush_queue = [&]() __attribute__((always_inline)) {
         for (uint32_t i = (uint32_t)lane; i < q_len; i += 64) {
@@ -678,7 +673,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     float U[QT];
     float Bq[Q8 ? QT : 1];
     float cell_scale = 0.f;
-    const bool q8_quick = Q8 && a.q8_quick && uniform(a.q8_quick[0]) != 0u;
+    uint32_t q8_seen = 0, q8_hits = 0;   // (MODE 2) products this wavefront has run / that had a candidate
     uint32_t iter = 0;
     uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0, r_hi_shift = 0;
     {
@@ -709,13 +704,123 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     const uint4 n_x = reinterpret_cast<const uint4*>(rn)[2];
 
 
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float nmax, uint32_t T) __attribute__((always_inline)) {
-        // query tiles to run on this row tile.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
-        // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
-        // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
-        // a flat one.)
+    // query tiles to run on row tile T.  (Written with masks on purpose: `T < t_a ? act_head : ...`, or the same with ifs, is a
+    // conditional between captured variables, which the optimiser turns into a select of ADDRESSES before the closure is
+    // dissolved — the closure, and the kernel arguments it refers to, then stay in scratch memory and every global access becomes
+    // a flat one.)
+    auto act_of = [&](uint32_t T) __attribute__((always_inline)) {
         const uint32_t in_head = T < t_a ? 0xFFu : 0u, in_sample = T < t_b ? 0xFFu & ~in_head : 0u;
-        const uint32_t act = (act_head & in_head) | (act_sample & in_sample) | (mask & ~(in_head | in_sample));
+        return (act_head & in_head) | (act_sample & in_sample) | (mask & ~(in_head | in_sample));
+    };
+    // the candidate bits of a row tile (bit r, + 16 for the odd query tile of pair qp: accumulator register r passed) -> the LDS queue
+    auto push_candidates = [&](const uint32_t (&cmask)[QT / 2], uint32_t T) __attribute__((always_inline)) {
+        uint32_t any_bits = 0;
+#pragma unroll
+        for (int qp = 0; qp < QT / 2; ++qp) any_bits |= cmask[qp];
+        if (!__any(any_bits != 0u)) return;
+#pragma unroll
+        for (int qp = 0; qp < QT / 2; ++qp) {
+            uint32_t bits = cmask[qp];
+            while (__any(bits != 0u)) {   // (wave-uniform: every lane takes its lowest set bit, if it has one)
+                const bool has = bits != 0u;
+                const int b = has ? __builtin_ctz(bits) : 0;
+                bits &= bits - 1u;
+                const int r = b & 15;
+                const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
+                const uint32_t prow = T * kGTileRows + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);   // (plane rows fit 32 bits: checked by the host)
+                const bool ok = has && tl < task_count;
+                const unsigned long long votes = __ballot(ok);
+                if (votes != 0ull) {
+                    if (q_len + 64u > kFQueue) flush_queue();
+                    const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
+                    if (ok) queue[pos] = make_uint2(task_begin + tl, prow);
+                    q_len += (uint32_t)__builtin_popcountll(votes);
+                }
+            }
+        }
+    };
+    // MODE 2: the test of one product's accumulators h (H.P') and l (L.P') — V = 254 h + l is the exact integer dot product of the quantised
+    // vectors, a row passes iff  fl(V) * s0 + nhn_row >= Bq  (Q8Threshold); `norms`: the tile's 32 norm words in LDS.
+    //   x = fl(fl(fl(254 h + l)) * s0 + nhn_row) - b0 >= 0,   s0 = the cell's step x the task's step / 254,
+    // with 254 h + l formed in fp32 (|h|, |l| < 2^24 are exact, the sum is rounded once: Q8Threshold's fp32 slack).  The sign bits of the
+    // 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies, compares and selects the
+    // same test took 165 vector instructions per product against 8 matrix instructions.)
+    auto test8 = [&](const i32x16& h0, const i32x16& l0, float nmax, const float* norms, int q0, uint32_t (&cmask)[QT / 2]) __attribute__((always_inline)) {
+        const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+        // Quick test, switched on by the wavefront's own statistics: while fewer than a quarter of its products had a candidate (data
+        // without structure — a uniform cloud: one product in nine), most of the 16 full tests per lane are wasted; the NS rest pass,
+        // with a candidate in most products, runs without it.
+        ++q8_seen;
+        if (q8_seen >= 16u && q8_hits * 4u < q8_seen) {
+            // an upper bound of every row's test value: the largest H.P' and the largest L.P' of the lane's 16 rows (they need not be the
+            // same row's) with the tile's largest norm word — monotone in each operand of the exact test below
+            int hm = h0[0], lm = l0[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                hm = max(hm, h0[r]);
+                lm = max(lm, l0[r]);
+            }
+            const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, (float)lm), s0, nmax) - b0;
+            if (!__any(!(xub < 0.f))) return;
+        }
+        uint32_t neg = 0;
+#pragma unroll
+        for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
+            const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float nn[4] = {n.x, n.y, n.z, n.w};
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const int r = 4 * gg + i;
+                const float fv = __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
+                const float x = __builtin_fmaf(fv, s0, nn[i]) - b0;
+                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x), 31);   // neg = neg << 1 | sign(x)
+            }
+        }
+        // (a NaN — a padding row's -inf norm against a -inf threshold — may read as a candidate: padding rows are dropped at the flush)
+        const uint32_t bits = ~neg & 0xFFFFu;
+        q8_hits += __any(bits != 0u) ? 1u : 0u;
+        cmask[q0 >> 1] |= bits << (16 * (q0 & 1));
+    };
+    // MODE 2, two row tiles that run the same query tiles: every B fragment read from LDS feeds both tiles' products (an MFMA per KiB of LDS
+    // read is what the LDS can just deliver: with one tile per fragment the uniform-cloud rest pass ran the matrix cores at 38 %)
+    auto compute_pair8 = [&](const Frag (&A0)[KS], const Frag (&A1)[KS], float nrm0, float nrm1, float nmax0, float nmax1, uint32_t T0, uint32_t act)
+                             __attribute__((always_inline)) {
+        if (METRIC == GPANN_METRIC_L2) {
+            if (h == 0) {
+                wave_norms[c] = nrm0;
+                wave_norms[kGTileRows + c] = nrm1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        my_products += 2u * (uint32_t)__builtin_popcount(act);
+        my_tiles += 2;
+        uint32_t cm0[QT / 2], cm1[QT / 2];
+#pragma unroll
+        for (int qp = 0; qp < QT / 2; ++qp) cm0[qp] = cm1[qp] = 0u;
+#pragma unroll
+        for (int q0 = 0; q0 < QT; ++q0) {
+            if (!(act >> q0 & 1u)) continue;
+            i32x16 h0, l0, h1, l1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h0[r] = l0[r] = h1[r] = l1[r] = 0;
+            const char* p0 = lane_lds + (q0 * KS) * 2048;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i32 a0 = __builtin_bit_cast(v4i32, A0[ks].q), a1 = __builtin_bit_cast(v4i32, A1[ks].q);
+                const v4i32 bh = *reinterpret_cast<const v4i32*>(p0 + ks * 2048), bl = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
+                h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bh, h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bh, h1, 0, 0, 0);
+                l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bl, l0, 0, 0, 0);
+                l1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bl, l1, 0, 0, 0);
+            }
+            test8(h0, l0, nmax0, wave_norms, q0, cm0);
+            test8(h1, l1, nmax1, wave_norms + kGTileRows, q0, cm1);
+        }
+        push_candidates(cm0, T0);
+        push_candidates(cm1, T0 + 1);
+    };
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float nmax, uint32_t T) __attribute__((always_inline)) {
+        const uint32_t act = act_of(T);
         if (act == 0) return;
         if (METRIC == GPANN_METRIC_L2) {
             if (h == 0) wave_norms[c] = nrm;
@@ -776,8 +881,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
                 cmask[qp] = bits;
             }
         };
-        // MODE 2: the same for the 8-bit planes.  Per query tile two integer accumulator chains, H.P' and L.P'; V = 254 H.P' + L.P' is
-        // the exact integer dot product of the quantised vectors; a row passes iff  fl(V) * s0 + nhn_row >= Bq  (Q8Threshold).
+        // MODE 2: the same for the 8-bit planes: per query tile two integer accumulator chains, H.P' and L.P' (test8)
         auto pass8 = [&](int q0) __attribute__((always_inline)) {   // (one query tile: its two chains already keep the matrix core busy)
             i32x16 h0, l0;
 #pragma unroll
@@ -793,39 +897,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
                 h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bh0, h0, 0, 0, 0);
                 l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bl0, l0, 0, 0, 0);
             }
-            // Every row of the tile is tested (no quick test: in the rest pass a product has a candidate more often than not):
-            //   x = fl(fl(fl(254 h + l)) * s0 + nhn_row) - b0 >= 0,   s0 = the cell's step x the task's step / 254,
-            // with 254 h + l formed in fp32 (|h|, |l| < 2^24 are exact, the sum is rounded once: Q8Threshold's fp32 slack).  The sign
-            // bits of the 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies,
-            // compares and selects the same test took 165 vector instructions per product against 8 matrix instructions.)
-            const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
-            if (q8_quick) {
-                // an upper bound of every row's test value: the largest H.P' and the largest L.P' of the lane's 16 rows (they need not be the
-                // same row's) with the tile's largest norm word — monotone in each operand of the exact test below
-                int hm = h0[0], lm = l0[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) {
-                    hm = max(hm, h0[r]);
-                    lm = max(lm, l0[r]);
-                }
-                const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, (float)lm), s0, nmax) - b0;
-                if (!__any(!(xub < 0.f))) return;
-            }
-            uint32_t neg = 0;
-#pragma unroll
-            for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
-                const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(wave_norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float nn[4] = {n.x, n.y, n.z, n.w};
-#pragma unroll
-                for (int i = 3; i >= 0; --i) {
-                    const int r = 4 * gg + i;
-                    const float fv = __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
-                    const float x = __builtin_fmaf(fv, s0, nn[i]) - b0;
-                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x), 31);   // neg = neg << 1 | sign(x)
-                }
-            }
-            // (a NaN — a padding row's -inf norm against a -inf threshold — may read as a candidate: padding rows are dropped at the flush)
-            cmask[q0 >> 1] |= (~neg & 0xFFFFu) << (16 * (q0 & 1));
+            test8(h0, l0, nmax, wave_norms, q0, cmask);
         };
 #pragma unroll
         for (int qp = 0; qp < QT / 2; ++qp) {
@@ -839,31 +911,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
                 else if (two == 2u) pass(std::false_type{}, 2 * qp + 1, qp, 16);
             }
         }
-        uint32_t any_bits = 0;
-#pragma unroll
-        for (int qp = 0; qp < QT / 2; ++qp) any_bits |= cmask[qp];
-        if (__any(any_bits != 0u)) {
-#pragma unroll
-            for (int qp = 0; qp < QT / 2; ++qp) {
-                uint32_t bits = cmask[qp];
-                while (__any(bits != 0u)) {   // (wave-uniform: every lane takes its lowest set bit, if it has one)
-                    const bool has = bits != 0u;
-                    const int b = has ? __builtin_ctz(bits) : 0;
-                    bits &= bits - 1u;
-                    const int r = b & 15;
-                    const uint32_t tl = 32u * (2 * qp + (b >> 4)) + c;
-                    const uint32_t prow = T * kGTileRows + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);   // (plane rows fit 32 bits: checked by the host)
-                    const bool ok = has && tl < task_count;
-                    const unsigned long long votes = __ballot(ok);
-                    if (votes != 0ull) {
-                        if (q_len + 64u > kFQueue) flush_queue();
-                        const uint32_t pos = q_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
-                        if (ok) queue[pos] = make_uint2(task_begin + tl, prow);
-                        q_len += (uint32_t)__builtin_popcountll(votes);
-                    }
-                }
-            }
-        }
+        push_candidates(cmask, T);
     };
 
     // Row tiles stream through registers, one tile ahead of the products (with one 512-thread workgroup per CU this, not occupancy,
@@ -916,6 +964,15 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     constexpr uint32_t kStride = NW * TW;   // tiles between two units of a wavefront
     // the tiles of the unit that begins at tile T0, from buffer b
     auto compute_unit = [&](int b, uint32_t T0) __attribute__((always_inline)) {
+        if constexpr (Q8 && TW == 2) {
+            if (T0 + 1 < t_end) {
+                const uint32_t a0 = act_of(T0), a1 = act_of(T0 + 1);
+                if (a0 == a1) {   // (the rule: both tiles in one segment of the cell)
+                    if (a0 != 0u) compute_pair8(Ah[b][0], Ah[b][TW - 1], nrm[b][0], nrm[b][TW - 1], nmax[b][0], nmax[b][TW - 1], T0, a0);
+                    return;
+                }
+            }
+        }
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw)
             if (tw == 0 || T0 + tw < t_end) compute_tile(Ah[b][tw], Al[HI_ONLY ? 0 : b], nrm[b][tw], nmax[b][tw], T0 + tw);
