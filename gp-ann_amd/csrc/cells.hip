@@ -374,8 +374,8 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     // Which tiles keep a bf16 hi / lo tile (shards.h).  lo: every one (GPANN_FILTER_LO_ROWS=all), or the sample tiles and the first rows of every
     // cell — the only ones the two-plane passes read (beyond 128 dimensions every pass is a hi-plane pass: no lo tiles at all).  hi: every one, or —
     // when the rest pass has the 8-bit plane — the sample tiles and the first max(head, 1 / kHiKeepDiv) of every cell: the head and sample passes
-    // never reach further (the sample pass covers at most 1 / 4 of a cell).  GPANN_FILTER_HI_ROWS=all keeps all (then GPANN_FILTER_Q8=0 works at scan time).
-    constexpr uint32_t kHiKeepDiv = 4;
+    // never reach further (the sample pass covers at most 1 / 8 of a cell: smaller shares were measured no better, profiles/r03/sweep_sample_div.md).  GPANN_FILTER_HI_ROWS=all keeps all (then GPANN_FILTER_Q8=0 works at scan time).
+    constexpr uint32_t kHiKeepDiv = 8;
     std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), cell_hi_begin(C.n_cells + 1, 0), tile_lo_index, tile_hi_index;
     {
         const char* lr = std::getenv("GPANN_FILTER_LO_ROWS");

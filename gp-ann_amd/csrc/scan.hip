@@ -576,7 +576,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the sample pass expects (rows / div) * k / m0 candidates per task: keep that near a quarter of a bucket
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap_plan - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap_plan);
     // (compact hi planes: the sample segment has to stay inside the tiles that kept a bf16 hi tile)
-    const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto))));
+    // (round 3, buckets of up to 16k candidates: half of that share is enough — NS 10 -> 8: 0.1 ms of 4.3, C5 18 -> 9; profiles/r03/sweep_sample_div.md)
+    const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto / 2))));
     if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] sample_div %u (auto %llu)\n", sample_div, (unsigned long long)div_auto);
     const bool l2 = s->metric == GPANN_METRIC_L2;
     (void)flags;
