@@ -1882,7 +1882,11 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     const uint64_t C = r->n_centroids;
     // dense + replay: all distances of a block of queries at once (exact, tiled), then the queue logic on the table
     const uint64_t dense_cap = 6ull << 30;   // bytes of distance table per block of queries
-    bool dense = budget > 0 && C <= 4ull * (uint64_t)budget && C < 0xFFFFFFFFull && C * 4 * 64 <= dense_cap;
+    // (which is cheaper: measured on the NS trees, search budget 50 000 — the walk costs ~1.2 us per (query, evaluated centroid) in its queue and
+    // its L2 traffic (252k-centroid tree: 602 ms per 10k queries), the table 0.02 us per (query, centroid) (139k centroids: 26 ms): the table
+    // wins until the tree is ~60x the budget.  Rounds 1-2 switched at 4x and sent the 200k and 1M indices of the reference's grid to the walk.)
+    const uint64_t dense_factor = (uint64_t)std::max(1, std::atoi(std::getenv("GPANN_ROUTER_DENSE_FACTOR") ? std::getenv("GPANN_ROUTER_DENSE_FACTOR") : "32"));
+    bool dense = budget > 0 && C <= dense_factor * (uint64_t)budget && C < 0xFFFFFFFFull && C * 4 * 64 <= dense_cap;
     if (force && std::string(force) == "walk") dense = false;
     if (force && std::string(force) == "dense" && C * 4 * 64 <= dense_cap) dense = budget > 0;
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
