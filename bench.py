@@ -649,8 +649,8 @@ def main():
                               "kernel": "gpann::FilterKernelCells (rest pass)", "kernel_ms": 1000.0 * r_s, "kernel_bytes": rest_bytes,
                               "kernel_row_bytes": stats["filter_rest_row_bytes"],
                               "kernel_plane": "int8 (per-cell scaled residuals)" if stats["filter_rest_row_bytes"] < 32 * ks_read + 4 else "bf16 hi",
-                              "note": "achieved = the bytes the dominant launch (the rest pass of FilterKernelCells) HAS TO read — its row tiles x (bf16 hi "
-                                      "plane + norm word) — / its own HIP-event time on the scan's stream; frac = achieved / 8 TB/s.  traffic = the PMC "
+                              "note": "achieved = the bytes the dominant launch (the rest pass of FilterKernelCells) HAS TO read — its row tiles x "
+                                      "kernel_row_bytes (the int8 or bf16 hi plane it streams + the norm word) — / its own HIP-event time on the scan's stream; frac = achieved / 8 TB/s.  traffic = the PMC "
                                       "figure (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) of that launch from the committed pass named in "
                                       "traffic_source (null if there is none for this workload).  algorithmic_GBps = SURVEY 8d's figure — rows x d x 4 "
                                       "per (query, probed shard), the bytes the REFERENCE streams — / HIP-event time of all scan kernels of the step; it "
