@@ -106,6 +106,9 @@ def main():
                     help="synthetic cloud: mixture = 1024 Gaussian clusters (the metric's workload); uniform = ONE Gaussian blob (no cluster structure: "
                          "cells cannot prune); offset = the mixture moved by +100 in every coordinate (non-centred, SIFT-like: the bf16 bound's error "
                          "term grows with (R + |q|)^2)")
+    ap.add_argument("--sigma", type=float, default=SIGMA,
+                    help="standard deviation of the mixture's components (0.35: the metric's workload; larger = the clusters overlap, routing gets "
+                         "harder and recall 0.9 needs more probes)")
     ap.add_argument("--search-budget", type=int, default=50000)
     ap.add_argument("--router-centroids", type=int, default=64)
     ap.add_argument("--router-min-cluster", type=int, default=350)
@@ -141,7 +144,7 @@ def main():
     if args.config != "ns" and "GPANN_BENCH_N" in os.environ:
         args.n = int(os.environ["GPANN_BENCH_N"])
     metric = 1 if args.metric == "ip" else 0
-    n_centers, sigma = (1, 1.0) if args.dist == "uniform" else (N_CENTERS, SIGMA)
+    n_centers, sigma = (1, 1.0) if args.dist == "uniform" else (N_CENTERS, args.sigma)
     offset = 100.0 if args.dist == "offset" else 0.0
     args.metric_id = metric
     ops_per_dim = 2 if metric else 3   # unfused VALU lane-ops per (pair, dimension): mul + add (inner product) / sub + mul + add (L2)

@@ -975,7 +975,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fprintf(stderr, "[gpann cells] %s candidates per task: mean %.1f  median %u  p90 %u  p99 %u  p99.9 %u  max %u\n", what, (double)sum / T, h_cnt[T / 2],
                 h_cnt[(size_t)T * 9 / 10], h_cnt[(size_t)T * 99 / 100], h_cnt[(size_t)T * 999 / 1000], h_cnt[T - 1]);
     };
-    if (seed_rows != 0 && C.n_sample_tiles != 0) {
+    if (seed_rows != 0 && C.n_sample_tiles != 0 && EnvU32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0) {
         const uint32_t piece = 32;   // row tiles per work item
         std::vector<CellItem> sitems;
         std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of this pass's lists
