@@ -351,6 +351,43 @@ static hipError_t UploadAsync(gpann_shards* s, void* dst, const void* src, size_
     return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st);
 }
 
+// The small host -> device arrays of a scan call travel TOGETHER: staged back to back in the handle's pinned area and copied with one
+// hipMemcpyAsync into a device mirror of that area (Flush); Add returns the address an array has there.  (One copy per array was a dozen
+// launches per call, each with its own few microseconds of stream time and host work between them.)  Without room in the stage an array goes to
+// its own destination at once, as before.
+struct UploadBatch {
+    gpann_shards* s;
+    hipStream_t st;
+    size_t first = SIZE_MAX, last = 0;
+    hipError_t err = hipSuccess;
+    template <typename T>
+    T* Add(T* own_dst, const void* src, size_t bytes) {
+        if (bytes == 0) return own_dst;
+        void* p = s->ws_stage_dev.ptr ? s->stage.Take(bytes) : nullptr;
+        if (!p || (size_t)(static_cast<char*>(p) - s->stage.base) + bytes > s->ws_stage_dev.bytes) {
+            const hipError_t e = UploadAsync(s, own_dst, src, bytes, st);
+            if (err == hipSuccess) err = e;
+            return own_dst;
+        }
+        std::memcpy(p, src, bytes);
+        const size_t off = (size_t)(static_cast<char*>(p) - s->stage.base);
+        first = std::min(first, off);
+        last = std::max(last, off + bytes);
+        return reinterpret_cast<T*>(s->ws_stage_dev.as<char>() + off);
+    }
+    hipError_t Flush() {
+        hipError_t e = err;
+        if (first < last) {
+            const hipError_t c = hipMemcpyAsync(s->ws_stage_dev.as<char>() + first, s->stage.base + first, last - first, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = c;
+        }
+        first = SIZE_MAX;
+        last = 0;
+        err = hipSuccess;
+        return e;
+    }
+};
+
 static uint32_t EnvU32(const char* name, uint32_t dflt) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
@@ -548,8 +585,8 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
-static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call, uint32_t k,
-                                        int flags, hipStream_t st, DeviceLists out, bool* overflow) {
+static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, UploadBatch& up, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call,
+                                        uint32_t k, int flags, hipStream_t st, DeviceLists out, bool* overflow) {
     *overflow = false;
     TaskArrays ta = ta_in;   // (query / out point to the re-ordered copies once the tasks are grouped by nearest cell; the caller's arrays keep the host's order)
     s->filter_passes_timed = 0;
@@ -637,8 +674,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     float* d_task_qscale = d_task_tscale + T;                          // ... and step / 254 in the NEW order (QueryImageQ8Kernel)
     float* cell_dist = d_task_qscale + T;
     uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
-    uint32_t* d_task_group = d_nearest + T;
-    CellTileRef* d_dtiles = reinterpret_cast<CellTileRef*>(d_task_group + T + (T & 1));
+    uint32_t* d_task_group_own = d_nearest + T;
+    CellTileRef* d_dtiles_own = reinterpret_cast<CellTileRef*>(d_task_group_own + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
     const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
     GPANN_REQUIRE(((uint64_t)C.sample_tile_base + C.n_sample_tiles + 2) * kGTileRows < 0xFFFFFFFFull, "plane rows beyond 32 bits");
@@ -660,17 +697,54 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     need_pass[1] = need_pass[0] + need_words;
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
-    CellGroup* d_groups = reinterpret_cast<CellGroup*>(done_head + need_words);
-    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups + G);   // [0..2] work counters (scan_cells.h), [3] = [1] before the rest pass
-    uint32_t* d_group_first = reinterpret_cast<uint32_t*>(d_work + 4);
-    uint32_t* d_group_count = d_group_first + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
-    CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first + gtab_words);
+    CellGroup* d_groups_own = reinterpret_cast<CellGroup*>(done_head + need_words);
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups_own + G);   // [0..2] work counters (scan_cells.h), [3] = [1] before the rest pass
+    uint32_t* d_group_first_own = reinterpret_cast<uint32_t*>(d_work + 4);
+    uint32_t* d_group_count = d_group_first_own + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
+    CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first_own + gtab_words);
     GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
     GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
-    GPANN_HIP_TRY(UploadAsync(s, d_dtiles, dtiles.data(), dtiles.size() * sizeof(CellTileRef), st));
-    GPANN_HIP_TRY(UploadAsync(s, d_groups, groups.data(), (size_t)G * sizeof(CellGroup), st));
-    GPANN_HIP_TRY(UploadAsync(s, d_group_first, group_first.data(), (size_t)(G + 1) * 4, st));
-    GPANN_HIP_TRY(UploadAsync(s, d_task_group, task_group.data(), (size_t)T * 4, st));
+    // the call's tables join the task arrays in the upload batch (one copy for all of them, flushed below)
+    const CellTileRef* d_dtiles = up.Add(d_dtiles_own, dtiles.data(), dtiles.size() * sizeof(CellTileRef));
+    const CellGroup* d_groups = up.Add(d_groups_own, groups.data(), (size_t)G * sizeof(CellGroup));
+    const uint32_t* d_group_first = up.Add(d_group_first_own, group_first.data(), (size_t)(G + 1) * 4);
+    const uint32_t* d_task_group = up.Add(d_task_group_own, task_group.data(), (size_t)T * 4);
+    // the shard-sample pass's work items (host-built: every group x its shard's sample tiles) and their list tables travel with them
+    std::vector<CellItem> sitems;
+    std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of that pass's lists
+    uint32_t* d_stab = nullptr;
+    CellItem* d_sitems = nullptr;
+    const bool shard_sample_pass = C.n_sample_tiles != 0 && EnvU32("GPANN_FILTER_SEED_ROWS", 128) != 0 && EnvU32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0;
+    if (shard_sample_pass) {
+        const uint32_t piece = 32;   // row tiles per work item
+        for (uint32_t g = 0; g < G; ++g) {
+            stab[g] = (uint32_t)sitems.size();
+            const uint64_t t0 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard + 1];
+            const uint32_t qtiles = (groups[g].task_count + 31) / 32, mask = (1u << qtiles) - 1u;
+            for (uint64_t t = t0; t < t1; t += piece) {
+                CellItem it;
+                it.t_begin = (uint32_t)t;
+                it.t_end = (uint32_t)std::min<uint64_t>(t1, t + piece);
+                it.t_a = it.t_b = it.t_begin;   // no head / sample segment: every query tile runs on every row tile
+                it.task_begin = groups[g].task_begin;
+                it.lo_shift = (uint32_t)(C.sample_tile_base - C.lo_sample_begin);   // sample tile j: row tile sample_tile_base + j, lo tile lo_sample_begin + j ...
+                it.hi_shift = (uint32_t)(C.sample_tile_base - C.hi_sample_begin);   // ... hi tile hi_sample_begin + j
+                it.block = 0;
+                it.cell_scale = 0.f;
+                it.pad1 = 0;
+                it.acts = mask | mask << 8 | mask << 16 | (groups[g].task_count - 1u) << 24;
+                it.group = g;
+                sitems.push_back(it);
+            }
+            stab[G + g] = (uint32_t)sitems.size() - stab[g];
+        }
+        if (!sitems.empty()) {
+            const size_t stab_words = ((size_t)3 * G + 3) / 4 * 4;
+            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + stab_words * 4 + 64));
+            d_stab = up.Add(s->ws_misc.as<uint32_t>(), stab.data(), (size_t)3 * G * 4);
+            d_sitems = up.Add(reinterpret_cast<CellItem*>(s->ws_misc.as<uint32_t>() + stab_words), sitems.data(), sitems.size() * sizeof(CellItem));
+        }
+    }
 
     CellDistArgs cd;
     cd.queries = d_queries;
@@ -692,14 +766,18 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 
     // ---- order the tasks of every shard by their nearest cell (on the device; the host copies of task_query / task_out are
     //      not consulted again in this call).  The table, the nearest cells and |q|^2 keep the old order: d_task_src maps.
+    const uint32_t* d_stb = nullptr;
+    {
+        uint32_t* stb_own = reinterpret_cast<uint32_t*>(d_dtiles_own + dtiles.size()) + 3 * (size_t)T;   // (behind tmp_q | tmp_o | task_src, below)
+        d_stb = up.Add(stb_own, plan.shard_task_begin.data(), (size_t)(S + 1) * 4);
+    }
+    GPANN_HIP_TRY(up.Flush());   // task arrays, tables, the shard-sample items: one copy
     GPANN_TRY(cell_table(true));
     uint32_t* d_task_src = nullptr;
     {
-        uint32_t* tmp_q = reinterpret_cast<uint32_t*>(d_dtiles + dtiles.size());
+        uint32_t* tmp_q = reinterpret_cast<uint32_t*>(d_dtiles_own + dtiles.size());
         uint32_t* tmp_o = tmp_q + T;
         d_task_src = tmp_o + T;
-        uint32_t* d_stb = d_task_src + T;
-        GPANN_HIP_TRY(UploadAsync(s, d_stb, plan.shard_task_begin.data(), (size_t)(S + 1) * 4, st));
         hipLaunchKernelGGL(TaskReorderKernel, dim3(S), dim3(256), (size_t)(kmax + 1) * 4, st, d_stb, d_nearest, C.d_shard_cell_begin, ta.query, ta.out, tmp_q, tmp_o,
                            d_task_src);
         GPANN_HIP_TRY(hipGetLastError());
@@ -975,38 +1053,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fprintf(stderr, "[gpann cells] %s candidates per task: mean %.1f  median %u  p90 %u  p99 %u  p99.9 %u  max %u\n", what, (double)sum / T, h_cnt[T / 2],
                 h_cnt[(size_t)T * 9 / 10], h_cnt[(size_t)T * 99 / 100], h_cnt[(size_t)T * 999 / 1000], h_cnt[T - 1]);
     };
-    if (seed_rows != 0 && C.n_sample_tiles != 0 && EnvU32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0) {
-        const uint32_t piece = 32;   // row tiles per work item
-        std::vector<CellItem> sitems;
-        std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of this pass's lists
-        for (uint32_t g = 0; g < G; ++g) {
-            stab[g] = (uint32_t)sitems.size();
-            const uint64_t t0 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard], t1 = C.sample_tile_base + C.sample_tile_begin[groups[g].shard + 1];
-            const uint32_t qtiles = (groups[g].task_count + 31) / 32, mask = (1u << qtiles) - 1u;
-            for (uint64_t t = t0; t < t1; t += piece) {
-                CellItem it;
-                it.t_begin = (uint32_t)t;
-                it.t_end = (uint32_t)std::min<uint64_t>(t1, t + piece);
-                it.t_a = it.t_b = it.t_begin;   // no head / sample segment: every query tile runs on every row tile
-                it.task_begin = groups[g].task_begin;
-                it.lo_shift = (uint32_t)(C.sample_tile_base - C.lo_sample_begin);   // sample tile j: row tile sample_tile_base + j, lo tile lo_sample_begin + j ...
-                it.hi_shift = (uint32_t)(C.sample_tile_base - C.hi_sample_begin);   // ... hi tile hi_sample_begin + j
-                it.block = 0;
-                it.cell_scale = 0.f;
-                it.pad1 = 0;
-                it.acts = mask | mask << 8 | mask << 16 | (groups[g].task_count - 1u) << 24;
-                it.group = g;
-                sitems.push_back(it);
-            }
-            stab[G + g] = (uint32_t)sitems.size() - stab[g];
-        }
+    if (seed_rows != 0 && shard_sample_pass) {
         if (!sitems.empty()) {
-            const size_t stab_words = ((size_t)3 * G + 3) / 4 * 4;
-            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + stab_words * 4 + 64));
-            uint32_t* d_stab = s->ws_misc.as<uint32_t>();
-            CellItem* d_sitems = reinterpret_cast<CellItem*>(d_stab + stab_words);
-            GPANN_HIP_TRY(UploadAsync(s, d_stab, stab.data(), (size_t)3 * G * 4, st));
-            GPANN_HIP_TRY(UploadAsync(s, d_sitems, sitems.data(), sitems.size() * sizeof(CellItem), st));
             GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
             th.hi_only = wide ? 1u : 0u;
             if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
@@ -1148,6 +1196,8 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
     // (task arrays, group / tile tables, unit lists: ~32 bytes per task + per-shard tables; exact-mode unit lists fall back to pageable copies if larger)
     s->stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
+    if (s->ws_stage_dev.Reserve(std::max<size_t>(s->stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
+    UploadBatch up{s, st};
     const size_t n_out = (size_t)nq * nprobe;
 
     const float* d_queries = nullptr;
@@ -1161,10 +1211,10 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     ta.part = ta.out + T;
     ta.nseg = ta.part + T;
     ta.shard = ta.nseg + T;
-    if (T) {
-        GPANN_HIP_TRY(UploadAsync(s, ta.query, plan.task_query.data(), T * 4, st));
-        GPANN_HIP_TRY(UploadAsync(s, ta.out, plan.task_out.data(), T * 4, st));
-        GPANN_HIP_TRY(UploadAsync(s, ta.shard, plan.task_shard.data(), T * 4, st));
+    if (T) {   // (flushed with the filtered pipeline's tables, or before the exact stage)
+        ta.query = up.Add(ta.query, plan.task_query.data(), (size_t)T * 4);
+        ta.out = up.Add(ta.out, plan.task_out.data(), (size_t)T * 4);
+        ta.shard = up.Add(ta.shard, plan.task_shard.data(), (size_t)T * 4);
     }
     // (the plan's host arrays live in the handle until the next scan call, so the async uploads stay valid)
 
@@ -1180,11 +1230,12 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->filter_passes_timed = 0;
     if (FilterWanted(s, k)) {
         bool overflow = false;
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, d_queries, nq, nprobe, k, flags, st, out, &overflow));
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, out, &overflow));
         done = !overflow;
         s->stats.filtered = done ? 1 : 0;
     }
     if (!done) {
+        GPANN_HIP_TRY(up.Flush());
         std::vector<int64_t> lo(s->offsets.begin(), s->offsets.end() - 1), hi(s->offsets.begin() + 1, s->offsets.end());
         plan.padded_pairs = 0;
         GPANN_TRY(BuildExactUnits(plan, S, lo, hi));

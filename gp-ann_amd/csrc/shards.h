@@ -153,6 +153,7 @@ struct gpann_shards {
     gpann_scan_stats stats{};
     gpann::ScanPlan plan;
     gpann::PinnedStage stage;
+    gpann::DeviceBuffer ws_stage_dev;   // device mirror of `stage`: the call's small arrays arrive in it with one copy (scan.hip UploadBatch)
 };
 
 namespace gpann {

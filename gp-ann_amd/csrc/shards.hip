@@ -255,6 +255,7 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     s->ws_image.Release();
     s->ws_q8.Release();
     s->ws_split.Release();
+    s->ws_stage_dev.Release();
     s->ws_queries.Release();
     s->ws_tasks.Release();
     s->ws_units.Release();

@@ -17,8 +17,9 @@ os.makedirs(outdir, exist_ok=True)
 
 
 def one(pattern):
+    """the NEWEST match: gpurun merges a call's files into gpurun_out/, so a re-run of the same tag leaves the older pass's files beside the new ones"""
     g = glob.glob(pattern, recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 
 lines = [f"# rocprofv3 summary `{tag}`", "",
