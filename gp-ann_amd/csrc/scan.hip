@@ -643,14 +643,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // GPANN_SCAN_FOR_MERGE: per query the smallest k-th distance any of its tasks has reached (OrderedKey; RescoreKernel lowers it, the
     // next pass's thresholds and cell tests of ALL the query's tasks read it)
     uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
-    if (for_merge) GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_query_tau), (int)kOrderedKeyInf, nq, st));
     uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
     uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + (size_t)T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + (size_t)T) & 4) ? 1 : 0));
-    GPANN_HIP_TRY(hipMemsetAsync(d_dirty_flag, 0, (size_t)T * 4, st));
     GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
     uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
-    GPANN_HIP_TRY(hipMemsetAsync(d_overflow, 0, 64, st));
 
     // groups of <= 256 tasks per shard; distance-table tiles of <= 64 tasks
     std::vector<CellGroup> groups;
@@ -702,8 +699,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     uint32_t* d_group_first_own = reinterpret_cast<uint32_t*>(d_work + 4);
     uint32_t* d_group_count = d_group_first_own + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
     CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first_own + gtab_words);
-    GPANN_HIP_TRY(hipMemsetAsync(need_pass[0], 0, 4 * need_words * 4, st));
-    GPANN_HIP_TRY(hipMemsetAsync(d_work, 0, 32, st));
     // the call's tables join the task arrays in the upload batch (one copy for all of them, flushed below)
     const CellTileRef* d_dtiles = up.Add(d_dtiles_own, dtiles.data(), dtiles.size() * sizeof(CellTileRef));
     const CellGroup* d_groups = up.Add(d_groups_own, groups.data(), (size_t)G * sizeof(CellGroup));
@@ -803,12 +798,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the 8-bit images and the (task, cell) threshold table of the rest pass
     char* q8_image = nullptr;
     float* q8_B = nullptr;
+    size_t q8_B_words = 0;
     if (use_q8) {
         const size_t img8 = (size_t)G * QT8 * KS8 * 2048, b_words = (size_t)G * kmax * 32u * QT8;
         GPANN_TRY(s->ws_q8.Reserve(img8 + b_words * 4 + 256));
         q8_image = s->ws_q8.as<char>();
         q8_B = reinterpret_cast<float*>(q8_image + img8);
-        GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, b_words, st));   // +inf: "this task does not need this cell"
+        q8_B_words = b_words;   // (set to +inf — "this task does not need this cell" — by FilterInitKernel below)
         switch (KS8) {
 #define GPANN_IMAGE8(KS_)                                                                                                                                   \
     case KS_:                                                                                                                                               \
@@ -819,6 +815,27 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #undef GPANN_IMAGE8
             default: GPANN_REQUIRE(false, "no 8-bit filter kernel for this number of k-steps");
         }
+        GPANN_HIP_TRY(hipGetLastError());
+    }
+
+    {   // every counter / table of the call in one launch (FilterInitKernel)
+        FilterInitArgs ia{};
+        ia.zero[0] = d_overflow;               // overflow / dirty counters, candidate total (16 words)
+        ia.zero_words[0] = 16;
+        ia.zero[1] = d_dirty_flag;             // [T]
+        ia.zero_words[1] = T;
+        ia.zero[2] = need_pass[0];             // the passes' need / done masks
+        ia.zero_words[2] = 4 * (uint64_t)need_words;
+        ia.zero[4] = reinterpret_cast<uint32_t*>(d_work);   // work counters (4 x u64)
+        ia.zero_words[4] = 8;
+        ia.zero[3] = cand_cnt;                 // [T]
+        ia.zero_words[3] = T;
+        ia.query_tau = d_query_tau;
+        ia.nq = nq;
+        ia.inf_floats = reinterpret_cast<uint32_t*>(q8_B);
+        ia.inf_words = q8_B_words;
+        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(ia.zero_words[2], q8_B_words), T);
+        hipLaunchKernelGGL(FilterInitKernel, dim3((uint32_t)std::min<uint64_t>(2048, (most + 255) / 256)), dim3(256), 0, st, ia);
         GPANN_HIP_TRY(hipGetLastError());
     }
 
@@ -1055,8 +1072,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     };
     if (seed_rows != 0 && shard_sample_pass) {
         if (!sitems.empty()) {
-            GPANN_HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)T * 4, st));
-            th.hi_only = wide ? 1u : 0u;
+            th.hi_only = wide ? 1u : 0u;   // (cand_cnt: zeroed by FilterInitKernel)
             if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
             else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
             CellFilterArgs fs = fa;

@@ -202,6 +202,25 @@ static __global__ void __launch_bounds__(256) TaskReorderKernel(const uint32_t* 
     }
 }
 
+// The per-call counters and tables of the filtered pipeline, set in ONE launch (seven runtime memsets were seven launches): zero words,
+// +inf keys of the queries' merge bounds, +inf floats of the 8-bit threshold table.
+struct FilterInitArgs {
+    uint32_t* zero[5];
+    uint64_t zero_words[5];
+    uint32_t* query_tau;     // [nq] -> OrderedKey(+inf), or null
+    uint64_t nq;
+    uint32_t* inf_floats;    // the (task, cell) threshold table of the 8-bit pass -> +inf, or null
+    uint64_t inf_words;
+};
+static __global__ void __launch_bounds__(256) FilterInitKernel(FilterInitArgs a) {
+    const uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int z = 0; z < 5; ++z)
+        for (uint64_t i = i0; i < a.zero_words[z]; i += stride) a.zero[z][i] = 0u;
+    for (uint64_t i = i0; i < a.nq && a.query_tau; i += stride) a.query_tau[i] = kOrderedKeyInf;
+    for (uint64_t i = i0; i < a.inf_words && a.inf_floats; i += stride) a.inf_floats[i] = 0x7F800000u;
+}
+
 struct NeedArgs {
     const float* cell_dist;             // [tasks][kmax]
     const uint32_t* task_shard;
