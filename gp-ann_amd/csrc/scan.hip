@@ -1024,6 +1024,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", 8)));
     GPANN_TRY(s->ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
     ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 128));
+    ra.stat_overflowed = d_overflow;
+    ra.stat_candidates = d_cand_total;
     ra.split_dist = s->ws_split.as<float>();
     ra.split_row = reinterpret_cast<uint32_t*>(ra.split_dist + (size_t)T * split_parts * k);
     auto launch_rescore = [&](uint32_t parts) {
@@ -1031,7 +1033,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         const uint32_t grid = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)parts * T);
         if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
         else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
-        if (parts > 1) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 3) / 4), dim3(256), 0, st, ra);
+        // (always after a bucket pass — it also keeps the pass's statistics; the seed launch has no buckets)
+        if (ra.seed_rows == 0) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 3) / 4), dim3(256), 0, st, ra);
     };
     const uint64_t need_threads = (uint64_t)T * kmax;
     int n_cus = 256;
@@ -1085,7 +1088,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             fs.done0 = fs.done0b = fs.done1 = nullptr;
             void* sargs[] = {&fs};
             GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
-            hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
             launch_rescore(split_parts);
             GPANN_HIP_TRY(hipGetLastError());
             if (std::getenv("GPANN_CELLS_DEBUG")) debug_candidate_counts("shard-sample pass");
@@ -1137,7 +1139,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // Overflowed buckets are counted on the device (cumulatively over the passes) and looked at once, after the last pass: a
         // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
         // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
-        hipLaunchKernelGGL(OverflowCountKernel, dim3((T + 255) / 256), dim3(256), 0, st, cand_cnt, T, cap, d_overflow, d_cand_total);
         launch_rescore(split_parts);
         GPANN_HIP_TRY(hipGetLastError());
         plan.filter_launches++;

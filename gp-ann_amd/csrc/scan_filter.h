@@ -207,6 +207,8 @@ struct RescoreArgs {
     uint32_t parts, split_min;
     float* split_dist;
     uint32_t* split_row;
+    uint32_t* stat_overflowed;             // (SplitMergeKernel) += buckets of this pass that overflowed
+    unsigned long long* stat_candidates;   // (SplitMergeKernel) += candidates of this pass
     // SEED mode (seed_rows > 0): the lists start EMPTY and the "candidates" of task t are the first seed_rows plane rows of its nearest
     // cell (plane_perm maps them to store rows; padding rows are skipped) — no bucket is read
     uint32_t seed_rows;
@@ -223,19 +225,6 @@ struct RescoreArgs {
     uint32_t seed_catch_up;             // second seed launch: the tasks of queries that still have no bound are seeded after all
     const uint32_t* task_out;           // [tasks] slot index q * nprobe + j of every task
 };
-
-// number of tasks whose candidate bucket overflowed in this pass
-static __global__ void OverflowCountKernel(const uint32_t* cand_cnt, uint32_t tasks, uint32_t cap, uint32_t* out, unsigned long long* total) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= tasks) return;
-    const uint32_t c = cand_cnt[t];
-    if (c > cap) atomicAdd(out, 1u);
-    // wave-level sum, one atomic per wavefront
-    unsigned long long v = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(total, v);
-}
 
 __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd, uint32_t cr, uint32_t k, int lane) {
     bool less = (lane >= (int)k) || PairLess(cd, cr, ld_, lr_);
@@ -510,12 +499,28 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
 
 // The lists of the tasks whose bucket RescoreKernel split (same rule: cand_cnt, split_min, parts): one wavefront per task merges the pieces'
 // lists — all grown from the task's list, so an entry of that list can be in several: duplicates are dropped by row — into the task's list.
+// It also keeps the pass's statistics (what OverflowCountKernel did in a launch of its own): buckets that overflowed, candidates in total.
 static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) {
+    __shared__ unsigned long long s_total;
+    __shared__ uint32_t s_overflowed;
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.tasks) return;
-    const uint32_t cnt = a.cand_cnt[t];
-    if (cnt == 0 || cnt > a.cand_cap) return;
+    if (threadIdx.x == 0) {
+        s_total = 0ull;
+        s_overflowed = 0u;
+    }
+    __syncthreads();
+    const uint32_t cnt = t < a.tasks ? a.cand_cnt[t] : 0u;
+    if (lane == 0 && cnt != 0u) {
+        atomicAdd(&s_total, (unsigned long long)cnt);
+        if (cnt > a.cand_cap) atomicAdd(&s_overflowed, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && a.stat_overflowed) {   // (one global atomic per workgroup of four tasks)
+        if (s_total) atomicAdd(a.stat_candidates, s_total);
+        if (s_overflowed) atomicAdd(a.stat_overflowed, s_overflowed);
+    }
+    if (t >= a.tasks || cnt == 0 || cnt > a.cand_cap) return;
     const uint32_t n_parts = min(a.parts, (cnt + a.split_min - 1) / a.split_min), k = a.k;
     if (n_parts <= 1) return;
     const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
