@@ -1242,6 +1242,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     }
 
     GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
+    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));   // (re-recorded where the scan kernels end; a call without tasks ends here)
     bool done = false;
     s->stats = gpann_scan_stats{};
     s->filter_passes_timed = 0;

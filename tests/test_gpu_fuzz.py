@@ -19,7 +19,7 @@ def _cut(wd, wi):
     return wd, wi
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(96))
 def test_random_configuration(orc, gp, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     d = int(rng.choice([3, 8, 17, 33, 64, 65, 96, 100, 127, 128, 129, 200, 256, 260]))
