@@ -210,7 +210,8 @@ public:
         CheckComm(gpann_mask_probes(all.data(), (uint32_t)nq, (uint32_t)P, (uint32_t)P, owner.data(), (uint32_t)num_shards, rank, masked.data()), "gpann_mask_probes");
         float ms = 0.f;
         Check(gpann_scan_buckets(store, d_queries_, (uint32_t)nq, (uint32_t)k, masked.data(), (uint32_t)P, (uint32_t)P, d_ids_, d_dist_, nullptr,
-                                 GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE, nullptr, &ms),
+                                 // (the slots are only merged, :238: lists cut at this rank's merge bound — same merged neighbours, far shards cost little)
+                                 GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE | GPANN_SCAN_FOR_MERGE, nullptr, &ms),
               "gpann_scan_buckets");
         last_scan_ms = ms;
         // 4. result exchange: local rows -> point ids, all-gather of the per-slot lists, owner selection
