@@ -1120,6 +1120,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             plan.filter_rest_hi_only = hi_pass;
         }
         if (q8_pass) {
+            // (measurement aid, WRONG RESULTS: GPANN_DEBUG_Q8_NO_CAND=1 raises every threshold to +inf after the items are built — the launch streams
+            // and multiplies the same tiles but finds no candidate: what the candidate hand-off costs)
+            if (EnvU32("GPANN_DEBUG_Q8_NO_CAND", 0) != 0)
+                GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             void* kargs8[] = {&f8};
