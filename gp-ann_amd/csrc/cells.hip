@@ -12,6 +12,8 @@
 #include "kmeans.h"
 #include "scan_filter.h"
 
+#include <hipcub/device/device_segmented_radix_sort.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -22,7 +24,59 @@ namespace gpann {
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
-// plane_perm / plane_norm of one cell: members in slab order, then padding up to the tile boundary.  One workgroup per cell.
+// the sort key of the cells' member rows (RowsByNorm below)
+__global__ void MemberNormKernel(const uint32_t* members, uint64_t n, const float* neg_half_norm, float* key) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) key[i] = neg_half_norm[members[i]];
+}
+
+// The cells' member lists with everything behind a cell's first `keep` tiles ordered by the rows' norm words (descending).  The head and
+// sample passes of the filter read the front of a cell and want a random sample of it (slab order is one); the rest pass streams what is
+// behind, tile by tile, and its 8-bit kernel first tests a (row tile, query tile) product against the LARGEST norm word of the tile
+// (scan_cells.h, test8): with 32 neighbours of the sorted order in a tile that bound is as good as the row's own word, where a random
+// tile's largest word sits about two standard deviations above its typical one (uniform 128-d cloud: 58 % of the products passed that
+// test, 12 % held a candidate).  Results do not depend on the order.  Returns nullptr (and leaves the lists alone) when it cannot.
+static uint32_t* RowsByNorm(const uint32_t* members, uint64_t rows, const std::vector<uint64_t>& member_begin, const std::vector<uint32_t>& cell_size,
+                            const std::vector<uint64_t>& cell_tile_begin, const float* neg_half_norm) {
+    const size_t cells = cell_size.size();
+    if (rows == 0 || rows >= (1ull << 31) || cells >= (1ull << 31)) return nullptr;
+    std::vector<uint32_t> seg_begin(cells), seg_end(cells);
+    bool any = false;
+    for (size_t c = 0; c < cells; ++c) {
+        const uint64_t tiles = cell_tile_begin[c + 1] - cell_tile_begin[c];
+        const uint64_t keep = std::min<uint64_t>(cell_size[c], FilterFrontTiles(tiles) * kGTileRows);
+        seg_begin[c] = (uint32_t)(member_begin[c] + keep);
+        seg_end[c] = (uint32_t)(member_begin[c] + cell_size[c]);
+        any = any || seg_end[c] - seg_begin[c] > kGTileRows;
+    }
+    if (!any) return nullptr;
+    float *key_in = nullptr, *key_out = nullptr;
+    uint32_t *out = nullptr, *d_begin = nullptr, *d_end = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    bool ok = hipMalloc(&key_in, rows * 4) == hipSuccess && hipMalloc(&key_out, rows * 4) == hipSuccess && hipMalloc(&out, rows * 4) == hipSuccess &&
+              hipMalloc(&d_begin, cells * 4) == hipSuccess && hipMalloc(&d_end, cells * 4) == hipSuccess &&
+              hipMemcpy(d_begin, seg_begin.data(), cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_end, seg_end.data(), cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(out, members, rows * 4, hipMemcpyDeviceToDevice) == hipSuccess;   // (rows outside the segments stay where they are)
+    if (ok) {
+        hipLaunchKernelGGL(MemberNormKernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, 0, members, rows, neg_half_norm, key_in);
+        ok = hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, temp_bytes, key_in, key_out, members, out, (int)rows, (int)cells, d_begin, d_end) == hipSuccess &&
+             hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) == hipSuccess &&
+             hipcub::DeviceSegmentedRadixSort::SortPairsDescending(temp, temp_bytes, key_in, key_out, members, out, (int)rows, (int)cells, d_begin, d_end) == hipSuccess &&
+             hipDeviceSynchronize() == hipSuccess;
+    }
+    for (void* p : {(void*)key_in, (void*)key_out, (void*)d_begin, (void*)d_end, temp})
+        if (p) (void)hipFree(p);
+    if (!ok) {
+        (void)hipGetLastError();
+        if (out) (void)hipFree(out);
+        return nullptr;
+    }
+    return out;
+}
+
+// plane_perm / plane_norm of one cell: members in list order, then padding up to the tile boundary.  One workgroup per cell.
 __global__ void __launch_bounds__(256) CellLayoutKernel(const uint32_t* members, const uint64_t* cell_member_begin, const uint32_t* cell_size,
                                                         const uint64_t* cell_tile_begin, const float* neg_half_norm, uint32_t* plane_perm,
                                                         float* plane_norm) {
@@ -215,19 +269,36 @@ __global__ void __launch_bounds__(256) CellQ8PlaneKernel(const float* points, co
     }
 }
 
-// max of plane_norm over every 32-row tile (-inf rows: padding)
-__global__ void TileNormMaxKernel(const float* plane_norm, uint64_t tiles, float* tile_nmax) {
-    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= tiles) return;
-    float m = -INFINITY;
-    for (int i = 0; i < kGTileRows; ++i) m = fmaxf(m, plane_norm[t * kGTileRows + i]);
-    tile_nmax[t] = m;
+// per 32-row tile of the 8-bit plane, what its products' first half is tested against (scan_cells.h, quick8): .x the largest norm word of
+// its rows (-inf rows: padding; 0 for the inner product, whose test has no norm word), .y = 127 max_row sum_i |P'_i| >= |L.P'| for every
+// int8 query plane L.  One wavefront per tile: lane (c, h) holds 16 dimensions of row c per k-step.
+__global__ void __launch_bounds__(64) TileBoundKernel(const float* plane_norm, const char* q8_planes, uint32_t q8_ks, uint64_t tiles, int l2, float2* tile_bound) {
+    const uint64_t t = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    uint32_t l1 = 0;
+    for (uint32_t ks = 0; ks < q8_ks; ++ks) {
+        const uint4 w = *reinterpret_cast<const uint4*>(q8_planes + t * ((uint64_t)q8_ks * 1024) + ks * 1024 + lane * 16);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        for (int j = 0; j < 4; ++j)
+            for (int b = 0; b < 4; ++b) {
+                const int v = (int)(int8_t)(ww[j] >> (8 * b) & 0xFFu);
+                l1 += (uint32_t)(v < 0 ? -v : v);
+            }
+    }
+    l1 += __shfl_xor(l1, 32);   // the row's two halves
+    float m = l2 && lane < 32 ? plane_norm[t * kGTileRows + lane] : (l2 ? -INFINITY : 0.f);
+    for (int o = 16; o > 0; o >>= 1) {
+        l1 = max(l1, (uint32_t)__shfl_xor(l1, o));
+        m = fmaxf(m, __shfl_xor(m, o));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane == 0) tile_bound[t] = make_float2(m, 127.0f * (float)l1);   // (127 x 127 x 256 < 2^24: exact)
 }
 
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.d_cell_hi_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_nmax})
+                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.d_cell_hi_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_bound})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -356,16 +427,16 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
         if (!(q8_env && q8_env[0] == '0')) {
             C.q8_ks = (s->d + 31) / 32;
             const bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
-                             hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_nmax, (C.n_tiles + 2) * 4) == hipSuccess &&
+                             hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_bound, (C.n_tiles + 2) * 8) == hipSuccess &&
                              hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess;
             if (!qok) {   // the store works without it
                 (void)hipGetLastError();
-                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_nmax})
+                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_bound})
                     if (p) (void)hipFree(p);
                 C.q8_planes = nullptr;
                 C.d_q8_scale = nullptr;
                 C.d_q8_cnorm = nullptr;
-                C.d_tile_nmax = nullptr;
+                C.d_tile_bound = nullptr;
                 C.q8_ks = 0;
                 fprintf(stderr, "[gpann] the 8-bit plane of the filter's rest pass could not be allocated; the rest pass streams the bf16 plane\n");
             }
@@ -375,7 +446,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     // cell — the only ones the two-plane passes read (beyond 128 dimensions every pass is a hi-plane pass: no lo tiles at all).  hi: every one, or —
     // when the rest pass has the 8-bit plane — the sample tiles and the first max(head, 1 / kHiKeepDiv) of every cell: the head and sample passes
     // never reach further (the sample pass covers at most 1 / 8 of a cell: smaller shares were measured no better, profiles/r03/sweep_sample_div.md).  GPANN_FILTER_HI_ROWS=all keeps all (then GPANN_FILTER_Q8=0 works at scan time).
-    constexpr uint32_t kHiKeepDiv = 8;
+    constexpr uint32_t kHiKeepDiv = kFilterFrontDiv;
     std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), cell_hi_begin(C.n_cells + 1, 0), tile_lo_index, tile_hi_index;
     {
         const char* lr = std::getenv("GPANN_FILTER_LO_ROWS");
@@ -399,7 +470,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
             }
             if (C.hi_compact) {
                 // (head: 512 rows, the scan's default and upper limit here; + 1: the sample segment's end is a rounded-up quotient)
-                const uint64_t keep = std::min<uint64_t>(tiles, std::max<uint64_t>(16, (tiles + kHiKeepDiv - 1) / kHiKeepDiv + 1));
+                const uint64_t keep = std::min<uint64_t>(tiles, FilterFrontTiles(tiles));
                 for (uint64_t i = 0; i < keep; ++i) tile_hi_index[t0 + i] = (uint32_t)(at_hi + i);
                 at_hi += keep;
             }
@@ -483,8 +554,15 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
         if (d_bad) (void)hipFree(d_bad);
     }
     if (ok) {
-        hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
+        // (GPANN_FILTER_SORT_ROWS=0: the cells' rows stay in slab order throughout — the layout of the earlier rounds, for comparison)
+        const char* sort_env = std::getenv("GPANN_FILTER_SORT_ROWS");
+        uint32_t* by_norm = sort_env && sort_env[0] == '0' ? nullptr : RowsByNorm(session.rows(), s->rows, member_begin, cell_size, C.cell_tile_begin, s->neg_half_norm);
+        hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, by_norm ? by_norm : session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
                            s->neg_half_norm, C.plane_perm, C.plane_norm);
+        if (by_norm) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(by_norm);
+        }
         const int g2 = (int)std::min<uint64_t>((plane_rows * 2 * C.plane_ks + 255) / 256, 256 * 64);
         hipLaunchKernelGGL(SplitFragPlanesPermKernel, dim3(g2), dim3(256), 0, 0, s->points, C.plane_perm, plane_rows, ld, s->frag_planes,
                            (uint64_t)C.lo_offset_tiles * tile_bytes, C.plane_ks, C.d_mu, d_tile_hi_index, d_tile_lo_index);
@@ -503,7 +581,8 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                            C.d_q8_cnorm);
         hipLaunchKernelGGL(CellQ8PlaneKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, C.d_q8_scale, ld, C.q8_ks,
                            C.q8_planes);
-        hipLaunchKernelGGL(TileNormMaxKernel, dim3((uint32_t)((C.n_tiles + 2 + 255) / 256)), dim3(256), 0, 0, C.plane_norm, C.n_tiles + 2, C.d_tile_nmax);
+        hipLaunchKernelGGL(TileBoundKernel, dim3((uint32_t)(C.n_tiles + 2)), dim3(64), 0, 0, C.plane_norm, C.q8_planes, C.q8_ks, C.n_tiles + 2,
+                           s->metric == GPANN_METRIC_L2 ? 1 : 0, C.d_tile_bound);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return give_up("8-bit plane");
     }
 

@@ -938,7 +938,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.image = s->ws_image.as<char>();
     fa.seg_tiles = seg_tiles;
     fa.q8_planes = C.q8_planes;
-    fa.tile_nmax = C.d_tile_nmax;
+    fa.tile_bound = C.d_tile_bound;
     fa.q8_B = q8_B;
     fa.task_qscale = d_task_qscale;
     fa.q8_scale = C.d_q8_scale;

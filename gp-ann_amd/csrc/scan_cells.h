@@ -392,7 +392,7 @@ struct CellFilterArgs {
     // 8-bit pass (MODE 2): the int8 plane (KS KiB per tile, KS = k-steps of 32 dimensions), the tiles' largest norm words, the per-(task,
     // cell) thresholds written by NeedKernel, the tasks' query quantisation steps / 254, the cells' steps (FilterItemsKernel copies them into the items)
     const char* q8_planes;
-    const float* tile_nmax;
+    const float2* tile_bound;    // [tiles] (the tile's largest norm word, 127 x its largest sum of |P'| over a row — cells.hip, TileBoundKernel)
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
@@ -625,24 +625,26 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     // A wavefront's unit of work is TW consecutive row tiles (1: two 4 KiB tiles of the 8-bit plane per unit were measured no faster).
     constexpr int TW = TW_;
     Frag Ah[2][TW][KS], Al[HI_ONLY ? 1 : 2][KS];   // (the lo set is never touched when HI_ONLY)
-    float nrm[2][TW], nmax[2][TW];   // (nmax, MODE 2: the tile's largest norm word)
+    float nrm[2][TW];
+    float2 nmax[2][TW];   // (MODE 2: the tile's largest norm word and its bound of |L.P'|)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int tw = 0; tw < TW; ++tw) nrm[b][tw] = nmax[b][tw] = 0.f;
+        for (int tw = 0; tw < TW; ++tw) {
+            nrm[b][tw] = 0.f;
+            nmax[b][tw] = make_float2(0.f, 0.f);
+        }
     const char* lane_q8 = Q8 ? a.q8_planes + lane * 16 : nullptr;
     // (tiles T .. T + TW - 1: the tile after a range is the next cell's or the zero padding behind the planes — loaded, never multiplied)
-    auto load_tile = [&](Frag (&Ah)[TW][KS], Frag (&Al)[KS], float (&nrm)[TW], float (&nmax)[TW], uint32_t T, uint32_t T_hi, uint32_t T_lo) __attribute__((always_inline)) {
+    auto load_tile = [&](Frag (&Ah)[TW][KS], Frag (&Al)[KS], float (&nrm)[TW], float2 (&nmax)[TW], uint32_t T, uint32_t T_hi, uint32_t T_lo) __attribute__((always_inline)) {
         if (Q8) {
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
                 const char* base = lane_q8 + (size_t)(T + tw) * (KS * 1024);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) Ah[tw][ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
-                if (METRIC == GPANN_METRIC_L2) {
-                    nrm[tw] = a.plane_norm[(size_t)(T + tw) * kGTileRows + c];
-                    nmax[tw] = a.tile_nmax[T + tw];
-                }
+                if (METRIC == GPANN_METRIC_L2) nrm[tw] = a.plane_norm[(size_t)(T + tw) * kGTileRows + c];
+                nmax[tw] = a.tile_bound[T + tw];   // (inner product: .x is 0)
             }
             return;
         }
@@ -764,24 +766,8 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     // with 254 h + l formed in fp32 (|h|, |l| < 2^24 are exact, the sum is rounded once: Q8Threshold's fp32 slack).  The sign bits of the
     // 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies, compares and selects the
     // same test took 165 vector instructions per product against 8 matrix instructions.)
-    auto test8 = [&](const i32x16& h0, const i32x16& l0, float nmax, const float* norms, int q0, uint32_t (&cmask)[QT / 2]) __attribute__((always_inline)) {
+    auto full8 = [&](const i32x16& h0, const i32x16& l0, const float* norms, int q0, uint32_t (&cmask)[QT / 2]) __attribute__((always_inline)) {
         const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
-        // Quick test, switched on by the wavefront's own statistics: while fewer than a quarter of its products had a candidate (data
-        // without structure — a uniform cloud: one product in nine), most of the 16 full tests per lane are wasted; the NS rest pass,
-        // with a candidate in most products, runs without it.
-        ++q8_seen;
-        if (q8_seen >= 16u && q8_hits * 4u < q8_seen) {
-            // an upper bound of every row's test value: the largest H.P' and the largest L.P' of the lane's 16 rows (they need not be the
-            // same row's) with the tile's largest norm word — monotone in each operand of the exact test below
-            int hm = h0[0], lm = l0[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                hm = max(hm, h0[r]);
-                lm = max(lm, l0[r]);
-            }
-            const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, (float)lm), s0, nmax) - b0;
-            if (!__any(!(xub < 0.f))) return;
-        }
         uint32_t neg = 0;
 #pragma unroll
         for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
@@ -800,9 +786,26 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         q8_hits += __any(bits != 0u) ? 1u : 0u;
         cmask[q0 >> 1] |= bits << (16 * (q0 & 1));
     };
+    // ... and what decides whether the product's second half is run at all, while fewer than a quarter of the wavefront's products had a
+    // candidate (data without structure — a uniform cloud: one product in nine; the NS rest pass, with a candidate in most products,
+    // runs both halves unconditionally): H.P' alone bounds the test value of every row of the tile from above,
+    //   x <= fl(fl(fl(254 max h + lb)) * s0 + nmax) - b0,    lb = 127 max_row sum |P'| >= L.P' (|L| <= 127),  nmax = the tile's largest norm word
+    // — each operand replaced by one that is no smaller, every operation monotone.  (The rows behind a cell's front are ordered by norm
+    // word, so nmax is as good as a row's own; lb costs about 0.13 standard deviations of V.)  No lane >= 0: no row of the tile can pass,
+    // the 4 KS matrix instructions of L.P' and the 16 row tests are skipped.
+    auto quick8 = [&](const i32x16& h0, float2 bound, int q0) __attribute__((always_inline)) {
+        ++q8_seen;
+        if (!(q8_seen >= 16u && q8_hits * 4u < q8_seen)) return true;
+        int hm = h0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) hm = max(hm, h0[r]);
+        const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+        const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, bound.y), s0, bound.x) - b0;
+        return __any(!(xub < 0.f)) != 0;
+    };
     // MODE 2, two row tiles that run the same query tiles: every B fragment read from LDS feeds both tiles' products (an MFMA per KiB of LDS
     // read is what the LDS can just deliver: with one tile per fragment the uniform-cloud rest pass ran the matrix cores at 38 %)
-    auto compute_pair8 = [&](const Frag (&A0)[KS], const Frag (&A1)[KS], float nrm0, float nrm1, float nmax0, float nmax1, uint32_t T0, uint32_t act)
+    auto compute_pair8 = [&](const Frag (&A0)[KS], const Frag (&A1)[KS], float nrm0, float nrm1, float2 bound0, float2 bound1, uint32_t T0, uint32_t act)
                              __attribute__((always_inline)) {
         if (METRIC == GPANN_METRIC_L2) {
             if (h == 0) {
@@ -826,19 +829,26 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v4i32 a0 = __builtin_bit_cast(v4i32, A0[ks].q), a1 = __builtin_bit_cast(v4i32, A1[ks].q);
-                const v4i32 bh = *reinterpret_cast<const v4i32*>(p0 + ks * 2048), bl = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
+                const v4i32 bh = *reinterpret_cast<const v4i32*>(p0 + ks * 2048);
                 h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bh, h0, 0, 0, 0);
                 h1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bh, h1, 0, 0, 0);
+            }
+            const bool run0 = quick8(h0, bound0, q0), run1 = quick8(h1, bound1, q0);
+            if (!(run0 || run1)) continue;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i32 a0 = __builtin_bit_cast(v4i32, A0[ks].q), a1 = __builtin_bit_cast(v4i32, A1[ks].q);
+                const v4i32 bl = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
                 l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bl, l0, 0, 0, 0);
                 l1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bl, l1, 0, 0, 0);
             }
-            test8(h0, l0, nmax0, wave_norms, q0, cm0);
-            test8(h1, l1, nmax1, wave_norms + kGTileRows, q0, cm1);
+            if (run0) full8(h0, l0, wave_norms, q0, cm0);
+            if (run1) full8(h1, l1, wave_norms + kGTileRows, q0, cm1);
         }
         push_candidates(cm0, T0);
         push_candidates(cm1, T0 + 1);
     };
-    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float nmax, uint32_t T) __attribute__((always_inline)) {
+    auto compute_tile = [&](const Frag (&Ah)[KS], const Frag (&Al)[KS], float nrm, float2 nmax, uint32_t T) __attribute__((always_inline)) {
         const uint32_t act = act_of(T);
         if (act == 0) return;
         if (METRIC == GPANN_METRIC_L2) {
@@ -912,11 +922,17 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v4i32 av = __builtin_bit_cast(v4i32, Ah[ks].q);
-                const v4i32 bh0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048), bl0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
+                const v4i32 bh0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048);
                 h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bh0, h0, 0, 0, 0);
+            }
+            if (!quick8(h0, nmax, q0)) return;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4i32 av = __builtin_bit_cast(v4i32, Ah[ks].q);
+                const v4i32 bl0 = *reinterpret_cast<const v4i32*>(p0 + ks * 2048 + 1024);
                 l0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bl0, l0, 0, 0, 0);
             }
-            test8(h0, l0, nmax, wave_norms, q0, cmask);
+            full8(h0, l0, wave_norms, q0, cmask);
         };
 #pragma unroll
         for (int qp = 0; qp < QT / 2; ++qp) {

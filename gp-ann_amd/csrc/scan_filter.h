@@ -60,6 +60,13 @@ __host__ __device__ constexpr uint32_t PlaneKSteps(uint32_t d) {
     const uint32_t need = (d + 15u) / 16u;
     return need <= 2 ? 2u : need <= 4 ? 4u : need <= 6 ? 6u : need <= 7 ? 7u : need <= 8 ? 8u : need <= 10 ? 10u : need <= 13 ? 13u : 16u;
 }
+// The front of a cell: its first max(16, tiles / 8 + 1) row tiles, in slab order (a random sample of the cell).  The head pass (512 rows) and the
+// sample pass (at most 1 / 8 of a cell by default) stay inside it; behind it the rows are ordered by norm word (cells.hip, RowsByNorm) and,
+// when the store has the 8-bit plane, keep no bf16 tile.
+constexpr uint32_t kFilterFrontDiv = 8;
+__host__ __device__ constexpr uint64_t FilterFrontTiles(uint64_t tiles) {
+    return (tiles + kFilterFrontDiv - 1) / kFilterFrontDiv + 1 > 16 ? (tiles + kFilterFrontDiv - 1) / kFilterFrontDiv + 1 : 16;
+}
 constexpr int kGPlaneBytes = kFKS * 1024;      // one plane of a tile: [ks][lane][16 B]
 constexpr int kGTileBytes = 2 * kGPlaneBytes;  // [plane hi|lo][ks][lane][16 B]: 16 KiB per 32 rows (512 B per row)
 constexpr int kGTasks = 256;                   // tasks per filter group: 8 query tiles of 32

@@ -135,7 +135,7 @@ struct gpann_shards {
         uint32_t q8_ks = 0;                        // k-steps of 32 dimensions = ceil(d / 32)
         float* d_q8_scale = nullptr;               // [n_cells] quantisation step of the cell: max |p~_i - c^_i| / 127, rounded up
         double* d_q8_cnorm = nullptr;              // [n_cells] |c^|^2
-        float* d_tile_nmax = nullptr;              // [tiles incl. the sample's] max over the tile's rows of plane_norm (= -min |p~|^2 / 2)
+        float2* d_tile_bound = nullptr;            // [cell tiles + 2] (max over the tile's rows of plane_norm = -min |p~|^2 / 2, 127 max_row sum |P'|): cells.hip, TileBoundKernel
         // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
         // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
         float* d_mu = nullptr;
