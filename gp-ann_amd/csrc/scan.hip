@@ -624,7 +624,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
     const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || EnvU32("GPANN_FILTER_Q8", 1) != 0);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
-    const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, EnvU32("GPANN_FILTER_Q8_FROM_PASS", 2)));
+    const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, EnvU32("GPANN_FILTER_Q8_FROM_PASS", 1)));
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
@@ -1103,10 +1103,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
-        // the rest pass (GPANN_FILTER_Q8_FROM_PASS=1: the sample pass too) on the 8-bit plane; its thresholds come from Q8Threshold, not from task_U
+        // the sample and rest passes (GPANN_FILTER_Q8_FROM_PASS=2: the rest pass only) on the 8-bit plane; their thresholds come from Q8Threshold, not from task_U
+        // (NeedKernel writes every (task, cell) slot of the table: a threshold or "nothing passes")
         const bool q8_pass = use_q8 && pass >= q8_from_pass;
-        if (q8_pass && pass != q8_from_pass)   // (the table of the earlier 8-bit pass: back to "not needed")
-            GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];

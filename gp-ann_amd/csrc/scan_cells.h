@@ -344,13 +344,17 @@ static __global__ void NeedKernel(NeedArgs a) {
             }
         }
     }
+    const uint32_t g = a.task_group[t];
     if (need) {
-        const uint32_t g = a.task_group[t];
         atomicOr(&a.need[(size_t)g * a.kmax + j], 1u << ((t - a.groups[g].task_begin) >> 5));
         if (a.q8_B)
             a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + (t - a.groups[g].task_begin)] =
                 Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
                                     (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j]);
+    } else if (a.q8_B) {
+        // "not needed" = a threshold nothing passes (the task's query tile may run on the cell for its neighbours' sake; an earlier 8-bit pass may
+        // have left the task's threshold here)
+        a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + (t - a.groups[g].task_begin)] = INFINITY;
     }
 }
 

@@ -262,6 +262,15 @@ def test_cells_rest_pass_on_the_8_bit_plane(orc, gp, metric, d, monkeypatch):
     probes = np.stack([rng.permutation(S) for _ in range(nq)]).astype(np.int32)
     st8 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
     assert st8["filter_rest_row_bytes"] == 32 * ((d + 31) // 32) + 4, st8
+    # the sample pass runs on the 8-bit plane too (default); GPANN_FILTER_Q8_FROM_PASS=2 leaves it on the bf16 hi plane.  The cells' rows behind
+    # their front are ordered by norm word (default) or left in slab order (GPANN_FILTER_SORT_ROWS=0 at store build): the same bits every way
+    monkeypatch.setenv("GPANN_FILTER_Q8_FROM_PASS", "2")
+    st8b = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    assert st8b["filter_rest_row_bytes"] == st8["filter_rest_row_bytes"] and st8b["filter_candidates"] <= st8["filter_candidates"] * 1.05 + 100, (st8, st8b)
+    monkeypatch.delenv("GPANN_FILTER_Q8_FROM_PASS")
+    monkeypatch.setenv("GPANN_FILTER_SORT_ROWS", "0")
+    _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
+    monkeypatch.delenv("GPANN_FILTER_SORT_ROWS")
     # (a store built with the 8-bit plane keeps bf16 hi tiles only where the head / sample passes reach: without the plane, all of them)
     monkeypatch.setenv("GPANN_FILTER_Q8", "0")
     st16 = _check(orc, gp, pts, clusters, queries, probes, 2, k, metric)
