@@ -1012,12 +1012,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #undef GPANN_PICK8
             default: break;
         }
-        // (measurement aid: GPANN_Q8_WAVES=16 — the 128-dimension kernel with 16 wavefronts of 128 registers, one row tile per unit)
-        if (KS8 == 4 && EnvU32("GPANN_Q8_WAVES", 8) == 16) {
-            fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, 4, 2, 8, 1, 16> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, 4, 2, 8, 1, 16>;
-            q8_waves = 16;
-            q8_unit_tiles = 1;
-        }
+        // (16 wavefronts of 128 registers per workgroup, one row tile per unit, were measured on the 128-dimension kernel: no faster on the NS rest
+        // pass nor on the uniform cloud's — profiles/r03/q8_kernel_variants.md)
         glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }

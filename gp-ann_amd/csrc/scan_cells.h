@@ -286,7 +286,11 @@ __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, d
     const double E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * radius + 0.5 * dd * s_c);
     // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2
     const double e_fp = 0x1p-21 * (qn * (radius + sqrt(dd) * s_c) + 0.5 * R * R + 1.0);
-    const double B = Ub - qc - E - e_tab - e_fp;
+    // the kernels for up to 128 dimensions evaluate the test on accumulators biased by 1.5 x 2^23 (FilterKernelCells, BIAS): V and the threshold
+    // both carry 255 x 12582912 (x s0), three roundings at that magnitude (< 640 s0 in all) and the relative ones of the norm word (in e_fp) and
+    // of the shifted threshold itself
+    const double B0 = Ub - qc - E - e_tab - e_fp;
+    const double B = B0 - 1024.0 * s_c * tscale / 254.0 * (1.0 + 1e-6) - 0x1p-22 * fabs(B0);
     float Bf = (float)B;
     if ((double)Bf > B) Bf = nextafterf(Bf, -INFINITY);
     return Bf;
@@ -698,6 +702,17 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     float U[QT];
     float Bq[Q8 ? QT : 1];
     float cell_scale = 0.f;
+    // MODE 2 up to 128 dimensions: the integer accumulators start at 0x4B400000 — the bit pattern of 1.5 x 2^23 — so that an accumulator
+    // 0x4B400000 + h (|h| <= 127 x 127 x 128 < 2^22) READ AS A FLOAT is 12582912 + h exactly: the row tests need no int -> float
+    // conversion (two of their six vector instructions per accumulator).  The constant sits in 16 registers of its own (the matrix
+    // instruction's C operand) and is opaque to the optimiser, which would otherwise rebuild it with 16 moves per product.
+    constexpr bool BIAS = Q8 && KS <= 4;
+    constexpr int kBiasBits = 0x4B400000;
+    constexpr float kBias = 12582912.0f, kBias255 = 3208642560.0f;   // (255 x 12582912 = 765 x 2^22: a float)
+    i32x16 acc_init;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_init[r] = BIAS ? kBiasBits : 0;
+    if constexpr (BIAS) asm volatile("" : "+v"(acc_init));
     uint32_t q8_seen = 0, q8_hits = 0;   // (MODE 2) products this wavefront has run / that had a candidate
     uint32_t iter = 0;
     uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0, r_hi_shift = 0;
@@ -771,7 +786,9 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     // 16 x are shifted into one word (v_alignbit), a set bit = "no candidate".  (Formed with integer multiplies, compares and selects the
     // same test took 165 vector instructions per product against 8 matrix instructions.)
     auto full8 = [&](const i32x16& h0, const i32x16& l0, const float* norms, int q0, uint32_t (&cmask)[QT / 2]) __attribute__((always_inline)) {
-        const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
+        // (BIAS: the accumulators read as floats are 12582912 + h, 12582912 + l; fv = fl(255 x 12582912 + V) and the threshold moves by
+        // 255 x 12582912 x s0 — Q8Threshold's e_bias covers the roundings at that magnitude)
+        const float s0 = cell_scale * U[q0], b0 = BIAS ? __builtin_fmaf(kBias255, s0, Bq[Q8 ? q0 : 0]) : Bq[Q8 ? q0 : 0];
         uint32_t neg = 0;
 #pragma unroll
         for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
@@ -780,7 +797,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
 #pragma unroll
             for (int i = 3; i >= 0; --i) {
                 const int r = 4 * gg + i;
-                const float fv = __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
+                const float fv = BIAS ? __builtin_fmaf(__int_as_float(h0[r]), 254.0f, __int_as_float(l0[r])) : __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
                 const float x = __builtin_fmaf(fv, s0, nn[i]) - b0;
                 neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x), 31);   // neg = neg << 1 | sign(x)
             }
@@ -803,8 +820,9 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         int hm = h0[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) hm = max(hm, h0[r]);
-        const float s0 = cell_scale * U[q0], b0 = Bq[Q8 ? q0 : 0];
-        const float xub = __builtin_fmaf(__builtin_fmaf((float)hm, 254.0f, bound.y), s0, bound.x) - b0;
+        // (BIAS: the largest accumulator is the largest float too; lb moves by 12582912 like every L.P')
+        const float s0 = cell_scale * U[q0], b0 = BIAS ? __builtin_fmaf(kBias255, s0, Bq[Q8 ? q0 : 0]) : Bq[Q8 ? q0 : 0];
+        const float xub = __builtin_fmaf(__builtin_fmaf(BIAS ? __int_as_float(hm) : (float)hm, 254.0f, BIAS ? bound.y + kBias : bound.y), s0, bound.x) - b0;
         return __any(!(xub < 0.f)) != 0;
     };
     // MODE 2, two row tiles that run the same query tiles: every B fragment read from LDS feeds both tiles' products (an MFMA per KiB of LDS
@@ -826,9 +844,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
 #pragma unroll
         for (int q0 = 0; q0 < QT; ++q0) {
             if (!(act >> q0 & 1u)) continue;
-            i32x16 h0, l0, h1, l1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h0[r] = l0[r] = h1[r] = l1[r] = 0;
+            i32x16 h0 = acc_init, l0 = acc_init, h1 = acc_init, l1 = acc_init;
             const char* p0 = lane_lds + (q0 * KS) * 2048;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -916,12 +932,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         };
         // MODE 2: the same for the 8-bit planes: per query tile two integer accumulator chains, H.P' and L.P' (test8)
         auto pass8 = [&](int q0) __attribute__((always_inline)) {   // (one query tile: its two chains already keep the matrix core busy)
-            i32x16 h0, l0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                h0[r] = 0;
-                l0[r] = 0;
-            }
+            i32x16 h0 = acc_init, l0 = acc_init;
             const char* p0 = lane_lds + (q0 * KS) * 2048;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
