@@ -999,7 +999,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = FilterLdsBytes((size_t)QT * KS * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    const void* fn_q8 = nullptr;
+    // the sample pass under a symbol of its own (TAG 1: the rest pass keeps rocprofv3's per-kernel statistics to itself) and with one row tile per
+    // unit of work: its items are the 20-odd tiles of a cell's front — three rounds of 8 tiles instead of two of 16, the second a fifth full
+    const void *fn_q8 = nullptr, *fn_q8_sample = nullptr;
     uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8), q8_waves = (uint32_t)FilterWaves(2, (int)KS8);
     size_t glds8 = 0;
     if (use_q8) {
@@ -1007,6 +1009,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 #define GPANN_PICK8(KS_)                                                                                                                       \
     case KS_:                                                                                                                                  \
         fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 2, 8>; \
+        fn_q8_sample = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 1, KS_, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 1, KS_, 2, 8, 1>; \
         break;
             GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
 #undef GPANN_PICK8
@@ -1016,6 +1019,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // pass nor on the uniform cloud's — profiles/r03/q8_kernel_variants.md)
         glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
     if (rlds > (48u << 10)) {
@@ -1110,7 +1114,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
-        fa.round_tiles = q8_pass ? q8_waves * q8_unit_tiles : (uint32_t)kFWaves;
+        fa.round_tiles = q8_pass ? q8_waves * (pass == 2 ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
@@ -1128,7 +1132,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             void* kargs8[] = {&f8};
-            GPANN_HIP_TRY(hipLaunchKernel(fn_q8, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
+            GPANN_HIP_TRY(hipLaunchKernel(pass == 2 ? fn_q8 : fn_q8_sample, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
             if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
