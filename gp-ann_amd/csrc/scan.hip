@@ -624,6 +624,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
     const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || EnvU32("GPANN_FILTER_Q8", 1) != 0);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
+    // (never the head pass: an 8-bit pass gives a task candidates only from the cells NeedKernel marked for it — its per-(task, cell) thresholds —
+    // while the later passes skip a segment for a whole query tile once the tile has run on it; the head pass marks one cell per task, the bf16
+    // kernel's per-task threshold tests every task of the tile against it all the same.  Measured with the clamp lifted: wrong lists.)
     const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, EnvU32("GPANN_FILTER_Q8_FROM_PASS", 1)));
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
