@@ -25,6 +25,9 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# N > 1: how long a rank waits for a collective before it gives the run up (gpann_comm_wait also returns as soon as another rank has left)
+COMM_WAIT_S = int(os.environ.get("GPANN_COMM_WAIT_S", "600"))
+_live_comm = []   # the communicator of this process, for the exit path of a failed run
 for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -173,6 +176,7 @@ def main():
         # RCCL over xGMI is the measured configuration: if it cannot be initialised the run FAILS — a number taken over host sockets must
         # be asked for explicitly (--backend tcp) and says so in the JSON line ("backend")
         comm = gcomm.Comm(gcomm.RCCL if args.backend == "rccl" else gcomm.TCP, device=local_rank)   # RANK / WORLD_SIZE / MASTER_* from the environment; the device the buffers are on
+        _live_comm.append(comm)
         if comm.world != args.gpus or comm.rank != rank:
             raise SystemExit(f"communicator has {comm.world} ranks (this is rank {comm.rank}), --gpus {args.gpus}")
     else:
@@ -374,7 +378,7 @@ def main():
                 comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(), stream=stream)
                 hd.copy_(gd, non_blocking=True)
                 hi.copy_(gi, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                comm.wait(stream, COMM_WAIT_S)   # (a synchronise that gives up when a rank has left: gpann_comm_wait)
             else:
                 hd.copy_(od, non_blocking=True)
                 hi.copy_(oi, non_blocking=True)
@@ -424,7 +428,7 @@ def main():
             route_dev_mine.copy_(route_mine_t, non_blocking=True)
             comm.allgather(route_dev_mine.data_ptr(), route_dev_all.data_ptr(), route_mine.nbytes, stream)
             route_all_t.copy_(route_dev_all, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            comm.wait(stream, COMM_WAIT_S)
         else:
             comm.allgather(route_mine, route_all, route_mine.nbytes)
         return route_all.reshape(-1, S)[:nq], r_ms
@@ -1042,4 +1046,11 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        # a rank that fails leaves without waiting for collectives the others may be in (ncclCommDestroy could block on them); closing the
+        # bootstrap connections is what makes their gpann_comm_wait return
+        for c in _live_comm:
+            c.abort()
+        raise

@@ -345,6 +345,75 @@ gpann_status gpann_comm_destroy(gpann_comm* c) {
     return GPANN_OK;
 }
 
+gpann_status gpann_comm_abort(gpann_comm* c) {
+    if (!c) return GPANN_OK;
+    if (c->nccl) (void)ncclCommAbort(c->nccl);   // (does not wait for outstanding collectives, unlike ncclCommDestroy)
+    for (int fd : c->peers)
+        if (fd >= 0) ::close(fd);   // the other ranks' gpann_comm_wait / host collectives see the hang-up
+    if (c->listen_fd >= 0) ::close(c->listen_fd);
+    delete c;
+    return GPANN_OK;
+}
+
+gpann_status gpann_comm_wait(gpann_comm* c, void* stream, int timeout_s) {
+    COMM_REQUIRE(c != nullptr, "comm is null");
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(std::max(timeout_s, 1));
+    // a rank that has hung up: its end of the bootstrap connection reads as closed (0 bytes); data waiting or nothing to read = alive
+    auto lost_peer = [&]() -> int {
+        for (size_t i = 0; i < c->peers.size(); ++i) {
+            const int fd = c->peers[i];
+            if (fd < 0) continue;
+            char b;
+            const ssize_t n = ::recv(fd, &b, 1, MSG_PEEK | MSG_DONTWAIT);
+            if (n == 0 || (n < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) return c->rank == 0 ? (int)i : 0;
+        }
+        return -1;
+    };
+    const bool device_work = c->backend == GPANN_COMM_RCCL;
+    for (uint64_t spin = 0;; ++spin) {
+        hipError_t q = device_work ? hipStreamQuery(static_cast<hipStream_t>(stream)) : hipSuccess;
+        if (q == hipSuccess) {
+            const int lost = c->world > 1 ? lost_peer() : -1;
+            if (lost < 0) return GPANN_OK;
+            q = hipErrorNotReady;   // (the work is done but a rank is gone: report it now rather than at the next collective)
+        }
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            SetErr("hipStreamQuery failed: %s", hipGetErrorString(q));
+            return GPANN_ERR_HIP;
+        }
+        const char* why = nullptr;
+        char buf[96];
+        if ((spin & 15) == 15 || spin == 0) {   // (the connections: every 16th poll)
+            const int lost = c->world > 1 ? lost_peer() : -1;
+            if (lost >= 0) {
+                snprintf(buf, sizeof buf, "rank %d has left (bootstrap connection closed)", lost);
+                why = buf;
+            }
+            if (!why && c->nccl) {
+                ncclResult_t async = ncclSuccess;
+                if (ncclCommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                    snprintf(buf, sizeof buf, "RCCL reports %s", ncclGetErrorString(async));
+                    why = buf;
+                }
+            }
+        }
+        if (!why && std::chrono::steady_clock::now() > deadline) {
+            snprintf(buf, sizeof buf, "no completion within %d s", timeout_s);
+            why = buf;
+        }
+        if (why) {
+            if (c->nccl) {   // unblock this rank: the collective it waits for will never complete
+                (void)ncclCommAbort(c->nccl);
+                c->nccl = nullptr;
+            }
+            SetErr("collective abandoned: %s", why);
+            return GPANN_ERR_INTERNAL;
+        }
+        if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(spin > 4096 ? 1000 : 50));
+    }
+}
+
 gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend) {
     COMM_REQUIRE(c != nullptr, "comm is null");
     if (rank) *rank = c->rank;

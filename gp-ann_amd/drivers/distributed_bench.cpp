@@ -50,6 +50,7 @@ int main(int argc, const char* argv[]) {
     try {
         gpann_host::SetDevice(device);
         DistributedQueryBenchmark bench(comm, device);
+        if (const char* w = std::getenv("GPANN_COMM_WAIT_S")) bench.wait_timeout_s = std::max(1, std::atoi(w));
         bench.num_neighbors = std::stoi(k_string);
         bench.num_probes = EnvInt("GPANN_DIST_PROBES", 2);
         bench.LoadPartition(partition_file);
@@ -130,6 +131,9 @@ int main(int argc, const char* argv[]) {
         std::cerr << "rank " << rank << ": " << e.what() << std::endl;
         rc = 1;
     }
-    gpann_comm_destroy(comm);   // (MPI_Finalize)
+    // (MPI_Finalize)  A rank that failed leaves WITHOUT waiting for collectives the others may be inside — ncclCommDestroy could block on
+    // them — and closes its bootstrap connections: the other ranks' gpann_comm_wait / host collectives return an error and they leave too
+    if (rc != 0) gpann_comm_abort(comm);
+    else gpann_comm_destroy(comm);
     return rc;
 }

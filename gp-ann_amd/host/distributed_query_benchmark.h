@@ -52,6 +52,7 @@ public:
     std::vector<float> result_dist;
     std::vector<uint32_t> result_ids;
     double last_route_ms = 0.0, last_scan_ms = 0.0;
+    int wait_timeout_s = 600;   // a collective that has not completed by then is given up (gpann_comm_wait; GPANN_COMM_WAIT_S)
 
     explicit DistributedQueryBenchmark(gpann_comm* c, int device_) : comm(c), device(device_) {
         Check(gpann_comm_info(comm, &rank, &comm_size, &backend_), "gpann_comm_info");
@@ -160,7 +161,7 @@ public:
         if (backend_ == GPANN_COMM_RCCL) {
             if (rank == 0) HipCheck(hipMemcpy(d_queries_, queries.coordinates.data(), bytes, hipMemcpyHostToDevice), "hipMemcpy");
             CheckComm(gpann_comm_broadcast(comm, d_queries_, bytes, 0, nullptr), "gpann_comm_broadcast");
-            HipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            CheckComm(gpann_comm_wait(comm, nullptr, wait_timeout_s), "gpann_comm_wait");   // (not a bare synchronise: it returns when a rank has left)
             if (rank != 0) HipCheck(hipMemcpy(queries.coordinates.data(), d_queries_, bytes, hipMemcpyDeviceToHost), "hipMemcpy");
         } else {
             CheckComm(gpann_comm_broadcast(comm, queries.coordinates.data(), bytes, 0, nullptr), "gpann_comm_broadcast");
@@ -200,6 +201,7 @@ public:
         if (backend_ == GPANN_COMM_RCCL) {
             HipCheck(hipMemcpyAsync(d_probes_, mine.data(), mine.size() * 4, hipMemcpyHostToDevice, nullptr), "hipMemcpyAsync");
             CheckComm(gpann_comm_allgather(comm, d_probes_, d_all_probes_, mine.size() * 4, nullptr), "gpann_comm_allgather");
+            CheckComm(gpann_comm_wait(comm, nullptr, wait_timeout_s), "gpann_comm_wait");
             HipCheck(hipMemcpy(all.data(), d_all_probes_, all.size() * 4, hipMemcpyDeviceToHost), "hipMemcpy");
         } else {
             CheckComm(gpann_comm_allgather(comm, mine.data(), all.data(), mine.size() * 4, nullptr), "gpann_comm_allgather");
@@ -220,6 +222,7 @@ public:
         std::vector<uint32_t> ids(n);
         if (backend_ == GPANN_COMM_RCCL) {
             CheckComm(gpann_comm_gather_slots(comm, d_dist_, d_ids_, n, d_out_dist_, d_out_ids_, d_scratch_, d_map_, nullptr), "gpann_comm_gather_slots");
+            CheckComm(gpann_comm_wait(comm, nullptr, wait_timeout_s), "gpann_comm_wait");
             HipCheck(hipMemcpyAsync(dist.data(), d_out_dist_, n * 4, hipMemcpyDeviceToHost, nullptr), "hipMemcpyAsync");
             HipCheck(hipMemcpy(ids.data(), d_out_ids_, n * 4, hipMemcpyDeviceToHost), "hipMemcpy");
         } else {

@@ -30,6 +30,8 @@ def lib():
         L.gpann_comm_init_from_env.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.gpann_comm_init_from_env_on.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gpann_comm_destroy.argtypes = [C.c_void_p]
+        L.gpann_comm_abort.argtypes = [C.c_void_p]
+        L.gpann_comm_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpann_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpann_comm_barrier.argtypes = [C.c_void_p]
         L.gpann_comm_max_double.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -149,6 +151,18 @@ class Comm:
         if getattr(self, "h", None) is not None and self.h.value:
             lib().gpann_comm_destroy(self.h)
             self.h = C.c_void_p()
+
+    def abort(self):
+        """leave after an error: no waiting for outstanding collectives, the bootstrap connections are closed (the other ranks' wait() notices)"""
+        if getattr(self, "h", None) is not None and self.h.value:
+            lib().gpann_comm_abort(self.h)
+            self.h = C.c_void_p()
+
+    def wait(self, stream=None, timeout_s=600):
+        """wait for the collectives enqueued on `stream` (RCCL) while watching the other ranks: raises GpannError when a rank has left, RCCL
+        reports an asynchronous error or nothing completes within timeout_s (this rank's RCCL side is then aborted) — instead of a stream
+        synchronise that would never return"""
+        _check(lib().gpann_comm_wait(self.h, C.c_void_p(stream or 0), int(timeout_s)))
 
     def __del__(self):
         try:

@@ -52,6 +52,15 @@ gpann_status gpann_comm_init_from_env(int backend, gpann_comm** out);
  * LOCAL_RANK names (GPANN_DIST_DEVICE, GPANN_BENCH_FORCE_DEVICE): the communicator has to live where the buffers do */
 gpann_status gpann_comm_init_from_env_on(int backend, int device, gpann_comm** out);
 gpann_status gpann_comm_destroy(gpann_comm* c);
+/* Failure handling (the reference relies on mpirun tearing the job down; distributed_bench.cpp has none).
+ * gpann_comm_abort: for a rank that leaves after an error — the communicator is torn down WITHOUT waiting for outstanding collectives
+ * (ncclCommAbort; ncclCommDestroy may block on them), the bootstrap connections are closed, which is how the other ranks notice; frees c.
+ * gpann_comm_wait: wait for the work enqueued on `stream` (RCCL backend; TCP: nothing to wait for) while watching the bootstrap connections,
+ * for at most timeout_s seconds.  When a rank has hung up, RCCL reports an asynchronous error or the time is over, this rank's RCCL side
+ * is aborted — the collective it waits for would never complete — and an error is returned; the handle stays valid for gpann_comm_abort /
+ * gpann_comm_destroy only.  Use it instead of a bare stream synchronise after gpann_comm_broadcast / _allgather / _gather_slots. */
+gpann_status gpann_comm_abort(gpann_comm* c);
+gpann_status gpann_comm_wait(gpann_comm* c, void* stream, int timeout_s);
 gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend);
 /* "rccl <version>" / "tcp": what the JSON line of bench.py reports as the backend that actually ran */
 const char* gpann_comm_backend_name(const gpann_comm* c);

@@ -128,3 +128,45 @@ def test_lpt_and_masks():
     m = gcomm.mask_probes(p, 3, owner, int(owner[0]))
     assert m[0, 0] == 0 and m[0, 2] == -1
     assert all(m[i, j] == -1 or owner[m[i, j]] == owner[0] for i in range(2) for j in range(3))
+
+
+def _abort_worker(rank, world, comm_port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "gp-ann_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import time
+    from pygpann import GpannError
+    from pygpann import comm as gcomm
+    comm = gcomm.Comm(gcomm.TCP, rank=rank, world=world, addr="127.0.0.1", port=comm_port)
+    comm.barrier()
+    comm.wait(None, 5)                      # every rank alive, nothing enqueued: returns at once
+    if rank == 1:
+        comm.abort()                        # "this rank failed": no farewell collective, the connections are closed
+        return
+    t0 = time.time()
+    lost, msg = False, ""
+    while time.time() - t0 < 20.0:          # rank 0 notices without taking part in a collective, long before the 60 s it is willing to wait
+        try:
+            comm.wait(None, 60)
+            time.sleep(0.05)
+        except GpannError as e:
+            lost, msg = True, str(e)
+            break
+    failed_collective = False
+    try:
+        comm.barrier()
+    except GpannError:
+        failed_collective = True
+    comm.abort()
+    np.savez(os.path.join(out_dir, "abort.npz"), lost=np.array([lost]), after=np.array([failed_collective]), seconds=np.array([time.time() - t0]),
+             msg=np.array([msg]))
+
+
+def test_a_rank_that_leaves_is_noticed(tmp_path):
+    """gpann_comm_abort / gpann_comm_wait (include/gpann_comm.h): the reference relies on mpirun to tear a broken job down; here a rank that
+    fails closes its bootstrap connections and the others' waits return an error instead of blocking for ever"""
+    import torch.multiprocessing as mp
+    mp.spawn(_abort_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = np.load(tmp_path / "abort.npz")
+    assert bool(r["lost"][0]) and bool(r["after"][0]) and float(r["seconds"][0]) < 20.0, r
+    assert "has left" in str(r["msg"][0])
