@@ -10,7 +10,7 @@ from . import LIB_PATH, GpannError, OK
 
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_comm.so")
 RCCL, TCP = 0, 1
-EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_init_from_env_on", "gpann_comm_destroy", "gpann_comm_info", "gpann_comm_backend_name",
+EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_init_from_env_on", "gpann_comm_destroy", "gpann_comm_abort", "gpann_comm_wait", "gpann_comm_info", "gpann_comm_backend_name",
            "gpann_comm_barrier", "gpann_comm_max_double", "gpann_comm_allgather_host", "gpann_comm_broadcast_host", "gpann_comm_broadcast",
            "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_comm_debug_select_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
            "gpann_comm_merge_router"]
