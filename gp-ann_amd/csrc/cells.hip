@@ -12,8 +12,6 @@
 #include "kmeans.h"
 #include "scan_filter.h"
 
-#include <hipcub/device/device_segmented_radix_sort.hpp>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -24,50 +22,76 @@ namespace gpann {
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
-// the sort key of the cells' member rows (RowsByNorm below)
-__global__ void MemberNormKernel(const uint32_t* members, uint64_t n, const float* neg_half_norm, float* key) {
-    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i < n) key[i] = neg_half_norm[members[i]];
+// One piece of a cell's member list — at most kSortChunk rows — ordered by norm word, descending (ties: by row): a bitonic network over
+// (key, row) pairs in LDS, one workgroup per piece.  piece = (first position in the member array, rows).
+constexpr uint32_t kSortChunk = 16384;   // 8 bytes per pair: 128 KiB of the 160 KiB of LDS
+__global__ void __launch_bounds__(1024) SortPieceByNormKernel(const uint2* pieces, const float* neg_half_norm, uint32_t* members) {
+    extern __shared__ uint2 pairs[];   // (key bits, row)
+    const uint2 piece = pieces[blockIdx.x];
+    const uint32_t first = piece.x, count = piece.y;
+    uint32_t n = 64;
+    while (n < count) n <<= 1;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t row = i < count ? members[first + i] : kNoRow;
+        // (norm words are finite and <= 0: -inf pads to the end; floats are compared as floats below)
+        pairs[i] = make_uint2(__float_as_uint(i < count ? neg_half_norm[row] : -INFINITY), row);
+    }
+    __syncthreads();
+    // `before(a, b)`: a belongs in front of b
+    auto before = [](uint2 a, uint2 b) {
+        const float ka = __uint_as_float(a.x), kb = __uint_as_float(b.x);
+        return ka > kb || (ka == kb && a.y < b.y);
+    };
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint2 a = pairs[i], b = pairs[l];
+                    const bool up = (i & k) == 0;   // this pair's run is sorted front-to-back
+                    if (before(b, a) == up) {
+                        pairs[i] = b;
+                        pairs[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) members[first + i] = pairs[i].y;
 }
 
-// The cells' member lists with everything behind a cell's first `keep` tiles ordered by the rows' norm words (descending).  The head and
+// The cells' member lists with everything behind a cell's front (FilterFrontTiles) ordered by the rows' norm words, descending.  The head and
 // sample passes of the filter read the front of a cell and want a random sample of it (slab order is one); the rest pass streams what is
 // behind, tile by tile, and its 8-bit kernel first tests a (row tile, query tile) product against the LARGEST norm word of the tile
-// (scan_cells.h, test8): with 32 neighbours of the sorted order in a tile that bound is as good as the row's own word, where a random
+// (scan_cells.h, quick8): with 32 neighbours of the sorted order in a tile that bound is as good as the row's own word, where a random
 // tile's largest word sits about two standard deviations above its typical one (uniform 128-d cloud: 58 % of the products passed that
-// test, 12 % held a candidate).  Results do not depend on the order.  Returns nullptr (and leaves the lists alone) when it cannot.
+// test, 12 % held a candidate).  A tail of more than kSortChunk rows is ordered piece by piece — what matters is that the rows of a TILE
+// are alike.  Results do not depend on the order.  Returns nullptr (and leaves the lists alone) when it cannot.
 static uint32_t* RowsByNorm(const uint32_t* members, uint64_t rows, const std::vector<uint64_t>& member_begin, const std::vector<uint32_t>& cell_size,
                             const std::vector<uint64_t>& cell_tile_begin, const float* neg_half_norm) {
     const size_t cells = cell_size.size();
-    if (rows == 0 || rows >= (1ull << 31) || cells >= (1ull << 31)) return nullptr;
-    std::vector<uint32_t> seg_begin(cells), seg_end(cells);
-    bool any = false;
+    if (rows == 0 || rows >= (1ull << 32)) return nullptr;
+    std::vector<uint2> pieces;
     for (size_t c = 0; c < cells; ++c) {
         const uint64_t tiles = cell_tile_begin[c + 1] - cell_tile_begin[c];
         const uint64_t keep = std::min<uint64_t>(cell_size[c], FilterFrontTiles(tiles) * kGTileRows);
-        seg_begin[c] = (uint32_t)(member_begin[c] + keep);
-        seg_end[c] = (uint32_t)(member_begin[c] + cell_size[c]);
-        any = any || seg_end[c] - seg_begin[c] > kGTileRows;
+        for (uint64_t at = keep; at + kGTileRows < cell_size[c]; at += kSortChunk)   // (a last piece of one tile or less: nothing to order)
+            pieces.push_back(make_uint2((uint32_t)(member_begin[c] + at), (uint32_t)std::min<uint64_t>(kSortChunk, cell_size[c] - at)));
     }
-    if (!any) return nullptr;
-    float *key_in = nullptr, *key_out = nullptr;
-    uint32_t *out = nullptr, *d_begin = nullptr, *d_end = nullptr;
-    void* temp = nullptr;
-    size_t temp_bytes = 0;
-    bool ok = hipMalloc(&key_in, rows * 4) == hipSuccess && hipMalloc(&key_out, rows * 4) == hipSuccess && hipMalloc(&out, rows * 4) == hipSuccess &&
-              hipMalloc(&d_begin, cells * 4) == hipSuccess && hipMalloc(&d_end, cells * 4) == hipSuccess &&
-              hipMemcpy(d_begin, seg_begin.data(), cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d_end, seg_end.data(), cells * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(out, members, rows * 4, hipMemcpyDeviceToDevice) == hipSuccess;   // (rows outside the segments stay where they are)
+    if (pieces.empty() || pieces.size() >= (1ull << 31)) return nullptr;
+    uint32_t* out = nullptr;
+    uint2* d_pieces = nullptr;
+    const size_t lds = (size_t)kSortChunk * sizeof(uint2);
+    bool ok = hipMalloc(&out, rows * 4) == hipSuccess && hipMalloc(&d_pieces, pieces.size() * sizeof(uint2)) == hipSuccess &&
+              hipMemcpy(d_pieces, pieces.data(), pieces.size() * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(out, members, rows * 4, hipMemcpyDeviceToDevice) == hipSuccess &&   // (rows outside the pieces stay where they are)
+              hipFuncSetAttribute(reinterpret_cast<const void*>(SortPieceByNormKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(MemberNormKernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, 0, members, rows, neg_half_norm, key_in);
-        ok = hipcub::DeviceSegmentedRadixSort::SortPairsDescending(nullptr, temp_bytes, key_in, key_out, members, out, (int)rows, (int)cells, d_begin, d_end) == hipSuccess &&
-             hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) == hipSuccess &&
-             hipcub::DeviceSegmentedRadixSort::SortPairsDescending(temp, temp_bytes, key_in, key_out, members, out, (int)rows, (int)cells, d_begin, d_end) == hipSuccess &&
-             hipDeviceSynchronize() == hipSuccess;
+        hipLaunchKernelGGL(SortPieceByNormKernel, dim3((uint32_t)pieces.size()), dim3(1024), lds, 0, d_pieces, neg_half_norm, out);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     }
-    for (void* p : {(void*)key_in, (void*)key_out, (void*)d_begin, (void*)d_end, temp})
-        if (p) (void)hipFree(p);
+    if (d_pieces) (void)hipFree(d_pieces);
     if (!ok) {
         (void)hipGetLastError();
         if (out) (void)hipFree(out);
