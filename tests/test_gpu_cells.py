@@ -319,3 +319,21 @@ def test_cells_all_hi_tiles_kept_allows_switching_the_rest_pass(orc, gp, monkeyp
         assert st["filtered"] == 1 and st["filter_rest_row_bytes"] == row_bytes, st
         assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
     shards.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_cells_without_structure_and_with_huge_cells(orc, gp, metric, monkeypatch):
+    """One Gaussian blob (no cell is ever skipped: a dense stream of products, the wavefronts switch to testing H.P' alone before they
+    multiply L.P' — scan_cells.h quick8) in cells of ~40 000 rows (the rows behind a cell's front are ordered by norm word in several pieces of
+    16 384 — cells.hip RowsByNorm), every query against every shard: the oracle's bits"""
+    monkeypatch.setenv("GPANN_CELL_ROWS", "40000")
+    rng = np.random.default_rng(5 + metric)
+    n, d, S, nq, k = 120000, 64, 2, 1500, 10
+    pts = rng.standard_normal((n, d)).astype(np.float32)
+    clusters = random_clusters(rng, n, S)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    st = _check(orc, gp, pts, clusters, queries, probes, S, k, metric, expect_filtered=True)
+    assert st["filter_rest_row_bytes"] == 32 * ((d + 31) // 32) + 4, st
+    assert st["filter_pairs"] > 0.5 * nq * n, st          # (nothing could be skipped)
+    assert st["filter_dirty_tasks"] == 0, st
