@@ -665,7 +665,7 @@ def main():
                                       "canonical re-scoring of the candidates only) and is not a roofline fraction",
                               "algorithmic_GBps": hbm_alg, "algorithmic_bytes_per_step": float(np.mean(algo_bytes)),
                               "filter_kernels_ms": 1000.0 * f_s, "filter_mfma_TFLOPs": tflops, "filter_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
-                              "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"],
+                              "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"], "filter_dirty_tasks": stats["filter_dirty_tasks"],
                               "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
         traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "ScanTileKernel<0, 0>", {"": 1})
@@ -725,7 +725,8 @@ def main():
             st_s = shards.stats()
             same = bool(np.array_equal(mi_s, mi) and np.array_equal(md_s.view(np.uint32), md.view(np.uint32)))
             sweep.append({"knobs": dict(zip([n_ for n_, _ in knobs], combo)), "ms_per_step": 1000.0 * dt, "scan_kernels_ms": st_s["scan_ms"], "rest_ms": st_s["filter_rest_ms"],
-                          "candidates": st_s["filter_candidates"], "rest_rows": st_s["filter_rest_rows"], "filtered": st_s["filtered"], "identical": same})
+                          "candidates": st_s["filter_candidates"], "rest_rows": st_s["filter_rest_rows"], "dirty_tasks": st_s["filter_dirty_tasks"], "filtered": st_s["filtered"],
+                          "identical": same})
             log(f"sweep {sweep[-1]}")
         for name, _ in knobs:
             os.environ.pop(name, None)

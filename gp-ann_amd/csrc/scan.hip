@@ -635,7 +635,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // dirty tasks (bucket overflow): at most dirty_cap of them are redone exactly on the device; more than that = the data defeats the
     // filter (masses of equal distances) and the whole call falls back to the plain exact scan
     const uint32_t dirty_cap = std::max<uint32_t>(16, std::min<uint32_t>(256, T / 100));
-    const uint32_t range_segs = 512;
+    // ... each shard cut into segments of about 512 rows, one wavefront each (a fixed 512 segments left a wavefront 6 500 rows of a 3.3M-row C5
+    // shard to walk, and DirtyMergeKernel walked the partial lists one dependent load after the other: ONE dirty task cost 2.4 ms of a 9 ms step)
+    uint32_t range_segs = 512;
+    {
+        int64_t largest = 0;
+        for (uint32_t b = 0; b < s->S; ++b) largest = std::max<int64_t>(largest, s->offsets[b + 1] - s->offsets[b]);
+        const uint64_t fit = (256ull << 20) / ((uint64_t)dirty_cap * k * 8);   // partial lists: at most 256 MiB
+        range_segs = (uint32_t)std::max<uint64_t>(512, std::min<uint64_t>(std::min<uint64_t>(8192, fit), (uint64_t)largest / 512));
+    }
     GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 8 + (size_t)dirty_cap * 8 + 64));
     GPANN_TRY(s->ws_partials.Reserve((size_t)dirty_cap * range_segs * k * 8 + 256));
     float* list_dist = s->ws_lists.as<float>();
@@ -901,6 +909,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.query_tau = d_query_tau;
     na.task_query = ta.query;
     na.q8_B = nullptr;   // (set for the pass that runs on the 8-bit plane)
+    na.dirty_flag = nullptr;   // (set below, with the re-scoring arguments)
     na.q8_scale = C.d_q8_scale;
     na.q8_cnorm = C.d_q8_cnorm;
     na.task_q1 = d_task_q1;
@@ -963,6 +972,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.cand_cap = cap;
     ra.dedupe = 1;
     ra.dirty_flag = d_dirty_flag;
+    na.dirty_flag = d_dirty_flag;
     ra.dirty_list = d_dirty_list;
     ra.dirty_count = d_overflow + 1;
     ra.dirty_cap = dirty_cap;
@@ -1170,8 +1180,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // (launched whatever the count — no host round trip: without dirty tasks both launches end at once)
         RescoreArgs rr = ra;
         rr.range_segs = range_segs;
-        if (l2) hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_L2, true>), dim3(2048), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
-        else hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_MIPS, true>), dim3(2048), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        if (l2) hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_L2, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        else hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_MIPS, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
         hipLaunchKernelGGL(DirtyMergeKernel, dim3(dirty_cap), dim3(64), 0, st, rr);
         GPANN_HIP_TRY(hipGetLastError());
     }

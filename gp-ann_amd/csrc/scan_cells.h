@@ -247,6 +247,10 @@ struct NeedArgs {
     // GPANN_SCAN_FOR_MERGE: the query's merge bound (OrderedKey, [nq]) caps the tau of each of its tasks
     const uint32_t* query_tau;
     const uint32_t* task_query;
+    // [tasks] != 0: the task's bucket overflowed in an earlier pass (RescoreArgs::dirty_flag) — its list comes from the exact evaluation of its
+    // whole shard after the last pass, so the remaining passes leave it out: no cell, a threshold nothing passes.  (Left in with the loose
+    // bound it was stuck with, ONE such task of 10 000 cost 2.4 ms of a 9 ms step at C5: cells nobody else needed, buckets that overflowed again.)
+    const uint32_t* dirty_flag;
     // 8-bit pass (q8_B != nullptr): the per-(task, cell) thresholds of FilterKernelCells MODE 2, [groups][kmax][group_tasks] floats — +inf
     // where the task does not need the cell (the array is filled with +inf before the launch)
     float* q8_B;
@@ -314,8 +318,9 @@ static __global__ void NeedKernel(NeedArgs a) {
     // the task's k-th distance so far — or, if smaller, the bound the query's other tasks have already reached
     double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
     if (a.query_tau) tau = fmin(tau, (double)OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
+    const bool dirty = a.dirty_flag && a.dirty_flag[t] != 0u;
     if (j == 0) {
-        a.task_U[t] = ThresholdOf<METRIC>(tau, a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
+        a.task_U[t] = dirty ? INFINITY : ThresholdOf<METRIC>(tau, a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
         a.cand_cnt[t] = 0;
         if (t < a.n_groups) {   // (every group has a task: tasks >= n_groups)
             a.group_zero[t] = 0;
@@ -324,7 +329,7 @@ static __global__ void NeedKernel(NeedArgs a) {
     }
     if (j >= K) return;
     bool need;
-    if (a.head && a.nearest[src] != j) {
+    if (dirty || (a.head && a.nearest[src] != j)) {
         need = false;
     } else {   // (head pass: the nearest cell — unless even its ball cannot reach tau, e.g. a far shard under the query's merge bound)
         if (!(tau < (double)INFINITY)) {
