@@ -1053,7 +1053,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
         else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
         // (always after a bucket pass — it also keeps the pass's statistics; the seed launch has no buckets)
-        if (ra.seed_rows == 0) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 3) / 4), dim3(256), 0, st, ra);
+        if (ra.seed_rows == 0) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 4 * kSplitMergeTasksPerWave - 1) / (4 * kSplitMergeTasksPerWave)), dim3(256), 0, st, ra);
     };
     const uint64_t need_threads = (uint64_t)T * kmax;
     int n_cus = 256;

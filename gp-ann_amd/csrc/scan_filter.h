@@ -507,59 +507,66 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
 // The lists of the tasks whose bucket RescoreKernel split (same rule: cand_cnt, split_min, parts): one wavefront per task merges the pieces'
 // lists — all grown from the task's list, so an entry of that list can be in several: duplicates are dropped by row — into the task's list.
 // It also keeps the pass's statistics (what OverflowCountKernel did in a launch of its own): buckets that overflowed, candidates in total.
+constexpr uint32_t kSplitMergeTasksPerWave = 8;   // (a wavefront per task: at C3, 40 000 wavefronts of which most return at once, the four launches were 0.30 ms of a 2.8 ms scan)
 static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) {
     __shared__ unsigned long long s_total;
     __shared__ uint32_t s_overflowed;
     const int lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSplitMergeTasksPerWave;   // this wavefront's tasks: t0 .. t0 + 7, lane i looks at task t0 + i
     if (threadIdx.x == 0) {
         s_total = 0ull;
         s_overflowed = 0u;
     }
     __syncthreads();
-    const uint32_t cnt = t < a.tasks ? a.cand_cnt[t] : 0u;
-    if (lane == 0 && cnt != 0u) {
-        atomicAdd(&s_total, (unsigned long long)cnt);
-        if (cnt > a.cand_cap) atomicAdd(&s_overflowed, 1u);
+    const uint32_t t_l = t0 + (uint32_t)lane;
+    const uint32_t cnt_l = lane < (int)kSplitMergeTasksPerWave && t_l < a.tasks ? a.cand_cnt[t_l] : 0u;
+    if (cnt_l != 0u) {
+        atomicAdd(&s_total, (unsigned long long)cnt_l);
+        if (cnt_l > a.cand_cap) atomicAdd(&s_overflowed, 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && a.stat_overflowed) {   // (one global atomic per workgroup of four tasks)
+    if (threadIdx.x == 0 && a.stat_overflowed) {   // (one global atomic per workgroup of 32 tasks)
         if (s_total) atomicAdd(a.stat_candidates, s_total);
         if (s_overflowed) atomicAdd(a.stat_overflowed, s_overflowed);
     }
-    if (t >= a.tasks || cnt == 0 || cnt > a.cand_cap) return;
-    const uint32_t n_parts = min(a.parts, (cnt + a.split_min - 1) / a.split_min), k = a.k;
-    if (n_parts <= 1) return;
-    const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
-    const uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
-    float ld_ = INFINITY;
-    uint32_t lr_ = kNoId;
-    if (lane < (int)k) {
-        ld_ = pd[lane];
-        lr_ = pr[lane];
-    }
-    for (uint32_t p = 1; p < n_parts; ++p) {
-        float cd_l = INFINITY;
-        uint32_t cr_l = kNoId;
+    const uint32_t parts_l = cnt_l == 0u || cnt_l > a.cand_cap ? 0u : min(a.parts, (cnt_l + a.split_min - 1) / a.split_min);
+    unsigned long long todo = __ballot(parts_l > 1u);
+    const uint32_t k = a.k;
+    while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t t = t0 + (uint32_t)i, n_parts = (uint32_t)__shfl((int)parts_l, i);
+        const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
+        const uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
+        float ld_ = INFINITY;
+        uint32_t lr_ = kNoId;
         if (lane < (int)k) {
-            cd_l = pd[(size_t)p * k + lane];
-            cr_l = pr[(size_t)p * k + lane];
+            ld_ = pd[lane];
+            lr_ = pr[lane];
         }
-        for (uint32_t e = 0; e < k; ++e) {
-            const float cd = __shfl(cd_l, e);
-            const uint32_t cr = __shfl(cr_l, e);
-            const float td = __shfl(ld_, k - 1);
-            const uint32_t tr = __shfl(lr_, k - 1);
-            if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
-            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
-            ListInsertF(ld_, lr_, cd, cr, k, lane);
+        for (uint32_t p = 1; p < n_parts; ++p) {
+            float cd_l = INFINITY;
+            uint32_t cr_l = kNoId;
+            if (lane < (int)k) {
+                cd_l = pd[(size_t)p * k + lane];
+                cr_l = pr[(size_t)p * k + lane];
+            }
+            for (uint32_t e = 0; e < k; ++e) {
+                const float cd = __shfl(cd_l, e);
+                const uint32_t cr = __shfl(cr_l, e);
+                const float td = __shfl(ld_, k - 1);
+                const uint32_t tr = __shfl(lr_, k - 1);
+                if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
+                if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+                ListInsertF(ld_, lr_, cd, cr, k, lane);
+            }
         }
+        if (lane < (int)k) {
+            a.list_dist[(size_t)t * k + lane] = ld_;
+            a.list_row[(size_t)t * k + lane] = lr_;
+        }
+        if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
     }
-    if (lane < (int)k) {
-        a.list_dist[(size_t)t * k + lane] = ld_;
-        a.list_row[(size_t)t * k + lane] = lr_;
-    }
-    if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
 }
 
 // The dirty tasks' lists: one wavefront per dirty task merges the range_segs partial lists RescoreKernel's RANGE mode left (ascending
