@@ -1040,7 +1040,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     }
     // re-scoring launches: `parts` wavefronts per task (heavy buckets are split, RescoreArgs::parts)
-    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", 8)));
+    // — as many as keep the launch near 128k wavefronts: every (task, part) is a workgroup, most of which find nothing to do and return, and
+    // at 40 000 tasks (C3) 8 parts cost more in workgroups started than the split saves (2, 4, 8 parts: 2.28, 2.33, 2.38 ms of scan kernels; NS with
+    // 10 000 tasks: 4.44, 4.19, 4.15)
+    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", std::max<uint32_t>(2, std::min<uint32_t>(8, 131072u / std::max<uint32_t>(T, 1u))))));
     GPANN_TRY(s->ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
     ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 128));
     ra.stat_overflowed = d_overflow;
