@@ -76,7 +76,7 @@ struct gpann_router {
     // a bound block whose counters (candidate slots, unset minima) have not been looked at yet: they travel to the host with the results and
     // are checked after the call's one synchronisation (a bad block is rare; the call is then repeated canonically)
     struct { bool active = false; uint32_t nb = 0, cand_cap = 0; } pending_bound;
-    uint32_t* pinned_counters = nullptr;   // [2]
+    uint32_t* pinned_counters = nullptr;   // [5]: the words of BoundArgs::cand_count
     bool canonical_once = false;           // the repeated call: no bound path
     gpann::DeviceBuffer ws_host_redo;      // packed table rows / results of those queries
     float* pinned_redo = nullptr;          // their table rows on the host
@@ -1618,7 +1618,7 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     // segments = 320 workgroups on 256 CUs ran as 256 + 64, i.e. at the pace of 160
     ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), std::max(1u, (uint32_t)r->num_cus / groups)));
     GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
-    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 16, st));   // candidate counter, the self-check's counter, (verify mode) two more words
+    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 32, st));   // [0] candidate slots, [1] unset minima after pass 2, [2..3] (verify mode), [4] pairs pass 1 left without a maximum / a finite threshold
     GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
     const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
     const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
@@ -1634,9 +1634,9 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     void* kargs[] = {&ba};
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[0], st));
     GPANN_HIP_TRY(hipLaunchKernel(f1, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
-    // (cand_count + 1: the self-check counter — pass 1's maxima / thresholds here, the unset minima after pass 2 below)
-    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 1);
-    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 1);
+    // (the self-check's two counters: pass 1's maxima / thresholds here — cand_count + 4 —, the unset minima after pass 2 below — cand_count + 1)
+    if (l2) hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 4);
+    else hipLaunchKernelGGL(BoundMarginKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, ba.queries, ba.max_bits, thr, S, r->d, ld, r->cent_rmax, ba.mu, r->shard_has_cent, ba.cand_count + 4);
     GPANN_HIP_TRY(hipLaunchKernel(f2, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
     GPANN_HIP_TRY(hipEventRecord(r->ev_bound[1], st));
     const uint32_t egrid = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)cand_cap + 255) / 256);
@@ -1787,8 +1787,8 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
     if (may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
         // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
-        if (!r->pinned_counters) GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_counters), 16, hipHostMallocDefault));
-        GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
+        if (!r->pinned_counters) GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_counters), 32, hipHostMallocDefault));
+        GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_counters, ba.cand_count, 20, hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
         GPANN_HIP_TRY(hipGetLastError());
         r->pending_bound.active = true;
@@ -1797,8 +1797,8 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
         *settled = true;
         return GPANN_OK;
     }
-    uint32_t counters[2] = {0, 0};   // candidate slots handed out, unset minima
-    GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 8, hipMemcpyDeviceToHost, st));
+    uint32_t counters[5] = {0, 0, 0, 0, 0};   // [0] candidate slots handed out, [1] unset minima, [4] pairs pass 1 left without a maximum / finite threshold
+    GPANN_HIP_TRY(hipMemcpyAsync(counters, ba.cand_count, 20, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
     ++r->stat_bound_calls;
     {   // matrix-core work of this block: both passes run 3 bf16 products over nb x C x d
@@ -1809,11 +1809,24 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     const uint32_t n_cand = counters[0];
     if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidate slots for %u x %u (query, shard) pairs\n", n_cand, nb, r->S);
     if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
-    if (counters[1] != 0) {
+    if (counters[1] != 0 || counters[4] != 0) {
         ++r->stat_bound_selfcheck;
-        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n", counters[1], nb_s);
+        fprintf(stderr,
+                "[gpann router] bound path self-check: pass 1 left %u of %zu (query, shard) pairs without a maximum or with a non-finite threshold, %u minima are unset "
+                "after pass 2 (%u candidate slots, cap %u); evaluating every pair canonically instead\n",
+                counters[4], nb_s, counters[1], n_cand, ba.cand_cap);
         if (std::getenv("GPANN_ROUTER_STRICT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
-            SetLastError("router bound path left %u of %zu minima unset (GPANN_ROUTER_STRICT)", counters[1], nb_s);
+            // (for the record of a rare event — seen once in round 3 after 5 900 clean fresh-process runs: is it the inputs or the moment?  The same
+            // block once more, same inputs, before the call fails)
+            uint32_t again[5] = {0, 0, 0, 0, 0};
+            hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+            BoundArgs ba2;
+            float* thr2 = nullptr;
+            if (EnqueueBound(r, da, nb, st, ba2, thr2) == GPANN_OK && hipMemcpyAsync(again, ba2.cand_count, 20, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                hipStreamSynchronize(st) == hipSuccess)
+                fprintf(stderr, "[gpann router] ... the same block once more: pass 1 %u, pass 2 %u, %u candidate slots\n", again[4], again[1], again[0]);
+            SetLastError("router bound path self-check fired: pass 1 %u, pass 2 %u of %zu (query, shard) pairs; a second run on the same inputs: pass 1 %u, pass 2 %u "
+                         "(GPANN_ROUTER_STRICT)", counters[4], counters[1], nb_s, again[4], again[1]);
             return GPANN_ERR_INTERNAL;
         }
         return GPANN_OK;
@@ -1838,13 +1851,15 @@ gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r->ev_bound[0], r->ev_bound[1]) == hipSuccess) r->stat_bound_ms += ms;
     r->stat_bound_flops += 2.0 * 2.0 * 3.0 * (double)r->pending_bound.nb * (double)r->n_centroids * (double)r->d;
-    const uint32_t n_cand = r->pinned_counters[0], unset = r->pinned_counters[1];
-    if (unset != 0) {
+    const uint32_t n_cand = r->pinned_counters[0], unset = r->pinned_counters[1], bad1 = r->pinned_counters[4];
+    if (unset != 0 || bad1 != 0) {
         ++r->stat_bound_selfcheck;
-        fprintf(stderr, "[gpann router] bound path left %u of %zu (query, shard) minima unset; evaluating every pair canonically instead\n", unset,
-                (size_t)r->pending_bound.nb * r->S);
+        fprintf(stderr,
+                "[gpann router] bound path self-check: pass 1 left %u of %zu (query, shard) pairs without a maximum or with a non-finite threshold, %u minima are unset "
+                "after pass 2 (%u candidate slots); evaluating every pair canonically instead\n",
+                bad1, (size_t)r->pending_bound.nb * r->S, unset, n_cand);
         if (std::getenv("GPANN_ROUTER_STRICT")) {
-            SetLastError("router bound path left %u minima unset (GPANN_ROUTER_STRICT)", unset);
+            SetLastError("router bound path self-check fired: pass 1 %u, pass 2 %u (query, shard) pairs (GPANN_ROUTER_STRICT)", bad1, unset);
             return GPANN_ERR_INTERNAL;
         }
         *repeat = true;

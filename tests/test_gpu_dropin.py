@@ -118,7 +118,7 @@ def test_reference_query_attribution_driver_unchanged(orc, dataset):
     r = subprocess.run([QA, f["points"], f["queries"], f["gt"] + ".qa", str(k), f["clusters"], out, "KMeans", str(S)], capture_output=True, text=True,
                        timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "minima unset" not in r.stderr and "VERIFY" not in r.stderr, r.stderr[-3000:]
+    assert "self-check" not in r.stderr and "VERIFY" not in r.stderr, r.stderr[-3000:]
     nq = len(dataset["queries"])
     routes = _parse_routes(out + ".routes")
     assert len(routes) == 2 * 10                      # budgets 20k and 100k: 1 tree-search + 9 frequency routes each

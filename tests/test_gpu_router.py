@@ -184,7 +184,7 @@ def test_router_bound_self_check_falls_back_to_canonical_evaluation(orc, gp, mon
     monkeypatch.setenv("GPANN_ROUTER_FORCE_RECHECK", "1")
     p, md, _ = router.query_batch(queries, 50000)
     assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
-    assert "minima unset" in capfd.readouterr().err
+    assert "bound path self-check" in capfd.readouterr().err
     st = router.stats()
     assert st["bound_calls"] >= 1 and st["bound_selfcheck"] >= 1 and st["verify_failures"] == 0
 
