@@ -33,6 +33,9 @@
 #include <vector>
 
 struct gpann_router {
+    // The reference's callers invoke Query / FrequencyQuery concurrently, one query per call (routes.cpp:194-200); a handle owns ONE set of
+    // device workspaces, so concurrent calls on it take turns (recursive: entry points call each other).
+    std::recursive_mutex call_mutex;
     int device = 0;
     int metric = 0;
     uint32_t d = 0, ld = 0, S = 0, n_nodes = 0;
@@ -2162,6 +2165,8 @@ static gpann_status QueryBatchTopImpl(gpann_router* r, const float* queries, uin
 
 gpann_status gpann_router_query_batch_top(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t n_top, int32_t* out_probes,
                                           float* out_min_dist, int flags, void* stream, float* elapsed_ms) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    std::lock_guard<std::recursive_mutex> turn(r->call_mutex);
     const gpann_status st = QueryBatchTopImpl(r, queries, nq, budget, n_top, out_probes, out_min_dist, flags, stream, elapsed_ms);
     // a call that failed between the launch of a bound block and the look at its counters must not leave them to the next call
     if (st != GPANN_OK && r) r->pending_bound.active = false;
@@ -2298,6 +2303,7 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
                                                 float* out_min_dist, float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count,
                                                 int flags, void* stream, float* elapsed_ms) {
     GPANN_REQUIRE(r != nullptr, "router handle is null");
+    std::lock_guard<std::recursive_mutex> turn(r->call_mutex);
     GPANN_REQUIRE(nq == 0 || (queries && out_min_dist && out_nn_dist && out_nn_shard && out_nn_count), "null argument");
     GPANN_TRY(EnsureDevice(r->device));
     if (elapsed_ms) *elapsed_ms = 0.f;

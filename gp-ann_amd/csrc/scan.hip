@@ -1361,6 +1361,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
                                 uint32_t nprobe, uint32_t* out_ids, float* out_dist, uint32_t* out_rows, int flags, void* stream,
                                 float* elapsed_ms) {
     GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);   // (concurrent calls on one handle take turns: shards.h)
     GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
     GPANN_REQUIRE(!(flags & GPANN_SCAN_FOR_MERGE) || !(flags & GPANN_OUTPUT_ON_DEVICE) || out_dist != nullptr, "GPANN_SCAN_FOR_MERGE with device output needs out_dist");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1397,6 +1398,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
 gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t probe_stride,
                                uint32_t nprobe, uint32_t* out_ids, float* out_dist, int flags, void* stream, float* elapsed_ms) {
     GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
     GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n_slot = (size_t)nq * nprobe * k, n = (size_t)nq * k;
@@ -1445,6 +1447,7 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
 gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const float* distance_to_kth,
                                      uint32_t* out_ids, uint32_t* out_count, int flags, void* stream, float* elapsed_ms) {
     GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
     const uint32_t S = s->S;
     std::vector<int32_t> probes((size_t)nq * S);
     for (uint32_t q = 0; q < nq; ++q)

@@ -1,6 +1,7 @@
 // shards.h — the device-resident shard store (InvertedIndex layout, reference src/inverted_index.h:8-41).
 #pragma once
 
+#include <mutex>
 #include <vector>
 #include <cstdint>
 
@@ -72,6 +73,9 @@ struct PinnedStage {
 }  // namespace gpann
 
 struct gpann_shards {
+    // The reference's callers invoke Query / QueryBucket concurrently, one query per call (shard_searches.cpp:48); a handle owns ONE set of
+    // device workspaces and one pinned staging area, so concurrent calls on it take turns (recursive: entry points call each other).
+    std::recursive_mutex call_mutex;
     int device = 0;
     int metric = 0;
     uint32_t d = 0;      // true dimension

@@ -218,6 +218,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
 
 gpann_status gpann_shards_build_filter(gpann_shards* s) {
     GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
     GPANN_TRY(EnsureDevice(s->device));
     if (s->cells.n_cells != 0 && s->frag_planes != nullptr) return GPANN_OK;   // already there
     if (s->rows == 0) return GPANN_OK;

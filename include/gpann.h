@@ -77,6 +77,11 @@ enum {
 typedef struct gpann_shards gpann_shards;   /* device-resident shard store (the InvertedIndex layout) */
 typedef struct gpann_router gpann_router;   /* device-resident flattened k-means tree router */
 
+/* Threads.  The reference's callers run Query / QueryBucket / FrequencyQuery from many threads at once, one query per call
+ * (routes.cpp:194-200, shard_searches.cpp:48).  Every entry point here may be called from any thread; a handle (gpann_shards, gpann_router)
+ * owns ONE set of device workspaces, so concurrent calls on the SAME handle take turns (a per-handle lock) — correct, and serial: the batch
+ * entry points are how the GPU is kept busy.  Calls on different handles run concurrently (bench.py routes batch i + 1 on one handle and
+ * stream while batch i is scanned on another). */
 /* thread-local, human-readable description of the last failure in the calling thread */
 const char* gpann_last_error(void);
 const char* gpann_version(void);

@@ -1,0 +1,52 @@
+"""The reference's callers run Query / QueryBucket from many threads at once, one query per call (routes.cpp:194-200, shard_searches.cpp:48).
+A handle owns one set of device workspaces: concurrent calls on it take turns (include/gpann.h, "Threads") and return what serial calls return."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import make_mixture, random_clusters
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_calls_on_one_handle_return_the_serial_results(orc, gp):
+    rng = np.random.default_rng(31)
+    n, d, S, nq, k = 30000, 32, 4, 240, 10
+    pts = make_mixture(orc, n, d, n_centers=16)
+    clusters = random_clusters(rng, n, S, overlap=0.1)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
+    tree = orc.kmtr_train(pts, clusters, 32, 200, 4000, 0, nthreads=4)
+    router = gp.Router(tree.flat(), 0)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(1)
+    # the serial answers, slice by slice (slices of different sizes, down to the reference's one query per call)
+    slices = [(0, 1), (1, 3), (3, 40), (40, 41), (41, 120), (120, 200), (200, 239), (239, 240)]
+    want = []
+    for lo, hi in slices:
+        p, md, _ = router.query_batch(queries[lo:hi], 10 ** 6)
+        ids, dist, _ = shards.scan_buckets(queries[lo:hi], k, p, 2)
+        want.append((p.copy(), md.copy(), ids.copy(), dist.copy()))
+    errors = []
+
+    def worker(i):
+        try:
+            lo, hi = slices[i]
+            for _ in range(6):
+                p, md, _ = router.query_batch(queries[lo:hi], 10 ** 6)
+                ids, dist, _ = shards.scan_buckets(queries[lo:hi], k, p, 2)
+                wp, wmd, wi, wd = want[i]
+                assert np.array_equal(p, wp) and np.array_equal(md.view(np.uint32), wmd.view(np.uint32))
+                assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+        except BaseException as e:   # (collected: an assertion in a thread would otherwise vanish)
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(slices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    st = router.stats()
+    assert st["verify_failures"] == 0 and st["bound_selfcheck"] == 0
+    shards.close()
