@@ -337,6 +337,8 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
         fprintf(stderr, "[gpann] filter support data (cells, bf16 planes) could not be built — step '%s'%s%s; scans on this store run in exact mode\n", why,
                 last != hipSuccess ? ", last HIP error: " : "", last != hipSuccess ? hipGetErrorString(last) : "");
         SetLastError("filter support data could not be built (step '%s'%s%s)", why, last != hipSuccess ? ": " : "", last != hipSuccess ? hipGetErrorString(last) : "");
+        // the cause, for callers that branch on the status (gpann_shards_build_filter): retry with less memory vs report a defect
+        s->filter_fail_status = last == hipErrorOutOfMemory ? GPANN_ERR_OOM : (last != hipSuccess ? GPANN_ERR_HIP : (std::string(why) == "no cells" ? GPANN_ERR_INTERNAL : GPANN_ERR_OOM));
         ReleaseCells(s);
         if (s->frag_planes) (void)hipFree(s->frag_planes);
         s->frag_planes = nullptr;

@@ -280,16 +280,9 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
             SetErr("RCCL backend: HIP device %d is not available (%d devices)", device, n_dev);
             return fail(GPANN_ERR_NO_DEVICE);
         }
-        // the communicator is bound to `device`; the calling thread's current device is put back afterwards (a caller that chose another
-        // device for its buffers — GPANN_DIST_DEVICE, GPANN_BENCH_FORCE_DEVICE — must pass THAT device here)
-        int prev_device = -1;
-        (void)hipGetDevice(&prev_device);
-        struct Restore {
-            int dev;
-            ~Restore() {
-                if (dev >= 0) (void)hipSetDevice(dev);
-            }
-        } restore{prev_device};
+        // the communicator is bound to `device`, which STAYS the calling thread's current device (include/gpann_comm.h): a rank process that
+        // has not touched HIP yet relies on this call to select its GPU — restoring "the previous device" would silently put its buffers on
+        // device 0 while the communicator lives on LOCAL_RANK.  A caller that works on another device calls hipSetDevice itself afterwards.
         if (hipSetDevice(device) != hipSuccess) {
             SetErr("hipSetDevice(%d) failed", device);
             return fail(GPANN_ERR_HIP);
@@ -355,37 +348,47 @@ gpann_status gpann_comm_abort(gpann_comm* c) {
     return GPANN_OK;
 }
 
+// a rank that has hung up: its end of the bootstrap connection reads as closed (0 bytes); data waiting or nothing to read = alive.
+// Returns the rank that left (rank 0 sees every peer; the others only see rank 0), or -1.
+static int LostPeer(const gpann_comm* c) {
+    for (size_t i = 0; i < c->peers.size(); ++i) {
+        const int fd = c->peers[i];
+        if (fd < 0) continue;
+        char b;
+        const ssize_t n = ::recv(fd, &b, 1, MSG_PEEK | MSG_DONTWAIT);
+        if (n == 0 || (n < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) return c->rank == 0 ? (int)i : 0;
+    }
+    return -1;
+}
+
+gpann_status gpann_comm_check_peers(gpann_comm* c, int* lost_rank) {
+    COMM_REQUIRE(c != nullptr, "comm is null");
+    const int lost = c->world > 1 ? LostPeer(c) : -1;
+    if (lost_rank) *lost_rank = lost;
+    if (lost < 0) return GPANN_OK;
+    SetErr("rank %d has left (bootstrap connection closed)", lost);
+    return GPANN_ERR_INTERNAL;
+}
+
 gpann_status gpann_comm_wait(gpann_comm* c, void* stream, int timeout_s) {
     COMM_REQUIRE(c != nullptr, "comm is null");
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(std::max(timeout_s, 1));
-    // a rank that has hung up: its end of the bootstrap connection reads as closed (0 bytes); data waiting or nothing to read = alive
-    auto lost_peer = [&]() -> int {
-        for (size_t i = 0; i < c->peers.size(); ++i) {
-            const int fd = c->peers[i];
-            if (fd < 0) continue;
-            char b;
-            const ssize_t n = ::recv(fd, &b, 1, MSG_PEEK | MSG_DONTWAIT);
-            if (n == 0 || (n < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) return c->rank == 0 ? (int)i : 0;
-        }
-        return -1;
-    };
     const bool device_work = c->backend == GPANN_COMM_RCCL;
     for (uint64_t spin = 0;; ++spin) {
-        hipError_t q = device_work ? hipStreamQuery(static_cast<hipStream_t>(stream)) : hipSuccess;
-        if (q == hipSuccess) {
-            const int lost = c->world > 1 ? lost_peer() : -1;
-            if (lost < 0) return GPANN_OK;
-            q = hipErrorNotReady;   // (the work is done but a rank is gone: report it now rather than at the next collective)
-        }
+        const hipError_t q = device_work ? hipStreamQuery(static_cast<hipStream_t>(stream)) : hipSuccess;
+        // completed work is a success whatever the peers do afterwards: a rank that finished the same last collective and called
+        // gpann_comm_destroy / _abort a few microseconds earlier is not an error of THIS call (gpann_comm_check_peers asks about the peers)
+        if (q == hipSuccess) return GPANN_OK;
         if (q != hipErrorNotReady) {
             (void)hipGetLastError();
             SetErr("hipStreamQuery failed: %s", hipGetErrorString(q));
             return GPANN_ERR_HIP;
         }
+        // the work is still pending: is it ever going to complete?
         const char* why = nullptr;
         char buf[96];
         if ((spin & 15) == 15 || spin == 0) {   // (the connections: every 16th poll)
-            const int lost = c->world > 1 ? lost_peer() : -1;
+            const int lost = c->world > 1 ? LostPeer(c) : -1;
             if (lost >= 0) {
                 snprintf(buf, sizeof buf, "rank %d has left (bootstrap connection closed)", lost);
                 why = buf;
@@ -403,6 +406,9 @@ gpann_status gpann_comm_wait(gpann_comm* c, void* stream, int timeout_s) {
             why = buf;
         }
         if (why) {
+            // (a peer that left right after the collective completed on ITS side: our side may be a moment behind — one last look)
+            if (device_work && hipStreamQuery(static_cast<hipStream_t>(stream)) == hipSuccess) return GPANN_OK;
+            (void)hipGetLastError();
             if (c->nccl) {   // unblock this rank: the collective it waits for will never complete
                 (void)ncclCommAbort(c->nccl);
                 c->nccl = nullptr;
@@ -523,6 +529,14 @@ gpann_status gpann_comm_debug_select_slots(int world, size_t n, const float* ran
                                            const uint64_t* id_map_begin, float* out_dist, uint32_t* out_ids, int device) {
     COMM_REQUIRE(world >= 1 && (n == 0 || (rank_dist && rank_ids && out_dist && out_ids)) && (!id_maps || id_map_begin), "argument");
     if (n == 0) return GPANN_OK;
+    int prev_device = -1;   // (a test hook: the caller's current device is put back)
+    (void)hipGetDevice(&prev_device);
+    struct Restore {
+        int dev;
+        ~Restore() {
+            if (dev >= 0) (void)hipSetDevice(dev);
+        }
+    } restore{prev_device};
     COMM_HIP(hipSetDevice(device));
     const size_t W = (size_t)world;
     float *g_dist = nullptr, *d_out_dist = nullptr;

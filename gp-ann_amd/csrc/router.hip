@@ -32,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 struct gpann_router {
     // The reference's callers invoke Query / FrequencyQuery concurrently, one query per call (routes.cpp:194-200); a handle owns ONE set of
     // device workspaces, so concurrent calls on it take turns (recursive: entry points call each other).
@@ -60,6 +62,7 @@ struct gpann_router {
     double cent_rmax = 0.0;              // largest centroid norm
     gpann::DeviceBuffer ws_bound, ws_verify;
     uint64_t stat_bound_calls = 0, stat_bound_selfcheck = 0, stat_bound_overflow = 0, stat_verified = 0, stat_verify_failures = 0;
+    uint64_t stat_probed = 0, stat_probe_failures = 0;   // GPANN_ROUTER_PROBE: blocks run twice / blocks whose two runs differed
     uint64_t stat_host_sorted = 0, stat_heap_redo = 0;
     hipEvent_t ev_bound[2] = {nullptr, nullptr};   // around the two RouterBoundKernel launches of the most recent bound block
     double stat_bound_ms = 0.0, stat_bound_flops = 0.0;   // accumulated over the blocks of the most recent call
@@ -1405,6 +1408,8 @@ gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* o
     out->heap_redo = r->stat_heap_redo;
     out->last_bound_ms = r->stat_bound_ms;
     out->last_bound_flops = r->stat_bound_flops;
+    out->probed = r->stat_probed;
+    out->probe_failures = r->stat_probe_failures;
     return GPANN_OK;
 }
 
@@ -1654,12 +1659,197 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     return GPANN_OK;
 }
 
+// Evidence for a bound block that went wrong (a verify difference, a fired self-check, a determinism-probe difference): the block's data
+// (run 1), the same pipeline once more on the same inputs (run 2), the canonical minima, and a report that localises the fault — which
+// stage's data differs between the runs, and for the first bad (query, shard) pairs whether the true minimiser passes the threshold and
+// whether it is in run 1's candidate list.  The text goes to stderr and $GPANN_VERIFY_REPORT; the arrays of BOTH runs (max_bits, thr,
+// min_bits, candidate lists, staged queries, canonical minima) go to $GPANN_VERIFY_REPORT.<pid>.<n>.bin (layout: BoundDumpHeader below).
+// `da.out_min_bits` must still hold run 1's ORDERED BITS.  Leaves run 2's results in the workspaces.
+struct BoundDumpHeader {
+    char magic[8];   // "GPANNBD1"
+    uint32_t nb, S, d, ld, n_seg, cand_cap, metric, plane_ks;
+    uint64_t C;
+    uint32_t counters1[8], counters2[8];
+    uint32_t n_cand1, n_cand2;
+    // then: max_bits1 [nb*S] u32 | thr1 [nb*S] f32 | min_bits1 [nb*S] u32 | queries1 [nb*ld] f32 | cand1 [n_cand1] uint2 |
+    //       max_bits2 | thr2 | min_bits2 | queries2 | cand2 [n_cand2] | want (canonical min bits) [nb*S] u32
+};
+static std::atomic<uint32_t> g_bound_dump_seq{0};
+
+gpann_status BoundEvidence(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float* thr, const float* caller_queries,
+                           bool caller_on_device, const char* why, size_t* bad_minima) {
+    const uint32_t S = r->S, ld = r->ld, d = r->d;
+    const uint64_t C = r->n_centroids;
+    const size_t nb_s = (size_t)nb * S;
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    struct Snap { std::vector<uint32_t> max_bits, min_bits; std::vector<float> thr, queries; std::vector<uint2> cand; uint32_t counters[8]; };
+    auto snap = [&](Snap& s) -> hipError_t {
+        s.max_bits.resize(nb_s); s.min_bits.resize(nb_s); s.thr.resize(nb_s); s.queries.resize((size_t)nb * ld);
+        hipError_t e = hipMemcpy(s.max_bits.data(), ba.max_bits, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.thr.data(), thr, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.min_bits.data(), da.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.queries.data(), da.queries, (size_t)nb * ld * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(s.counters, ba.cand_count, 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        s.cand.resize(std::min<uint32_t>(s.counters[0], ba.cand_cap));
+        if (!s.cand.empty()) e = hipMemcpy(s.cand.data(), ba.cand, s.cand.size() * 8, hipMemcpyDeviceToHost);
+        return e;
+    };
+    Snap s1, s2;
+    GPANN_HIP_TRY(snap(s1));
+    // the canonical minima of the block
+    GPANN_TRY(r->ws_verify.Reserve(nb_s * 4 + 16));
+    DenseArgs dv = da;
+    dv.out_min_bits = r->ws_verify.as<uint32_t>();
+    const dim3 dgrid((uint32_t)((C + 63) / 64), (nb + 63) / 64);
+    const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+    const uint32_t fgrid = (uint32_t)((nb_s + 255) / 256);
+    hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, dv.out_min_bits, nb_s);
+    if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, dv);
+    else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, true>), dgrid, dim3(256), dlds, st, dv);
+    GPANN_HIP_TRY(hipGetLastError());
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> want(nb_s);
+    GPANN_HIP_TRY(hipMemcpy(want.data(), dv.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    // run 2: the same pipeline on the same inputs
+    hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, da.out_min_bits, nb_s);
+    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    GPANN_HIP_TRY(snap(s2));
+    std::vector<float> cents((size_t)C * ld);
+    std::vector<uint32_t> cshard(C);
+    GPANN_HIP_TRY(hipMemcpy(cents.data(), r->centroids, cents.size() * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(cshard.data(), r->cent_shard, C * 4, hipMemcpyDeviceToHost));
+    std::vector<float> nhn(C);
+    GPANN_HIP_TRY(hipMemcpy(nhn.data(), r->cent_nhn, C * 4, hipMemcpyDeviceToHost));
+    std::vector<float> mu(ld, 0.f);   // the frame of the bound (zero when the router is not centred)
+    if (r->cent_mu) GPANN_HIP_TRY(hipMemcpy(mu.data(), r->cent_mu, (size_t)ld * 4, hipMemcpyDeviceToHost));
+
+    auto bits_to_float = [](uint32_t o) { uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; std::memcpy(&f, &b, 4); return f; };
+    size_t bad1 = 0, bad2 = 0, unset1 = 0, max_diff = 0, thr_diff = 0, thr_nan1 = 0, max_zero1 = 0, q_diff = 0, q_vs_caller = 0, min_diff = 0;
+    for (size_t i = 0; i < nb_s; ++i) {
+        bad1 += s1.min_bits[i] != want[i];
+        bad2 += s2.min_bits[i] != want[i];
+        min_diff += s1.min_bits[i] != s2.min_bits[i];
+        unset1 += s1.min_bits[i] == 0xFF7FFFFFu;
+        max_diff += s1.max_bits[i] != s2.max_bits[i];
+        thr_diff += std::memcmp(&s1.thr[i], &s2.thr[i], 4) != 0;
+        thr_nan1 += std::isnan(s1.thr[i]);
+        max_zero1 += s1.max_bits[i] == 0;
+    }
+    for (size_t i = 0; i < s1.queries.size(); ++i) q_diff += std::memcmp(&s1.queries[i], &s2.queries[i], 4) != 0;
+    if (caller_queries && !caller_on_device)
+        for (uint32_t q = 0; q < nb; ++q)
+            for (uint32_t x = 0; x < d; ++x) q_vs_caller += std::memcmp(&s1.queries[(size_t)q * ld + x], &caller_queries[(size_t)q * d + x], 4) != 0;
+    // the candidate SETS of the two runs (slot order depends on which wavefront claimed which chunk)
+    auto cand_set = [](const std::vector<uint2>& c) {
+        std::vector<uint64_t> v;
+        for (const uint2& e : c)
+            if (e.x != 0xFFFFFFFFu) v.push_back((uint64_t)e.x << 32 | e.y);
+        std::sort(v.begin(), v.end());
+        return v;
+    };
+    const std::vector<uint64_t> set1 = cand_set(s1.cand), set2 = cand_set(s2.cand);
+    std::vector<uint64_t> only1, only2;
+    std::set_difference(set1.begin(), set1.end(), set2.begin(), set2.end(), std::back_inserter(only1));
+    std::set_difference(set2.begin(), set2.end(), set1.begin(), set1.end(), std::back_inserter(only2));
+    std::string rep;
+    char line[1536];
+    snprintf(line, sizeof line,
+             "[gpann router EVIDENCE] %s: %zu of %zu minima differ from the canonical evaluation (run 1), %zu (run 2 on the same inputs); run 1: %zu unset, "
+             "%zu thr NaN, %zu max_bits zero, candidate slots %u (cap %u), counters pass-1 %u unset-minima %u; between the runs: %zu max_bits differ, %zu thr "
+             "differ, %zu min_bits differ, %zu query words differ, candidate sets %zu / %zu entries (%zu only in run 1, %zu only in run 2); device queries vs "
+             "caller's host queries: %zu words differ; nq %u S %u C %llu d %u n_seg %u pid %d\n",
+             why, bad1, nb_s, bad2, unset1, thr_nan1, max_zero1, s1.counters[0], ba.cand_cap, s1.counters[4], s1.counters[1], max_diff, thr_diff, min_diff, q_diff,
+             set1.size(), set2.size(), only1.size(), only2.size(), q_vs_caller, nb, S, (unsigned long long)C, d, ba.n_seg, (int)getpid());
+    rep += line;
+    {   // where the bad pairs sit: per shard, and per 32-query tile of the block
+        std::vector<size_t> per_shard(S, 0), per_qtile((nb + 31) / 32, 0);
+        for (size_t i = 0; i < nb_s; ++i)
+            if (s1.min_bits[i] != want[i]) {
+                per_shard[i % S]++;
+                per_qtile[(i / S) / 32]++;
+            }
+        std::string a = "  bad pairs per shard:", b = "  bad pairs per 32-query tile:";
+        for (uint32_t x = 0; x < S && x < 64; ++x) a += " " + std::to_string(per_shard[x]);
+        for (size_t x = 0; x < per_qtile.size() && x < 64; ++x) b += " " + std::to_string(per_qtile[x]);
+        rep += a + "\n" + b + "\n";
+    }
+    int shown = 0;
+    for (size_t i = 0; i < nb_s && shown < 8; ++i) {
+        if (s1.min_bits[i] == want[i] && s1.max_bits[i] == s2.max_bits[i]) continue;
+        ++shown;
+        const uint32_t q = (uint32_t)(i / S), b = (uint32_t)(i % S);
+        // in double: the true acc of every centroid of the shard, the true minimiser
+        double best_acc = -1e300, best_dist = 1e300, acc_of_min = 0;
+        uint64_t arg_acc = 0, arg_min = 0, n_in = 0;
+        const float* qv = &s1.queries[(size_t)q * ld];
+        for (uint64_t c = 0; c < C; ++c) {
+            if (cshard[c] != b) continue;
+            ++n_in;
+            double dot = 0, dist = 0;
+            for (uint32_t x = 0; x < d; ++x) {
+                dot += (double)(qv[x] - mu[x]) * (double)(cents[c * ld + x] - mu[x]);
+                const double df = (double)qv[x] - cents[c * ld + x];
+                dist += df * df;
+            }
+            const double acc = r->metric == GPANN_METRIC_L2 ? dot + (double)nhn[c] : dot;
+            const double key = r->metric == GPANN_METRIC_L2 ? dist : 1.0 - dot;
+            if (acc > best_acc) { best_acc = acc; arg_acc = c; }
+            if (key < best_dist) { best_dist = key; arg_min = c; acc_of_min = acc; }
+        }
+        size_t in_list = 0, list_has_min = 0, in_list2 = 0;
+        for (const uint2& qc : s1.cand)
+            if (qc.x == q && qc.y != 0xFFFFFFFFu && qc.y < C && cshard[qc.y] == b) { ++in_list; list_has_min += qc.y == arg_min; }
+        for (const uint2& qc : s2.cand)
+            if (qc.x == q && qc.y != 0xFFFFFFFFu && qc.y < C && cshard[qc.y] == b) ++in_list2;
+        snprintf(line, sizeof line,
+                 "  (q %u, shard %u, %llu centroids): got %08x (%g) want %08x (%g); run 1 max %g thr %g | run 2 max %g thr %g min %08x; host: max acc %.9g at %llu, "
+                 "minimiser %llu dist %.9g acc %.9g (%s thr 1); candidates of the pair in run 1's list: %zu (run 2: %zu), minimiser among them: %zu\n",
+                 q, b, (unsigned long long)n_in, s1.min_bits[i], bits_to_float(s1.min_bits[i]), want[i], bits_to_float(want[i]), bits_to_float(s1.max_bits[i]),
+                 s1.thr[i], bits_to_float(s2.max_bits[i]), s2.thr[i], s2.min_bits[i], best_acc, (unsigned long long)arg_acc, (unsigned long long)arg_min, best_dist,
+                 acc_of_min, acc_of_min >= (double)s1.thr[i] ? ">=" : "<", in_list, in_list2, list_has_min);
+        rep += line;
+    }
+    fputs(rep.c_str(), stderr);
+    if (const char* path = std::getenv("GPANN_VERIFY_REPORT")) {
+        if (FILE* f = fopen(path, "a")) {
+            fputs(rep.c_str(), f);
+            fclose(f);
+        }
+        // the arrays of both runs, for an offline look
+        const std::string dump = std::string(path) + "." + std::to_string((int)getpid()) + "." + std::to_string(g_bound_dump_seq.fetch_add(1)) + ".bin";
+        if (FILE* f = fopen(dump.c_str(), "wb")) {
+            BoundDumpHeader h{};
+            std::memcpy(h.magic, "GPANNBD1", 8);
+            h.nb = nb; h.S = S; h.d = d; h.ld = ld; h.n_seg = ba.n_seg; h.cand_cap = ba.cand_cap; h.metric = (uint32_t)r->metric; h.plane_ks = r->plane_ks;
+            h.C = C;
+            std::memcpy(h.counters1, s1.counters, 32);
+            std::memcpy(h.counters2, s2.counters, 32);
+            h.n_cand1 = (uint32_t)s1.cand.size();
+            h.n_cand2 = (uint32_t)s2.cand.size();
+            fwrite(&h, sizeof h, 1, f);
+            for (const Snap* s : {&s1, &s2}) {
+                fwrite(s->max_bits.data(), 4, nb_s, f);
+                fwrite(s->thr.data(), 4, nb_s, f);
+                fwrite(s->min_bits.data(), 4, nb_s, f);
+                fwrite(s->queries.data(), 4, s->queries.size(), f);
+                fwrite(s->cand.data(), 8, s->cand.size(), f);
+            }
+            fwrite(want.data(), 4, nb_s, f);
+            fclose(f);
+        }
+    }
+    if (bad_minima) *bad_minima = bad1;
+    return GPANN_OK;
+}
+
 // GPANN_ROUTER_VERIFY=1: every bound-path result is compared, minimum by minimum, with the canonical evaluation of ALL pairs
 // (DenseDistKernel<.., MIN_ONLY>).  A difference ends the call with GPANN_ERR_INTERNAL after a second run of the bound path on the same
-// inputs and a report that says which stage's data differed between the two runs (stderr, and appended to $GPANN_VERIFY_REPORT).
+// inputs and a report that says which stage's data differed between the two runs (BoundEvidence).
 gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float* thr, const float* caller_queries,
                          bool caller_on_device) {
-    const uint32_t S = r->S, ld = r->ld, d = r->d;
+    const uint32_t S = r->S;
     const uint64_t C = r->n_centroids;
     const size_t nb_s = (size_t)nb * S;
     GPANN_TRY(r->ws_verify.Reserve(nb_s * 4 + 16));
@@ -1681,103 +1871,66 @@ gpann_status VerifyBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipS
     ++r->stat_verified;
     if (diff[0] == 0) return GPANN_OK;
     ++r->stat_verify_failures;
+    size_t bad1 = 0;
+    GPANN_TRY(BoundEvidence(r, da, nb, st, ba, thr, caller_queries, caller_on_device, "bound path differs from the canonical evaluation (GPANN_ROUTER_VERIFY)", &bad1));
+    SetLastError("router bound path failed verification: %zu of %zu minima differ from the canonical evaluation (GPANN_ROUTER_VERIFY)", bad1, nb_s);
+    return GPANN_ERR_INTERNAL;
+}
 
-    // ---- evidence: run 1's data, then the same pipeline once more on the same inputs
-    struct Snap { std::vector<uint32_t> max_bits, min_bits; std::vector<float> thr, queries; uint32_t counters[2]; };
-    auto snap = [&](Snap& s) -> hipError_t {
-        s.max_bits.resize(nb_s); s.min_bits.resize(nb_s); s.thr.resize(nb_s); s.queries.resize((size_t)nb * ld);
-        hipError_t e = hipMemcpy(s.max_bits.data(), ba.max_bits, nb_s * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s.thr.data(), thr, nb_s * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s.min_bits.data(), da.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s.queries.data(), da.queries, (size_t)nb * ld * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(s.counters, ba.cand_count, 8, hipMemcpyDeviceToHost);
+// GPANN_ROUTER_PROBE=1 (debugging aid; synchronises): the bound pipeline is run a SECOND time on the same block and everything it left —
+// pass-1 maxima, thresholds, the candidate SET, the minima — must be bit-equal to the first run's.  A difference is reported through
+// BoundEvidence (which runs the pipeline a third time) and ends the call with GPANN_ERR_INTERNAL.  Far more sensitive than the self-check:
+// it also sees disturbances that happen not to lose a minimum.
+gpann_status ProbeBoundDeterminism(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float* thr, const float* caller_queries,
+                                   bool caller_on_device) {
+    const size_t nb_s = (size_t)nb * r->S;
+    GPANN_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> max1(nb_s), min1(nb_s), max2(nb_s), min2(nb_s);
+    std::vector<float> thr1(nb_s), thr2(nb_s);
+    uint32_t c1[8], c2[8];
+    auto cands = [&](const uint32_t* counters, std::vector<uint64_t>& out) -> hipError_t {
+        std::vector<uint2> c(std::min<uint32_t>(counters[0], ba.cand_cap));
+        hipError_t e = c.empty() ? hipSuccess : hipMemcpy(c.data(), ba.cand, c.size() * 8, hipMemcpyDeviceToHost);
+        out.clear();
+        for (const uint2& x : c)
+            if (x.x != 0xFFFFFFFFu) out.push_back((uint64_t)x.x << 32 | x.y);
+        std::sort(out.begin(), out.end());
         return e;
     };
-    Snap s1, s2;
-    GPANN_HIP_TRY(snap(s1));
-    std::vector<uint2> cand1(std::min<uint32_t>(s1.counters[0], ba.cand_cap));
-    if (!cand1.empty()) GPANN_HIP_TRY(hipMemcpy(cand1.data(), ba.cand, cand1.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> want(nb_s);
-    GPANN_HIP_TRY(hipMemcpy(want.data(), dv.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost));
-    hipLaunchKernelGGL(FillMinBitsKernel, dim3(fgrid), dim3(256), 0, st, da.out_min_bits, nb_s);
-    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
+    std::vector<uint64_t> set1, set2;
+    GPANN_HIP_TRY(hipMemcpy(max1.data(), ba.max_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(thr1.data(), thr, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(min1.data(), da.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(c1, ba.cand_count, 32, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(cands(c1, set1));
+    hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+    BoundArgs ba2;
+    float* thr_b = nullptr;
+    GPANN_TRY(EnqueueBound(r, da, nb, st, ba2, thr_b));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
-    GPANN_HIP_TRY(snap(s2));
-    std::vector<float> cents((size_t)C * ld);
-    std::vector<uint32_t> cshard(C);
-    GPANN_HIP_TRY(hipMemcpy(cents.data(), r->centroids, cents.size() * 4, hipMemcpyDeviceToHost));
-    GPANN_HIP_TRY(hipMemcpy(cshard.data(), r->cent_shard, C * 4, hipMemcpyDeviceToHost));
-    std::vector<float> nhn(C);
-    GPANN_HIP_TRY(hipMemcpy(nhn.data(), r->cent_nhn, C * 4, hipMemcpyDeviceToHost));
-    std::vector<float> mu(ld, 0.f);   // the frame of the bound (zero when the router is not centred)
-    if (r->cent_mu) GPANN_HIP_TRY(hipMemcpy(mu.data(), r->cent_mu, (size_t)ld * 4, hipMemcpyDeviceToHost));
-
-    auto bits_to_float = [](uint32_t o) { uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; std::memcpy(&f, &b, 4); return f; };
-    size_t bad1 = 0, bad2 = 0, unset1 = 0, max_diff = 0, thr_diff = 0, thr_nan1 = 0, max_zero1 = 0, q_diff = 0, q_vs_caller = 0;
+    GPANN_HIP_TRY(hipMemcpy(max2.data(), ba2.max_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(thr2.data(), thr_b, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(min2.data(), da.out_min_bits, nb_s * 4, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(hipMemcpy(c2, ba2.cand_count, 32, hipMemcpyDeviceToHost));
+    GPANN_HIP_TRY(cands(c2, set2));
+    ++r->stat_probed;
+    const bool same = max1 == max2 && min1 == min2 && std::memcmp(thr1.data(), thr2.data(), nb_s * 4) == 0 && set1 == set2 && c1[1] == c2[1] && c1[4] == c2[4];
+    if (same) return GPANN_OK;
+    ++r->stat_probe_failures;
+    size_t dm = 0, dt = 0, dn = 0;
     for (size_t i = 0; i < nb_s; ++i) {
-        bad1 += s1.min_bits[i] != want[i];
-        bad2 += s2.min_bits[i] != want[i];
-        unset1 += s1.min_bits[i] == 0xFF7FFFFFu;
-        max_diff += s1.max_bits[i] != s2.max_bits[i];
-        thr_diff += std::memcmp(&s1.thr[i], &s2.thr[i], 4) != 0;
-        thr_nan1 += std::isnan(s1.thr[i]);
-        max_zero1 += s1.max_bits[i] == 0;
+        dm += max1[i] != max2[i];
+        dt += std::memcmp(&thr1[i], &thr2[i], 4) != 0;
+        dn += min1[i] != min2[i];
     }
-    for (size_t i = 0; i < s1.queries.size(); ++i) q_diff += std::memcmp(&s1.queries[i], &s2.queries[i], 4) != 0;
-    if (caller_queries && !caller_on_device)
-        for (uint32_t q = 0; q < nb; ++q)
-            for (uint32_t x = 0; x < d; ++x) q_vs_caller += std::memcmp(&s1.queries[(size_t)q * ld + x], &caller_queries[(size_t)q * d + x], 4) != 0;
-    std::string rep;
-    char line[1024];
-    snprintf(line, sizeof line,
-             "[gpann router VERIFY] bound path differs from the canonical evaluation: %zu of %zu minima (run 1), %zu (run 2 on the same inputs); run 1: %zu unset, "
-             "%zu thr NaN, %zu max_bits zero, candidates %u (cap %u), self-check counter %u; between the runs: %zu max_bits differ, %zu thr differ, %zu query words "
-             "differ; device queries vs caller's host queries: %zu words differ; nq %u S %u C %llu d %u n_seg %u\n",
-             bad1, nb_s, bad2, unset1, thr_nan1, max_zero1, s1.counters[0], ba.cand_cap, s1.counters[1], max_diff, thr_diff, q_diff, q_vs_caller, nb, S,
-             (unsigned long long)C, d, ba.n_seg);
-    rep += line;
-    int shown = 0;
-    for (size_t i = 0; i < nb_s && shown < 6; ++i) {
-        if (s1.min_bits[i] == want[i]) continue;
-        ++shown;
-        const uint32_t q = (uint32_t)(i / S), b = (uint32_t)(i % S);
-        // in double: the true acc of every centroid of the shard, the true minimiser
-        double best_acc = -1e300, best_dist = 1e300, acc_of_min = 0;
-        uint64_t arg_acc = 0, arg_min = 0, n_in = 0;
-        const float* qv = &s1.queries[(size_t)q * ld];
-        for (uint64_t c = 0; c < C; ++c) {
-            if (cshard[c] != b) continue;
-            ++n_in;
-            double dot = 0, dist = 0;
-            for (uint32_t x = 0; x < d; ++x) {
-                dot += (double)(qv[x] - mu[x]) * (double)(cents[c * ld + x] - mu[x]);
-                const double df = (double)qv[x] - cents[c * ld + x];
-                dist += df * df;
-            }
-            const double acc = r->metric == GPANN_METRIC_L2 ? dot + (double)nhn[c] : dot;
-            const double key = r->metric == GPANN_METRIC_L2 ? dist : 1.0 - dot;
-            if (acc > best_acc) { best_acc = acc; arg_acc = c; }
-            if (key < best_dist) { best_dist = key; arg_min = c; acc_of_min = acc; }
-        }
-        size_t in_list = 0, list_has_min = 0;
-        for (const uint2& qc : cand1)
-            if (qc.x == q && qc.y != 0xFFFFFFFFu && cshard[qc.y] == b) { ++in_list; list_has_min += qc.y == arg_min; }
-        snprintf(line, sizeof line,
-                 "  (q %u, shard %u, %llu centroids): got %08x (%g) want %08x (%g); run 1 max %g thr %g | run 2 max %g thr %g min %08x; host: max acc %.9g at %llu, "
-                 "minimiser %llu dist %.9g acc %.9g (%s thr 1); candidates of the pair in run 1's list: %zu, minimiser among them: %zu\n",
-                 q, b, (unsigned long long)n_in, s1.min_bits[i], bits_to_float(s1.min_bits[i]), want[i], bits_to_float(want[i]), bits_to_float(s1.max_bits[i]),
-                 s1.thr[i], bits_to_float(s2.max_bits[i]), s2.thr[i], s2.min_bits[i], best_acc, (unsigned long long)arg_acc, (unsigned long long)arg_min, best_dist,
-                 acc_of_min, acc_of_min >= (double)s1.thr[i] ? ">=" : "<", in_list, list_has_min);
-        rep += line;
-    }
-    fputs(rep.c_str(), stderr);
-    if (const char* path = std::getenv("GPANN_VERIFY_REPORT")) {
-        if (FILE* f = fopen(path, "a")) {
-            fputs(rep.c_str(), f);
-            fclose(f);
-        }
-    }
-    SetLastError("router bound path failed verification: %zu of %zu minima differ from the canonical evaluation (GPANN_ROUTER_VERIFY)", bad1, nb_s);
+    fprintf(stderr, "[gpann router PROBE] two runs of the bound pipeline on the same block differ: %zu max_bits, %zu thr, %zu minima, candidate sets %zu vs %zu, "
+                    "counters pass-1 %u / %u, unset %u / %u\n", dm, dt, dn, set1.size(), set2.size(), c1[4], c2[4], c1[1], c2[1]);
+    // (BoundEvidence takes its "run 1" from the workspaces, which now hold THIS probe's second run; its "run 2" is a third run.  The
+    // first run's arrays are summarised in the line above.)
+    size_t bad = 0;
+    GPANN_TRY(BoundEvidence(r, da, nb, st, ba2, thr_b, caller_queries, caller_on_device, "determinism probe: runs 2 and 3 of the block (GPANN_ROUTER_PROBE)", &bad));
+    ba = ba2;
+    SetLastError("router bound path is not deterministic: two runs on the same block differ in %zu max_bits, %zu thr, %zu minima (GPANN_ROUTER_PROBE)", dm, dt, dn);
     return GPANN_ERR_INTERNAL;
 }
 
@@ -1788,7 +1941,8 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     BoundArgs ba;
     float* thr = nullptr;
     GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
-    if (may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
+    if (may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK") &&
+        !std::getenv("GPANN_ROUTER_PROBE")) {
         // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
         if (!r->pinned_counters) GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_counters), 32, hipHostMallocDefault));
         GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_counters, ba.cand_count, 20, hipMemcpyDeviceToHost, st));
@@ -1818,19 +1972,19 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
                 "[gpann router] bound path self-check: pass 1 left %u of %zu (query, shard) pairs without a maximum or with a non-finite threshold, %u minima are unset "
                 "after pass 2 (%u candidate slots, cap %u); evaluating every pair canonically instead\n",
                 counters[4], nb_s, counters[1], n_cand, ba.cand_cap);
-        if (std::getenv("GPANN_ROUTER_STRICT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK")) {
-            // (for the record of a rare event — seen once in round 3 after 5 900 clean fresh-process runs: is it the inputs or the moment?  The same
-            // block once more, same inputs, before the call fails)
-            uint32_t again[5] = {0, 0, 0, 0, 0};
-            hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
-            BoundArgs ba2;
-            float* thr2 = nullptr;
-            if (EnqueueBound(r, da, nb, st, ba2, thr2) == GPANN_OK && hipMemcpyAsync(again, ba2.cand_count, 20, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                hipStreamSynchronize(st) == hipSuccess)
-                fprintf(stderr, "[gpann router] ... the same block once more: pass 1 %u, pass 2 %u, %u candidate slots\n", again[4], again[1], again[0]);
-            SetLastError("router bound path self-check fired: pass 1 %u, pass 2 %u of %zu (query, shard) pairs; a second run on the same inputs: pass 1 %u, pass 2 %u "
-                         "(GPANN_ROUTER_STRICT)", counters[4], counters[1], nb_s, again[4], again[1]);
-            return GPANN_ERR_INTERNAL;
+        const bool strict = std::getenv("GPANN_ROUTER_STRICT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK");
+        if (strict || (std::getenv("GPANN_VERIFY_REPORT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK"))) {
+            // the record of a rare event (3 in ~50 test suites of rounds 1-3, none in 7 200 stand-alone runs): the block's arrays, the same block once
+            // more on the same inputs, the canonical minima — as text and as a binary dump (BoundEvidence)
+            size_t bad = 0;
+            BoundArgs ba2 = ba;
+            float* thr2 = thr;
+            const gpann_status ev = BoundEvidence(r, da, nb, st, ba2, thr2, caller_queries, caller_on_device, "self-check fired", &bad);
+            if (strict) {
+                SetLastError("router bound path self-check fired: pass 1 %u, pass 2 %u of %zu (query, shard) pairs; %zu minima differ from the canonical "
+                             "evaluation%s (GPANN_ROUTER_STRICT)", counters[4], counters[1], nb_s, bad, ev == GPANN_OK ? "" : " [evidence incomplete]");
+                return GPANN_ERR_INTERNAL;
+            }
         }
         return GPANN_OK;
     }
@@ -1839,6 +1993,7 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
         return GPANN_OK;
     }
     if (std::getenv("GPANN_ROUTER_VERIFY")) GPANN_TRY(VerifyBound(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
+    if (std::getenv("GPANN_ROUTER_PROBE")) GPANN_TRY(ProbeBoundDeterminism(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
     hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
     GPANN_HIP_TRY(hipGetLastError());
     *settled = true;

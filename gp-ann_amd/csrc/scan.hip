@@ -1294,7 +1294,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
             hipLaunchKernelGGL(TruncateForMergeKernel, dim3((nq + 255) / 256), dim3(256), 0, st, out.dist, out.ids, out.rows, nq, nprobe, k);
     }
     GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
-    GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));   // every staged upload of this call is queued before this point
+    GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));   // the end of the device work of this call so far (uploads AND kernels: the next call on the handle waits for it; an entry point that enqueues more records it again)
     s->stage_in_flight = true;
 
     s->stats.pairs = plan.pairs;
@@ -1434,6 +1434,10 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
         hipLaunchKernelGGL(MergeListsKernel<1>, dim3((nq + 3) / 4), dim3(256), 0, st, m);
         GPANN_HIP_TRY(hipGetLastError());
         GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
+        // ev[3] = the end of ALL device work of this call on the handle (the merge reads the slot lists in ws_out: a following call on this
+        // handle — another thread, another stream — waits for it before it touches the workspaces)
+        GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));
+        s->stage_in_flight = true;
     }
     if (!dev_out) {
         GPANN_HIP_TRY(hipMemcpyAsync(out_ids, d_out_ids, n * 4, hipMemcpyDeviceToHost, st));

@@ -263,8 +263,9 @@ struct NeedArgs {
 
 // The threshold of the 8-bit pass for task t and cell j (derivation in DESIGN.md §3.1c).  With p~ = c^ + s P' + e (|e_i| <= s/2) and
 // q~ = t_q (H + L / 254) + f (|f_i| <= t_q / 508), I = 254 H.P' + L.P' (exact integers):
-//     q~.p~ = q~.c^ + (s t_q / 254) I + E,   |E| <= (s / 2) |q~|_1 + (t_q / 508) (sqrt(d) r + d s / 2)  =: E_tc
-// (r = the cell's radius: s |P'|_1 <= |p~ - c^|_1 + d s / 2 <= sqrt(d) r + d s / 2).  A row whose canonical distance is within tau has
+//     q~.p~ = q~.c^ + (s t_q / 254) I + E,   |E| <= (s / 2) |q~|_1 + (t_q / 508) (sqrt(d) r' + d s / 2)  =: E_tc
+// (s |P'|_1 <= |p~ - c^|_1 + d s / 2 <= sqrt(d) r' + d s / 2;  r' = r + 2^-23 (R + |c^|) bounds |p~ - c^| — r, the cell's radius, is taken in
+// the original coordinates, the second term is the rounding of the centred ones).  A row whose canonical distance is within tau has
 // true acc* = q~.p~ - |p~|^2/2 >= U_base (ThresholdOf without the bf16 terms), so it passes   (s t_q / 254) I + nhn_p >= B  with
 //     B = U_base - q~.c^ - E_tc - (table error) - (fp32 evaluation slack),   q~.c^ = (|q~|^2 + |c^|^2 - |q~ - c^|^2) / 2  from the cell table.
 template <int METRIC>
@@ -287,9 +288,13 @@ __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, d
     // difference between |q - c|^2 and |q~ - c^|^2 (roundings of the centred coordinates: <= 2^-22 (|q~| + |c^|) sqrt(D))
     const double cn = sqrt(nc);
     const double e_tab = 0.5 * ((dd + 8.0) * 0x1p-23 * fabs(D_table) + 0x1p-21 * (qn + cn) * sqrt(fabs(D_table)) + 0x1p-40 * (nq + nc));
-    const double E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * radius + 0.5 * dd * s_c);
+    // `radius` bounds |p - c| in the ORIGINAL coordinates (CellRadiusKernel); the plane holds the residuals of the CENTRED fp32 coordinates
+    // p~ = fl(p - mu), c^ = fl(c - mu):  |p~ - c^| <= |p - c| + 2^-24 (|p - mu| + |c - mu|) <= radius + 2^-23 (R + |c^|)   (R, |c^| are norms in the
+    // centred frame, each within 2^-24 of the exact one).  For a cell of (nearly) equal rows far from the store's mean this term IS the radius.
+    const double r_eff = radius + 0x1p-23 * (R + cn);
+    const double E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * r_eff + 0.5 * dd * s_c);
     // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2
-    const double e_fp = 0x1p-21 * (qn * (radius + sqrt(dd) * s_c) + 0.5 * R * R + 1.0);
+    const double e_fp = 0x1p-21 * (qn * (r_eff + sqrt(dd) * s_c) + 0.5 * R * R + 1.0);
     // the kernels for up to 128 dimensions evaluate the test on accumulators biased by 1.5 x 2^23 (FilterKernelCells, BIAS): V and the threshold
     // both carry 255 x 12582912 (x s0), three roundings at that magnitude (< 640 s0 in all) and the relative ones of the norm word (in e_fp) and
     // of the shifted threshold itself

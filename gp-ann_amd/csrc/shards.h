@@ -145,6 +145,7 @@ struct gpann_shards {
         float* d_mu = nullptr;
     } cells;
     bool filter_ok = false;
+    gpann_status filter_fail_status = GPANN_OK;   // why BuildCells gave up (cells.hip): GPANN_ERR_OOM (an allocation), GPANN_ERR_HIP (a device / kernel error), GPANN_ERR_INTERNAL (no cells)
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
     // per-call workspace, grown on demand and reused

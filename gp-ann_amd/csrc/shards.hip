@@ -226,9 +226,11 @@ gpann_status gpann_shards_build_filter(gpann_shards* s) {
         SetLastError("the store's data is not fit for the filter (non-finite values or d > 256)");
         return GPANN_ERR_UNSUPPORTED;
     }
+    s->filter_fail_status = GPANN_OK;
     GPANN_TRY(BuildCells(s, DefaultCellRows(s)));
-    // asked for explicitly: a store that still has no filter data is an error here (gpann_last_error() names the step that failed)
-    if (s->cells.n_cells == 0 || s->frag_planes == nullptr) return GPANN_ERR_OOM;
+    // asked for explicitly: a store that still has no filter data is an error here (gpann_last_error() names the step that failed; the status
+    // says what kind: GPANN_ERR_OOM an allocation, GPANN_ERR_HIP a device / kernel error, GPANN_ERR_INTERNAL no cells)
+    if (s->cells.n_cells == 0 || s->frag_planes == nullptr) return s->filter_fail_status != GPANN_OK ? s->filter_fail_status : GPANN_ERR_OOM;
     return GPANN_OK;
 }
 

@@ -10,7 +10,7 @@ from . import LIB_PATH, GpannError, OK
 
 COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpann_comm.so")
 RCCL, TCP = 0, 1
-EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_init_from_env_on", "gpann_comm_destroy", "gpann_comm_abort", "gpann_comm_wait", "gpann_comm_info", "gpann_comm_backend_name",
+EXPORTS = ["gpann_comm_last_error", "gpann_comm_init", "gpann_comm_init_from_env", "gpann_comm_init_from_env_on", "gpann_comm_destroy", "gpann_comm_abort", "gpann_comm_wait", "gpann_comm_check_peers", "gpann_comm_info", "gpann_comm_backend_name",
            "gpann_comm_barrier", "gpann_comm_max_double", "gpann_comm_allgather_host", "gpann_comm_broadcast_host", "gpann_comm_broadcast",
            "gpann_comm_allgather", "gpann_comm_gather_slots_scratch", "gpann_comm_gather_slots", "gpann_comm_debug_select_slots", "gpann_lpt_owner", "gpann_mask_probes", "gpann_plan_replicas", "gpann_mask_probes_replicated",
            "gpann_comm_merge_router"]
@@ -32,6 +32,7 @@ def lib():
         L.gpann_comm_destroy.argtypes = [C.c_void_p]
         L.gpann_comm_abort.argtypes = [C.c_void_p]
         L.gpann_comm_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.gpann_comm_check_peers.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.gpann_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpann_comm_barrier.argtypes = [C.c_void_p]
         L.gpann_comm_max_double.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -159,10 +160,15 @@ class Comm:
             self.h = C.c_void_p()
 
     def wait(self, stream=None, timeout_s=600):
-        """wait for the collectives enqueued on `stream` (RCCL) while watching the other ranks: raises GpannError when a rank has left, RCCL
-        reports an asynchronous error or nothing completes within timeout_s (this rank's RCCL side is then aborted) — instead of a stream
-        synchronise that would never return"""
+        """wait for the collectives enqueued on `stream` (RCCL).  Completed work is a success whatever the peers did afterwards; while the
+        work is pending the other ranks are watched: raises GpannError when a rank has left, RCCL reports an asynchronous error or nothing
+        completes within timeout_s (this rank's RCCL side is then aborted) — instead of a stream synchronise that would never return"""
         _check(lib().gpann_comm_wait(self.h, C.c_void_p(stream or 0), int(timeout_s)))
+
+    def check_peers(self):
+        """raises GpannError if a rank has hung up (gpann_comm_check_peers); never blocks"""
+        lost = C.c_int(-1)
+        _check(lib().gpann_comm_check_peers(self.h, C.byref(lost)))
 
     def __del__(self):
         try:

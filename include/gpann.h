@@ -99,7 +99,9 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
 gpann_status gpann_shards_destroy(gpann_shards* s);
 /* Builds the filter support data (bf16 planes grouped by cell, radii) of a store created with GPANN_STORE_PLAIN — i.e. in a second step,
  * after the caller has released its own copy of the points: at 100M x 200 the rows are 80 GB and the planes 102 GB, and three copies
- * do not fit one GPU.  No-op if the data is already there; GPANN_ERR_UNSUPPORTED if the store's data is unfit (non-finite, d > 256). */
+ * do not fit one GPU.  No-op if the data is already there; GPANN_ERR_UNSUPPORTED if the store's data is unfit (non-finite, d > 256).
+ * If the data still cannot be built the status names the kind of failure — GPANN_ERR_OOM: an allocation (retry with less resident),
+ * GPANN_ERR_HIP: a device / kernel error, GPANN_ERR_INTERNAL: the cell clustering produced no cells — and gpann_last_error() the step. */
 gpann_status gpann_shards_build_filter(gpann_shards* s);
 /* rows = sum of shard sizes; any out pointer may be NULL */
 gpann_status gpann_shards_info(const gpann_shards* s, uint64_t* rows, uint32_t* d, uint32_t* S, int* metric, int* device);
@@ -223,6 +225,8 @@ typedef struct gpann_router_stats {
     uint64_t heap_redo;         /* queries replayed with the real priority queue after a sorted / threshold replay */
     double last_bound_ms;       /* most recent call: HIP-event time of its RouterBoundKernel launches (pass 1 + margins + pass 2) */
     double last_bound_flops;    /* most recent call: matrix-core flops of those launches, 2 passes x 3 bf16 products x 2 nq C d */
+    uint64_t probed;            /* GPANN_ROUTER_PROBE=1 (debugging aid): blocks whose bound pipeline was run twice on the same inputs ... */
+    uint64_t probe_failures;    /* ... and whose two runs differed in any bit (maxima, thresholds, candidate set, minima): GPANN_ERR_INTERNAL */
 } gpann_router_stats;
 gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* out);
 

@@ -43,7 +43,9 @@ typedef struct gpann_comm gpann_comm;
 
 const char* gpann_comm_last_error(void);
 
-/* device: HIP device of this rank (RCCL backend; ignored by TCP).  timeout_s: how long to wait for the other ranks to show up. */
+/* device: HIP device of this rank (RCCL backend; ignored by TCP) — the communicator lives there, and on return it IS the calling thread's
+ * current HIP device (a rank process that has not touched HIP yet selects its GPU through this call; a caller that keeps its buffers on
+ * another device must pass THAT device, or call hipSetDevice itself afterwards).  timeout_s: how long to wait for the other ranks. */
 gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int port, int backend, int device, int timeout_s, gpann_comm** out);
 /* RANK, WORLD_SIZE, MASTER_ADDR, GPANN_COMM_PORT (default MASTER_PORT + 1), LOCAL_RANK (device), GPANN_COMM_TIMEOUT (seconds to wait for
  * the other ranks, default 600: the first `import torch` of a rank on a fresh machine can take minutes) from the environment */
@@ -55,12 +57,17 @@ gpann_status gpann_comm_destroy(gpann_comm* c);
 /* Failure handling (the reference relies on mpirun tearing the job down; distributed_bench.cpp has none).
  * gpann_comm_abort: for a rank that leaves after an error — the communicator is torn down WITHOUT waiting for outstanding collectives
  * (ncclCommAbort; ncclCommDestroy may block on them), the bootstrap connections are closed, which is how the other ranks notice; frees c.
- * gpann_comm_wait: wait for the work enqueued on `stream` (RCCL backend; TCP: nothing to wait for) while watching the bootstrap connections,
- * for at most timeout_s seconds.  When a rank has hung up, RCCL reports an asynchronous error or the time is over, this rank's RCCL side
- * is aborted — the collective it waits for would never complete — and an error is returned; the handle stays valid for gpann_comm_abort /
- * gpann_comm_destroy only.  Use it instead of a bare stream synchronise after gpann_comm_broadcast / _allgather / _gather_slots. */
+ * gpann_comm_wait: wait for the work enqueued on `stream` (RCCL backend; TCP: nothing to wait for) for at most timeout_s seconds.  Work that
+ * HAS COMPLETED is a success whatever the other ranks did afterwards (a peer that finished the same collective and left a moment earlier is
+ * not an error of this call).  While the work is pending the bootstrap connections and RCCL's asynchronous error state are watched: when a
+ * rank has hung up, RCCL reports an error or the time is over, this rank's RCCL side is aborted — the collective it waits for would never
+ * complete — and an error is returned; the handle then stays valid for gpann_comm_abort / gpann_comm_destroy only.  Use it instead of a bare
+ * stream synchronise after gpann_comm_broadcast / _allgather / _gather_slots.
+ * gpann_comm_check_peers: has a rank hung up?  GPANN_OK and *lost_rank = -1 if all bootstrap connections are alive; otherwise
+ * GPANN_ERR_INTERNAL and the rank (rank 0 sees every rank, the others only rank 0).  Never blocks, touches neither the stream nor RCCL. */
 gpann_status gpann_comm_abort(gpann_comm* c);
 gpann_status gpann_comm_wait(gpann_comm* c, void* stream, int timeout_s);
+gpann_status gpann_comm_check_peers(gpann_comm* c, int* lost_rank /* may be NULL */);
 gpann_status gpann_comm_info(const gpann_comm* c, int* rank, int* world, int* backend);
 /* "rccl <version>" / "tcp": what the JSON line of bench.py reports as the backend that actually ran */
 const char* gpann_comm_backend_name(const gpann_comm* c);

@@ -67,15 +67,29 @@ def data(orc, tmp_path_factory):
     return dict(tmp=tmp, files=f, nq=nq, k=k, want_d=md.reshape(nq, k), want_i=mi.reshape(nq, k), recall=recall)
 
 
-def _run(data, world, backend, tag, router_name):
+def _gpu_count():
+    """GPUs of this box without initialising HIP in the pytest process (device_count() does not, on this image)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank=False, **extra):
+    dev = str(rank) if one_gpu_per_rank else "0"
+    return dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=dev, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPANN_COMM_BACKEND=backend,
+                GPANN_DIST_DEVICE=dev, GPANN_DIST_OUT=out, GPANN_DIST_REPS="2", GPANN_ROUTER_VERIFY="1", GPANN_ROUTER_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+
+
+def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False):
     f = data["files"]
     out = str(data["tmp"] / f"out_{tag}.bin")
     router = str(data["tmp"] / router_name)
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   GPANN_COMM_BACKEND=backend, GPANN_DIST_DEVICE="0", GPANN_DIST_OUT=out, GPANN_DIST_REPS="2", GPANN_ROUTER_VERIFY="1", GPANN_ROUTER_STRICT="1")
+        env = _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank)
         procs.append(subprocess.Popen([DB, f["points"], f["queries"], f["gt"], str(data["k"]), f["part"], router], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -111,6 +125,50 @@ def test_ranks_sharing_one_gpu_over_tcp(data, world):
     single = str(data["tmp"] / "router_r1.tree")
     if os.path.exists(single):
         assert a == open(single, "rb").read()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the 1-GPU boxes of rounds 1-4 skip this)")
+def test_two_rank_rccl(data):
+    """The N > 1 RCCL path itself — ncclCommInitRank with world 2, ncclBroadcast of the query block, the probe all-gather, the grouped
+    all-gather of the slot lists and the owner selection — one rank per GPU over xGMI: neighbours of all queries bit-identical to the CPU
+    oracle's single-process result, the tree trained part by part identical to the single-rank tree."""
+    line = _run(data, 2, "rccl", "rccl2", "router_rccl2.tree", one_gpu_per_rank=True)
+    assert line.startswith("backend rccl ") and "ranks 2" in line
+    single = str(data["tmp"] / "router_r1.tree")
+    if os.path.exists(single):
+        assert open(str(data["tmp"] / "router_rccl2.tree"), "rb").read() == open(single, "rb").read()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (see test_two_rank_rccl)")
+def test_two_rank_rccl_a_rank_dies_mid_run(data):
+    """Failure handling of the RCCL path (gpann_comm_wait's ncclCommGetAsyncError / lost-peer branch, ncclCommAbort): rank 1 is killed while
+    the ranks loop over batches; rank 0 must come back from its collective through gpann_comm_wait within GPANN_COMM_WAIT_S instead of hanging
+    in RCCL, and end with an error that names the reason."""
+    import signal
+    import time
+    f = data["files"]
+    out = str(data["tmp"] / "out_rccl2_dead.bin")
+    router = str(data["tmp"] / "router_rccl2.tree")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = _rank_env(data, rank, 2, "rccl", port, out, True, GPANN_COMM_WAIT_S="10")
+        env["GPANN_DIST_REPS"] = "200000"   # (keeps the ranks in the batch loop until rank 1 is killed)
+        procs.append(subprocess.Popen([DB, f["points"], f["queries"], f["gt"], str(data["k"]), f["part"], router], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    time.sleep(20.0)   # set-up (store build, training or tree load, RCCL init) is over, the batch loop is running
+    assert procs[1].poll() is None and procs[0].poll() is None, "a rank ended before it could be killed: " + str([p.poll() for p in procs])
+    procs[1].send_signal(signal.SIGKILL)
+    t0 = time.time()
+    try:
+        so, se = procs[0].communicate(timeout=90)
+    except subprocess.TimeoutExpired:
+        procs[0].kill()
+        pytest.fail("rank 0 hung after rank 1 was killed (gpann_comm_wait did not abandon the collective)")
+    procs[1].communicate()
+    assert procs[0].returncode != 0
+    assert time.time() - t0 < 60.0
+    assert "collective abandoned" in se or "has left" in se or "connection" in se, se[-2000:]
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -154,3 +212,30 @@ def test_owner_selection_kernels_on_a_fabricated_world(gp, world):
     got_d2, got_i2 = gcomm.debug_select_slots(rank_dist.reshape(world, n), rank_ids.reshape(world, n))
     sel = rank_ids.reshape(world, n)
     assert np.array_equal(got_i2, np.where((sel != 0xFFFFFFFF).any(axis=0), sel.min(axis=0), 0xFFFFFFFF).astype(np.uint32))
+
+
+def test_one_rank_rccl_wait_and_abort(gp):
+    """gpann_comm_wait / gpann_comm_abort on the RCCL backend (one rank, in-process): a wait on enqueued collectives returns once they
+    have completed and leaves their results in place; a wait with nothing pending is a success; abort tears the communicator down without
+    a farewell collective (ncclCommAbort) and the handle is gone afterwards."""
+    import torch
+    from pygpann import comm as gcomm
+    port = _free_port()
+    comm = gcomm.Comm(gcomm.RCCL, rank=0, world=1, addr="127.0.0.1", port=port + 1, device=0)
+    assert comm.name.startswith("rccl") and comm.world == 1
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    send = torch.arange(1 << 20, dtype=torch.int32, device=dev)
+    recv = torch.zeros_like(send)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(8):
+            comm.allgather(send.data_ptr(), recv.data_ptr(), send.numel() * 4, stream.cuda_stream)
+    comm.wait(stream.cuda_stream, 30)          # pending -> completed
+    assert stream.query()
+    assert torch.equal(send, recv)
+    comm.wait(stream.cuda_stream, 1)           # nothing pending: at once
+    comm.check_peers()
+    comm.abort()
+    assert not comm.h.value
+    comm.abort()                               # idempotent on a released handle

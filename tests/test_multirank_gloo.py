@@ -140,14 +140,16 @@ def _abort_worker(rank, world, comm_port, out_dir):
     comm = gcomm.Comm(gcomm.TCP, rank=rank, world=world, addr="127.0.0.1", port=comm_port)
     comm.barrier()
     comm.wait(None, 5)                      # every rank alive, nothing enqueued: returns at once
+    comm.check_peers()
     if rank == 1:
         comm.abort()                        # "this rank failed": no farewell collective, the connections are closed
         return
     t0 = time.time()
     lost, msg = False, ""
-    while time.time() - t0 < 20.0:          # rank 0 notices without taking part in a collective, long before the 60 s it is willing to wait
+    while time.time() - t0 < 20.0:          # rank 0 notices without taking part in a collective
+        comm.wait(None, 60)                 # (nothing pending: a success whatever rank 1 has done meanwhile — completed work is never an error)
         try:
-            comm.wait(None, 60)
+            comm.check_peers()
             time.sleep(0.05)
         except GpannError as e:
             lost, msg = True, str(e)

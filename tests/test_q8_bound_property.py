@@ -43,8 +43,9 @@ def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius):
     qc = 0.5 * (nq + nc - D_table)
     cn = np.sqrt(nc)
     e_tab = 0.5 * ((d + 8.0) * 2.0 ** -23 * abs(D_table) + 2.0 ** -21 * (qn + cn) * np.sqrt(abs(D_table)) + 2.0 ** -40 * (nq + nc))
-    E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (np.sqrt(d) * radius + 0.5 * d * s_c)
-    e_fp = 2.0 ** -21 * (qn * (radius + np.sqrt(d) * s_c) + 0.5 * R * R + 1.0)
+    r_eff = radius + 2.0 ** -23 * (R + cn)          # |p~ - c^| <= |p - c| + the rounding of the centred coordinates
+    E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (np.sqrt(d) * r_eff + 0.5 * d * s_c)
+    e_fp = 2.0 ** -21 * (qn * (r_eff + np.sqrt(d) * s_c) + 0.5 * R * R + 1.0)
     Bd0 = Ub - qc - E - e_tab - e_fp
     Bd = Bd0 - 1024.0 * s_c * tscale / 254.0 * (1.0 + 1e-6) - 2.0 ** -22 * abs(Bd0)
     Bf = f32(Bd)
@@ -56,21 +57,36 @@ def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius):
 def make_cell(rng, n, d, centre_offset, sigma, outliers):
     c_true = rng.standard_normal(d) * 1.0 + centre_offset
     pts = (c_true + sigma * rng.standard_normal((n, d))).astype(f32)
+    if sigma == 0.0:
+        return pts
     for _ in range(outliers):
         pts[rng.integers(0, n), rng.integers(0, d)] += f32(40.0 * sigma)
     return pts
 
 
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("case", ["plain", "offset", "outliers", "tiny", "huge"])
+@pytest.mark.parametrize("case", ["plain", "offset", "outliers", "tiny", "huge", "degenerate", "degenerate_ulp"])
 def test_rows_within_tau_pass_the_8_bit_test(metric, case):
-    rng = np.random.default_rng(1000 * metric + ["plain", "offset", "outliers", "tiny", "huge"].index(case))
+    cases = ["plain", "offset", "outliers", "tiny", "huge", "degenerate", "degenerate_ulp"]
+    rng = np.random.default_rng(1000 * metric + cases.index(case))
     d, n, nq = 48, 640, 24
     scale = {"tiny": 1e-3, "huge": 3e3}.get(case, 1.0)
     off = 100.0 if case == "offset" else 0.0
-    pts = make_cell(rng, n, d, off, 0.35 * scale, 12 if case == "outliers" else 0)
-    others = make_cell(rng, 2000, d, off, 3.0 * scale, 0)                       # the rest of the store: sets the frame and R
-    queries = (pts[rng.integers(0, n, nq)] + (0.3 * scale * rng.standard_normal((nq, d))).astype(f32)).astype(f32)
+    degenerate = case.startswith("degenerate")
+    if degenerate:
+        # a cell of equal rows (radius 0 in the original coordinates), or of rows that differ by an ulp or two of their coordinates, FAR from
+        # the store's mean: the quantisation step is tiny or the 1e-30 clamp, and |p~ - c^| is made of the roundings of the centred
+        # coordinates alone — the term Q8Threshold carries explicitly (r_eff)
+        base = (rng.standard_normal(d) + 100.0).astype(f32)
+        pts = np.tile(base, (n, 1))
+        if case == "degenerate_ulp":
+            pts = (pts.astype(np.float64) + 1e-5 * rng.standard_normal((n, d))).astype(f32)   # (spacing of floats near 100: 7.6e-6)
+        others = make_cell(rng, 2000, d, 0.0, 3.0, 0)                           # the rest of the store sits around the origin
+        queries = (pts[rng.integers(0, n, nq)].astype(np.float64) + rng.choice([0.0, 1e-5, 0.3], nq)[:, None] * rng.standard_normal((nq, d))).astype(f32)
+    else:
+        pts = make_cell(rng, n, d, off, 0.35 * scale, 12 if case == "outliers" else 0)
+        others = make_cell(rng, 2000, d, off, 3.0 * scale, 0)                       # the rest of the store: sets the frame and R
+        queries = (pts[rng.integers(0, n, nq)] + (0.3 * scale * rng.standard_normal((nq, d))).astype(f32)).astype(f32)
     store = np.vstack([pts, others])
     # the frame (cells.hip: the store's mean row for squared L2, none for the inner product)
     mu = store.astype(np.float64).mean(axis=0).astype(f32) if metric == 0 else np.zeros(d, f32)
@@ -81,7 +97,8 @@ def test_rows_within_tau_pass_the_8_bit_test(metric, case):
     s_c = up32(max(float(np.abs(res).max()) * (1.0 + 1e-6) / 127.0, 1e-30))
     Pq = np.clip(np.rint((pt.astype(np.float64) - ct.astype(np.float64)) / float(s_c)), -127, 127).astype(np.int64)
     nhn = (-0.5 * (pt.astype(np.float64) ** 2).sum(axis=1)).astype(f32) if metric == 0 else np.zeros(n, f32)
-    radius = float(np.sqrt(((pt.astype(np.float64) - ct.astype(np.float64)) ** 2).sum(axis=1)).max()) * (1.0 + 1e-6)
+    # CellRadiusKernel: max |p - c| in the ORIGINAL coordinates (double), x (1 + 1e-6), rounded up to a float
+    radius = float(up32(float(np.sqrt(((pts.astype(np.float64) - c.astype(np.float64)) ** 2).sum(axis=1)).max()) * (1.0 + 1e-6)))
     R = float(np.sqrt((((store - mu).astype(f32).astype(np.float64)) ** 2).sum(axis=1)).max()) * (1.0 + 1e-12)
     nc = float((ct.astype(np.float64) ** 2).sum())
     # tiles of 32 rows in the order of the norm words (RowsByNorm) — and in slab order: the tile test must hold either way
@@ -101,7 +118,7 @@ def test_rows_within_tau_pass_the_8_bit_test(metric, case):
             for x in range(d):                                                      # CellDistKernel: plain fp32 sum of squared fp32 differences
                 df = f32(q[x] - c[x])
                 D_table = f32(D_table + f32(df * df))
-            for tau in (float(np.sort(E)[9]), float(np.sort(E)[0]), float(np.sort(E)[n // 2]), float(np.sort(E)[9]) * 1.5):
+            for tau in (float(np.sort(E)[9]), float(np.sort(E)[0]), float(np.sort(E)[n // 2]), float(np.sort(E)[9]) * 1.5 + (1e-9 if degenerate else 0.0)):
                 B = q8_threshold(metric, tau, nqd, q1, float(t_q), R, float(d), float(D_table), nc, float(s_c), radius)
                 h = Pq @ H
                 l = Pq @ L

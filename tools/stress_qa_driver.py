@@ -47,7 +47,7 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         print("run", i, "failed:", r.stderr[-500:])
         bad += 1
         continue
-    if "VERIFY" in r.stderr or "minima unset" in r.stderr:
+    if any(w in r.stderr for w in ("VERIFY", "minima unset", "EVIDENCE", "PROBE", "self-check")):
         bad += 1
         print("run", i, "router report:", r.stderr[-3000:], flush=True)
     lines = probe_lines(out + ".routes")
