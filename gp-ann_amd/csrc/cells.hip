@@ -293,6 +293,45 @@ __global__ void __launch_bounds__(256) CellQ8PlaneKernel(const float* points, co
     }
 }
 
+// The 8-bit passes' norm words (squared L2; shards.h q8_norm): per plane row  -|p~|^2/2 + c^.e,  e = (p~ - c^) - s P' with P' READ BACK from the
+// plane (so e is exactly the error of what the kernels multiply), all in double, rounded once to a float; -inf on padding rows.  One wavefront
+// per plane row.
+__global__ void __launch_bounds__(256) CellQ8NormKernel(const float* points, const uint32_t* plane_perm, const uint64_t* cell_tile_begin, const uint32_t* row_cell,
+                                                        const float* center, const float* mu, const float* scale, uint32_t d, uint32_t ld, uint32_t q8_ks,
+                                                        const char* planes, uint64_t plane_rows, float* q8_norm) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_id = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave_id; r < plane_rows; r += n_waves) {
+        const uint32_t row = plane_perm[r];
+        if (row == kNoRow) {
+            if (lane == 0) q8_norm[r] = -INFINITY;
+            continue;
+        }
+        const uint32_t cell = row_cell[r >> 5];   // (a tile belongs to one cell)
+        const float* c = center + (size_t)cell * ld;
+        const double sc = (double)scale[cell];
+        const char* tile = planes + (r >> 5) * ((uint64_t)q8_ks * 1024);
+        double acc = 0.0;
+        for (uint32_t x = lane; x < d; x += 64) {
+            const float pv = mu ? points[(size_t)row * ld + x] - mu[x] : points[(size_t)row * ld + x];
+            const float cv = mu ? c[x] - mu[x] : c[x];
+            const int P = (int)(int8_t)tile[(x >> 5) * 1024 + ((uint32_t)(r & 31) + 32u * ((x >> 4) & 1u)) * 16 + (x & 15u)];
+            const double e = ((double)pv - (double)cv) - sc * (double)P;
+            acc += -0.5 * (double)pv * (double)pv + (double)cv * e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) q8_norm[r] = (float)acc;
+    }
+}
+// tile -> cell of the cell tiles (one thread per cell writes its tiles' entries)
+__global__ void TileCellKernel(const uint64_t* cell_tile_begin, uint32_t n_cells, uint32_t* row_cell) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    for (uint64_t t = cell_tile_begin[cell]; t < cell_tile_begin[cell + 1]; ++t) row_cell[t] = cell;
+}
+
 // per 32-row tile of the 8-bit plane, what its products' first half is tested against (scan_cells.h, quick8): .x the largest norm word of
 // its rows (-inf rows: padding; 0 for the inner product, whose test has no norm word), .y = 127 max_row sum_i |P'_i| >= |L.P'| for every
 // int8 query plane L.  One wavefront per tile: lane (c, h) holds 16 dimensions of row c per k-step.
@@ -322,7 +361,7 @@ __global__ void __launch_bounds__(64) TileBoundKernel(const float* plane_norm, c
 void ReleaseCells(gpann_shards* s) {
     auto& c = s->cells;
     for (void* p : {(void*)c.d_shard_cell_begin, (void*)c.d_cell_tile_begin, (void*)c.d_center, (void*)c.d_radius, (void*)c.d_cnorm, (void*)c.plane_perm,
-                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.d_cell_hi_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_bound})
+                    (void*)c.plane_norm, (void*)c.d_mu, (void*)c.d_cell_lo_begin, (void*)c.d_cell_hi_begin, (void*)c.q8_planes, (void*)c.d_q8_scale, (void*)c.d_q8_cnorm, (void*)c.d_tile_bound, (void*)c.q8_norm})
         if (p) (void)hipFree(p);
     c = gpann_shards::Cells{};
 }
@@ -454,11 +493,15 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
             C.q8_ks = (s->d + 31) / 32;
             const bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
                              hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_bound, (C.n_tiles + 2) * 8) == hipSuccess &&
-                             hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess;
+                             hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess &&
+                             // (GPANN_FILTER_Q8_CELL_FRAME=0 at store build: the plain norm words and the looser (s/2) |q~|_1 error term of round 3)
+                             (s->metric != GPANN_METRIC_L2 || (std::getenv("GPANN_FILTER_Q8_CELL_FRAME") && std::getenv("GPANN_FILTER_Q8_CELL_FRAME")[0] == '0') ||
+                              hipMalloc(&C.q8_norm, ((C.n_tiles + 2) * kGTileRows + 64) * 4) == hipSuccess);
             if (!qok) {   // the store works without it
                 (void)hipGetLastError();
-                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_bound})
+                for (void* p : {(void*)C.q8_planes, (void*)C.d_q8_scale, (void*)C.d_q8_cnorm, (void*)C.d_tile_bound, (void*)C.q8_norm})
                     if (p) (void)hipFree(p);
+                C.q8_norm = nullptr;
                 C.q8_planes = nullptr;
                 C.d_q8_scale = nullptr;
                 C.d_q8_cnorm = nullptr;
@@ -607,7 +650,21 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
                            C.d_q8_cnorm);
         hipLaunchKernelGGL(CellQ8PlaneKernel, dim3(C.n_cells), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, C.d_center, C.d_mu, C.d_q8_scale, ld, C.q8_ks,
                            C.q8_planes);
-        hipLaunchKernelGGL(TileBoundKernel, dim3((uint32_t)(C.n_tiles + 2)), dim3(64), 0, 0, C.plane_norm, C.q8_planes, C.q8_ks, C.n_tiles + 2,
+        if (C.q8_norm) {   // squared L2: the 8-bit passes' own norm words (shards.h)
+            uint32_t* d_tile_cell = nullptr;
+            bool nok = hipMalloc(&d_tile_cell, (C.n_tiles + 2) * 4) == hipSuccess && hipMemset(d_tile_cell, 0, (C.n_tiles + 2) * 4) == hipSuccess &&
+                       hipMemset(C.q8_norm + (C.n_tiles + 2) * kGTileRows, 0, 64 * 4) == hipSuccess;
+            if (nok) {
+                hipLaunchKernelGGL(TileCellKernel, dim3((C.n_cells + 255) / 256), dim3(256), 0, 0, C.d_cell_tile_begin, C.n_cells, d_tile_cell);
+                // (the two zero tiles behind the cell tiles: perm = kNoRow there -> -inf, like plane_norm)
+                hipLaunchKernelGGL(CellQ8NormKernel, dim3(4096), dim3(256), 0, 0, s->points, C.plane_perm, C.d_cell_tile_begin, d_tile_cell, C.d_center, C.d_mu, C.d_q8_scale,
+                                   s->d, ld, C.q8_ks, C.q8_planes, (C.n_tiles + 2) * kGTileRows, C.q8_norm);
+                nok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            }
+            if (d_tile_cell) (void)hipFree(d_tile_cell);
+            if (!nok) return give_up("8-bit norm words");
+        }
+        hipLaunchKernelGGL(TileBoundKernel, dim3((uint32_t)(C.n_tiles + 2)), dim3(64), 0, 0, C.q8_norm ? C.q8_norm : C.plane_norm, C.q8_planes, C.q8_ks, C.n_tiles + 2,
                            s->metric == GPANN_METRIC_L2 ? 1 : 0, C.d_tile_bound);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return give_up("8-bit plane");
     }

@@ -535,6 +535,14 @@ __global__ void CountUnsetMinBitsKernel(const uint32_t* bits, size_t n, uint32_t
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n && bits[i] == 0xFF7FFFFFu && shard_has_cent[i % S] != 0u) atomicAdd(unset, 1u);
 }
+// ... the same and, in the same pass, the ordered bits -> floats (the shipping path of the bound: one launch instead of two)
+__global__ void CountUnsetAndConvertKernel(uint32_t* io, size_t n, uint32_t S, const uint32_t* shard_has_cent, uint32_t* unset) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = io[i];
+    if (o == 0xFF7FFFFFu && shard_has_cent[i % S] != 0u) atomicAdd(unset, 1u);
+    io[i] = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+}
 __global__ void MinBitsToFloatKernel(uint32_t* io, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1591,9 +1599,21 @@ __global__ void DiffBitsKernel(const uint32_t* a, const uint32_t* b, size_t n, u
     }
 }
 
+// The workspace of a bound block in ONE launch (three runtime memsets and the caller's FillMinBitsKernel were four): pass-1 maxima -> 0, the
+// candidate list -> (~0, ~0) = unused slot, the counters -> 0, the block's minima -> OrderedBits(FLT_MAX).
+__global__ void __launch_bounds__(256) BoundInitKernel(uint32_t* max_bits, size_t nb_s, uint2* cand, size_t cand_cap, uint32_t* counters, uint32_t* min_bits) {
+    const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < nb_s; i += stride) {
+        max_bits[i] = 0u;
+        min_bits[i] = 0xFF7FFFFFu;
+    }
+    for (size_t i = i0; i < cand_cap; i += stride) cand[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (i0 < 8) counters[i0] = 0u;
+}
+
 // Enqueues pass 1, the margins, pass 2, the canonical evaluation of the candidates and the unset-minima count for the query block of
-// `da` (whose out_min_bits the caller has filled with OrderedBits(FLT_MAX)).  On return `ba` describes the workspace that was used.
-gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float*& thr) {
+// `da` (whose out_min_bits are set to OrderedBits(FLT_MAX) here).  On return `ba` describes the workspace that was used.
+gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hipStream_t st, BoundArgs& ba, float*& thr, bool convert_minima = false) {
     const uint32_t S = r->S, ld = r->ld;
     const uint64_t C = r->n_centroids;
     const size_t nb_s = (size_t)nb * S;
@@ -1625,9 +1645,10 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     // one round of workgroups: (query groups) x (centroid segments) <= the CUs (a workgroup per CU, 132 KiB of LDS each) — 40 groups x 8
     // segments = 320 workgroups on 256 CUs ran as 256 + 64, i.e. at the pace of 160
     ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), std::max(1u, (uint32_t)r->num_cus / groups)));
-    GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
-    GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 32, st));   // [0] candidate slots, [1] unset minima after pass 2, [2..3] (verify mode), [4] pairs pass 1 left without a maximum / a finite threshold
-    GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
+    // counters: [0] candidate slots, [1] unset minima after pass 2, [2..3] (verify mode), [4] pairs pass 1 left without a maximum / a finite threshold
+    hipLaunchKernelGGL(BoundInitKernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)cand_cap + 255) / 256)), dim3(256), 0, st, ba.max_bits, nb_s, ba.cand, (size_t)cand_cap,
+                       ba.cand_count, da.out_min_bits);
+    GPANN_HIP_TRY(hipGetLastError());
     const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
     const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
     const void *f1, *f2;
@@ -1654,7 +1675,9 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
                             r->cent_shard, da.out_min_bits, S, r->d, ld);
     GPANN_HIP_TRY(hipGetLastError());
     // self-check: after a full visit every shard with centroids has a minimum.  (cand_count + 1 = the counter)
-    hipLaunchKernelGGL(CountUnsetMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent, ba.cand_count + 1);
+    // (convert_minima: the minima leave as floats — nobody is going to look at their bits again)
+    if (convert_minima) hipLaunchKernelGGL(CountUnsetAndConvertKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent, ba.cand_count + 1);
+    else hipLaunchKernelGGL(CountUnsetMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s, S, r->shard_has_cent, ba.cand_count + 1);
     GPANN_HIP_TRY(hipGetLastError());
     return GPANN_OK;
 }
@@ -1940,14 +1963,13 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     const size_t nb_s = (size_t)nb * r->S;
     BoundArgs ba;
     float* thr = nullptr;
-    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr));
-    if (may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK") &&
-        !std::getenv("GPANN_ROUTER_PROBE")) {
+    const bool defer = may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK") &&
+                       !std::getenv("GPANN_ROUTER_PROBE");
+    GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr, /*convert_minima=*/defer));
+    if (defer) {
         // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
         if (!r->pinned_counters) GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->pinned_counters), 32, hipHostMallocDefault));
         GPANN_HIP_TRY(hipMemcpyAsync(r->pinned_counters, ba.cand_count, 20, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
-        GPANN_HIP_TRY(hipGetLastError());
         r->pending_bound.active = true;
         r->pending_bound.nb = nb;
         r->pending_bound.cand_cap = ba.cand_cap;
@@ -2098,16 +2120,15 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             if (min_only) {
                 // the budget exceeds the tree and nobody asked for the evaluated distances: the per-shard minima are the whole answer
                 const size_t nb_s = (size_t)nb * S;
-                hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                 const char* bmode = std::getenv("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
                 if (r->cent_planes && !(bmode && bmode[0] == '0') && !r->canonical_once) {
-                    // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h)
+                    // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h; its init launch sets the minima to FLT_MAX)
                     bool settled = false;
                     GPANN_TRY(RunBoundPath(r, da, nb, st, &settled, queries + (size_t)q0 * r->d, (flags & GPANN_QUERIES_ON_DEVICE) != 0, /*may_defer=*/nb == nq));
                     if (settled) continue;
                     // (masses of equal distances / self-check) fall through to the canonical evaluation of every pair
-                    hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                 }
+                hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
                 if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, true>), dgrid, dim3(256), dlds, st, da);
                 else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, true>), dgrid, dim3(256), dlds, st, da);
                 hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);

@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <vector>
 
+#define CS(s) ((s)->cs[(s)->cur])   // the per-call host state of the call in progress (shards.h)
+
 namespace gpann {
 
 constexpr int kQT = 64;          // queries (tasks) per unit
@@ -345,7 +347,7 @@ __global__ void ShardHitsKernel(const float* dist, const uint32_t* ids, const fl
 // host -> device copy of a small per-call array through the handle's pinned staging area (asynchronous; pageable fallback if it is full)
 static hipError_t UploadAsync(gpann_shards* s, void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
-    void* p = s->stage.Take(bytes);
+    void* p = CS(s).stage.Take(bytes);
     if (!p) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
     std::memcpy(p, src, bytes);
     return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st);
@@ -363,14 +365,14 @@ struct UploadBatch {
     template <typename T>
     T* Add(T* own_dst, const void* src, size_t bytes) {
         if (bytes == 0) return own_dst;
-        void* p = s->ws_stage_dev.ptr ? s->stage.Take(bytes) : nullptr;
-        if (!p || (size_t)(static_cast<char*>(p) - s->stage.base) + bytes > s->ws_stage_dev.bytes) {
+        void* p = s->ws_stage_dev.ptr ? CS(s).stage.Take(bytes) : nullptr;
+        if (!p || (size_t)(static_cast<char*>(p) - CS(s).stage.base) + bytes > s->ws_stage_dev.bytes) {
             const hipError_t e = UploadAsync(s, own_dst, src, bytes, st);
             if (err == hipSuccess) err = e;
             return own_dst;
         }
         std::memcpy(p, src, bytes);
-        const size_t off = (size_t)(static_cast<char*>(p) - s->stage.base);
+        const size_t off = (size_t)(static_cast<char*>(p) - CS(s).stage.base);
         first = std::min(first, off);
         last = std::max(last, off + bytes);
         return reinterpret_cast<T*>(s->ws_stage_dev.as<char>() + off);
@@ -378,7 +380,7 @@ struct UploadBatch {
     hipError_t Flush() {
         hipError_t e = err;
         if (first < last) {
-            const hipError_t c = hipMemcpyAsync(s->ws_stage_dev.as<char>() + first, s->stage.base + first, last - first, hipMemcpyHostToDevice, st);
+            const hipError_t c = hipMemcpyAsync(s->ws_stage_dev.as<char>() + first, CS(s).stage.base + first, last - first, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = c;
         }
         first = SIZE_MAX;
@@ -547,7 +549,7 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
         }
         GPANN_HIP_TRY(hipGetLastError());
     }
-    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+    GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));
     if (T) {
         m.in_dist = d_part_dist;
         m.in_row = d_part_row;
@@ -586,12 +588,16 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
 static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, UploadBatch& up, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call,
-                                        uint32_t k, int flags, hipStream_t st, DeviceLists out, bool* overflow) {
-    *overflow = false;
+                                        uint32_t k, int flags, hipStream_t st, DeviceLists out) {
     TaskArrays ta = ta_in;   // (query / out point to the re-ordered copies once the tasks are grouped by nearest cell; the caller's arrays keep the host's order)
-    s->filter_passes_timed = 0;
+    CS(s).filter_passes_timed = 0;
     const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
-    if (T == 0) return GPANN_OK;
+    if (T == 0) {   // no task: every slot reads (+inf, NO_ID)
+        const size_t n = (size_t)nq * nprobe_of_call * k;
+        if (n) hipLaunchKernelGGL(FillKernel, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, out.dist, out.ids, out.rows, n);
+        GPANN_HIP_TRY(hipGetLastError());
+        return GPANN_OK;
+    }
     const auto& C = s->cells;
     const uint32_t kmax = C.kmax;
     const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
@@ -675,13 +681,16 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
+    // (the 8-bit passes of a squared-L2 store whose plane has its own norm words bound the quantisation error in the frame of the cell: |q - c|_1 per (task, cell))
+    const bool cell_l1 = use_q8 && C.q8_norm != nullptr;
+    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 * (cell_l1 ? 2 : 1) + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     double* d_task_nq = s->ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
     double* d_task_q1 = d_task_nq + T;              // |q~|_1 (old order) ...
     float* d_task_tscale = reinterpret_cast<float*>(d_task_q1 + T);   // ... the 8-bit query step (old order) ...
     float* d_task_qscale = d_task_tscale + T;                          // ... and step / 254 in the NEW order (QueryImageQ8Kernel)
     float* cell_dist = d_task_qscale + T;
-    uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax);
+    float* cell_l1_tab = cell_l1 ? cell_dist + (size_t)T * kmax : nullptr;
+    uint32_t* d_nearest = reinterpret_cast<uint32_t*>(cell_dist + (size_t)T * kmax * (cell_l1 ? 2 : 1));
     uint32_t* d_task_group_own = d_nearest + T;
     CellTileRef* d_dtiles_own = reinterpret_cast<CellTileRef*>(d_task_group_own + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
@@ -762,8 +771,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     cd.kmax = kmax;
     cd.d = s->d;
     cd.ld = s->ld;
+    cd.out_l1 = cell_l1_tab;
     auto cell_table = [&](bool with_qnorm) -> gpann_status {
-        hipLaunchKernelGGL(CellDistKernel, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
+        if (cell_l1) hipLaunchKernelGGL(CellDistKernel<true>, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
+        else hipLaunchKernelGGL(CellDistKernel<false>, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
         hipLaunchKernelGGL(NearestCellKernel, dim3((T + 15) / 16), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
                            s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr, C.d_mu, use_q8 ? d_task_q1 : nullptr, use_q8 ? d_task_tscale : nullptr);
         GPANN_HIP_TRY(hipGetLastError());
@@ -845,7 +856,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ia.nq = nq;
         ia.inf_floats = reinterpret_cast<uint32_t*>(q8_B);
         ia.inf_words = q8_B_words;
-        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(ia.zero_words[2], q8_B_words), T);
+        ia.fill_dist = out.dist;   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID): FillKernel's job, in this launch
+        ia.fill_ids = out.ids;
+        ia.fill_rows = out.rows;
+        ia.fill_n = (uint64_t)nq * nprobe_of_call * k;
+        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(ia.zero_words[2], q8_B_words), T), ia.fill_n);
         hipLaunchKernelGGL(FilterInitKernel, dim3((uint32_t)std::min<uint64_t>(2048, (most + 255) / 256)), dim3(256), 0, st, ia);
         GPANN_HIP_TRY(hipGetLastError());
     }
@@ -915,6 +930,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.task_q1 = d_task_q1;
     na.task_tscale = d_task_tscale;
     na.group_tasks = 32u * QT8;
+    na.cell_l1 = cell_l1_tab;
     th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
@@ -950,6 +966,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.image = s->ws_image.as<char>();
     fa.seg_tiles = seg_tiles;
     fa.q8_planes = C.q8_planes;
+    fa.q8_norm = C.q8_norm ? C.q8_norm : C.plane_norm;
     fa.tile_bound = C.d_tile_bound;
     fa.q8_B = q8_B;
     fa.task_qscale = d_task_qscale;
@@ -990,6 +1007,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.seed_first_slot_of = 0;
     ra.seed_catch_up = 0;
     ra.task_out = ta.out;
+    ra.seed_task_U = nullptr;
+    ra.task_nq = d_task_nq;
+    ra.shard_rmax = s->d_shard_rmax;
+    ra.seed_hi_only = 0;
     // the kernel for this store's k-steps: both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
     const void *fn = nullptr, *fn_hi = nullptr;
     switch (KS) {
@@ -1055,19 +1076,27 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         const uint32_t grid = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)parts * T);
         if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
         else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
-        // (always after a bucket pass — it also keeps the pass's statistics; the seed launch has no buckets)
-        if (ra.seed_rows == 0) hipLaunchKernelGGL(SplitMergeKernel, dim3((T + 4 * kSplitMergeTasksPerWave - 1) / (4 * kSplitMergeTasksPerWave)), dim3(256), 0, st, ra);
+        // (the pieces of split buckets are merged — and the pass's statistics kept — by the NEXT launch that reads the lists: PassSetupKernel of
+        // the following pass, FinalMergeKernel after the last one)
     };
-    const uint64_t need_threads = (uint64_t)T * kmax;
+    bool buckets_pending = false;   // a bucket re-scoring has run and the pieces of its split buckets are not merged yet
     int n_cus = 256;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
 
+    bool seed_wrote_U = false;
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
         // (under the merge bound only the first slot of a query is seeded: RescoreArgs::seed_first_slot_of)
         ra.seed_first_slot_of = for_merge && nprobe_of_call > 1 && EnvU32("GPANN_FILTER_SEED_ALL", 0) == 0 ? nprobe_of_call : 0u;
         ra.seed_catch_up = 0;
+        // every task seeded: the seed launch also writes the shard-sample pass's thresholds (one launch less); under the merge bound with several
+        // probes only the first slots are seeded and the thresholds need the queries' bounds: ThresholdKernel, below
+        const bool seed_sets_U = ra.seed_first_slot_of == 0 && shard_sample_pass && !sitems.empty();
+        ra.seed_task_U = seed_sets_U ? task_U : nullptr;
+        ra.seed_hi_only = wide ? 1u : 0u;
         launch_rescore(1);   // (seed mode: a fixed number of rows per task)
+        ra.seed_task_U = nullptr;
+        seed_wrote_U = seed_sets_U;
         if (ra.seed_first_slot_of != 0) {
             ra.seed_catch_up = 1;
             launch_rescore(1);
@@ -1098,8 +1127,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     if (seed_rows != 0 && shard_sample_pass) {
         if (!sitems.empty()) {
             th.hi_only = wide ? 1u : 0u;   // (cand_cnt: zeroed by FilterInitKernel)
-            if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
-            else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            if (!seed_wrote_U) {
+                if (l2) hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_L2>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+                else hipLaunchKernelGGL(ThresholdKernel<GPANN_METRIC_MIPS>, dim3((T + 255) / 256), dim3(256), 0, st, th);
+            }
             CellFilterArgs fs = fa;
             fs.items = d_sitems;
             fs.group_first = d_stab;
@@ -1111,12 +1142,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             void* sargs[] = {&fs};
             GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
             launch_rescore(split_parts);
+            buckets_pending = true;
             GPANN_HIP_TRY(hipGetLastError());
             if (std::getenv("GPANN_CELLS_DEBUG")) debug_candidate_counts("shard-sample pass");
         }
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
-        if (s->filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed], st));
+        GPANN_REQUIRE(PassSetupLdsBytes(kmax) <= (64u << 10), "too many cells in one shard for the pass set-up kernel");
+        if (CS(s).filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
         // the sample and rest passes (GPANN_FILTER_Q8_FROM_PASS=2: the rest pass only) on the 8-bit plane; their thresholds come from Q8Threshold, not from task_U
@@ -1126,8 +1159,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];
         na.q8_B = q8_pass ? q8_B : nullptr;
-        if (l2) hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_L2>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
-        else hipLaunchKernelGGL(NeedKernel<GPANN_METRIC_MIPS>, dim3((uint32_t)((need_threads + 255) / 256)), dim3(256), 0, st, na);
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
         fa.round_tiles = q8_pass ? q8_waves * (pass == 2 ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
@@ -1135,9 +1166,20 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
         void* kargs[] = {&fa};
-        hipLaunchKernelGGL(FilterItemsKernel, dim3((uint32_t)((need_words + 255) / 256)), dim3(256), 0, st, fa);
+        {   // one launch sets the pass up: split buckets of the previous pass merged, thresholds, cell tests, work items (PassSetupKernel)
+            PassSetupArgs ps;
+            ps.need = na;
+            ps.filt = fa;
+            ps.merge = ra;
+            ps.merge.parts = split_parts;
+            ps.merge_splits = buckets_pending ? 1u : 0u;
+            const size_t slds = PassSetupLdsBytes(kmax);
+            if (l2) hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_L2>, dim3(G), dim3(kSetupThreads), slds, st, ps);
+            else hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_MIPS>, dim3(G), dim3(kSetupThreads), slds, st, ps);
+            buckets_pending = false;
+        }
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it (FilterItemsKernel keeps the count, work[3]), and its begin / end
-            GPANN_HIP_TRY(hipEventRecord(s->ev_filter[4], st));
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
         }
         if (q8_pass) {
@@ -1155,16 +1197,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             if (pass == 2) plan.filter_rest_row_bytes = (hi_pass ? 32u : 64u) * KS + 4u;
         }
         GPANN_HIP_TRY(hipGetLastError());
-        if (pass == 2) GPANN_HIP_TRY(hipEventRecord(s->ev_filter[5], st));
+        if (pass == 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[5], st));
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
         if (pass == 0 || pass == 2) {
-            GPANN_HIP_TRY(hipEventRecord(s->ev_filter[2 * s->filter_passes_timed + 1], st));
-            s->filter_passes_timed++;
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed + 1], st));
+            CS(s).filter_passes_timed++;
         }
         // Overflowed buckets are counted on the device (cumulatively over the passes) and looked at once, after the last pass: a
         // handful (the tail of the candidate-count distribution) is re-read exactly inside RescoreKernel; once the count passes
         // the limit RescoreKernel stops doing that — the call is going to fall back to the plain exact scan anyway.
         launch_rescore(split_parts);
+        buckets_pending = true;
         GPANN_HIP_TRY(hipGetLastError());
         plan.filter_launches++;
         if (std::getenv("GPANN_CELLS_DEBUG")) {
@@ -1185,35 +1228,44 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         rr.range_segs = range_segs;
         if (l2) hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_L2, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
         else hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_MIPS, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
-        hipLaunchKernelGGL(DirtyMergeKernel, dim3(dirty_cap), dim3(64), 0, st, rr);
+        // ... and, in the same launch, the pieces of the last pass's split buckets into their lists (FinalMergeKernel)
+        rr.parts = split_parts;
+        const uint32_t merge_blocks = buckets_pending ? (T + 4 * kSplitMergeTasksPerWave - 1) / (4 * kSplitMergeTasksPerWave) : 0u;
+        hipLaunchKernelGGL(FinalMergeKernel, dim3(merge_blocks + dirty_cap), dim3(256), 0, st, rr, merge_blocks);
+        buckets_pending = false;
         GPANN_HIP_TRY(hipGetLastError());
     }
     {
-        // the lists go out before the overflow words are looked at (one host round trip less on the way; an overflowed call rewrites
-        // them in the plain exact scan)
-        uint32_t words_local[4] = {0, 0, 0, 0};
-        unsigned long long work_local[4] = {0, 0, 0, 0};
-        void* pin = s->stage.Take(48);   // pinned landing area: the two copies do not stall the stream
-        uint32_t* h_words = pin ? static_cast<uint32_t*>(pin) : words_local;
-        unsigned long long* h_work = pin ? reinterpret_cast<unsigned long long*>(static_cast<char*>(pin) + 16) : work_local;
-        GPANN_HIP_TRY(hipMemcpyAsync(h_words, d_overflow, 16, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(h_work, d_work, 32, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));
+        // the pipeline's counters travel to the call's pinned words; they are looked at when the call is completed (CollectFilterCounters: right
+        // after this function in a plain call, in gpann_scan_finish for a deferred one) — nothing here waits for the device
+        uint32_t* pin = CS(s).pin_words;
+        GPANN_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 16, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(pin + 4, d_work, 32, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));
         const size_t n = (size_t)T * k;
         hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k,
                            out.dist, out.ids, out.rows, (const uint32_t*)d_query_tau, (const uint32_t*)ta.query);
         GPANN_HIP_TRY(hipGetLastError());
-        GPANN_HIP_TRY(hipStreamSynchronize(st));
-        plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
-        plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
-        plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
-        plan.filter_rows = (uint64_t)(h_work[1] + h_work[2]) * kGTileRows;
-        plan.filter_two_plane_rows = (uint64_t)h_work[2] * kGTileRows;
-        plan.filter_dirty_tasks = h_words[1];
-        if (h_words[1] > dirty_cap) *overflow = true;
-        if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] buckets overflowed (task x pass) %u, dirty tasks redone exactly %u (cap %u)\n", h_words[0], h_words[1], dirty_cap);
+        CS(s).dirty_cap = dirty_cap;
     }
     return GPANN_OK;
+}
+
+// After the call's device work has completed: the filtered pipeline's counters (pin_words) -> the plan's statistics; *overflow = more dirty tasks
+// than the pipeline redoes itself: the data defeats the filter, the call has to be redone with the plain exact scan.
+static void CollectFilterCounters(gpann_shards::CallState& c, bool* overflow) {
+    const uint32_t* h_words = c.pin_words;
+    unsigned long long h_work[4];
+    std::memcpy(h_work, c.pin_words + 4, 32);
+    ScanPlan& plan = c.plan;
+    plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
+    plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
+    plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
+    plan.filter_rows = (uint64_t)(h_work[1] + h_work[2]) * kGTileRows;
+    plan.filter_two_plane_rows = (uint64_t)h_work[2] * kGTileRows;
+    plan.filter_dirty_tasks = h_words[1];
+    *overflow = h_words[1] > c.dirty_cap;
+    if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] buckets overflowed (task x pass) %u, dirty tasks redone exactly %u (cap %u)\n", h_words[0], h_words[1], c.dirty_cap);
 }
 
 static bool FilterWanted(const gpann_shards* s, uint32_t k) {
@@ -1223,22 +1275,59 @@ static bool FilterWanted(const gpann_shards* s, uint32_t k) {
     return s->scan_mode == 1;
 }
 
-// Runs tasks + scan + merge; results land in device arrays (caller-provided or workspace).
+// The plain exact scan of the call in progress (CS(s)): every task against its whole shard, lists to `out` — the path of a store / call without
+// filter, and the redo of a call the filtered pipeline gave up on.  `ta` = the call's device task arrays (query / out / shard filled or queued in `up`).
+static gpann_status RunExactPath(gpann_shards* s, const TaskArrays& ta, UploadBatch& up, const float* d_queries, uint32_t nq, uint32_t nprobe, uint32_t k, int flags,
+                                 hipStream_t st, DeviceLists out) {
+    ScanPlan& plan = CS(s).plan;
+    GPANN_HIP_TRY(up.Flush());
+    std::vector<int64_t> lo(s->offsets.begin(), s->offsets.end() - 1), hi(s->offsets.begin() + 1, s->offsets.end());
+    plan.padded_pairs = 0;
+    GPANN_TRY(BuildExactUnits(plan, s->S, lo, hi));
+    MergeArgs m{};
+    m.out_index = ta.out;
+    m.permutation = s->permutation;
+    m.out_dist = out.dist;
+    m.out_ids = out.ids;
+    m.out_rows = out.rows;
+    GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
+    // GPANN_SCAN_FOR_MERGE in exact mode: the full lists are there — cut them at the query's merge bound, as the filtered pipeline does
+    if ((flags & GPANN_SCAN_FOR_MERGE) && nq && nprobe)
+        hipLaunchKernelGGL(TruncateForMergeKernel, dim3((nq + 255) / 256), dim3(256), 0, st, out.dist, out.ids, out.rows, nq, nprobe, k);
+    GPANN_HIP_TRY(hipGetLastError());
+    return GPANN_OK;
+}
+
+static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms);
+
+// Plans the call and ENQUEUES its device work (tasks + scan + merge; results land in the device arrays `out`): nothing here waits for the
+// device.  The call is completed — counters read, an overflowed filter call redone exactly, statistics, timing — by CompleteCall, which the
+// entry points run before they return unless the caller asked for GPANN_SCAN_DEFER.
 static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
                                  uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
-    ScanPlan& plan = s->plan;
-    // The pinned staging area and the plan's host arrays are the sources of the previous call's asynchronous uploads: that call may have
-    // returned with them still queued (device output, no timing — nothing made it synchronise), so wait for its last upload first.
-    if (s->stage_in_flight) {
-        GPANN_HIP_TRY(hipEventSynchronize(s->ev[3]));
-        s->stage_in_flight = false;
+    // the slot of the call before last: if that call is still waiting for its gpann_scan_finish it is completed now
+    {
+        const int n = s->cur ^ 1;
+        if (s->cs[n].pending) GPANN_TRY(CompleteCall(s, n, nullptr));
+        // the most recent call's device work shares the handle's device workspaces with this one: on the same stream the stream orders them,
+        // on another stream this call waits for it (concurrent callers of one handle take turns)
+        gpann_shards::CallState& last = s->cs[s->cur];
+        if (last.stage_in_flight && last.stream != static_cast<void*>(st)) GPANN_HIP_TRY(hipEventSynchronize(last.ev[3]));
+        s->cur = n;
+    }
+    ScanPlan& plan = CS(s).plan;
+    // The pinned staging area and the plan's host arrays of this slot are the sources of an earlier call's asynchronous uploads: that call may
+    // have returned with them still queued (device output, no timing — nothing made it synchronise), so wait for the end of its work first.
+    if (CS(s).stage_in_flight) {
+        GPANN_HIP_TRY(hipEventSynchronize(CS(s).ev[3]));
+        CS(s).stage_in_flight = false;
     }
     plan.Clear();
     GPANN_TRY(BuildTasks(s, nq, probes, probe_stride, nprobe, plan));
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
     // (task arrays, group / tile tables, unit lists: ~32 bytes per task + per-shard tables; exact-mode unit lists fall back to pageable copies if larger)
-    s->stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
-    if (s->ws_stage_dev.Reserve(std::max<size_t>(s->stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
+    CS(s).stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
+    if (s->ws_stage_dev.Reserve(std::max<size_t>(CS(s).stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
     UploadBatch up{s, st};
     const size_t n_out = (size_t)nq * nprobe;
 
@@ -1258,48 +1347,53 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         ta.out = up.Add(ta.out, plan.task_out.data(), (size_t)T * 4);
         ta.shard = up.Add(ta.shard, plan.task_shard.data(), (size_t)T * 4);
     }
-    // (the plan's host arrays live in the handle until the next scan call, so the async uploads stay valid)
+    // (the plan's host arrays live in the slot until the call after next, so the async uploads stay valid)
 
-    {   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID)
+    const bool want_filter = FilterWanted(s, k);
+    if (!want_filter) {   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID); the filtered pipeline's FilterInitKernel does it in its own launch
         size_t n = n_out * k;
         int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
         if (n) hipLaunchKernelGGL(FillKernel, dim3(grid), dim3(256), 0, st, out.dist, out.ids, out.rows, n);
     }
 
-    GPANN_HIP_TRY(hipEventRecord(s->ev[0], st));
-    GPANN_HIP_TRY(hipEventRecord(s->ev[1], st));   // (re-recorded where the scan kernels end; a call without tasks ends here)
-    bool done = false;
-    s->stats = gpann_scan_stats{};
-    s->filter_passes_timed = 0;
-    if (FilterWanted(s, k)) {
-        bool overflow = false;
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, out, &overflow));
-        done = !overflow;
-        s->stats.filtered = done ? 1 : 0;
+    GPANN_HIP_TRY(hipEventRecord(CS(s).ev[0], st));
+    GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));   // (re-recorded where the scan kernels end; a call without tasks ends here)
+    gpann_shards::CallState& c = CS(s);
+    c.filter_passes_timed = 0;
+    c.filtered = false;
+    c.dirty_cap = 0;
+    c.d_queries = d_queries;
+    c.nq = nq;
+    c.k = k;
+    c.nprobe = nprobe;
+    c.T = T;
+    c.flags = flags;
+    c.stream = st;
+    c.out_dist = out.dist;
+    c.out_ids = out.ids;
+    c.out_rows = out.rows;
+    c.host_dist = nullptr;
+    c.host_ids = c.host_rows = nullptr;
+    if (want_filter) {
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, out));
+        c.filtered = T != 0;
+    } else {
+        GPANN_TRY(RunExactPath(s, ta, up, d_queries, nq, nprobe, k, flags, st, out));
     }
-    if (!done) {
-        GPANN_HIP_TRY(up.Flush());
-        std::vector<int64_t> lo(s->offsets.begin(), s->offsets.end() - 1), hi(s->offsets.begin() + 1, s->offsets.end());
-        plan.padded_pairs = 0;
-        GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
-        MergeArgs m{};
-        m.out_index = ta.out;
-        m.permutation = s->permutation;
-        m.out_dist = out.dist;
-        m.out_ids = out.ids;
-        m.out_rows = out.rows;
-        GPANN_TRY(RunExactStage(s, plan, ta, d_queries, k, flags, st, m));
-        // GPANN_SCAN_FOR_MERGE in exact mode: the full lists are there — cut them at the query's merge bound, as the filtered pipeline does
-        if ((flags & GPANN_SCAN_FOR_MERGE) && nq && nprobe)
-            hipLaunchKernelGGL(TruncateForMergeKernel, dim3((nq + 255) / 256), dim3(256), 0, st, out.dist, out.ids, out.rows, nq, nprobe, k);
-    }
-    GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
-    GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));   // the end of the device work of this call so far (uploads AND kernels: the next call on the handle waits for it; an entry point that enqueues more records it again)
-    s->stage_in_flight = true;
+    GPANN_HIP_TRY(hipEventRecord(c.ev[2], st));
+    GPANN_HIP_TRY(hipEventRecord(c.ev[3], st));   // the end of the device work of this call so far (uploads AND kernels: a later call on this slot waits for it; an entry point that enqueues more records it again)
+    c.stage_in_flight = true;
+    c.pending = true;
+    return GPANN_OK;
+}
 
+static void FillStats(gpann_shards* s, const gpann_shards::CallState& c, bool filtered) {
+    const ScanPlan& plan = c.plan;
+    s->stats = gpann_scan_stats{};
+    s->stats.filtered = filtered ? 1 : 0;
     s->stats.pairs = plan.pairs;
-    s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)T * k * 8ull;
-    s->stats.tasks = T;
+    s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)c.T * c.k * 8ull;
+    s->stats.tasks = c.T;
     s->stats.units = plan.units.size();
     s->stats.padded_pairs = plan.padded_pairs;
     s->stats.filter_pairs = plan.filter_pairs;
@@ -1307,33 +1401,97 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     s->stats.filter_rest_rows = plan.filter_rest_rows;
     s->stats.filter_rest_hi_only = plan.filter_rest_hi_only ? 1u : 0u;
     s->stats.filter_candidates = plan.filter_candidates;
-    s->stats.filter_plane_ksteps = s->stats.filtered ? s->cells.plane_ks : 0u;
+    s->stats.filter_plane_ksteps = filtered ? s->cells.plane_ks : 0u;
     s->stats.filter_two_plane_rows = plan.filter_two_plane_rows;
     s->stats.filter_dirty_tasks = plan.filter_dirty_tasks;
-    s->stats.filter_rest_row_bytes = s->stats.filtered ? plan.filter_rest_row_bytes : 0u;
-    s->stats.filter_seed_rows = s->stats.filtered ? plan.padded_pairs : 0;
-    return GPANN_OK;
+    s->stats.filter_rest_row_bytes = filtered ? plan.filter_rest_row_bytes : 0u;
+    s->stats.filter_seed_rows = filtered ? plan.padded_pairs : 0;
 }
 
-static gpann_status FinishTiming(gpann_shards* s, float* elapsed_ms) {
-    GPANN_HIP_TRY(hipEventSynchronize(s->ev[2]));
+static gpann_status FinishTiming(gpann_shards* s, gpann_shards::CallState& c, float* elapsed_ms) {
+    GPANN_HIP_TRY(hipEventSynchronize(c.ev[2]));
     float a = 0.f, b = 0.f;
-    GPANN_HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-    GPANN_HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    GPANN_HIP_TRY(hipEventElapsedTime(&a, c.ev[0], c.ev[1]));
+    GPANN_HIP_TRY(hipEventElapsedTime(&b, c.ev[1], c.ev[2]));
     s->stats.scan_ms = a;
     s->stats.merge_ms = b;
     s->stats.filter_ms = 0.f;
     if (s->stats.filtered) {
-        for (int p = 0; p < s->filter_passes_timed; ++p) {
+        for (int p = 0; p < c.filter_passes_timed; ++p) {
             float f = 0.f;
-            GPANN_HIP_TRY(hipEventElapsedTime(&f, s->ev_filter[2 * p], s->ev_filter[2 * p + 1]));
+            GPANN_HIP_TRY(hipEventElapsedTime(&f, c.ev_filter[2 * p], c.ev_filter[2 * p + 1]));
             s->stats.filter_ms += f;
         }
         s->stats.filter_rest_ms = 0.f;
-        if (s->filter_passes_timed >= 1) GPANN_HIP_TRY(hipEventElapsedTime(&s->stats.filter_rest_ms, s->ev_filter[4], s->ev_filter[5]));
+        if (c.filter_passes_timed >= 1) GPANN_HIP_TRY(hipEventElapsedTime(&s->stats.filter_rest_ms, c.ev_filter[4], c.ev_filter[5]));
     }
     if (elapsed_ms) *elapsed_ms = a + b;
     return GPANN_OK;
+}
+
+// host destinations of a call without GPANN_OUTPUT_ON_DEVICE: the copies are queued behind the call's kernels (and again after a redo)
+static gpann_status EnqueueHostCopies(gpann_shards* s, gpann_shards::CallState& c) {
+    hipStream_t st = static_cast<hipStream_t>(c.stream);
+    const size_t n = (size_t)c.nq * c.nprobe * c.k;
+    if (c.host_ids) GPANN_HIP_TRY(hipMemcpyAsync(c.host_ids, c.out_ids, n * 4, hipMemcpyDeviceToHost, st));
+    if (c.host_dist) GPANN_HIP_TRY(hipMemcpyAsync(c.host_dist, c.out_dist, n * 4, hipMemcpyDeviceToHost, st));
+    if (c.host_rows) GPANN_HIP_TRY(hipMemcpyAsync(c.host_rows, c.out_rows, n * 4, hipMemcpyDeviceToHost, st));
+    GPANN_HIP_TRY(hipEventRecord(c.ev[3], st));
+    return GPANN_OK;
+}
+
+// Completes the call of `slot`: waits for its device work, reads the filtered pipeline's counters, redoes the call with the plain exact scan
+// if the data defeated the filter (more dirty tasks than the pipeline redoes itself), fills the statistics and the timing.
+static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms) {
+    gpann_shards::CallState& c = s->cs[slot];
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (!c.pending) return GPANN_OK;
+    c.pending = false;
+    GPANN_HIP_TRY(hipEventSynchronize(c.ev[3]));
+    c.stage_in_flight = false;
+    bool overflow = false;
+    if (c.filtered) CollectFilterCounters(c, &overflow);
+    if (overflow) {
+        // the redo runs as "the call in progress" of its own slot (its plan's host arrays are intact, its pinned stage is free again); a later
+        // call that is already queued on the stream simply runs before it
+        const int keep = s->cur;
+        s->cur = slot;
+        hipStream_t st = static_cast<hipStream_t>(c.stream);
+        ScanPlan& plan = c.plan;
+        const uint32_t T = c.T;
+        c.stage.used = 0;
+        UploadBatch up{s, st};
+        gpann_status rc = s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256));
+        if (rc == GPANN_OK) {
+            TaskArrays ta;
+            ta.query = s->ws_tasks.as<uint32_t>();
+            ta.out = ta.query + T;
+            ta.part = ta.out + T;
+            ta.nseg = ta.part + T;
+            ta.shard = ta.nseg + T;
+            ta.query = up.Add(ta.query, plan.task_query.data(), (size_t)T * 4);
+            ta.out = up.Add(ta.out, plan.task_out.data(), (size_t)T * 4);
+            ta.shard = up.Add(ta.shard, plan.task_shard.data(), (size_t)T * 4);
+            if (c.host_ids) {   // a call with host outputs: its device lists live in ws_out, which a later call may have re-grown (same layout)
+                const size_t n = (size_t)c.nq * c.nprobe * c.k;
+                c.out_dist = s->ws_out.as<float>();
+                c.out_ids = reinterpret_cast<uint32_t*>(c.out_dist + n);
+                c.out_rows = c.out_ids + n;
+            }
+            DeviceLists out;
+            out.dist = c.out_dist;
+            out.ids = c.out_ids;
+            out.rows = c.out_rows;
+            rc = RunExactPath(s, ta, up, c.d_queries, c.nq, c.nprobe, c.k, c.flags, st, out);
+        }
+        if (rc == GPANN_OK && hipEventRecord(c.ev[2], st) != hipSuccess) rc = GPANN_ERR_HIP;
+        if (rc == GPANN_OK) rc = EnqueueHostCopies(s, c);
+        if (rc == GPANN_OK && hipStreamSynchronize(st) != hipSuccess) rc = GPANN_ERR_HIP;
+        s->cur = keep;
+        if (rc != GPANN_OK) return rc;
+    }
+    FillStats(s, c, c.filtered && !overflow);
+    return FinishTiming(s, c, elapsed_ms);
 }
 
 static gpann_status CheckScanArgs(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t nprobe,
@@ -1383,16 +1541,32 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
         dl.rows = dl.ids + n;
     }
     GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags, st, dl));
-    if (!dev_out) {
-        GPANN_HIP_TRY(hipMemcpyAsync(out_ids, dl.ids, n * 4, hipMemcpyDeviceToHost, st));
-        if (out_dist) GPANN_HIP_TRY(hipMemcpyAsync(out_dist, dl.dist, n * 4, hipMemcpyDeviceToHost, st));
-        if (out_rows) GPANN_HIP_TRY(hipMemcpyAsync(out_rows, dl.rows, n * 4, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipStreamSynchronize(st));
-        GPANN_TRY(FinishTiming(s, elapsed_ms));
-    } else if (elapsed_ms) {
-        GPANN_TRY(FinishTiming(s, elapsed_ms));
+    gpann_shards::CallState& c = CS(s);
+    if (!dev_out) {   // the lists travel to the caller's host arrays behind the kernels
+        c.host_ids = out_ids;
+        c.host_dist = out_dist;
+        c.host_rows = out_rows;
+        GPANN_TRY(EnqueueHostCopies(s, c));
     }
-    return GPANN_OK;
+    // GPANN_SCAN_DEFER: the call is completed by gpann_scan_finish — provided a redo could still find its inputs: device queries read in place
+    if ((flags & GPANN_SCAN_DEFER) && c.d_queries == queries) return GPANN_OK;
+    // a plain exact call with device output and no timing stays asynchronous, as documented (nothing to collect)
+    if (dev_out && !elapsed_ms && !c.filtered) {
+        c.pending = false;
+        FillStats(s, c, false);
+        return GPANN_OK;
+    }
+    return CompleteCall(s, s->cur, elapsed_ms);
+}
+
+gpann_status gpann_scan_finish(gpann_shards* s, float* elapsed_ms) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
+    GPANN_TRY(EnsureDevice(s->device));
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    const int older = s->cur ^ 1;
+    if (s->cs[older].pending) return CompleteCall(s, older, elapsed_ms);   // the oldest deferred call first
+    return CompleteCall(s, s->cur, elapsed_ms);
 }
 
 gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t probe_stride,
@@ -1420,7 +1594,9 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
                            (uint32_t*)nullptr, n);
     } else {
         // (one TopN over the slots: entries beyond the smallest k-th distance of the query's slots cannot be in it — GPANN_SCAN_FOR_MERGE)
-        GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, flags | GPANN_SCAN_FOR_MERGE, st, slot));
+        GPANN_TRY(ScanToDevice(s, queries, nq, k, probes, probe_stride, nprobe, (flags & ~GPANN_SCAN_DEFER) | GPANN_SCAN_FOR_MERGE, st, slot));
+        float scan_ms = 0.f;
+        GPANN_TRY(CompleteCall(s, s->cur, &scan_ms));   // (the slot lists are final — an overflowed filter call has been redone — before they are merged)
         MergeArgs m{};
         m.in_dist = slot.dist;
         m.in_row = slot.rows;
@@ -1433,18 +1609,20 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
         m.lists_per_out = nprobe;
         hipLaunchKernelGGL(MergeListsKernel<1>, dim3((nq + 3) / 4), dim3(256), 0, st, m);
         GPANN_HIP_TRY(hipGetLastError());
-        GPANN_HIP_TRY(hipEventRecord(s->ev[2], st));
+        GPANN_HIP_TRY(hipEventRecord(CS(s).ev[2], st));
         // ev[3] = the end of ALL device work of this call on the handle (the merge reads the slot lists in ws_out: a following call on this
-        // handle — another thread, another stream — waits for it before it touches the workspaces)
-        GPANN_HIP_TRY(hipEventRecord(s->ev[3], st));
-        s->stage_in_flight = true;
+        // slot waits for it before it touches the stage; the NEXT call on the handle — another thread, another stream — must not overwrite
+        // ws_out under the merge either: it is made to wait below when this call does not synchronise itself)
+        GPANN_HIP_TRY(hipEventRecord(CS(s).ev[3], st));
+        CS(s).stage_in_flight = true;
     }
     if (!dev_out) {
         GPANN_HIP_TRY(hipMemcpyAsync(out_ids, d_out_ids, n * 4, hipMemcpyDeviceToHost, st));
         if (out_dist) GPANN_HIP_TRY(hipMemcpyAsync(out_dist, d_out_dist, n * 4, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipStreamSynchronize(st));
     }
-    if (nprobe && (!dev_out || elapsed_ms)) GPANN_TRY(FinishTiming(s, elapsed_ms));
+    if (nprobe && (!dev_out || elapsed_ms)) GPANN_TRY(FinishTiming(s, CS(s), elapsed_ms));
+    else if (nprobe) GPANN_HIP_TRY(hipEventSynchronize(CS(s).ev[3]));   // (device output, untimed: the merge kernel still reads ws_out — the next call on the handle may not start under it)
     return GPANN_OK;
 }
 
@@ -1472,13 +1650,14 @@ gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint
     float* d_kth = reinterpret_cast<float*>(d_count + (size_t)nq * S);
     GPANN_HIP_TRY(hipMemcpyAsync(d_kth, distance_to_kth, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     GPANN_TRY(ScanToDevice(s, queries, nq, k, probes.data(), S, S, flags & (GPANN_QUERIES_ON_DEVICE | GPANN_AUX_PASS), st, slot));
+    GPANN_TRY(CompleteCall(s, s->cur, nullptr));
     const size_t tt = (size_t)nq * S;
     hipLaunchKernelGGL(ShardHitsKernel, dim3((uint32_t)((tt + 255) / 256)), dim3(256), 0, st, slot.dist, slot.ids, d_kth, nq, S, k, d_hits, d_count);
     GPANN_HIP_TRY(hipGetLastError());
     GPANN_HIP_TRY(hipMemcpyAsync(out_ids, d_hits, n * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipMemcpyAsync(out_count, d_count, tt * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
-    GPANN_TRY(FinishTiming(s, elapsed_ms));
+    GPANN_TRY(FinishTiming(s, CS(s), elapsed_ms));
     return GPANN_OK;
 }
 

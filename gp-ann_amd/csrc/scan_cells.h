@@ -59,10 +59,12 @@ struct CellDistArgs {
     const CellTileRef* tiles;
     float* out;                         // [tasks][kmax]
     uint32_t kmax, d, ld;
+    float* out_l1;                      // WITH_L1: [tasks][kmax] |q - c|_1 (plain fp32; the 8-bit passes' error bound lives in the frame of the cell, Q8Threshold)
 };
 
 // 64 tasks x 64 cells per pass of the cell loop; squared L2 distance in plain fp32 (bounds carry their own slack)
-static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) {
+template <bool WITH_L1>
+static __global__ void __launch_bounds__(256, WITH_L1 ? 2 : 3) CellDistKernel(CellDistArgs a) {
     constexpr int kStride = 36;
     __shared__ float sC[64 * kStride];
     __shared__ float sQ[64 * kStride];
@@ -79,11 +81,14 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
     for (uint32_t ct = 0; ct < K; ct += 64) {
         const float* crow0 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row0, K - 1)) * ld;
         const float* crow1 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row1, K - 1)) * ld;
-        float acc[4][4];
+        float acc[4][4], acc1[WITH_L1 ? 4 : 1][WITH_L1 ? 4 : 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = 0.f;
+                if (WITH_L1) acc1[WITH_L1 ? i : 0][WITH_L1 ? j : 0] = 0.f;
+            }
         for (uint32_t ch = 0; ch < nchunks; ++ch) {
             const uint32_t col = ch * 32 + 4u * st_c4;
             const bool in = col < ld;
@@ -105,6 +110,13 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(sQ + (tx + 16 * j) * kStride + 4 * g);
                 AccumulateGroup<GPANN_METRIC_L2>(acc, cv, qv);   // pad columns are zero on both sides
+                if (WITH_L1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc1[WITH_L1 ? i : 0][WITH_L1 ? j : 0] += (fabsf(qv[j].x - cv[i].x) + fabsf(qv[j].y - cv[i].y)) + (fabsf(qv[j].z - cv[i].z) + fabsf(qv[j].w - cv[i].w));
+                }
             }
         }
 #pragma unroll
@@ -112,7 +124,10 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t cell = ct + ty + 16 * i, tl = tx + 16 * j;
-                if (cell < K && tl < count) a.out[(size_t)(first + tl) * a.kmax + cell] = acc[i][j];
+                if (cell < K && tl < count) {
+                    a.out[(size_t)(first + tl) * a.kmax + cell] = acc[i][j];
+                    if (WITH_L1) a.out_l1[(size_t)(first + tl) * a.kmax + cell] = acc1[WITH_L1 ? i : 0][WITH_L1 ? j : 0];
+                }
             }
     }
 }
@@ -211,6 +226,10 @@ struct FilterInitArgs {
     uint64_t nq;
     uint32_t* inf_floats;    // the (task, cell) threshold table of the 8-bit pass -> +inf, or null
     uint64_t inf_words;
+    float* fill_dist;        // the call's output arrays -> (+inf, NO_ID, NO_ID): slots no task writes (skipped probes, short shards); each may be null
+    uint32_t* fill_ids;
+    uint32_t* fill_rows;
+    uint64_t fill_n;
 };
 static __global__ void __launch_bounds__(256) FilterInitKernel(FilterInitArgs a) {
     const uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
@@ -219,6 +238,11 @@ static __global__ void __launch_bounds__(256) FilterInitKernel(FilterInitArgs a)
         for (uint64_t i = i0; i < a.zero_words[z]; i += stride) a.zero[z][i] = 0u;
     for (uint64_t i = i0; i < a.nq && a.query_tau; i += stride) a.query_tau[i] = kOrderedKeyInf;
     for (uint64_t i = i0; i < a.inf_words && a.inf_floats; i += stride) a.inf_floats[i] = 0x7F800000u;
+    for (uint64_t i = i0; i < a.fill_n; i += stride) {
+        if (a.fill_dist) a.fill_dist[i] = INFINITY;
+        if (a.fill_ids) a.fill_ids[i] = kNoId;
+        if (a.fill_rows) a.fill_rows[i] = kNoId;
+    }
 }
 
 struct NeedArgs {
@@ -259,6 +283,7 @@ struct NeedArgs {
     const double* task_q1;              // [tasks] |q~|_1 (through task_src)
     const float* task_tscale;           // [tasks] query quantisation step (through task_src)
     uint32_t group_tasks;
+    const float* cell_l1;               // [tasks][kmax] |q - c|_1 (CellDistKernel<true>; squared L2 stores whose 8-bit plane has its own norm words), or null
 };
 
 // The threshold of the 8-bit pass for task t and cell j (derivation in DESIGN.md §3.1c).  With p~ = c^ + s P' + e (|e_i| <= s/2) and
@@ -270,7 +295,7 @@ struct NeedArgs {
 //     B = U_base - q~.c^ - E_tc - (table error) - (fp32 evaluation slack),   q~.c^ = (|q~|^2 + |c^|^2 - |q~ - c^|^2) / 2  from the cell table.
 template <int METRIC>
 __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, double tscale, double R, double dd, double D_table, double nc, double s_c,
-                                             double radius) {
+                                             double radius, double l1_table = -1.0) {
     if (!(tau < (double)INFINITY)) return -INFINITY;
     const double qn = sqrt(nq) * (1.0 + 1e-12);
     double Ub;
@@ -292,9 +317,16 @@ __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, d
     // p~ = fl(p - mu), c^ = fl(c - mu):  |p~ - c^| <= |p - c| + 2^-24 (|p - mu| + |c - mu|) <= radius + 2^-23 (R + |c^|)   (R, |c^| are norms in the
     // centred frame, each within 2^-24 of the exact one).  For a cell of (nearly) equal rows far from the store's mean this term IS the radius.
     const double r_eff = radius + 0x1p-23 * (R + cn);
-    const double E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * r_eff + 0.5 * dd * s_c);
-    // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2
-    const double e_fp = 0x1p-21 * (qn * (r_eff + sqrt(dd) * s_c) + 0.5 * R * R + 1.0);
+    // The row's quantisation error e (|e_i| <= s/2) meets the query as q~.e.  With the plain norm words (-|p~|^2/2; inner product: none) all of
+    // it is unknown: |q~.e| <= (s/2) |q~|_1.  With the 8-bit plane's OWN norm words (squared L2, round 4: -|p~|^2/2 + c^.e, shards.h) the part c^.e
+    // is in the row's word and only (q~ - c^).e is left: <= (s/2) |q~ - c^|_1, the query seen from the CELL — 2-3x smaller for a query inside its
+    // cluster.  |q~ - c^|_1 <= l1_table (1 + (d + 8) 2^-24) + 2^-23 sqrt(d) (|q~| + |c^|): the table is a plain fp32 sum of d fp32 terms
+    // |q_i - c_i| in the ORIGINAL coordinates, the second term the rounding of the centred ones.
+    const double q1_eff = l1_table >= 0.0 ? l1_table * (1.0 + (dd + 8.0) * 0x1p-24) + 0x1p-23 * sqrt(dd) * (qn + cn) : q1;
+    const double E = 0.5 * s_c * (1.0 + 1e-6) * q1_eff + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * r_eff + 0.5 * dd * s_c);
+    // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2 (the own norm
+    // words add |c^.e| <= |c^| sqrt(d) s / 2 to the word's magnitude)
+    const double e_fp = 0x1p-21 * (qn * (r_eff + sqrt(dd) * s_c) + 0.5 * R * R + cn * sqrt(dd) * s_c + 1.0);
     // the kernels for up to 128 dimensions evaluate the test on accumulators biased by 1.5 x 2^23 (FilterKernelCells, BIAS): V and the threshold
     // both carry 255 x 12582912 (x s0), three roundings at that magnitude (< 640 s0 in all) and the relative ones of the norm word (in e_fp) and
     // of the shifted threshold itself
@@ -305,72 +337,12 @@ __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, d
     return Bf;
 }
 
-// One thread per (task, cell).
-
-// One thread per (task, cell).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
+// The cell test (PassSetupKernel, phase 2).  A cell is needed unless its ball provably holds no row within the task's k-th distance tau:
 //   L2   canonical E <= tau  =>  D <= tau (1 + 2 g1), g1 = (d + 32) 2^-23 (ThresholdKernel);  D >= (|q - c| - r)^2.
 //        |q - c|^2 comes from a plain fp32 sum of d squares: relative error <= (d + 2) 2^-24, covered by the factor (1 - s).
 //   MIPS E = fl(1 - fl(q.p)) <= tau  =>  q.p >= 1 - tau - e1 (ThresholdKernel);  q.p <= q.c + |q| r, and
 //        q.c = (|q|^2 + |c|^2 - |q - c|^2) / 2 from the same table, absolute error <= s (|q|^2 + |c|^2 + |q - c|^2).
-template <int METRIC>
-static __global__ void NeedKernel(NeedArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)a.tasks * a.kmax) return;
-    const uint32_t t = (uint32_t)(i / a.kmax), j = (uint32_t)(i % a.kmax);
-    const uint32_t src = a.task_src[t];
-    const uint32_t b = a.task_shard[t];
-    const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
-    // the task's k-th distance so far — or, if smaller, the bound the query's other tasks have already reached
-    double tau = (double)a.list_dist[(size_t)t * a.k + a.k - 1];
-    if (a.query_tau) tau = fmin(tau, (double)OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
-    const bool dirty = a.dirty_flag && a.dirty_flag[t] != 0u;
-    if (j == 0) {
-        a.task_U[t] = dirty ? INFINITY : ThresholdOf<METRIC>(tau, a.task_nq[src], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
-        a.cand_cnt[t] = 0;
-        if (t < a.n_groups) {   // (every group has a task: tasks >= n_groups)
-            a.group_zero[t] = 0;
-            a.group_zero[a.n_groups + t] = 0;
-        }
-    }
-    if (j >= K) return;
-    bool need;
-    if (dirty || (a.head && a.nearest[src] != j)) {
-        need = false;
-    } else {   // (head pass: the nearest cell — unless even its ball cannot reach tau, e.g. a far shard under the query's merge bound)
-        if (!(tau < (double)INFINITY)) {
-            need = true;
-        } else {
-            const double dd = (double)a.d;
-            const double s = (dd + 64.0) * 0x1p-22;
-            const double D = (double)a.cell_dist[(size_t)src * a.kmax + j];
-            const double r = (double)a.radius[cell0 + j];
-            if (METRIC == GPANN_METRIC_L2) {
-                const double g1 = (dd + 32.0) * 0x1p-23;
-                const double lb = sqrt(fmax(D, 0.0)) * (1.0 - s) - r;
-                need = !(lb > 0.0 && lb * lb > tau * (1.0 + 2.0 * g1) * (1.0 + s) + 1e-30);
-            } else {
-                const double nq = a.task_nq[src] * (1.0 + 1e-6), nc = (double)a.cell_cnorm[cell0 + j];
-                const double R = a.shard_rmax[b];
-                const double qn = sqrt(nq);
-                const double dot_ub = 0.5 * (nq + nc - D) + s * (nq + nc + fabs(D));
-                const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
-                need = dot_ub + qn * r * (1.0 + s) >= 1.0 - tau - e1 - s;
-            }
-        }
-    }
-    const uint32_t g = a.task_group[t];
-    if (need) {
-        atomicOr(&a.need[(size_t)g * a.kmax + j], 1u << ((t - a.groups[g].task_begin) >> 5));
-        if (a.q8_B)
-            a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + (t - a.groups[g].task_begin)] =
-                Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
-                                    (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j]);
-    } else if (a.q8_B) {
-        // "not needed" = a threshold nothing passes (the task's query tile may run on the cell for its neighbours' sake; an earlier 8-bit pass may
-        // have left the task's threshold here)
-        a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + (t - a.groups[g].task_begin)] = INFINITY;
-    }
-}
+// (Until round 3 NeedKernel — a thread per (task, cell) — and FilterItemsKernel were launches of their own, with SplitMergeKernel before them.)
 
 struct CellFilterArgs {
     const float* queries;
@@ -410,6 +382,7 @@ struct CellFilterArgs {
     // 8-bit pass (MODE 2): the int8 plane (KS KiB per tile, KS = k-steps of 32 dimensions), the tiles' largest norm words, the per-(task,
     // cell) thresholds written by NeedKernel, the tasks' query quantisation steps / 254, the cells' steps (FilterItemsKernel copies them into the items)
     const char* q8_planes;
+    const float* q8_norm;        // the 8-bit passes' norm words (squared L2 stores: shards.h q8_norm; else = plane_norm)
     const float2* tile_bound;    // [tiles] (the tile's largest norm word, 127 x its largest sum of |P'| over a row — cells.hip, TileBoundKernel)
     const float* q8_B;           // [groups][kmax][32 QT]
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
@@ -425,53 +398,206 @@ constexpr uint32_t kFQueue = 448;
 // dynamic LDS of FilterKernelCells
 constexpr size_t FilterLdsBytes(size_t image_bytes, int waves = kFWaves) { return image_bytes + waves * 2 * kGTileRows * sizeof(float) + (size_t)waves * kFQueue * 8; }
 
-// The work items of one pass: every (task group, cell) block with something left to run, its tile range cut into equal pieces of at
-// most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the launch;
-// blocks without work never reach them), one list per task group.  Order of the lists is irrelevant for the result.
-static __global__ void __launch_bounds__(256) FilterItemsKernel(CellFilterArgs a) {
-    const uint32_t block = blockIdx.x * 256 + threadIdx.x;
-    if (block == 0 && a.pass == 2 && a.work) a.work[3] = a.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
-    if (block >= a.n_groups * a.kmax) return;
-    const uint32_t mask = a.need[block];
-    if (mask == 0) return;
-    const uint32_t g = block / a.kmax, j = block - g * a.kmax;
-    const uint32_t shard = a.groups[g].shard;
-    const uint32_t cell0 = a.shard_cell_begin[shard];
-    if (j >= a.shard_cell_begin[shard + 1] - cell0) return;
-    const uint32_t d0 = (a.done0 ? a.done0[block] : 0u) | (a.done0b ? a.done0b[block] : 0u);
-    const uint32_t d1 = a.done1 ? a.done1[block] : 0u;
-    const int64_t t_cell = (int64_t)a.cell_tile_begin[cell0 + j];
-    const int64_t t_cell_end = (int64_t)a.cell_tile_begin[cell0 + j + 1];
-    const int64_t t_a = min(t_cell_end, t_cell + (int64_t)a.head_tiles);
-    const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + a.sample_div - 1) / a.sample_div));
-    const int64_t t_pass_end = a.pass == 0 ? t_a : (a.pass == 1 ? t_b : t_cell_end);
-    // segments every query tile of this block has already been run on need not be streamed again (the later passes would otherwise
-    // re-read the head and the sample of every cell: 1/sample_div of the store)
-    const int64_t t_first = (mask & ~d0) ? t_cell : ((mask & ~d1) ? t_a : t_b);
-    if (t_first >= t_pass_end) return;
-    const int64_t range = t_pass_end - t_first;
-    const uint32_t n = (uint32_t)((range + a.seg_tiles - 1) / a.seg_tiles);
-    // equal pieces, whole rounds of the workgroup's wavefronts (a wavefront with one tile more than the others keeps them waiting at
-    // the end of the item for a full memory latency)
-    const int64_t round = (int64_t)a.round_tiles;
-    const int64_t per = ((range + n - 1) / n + round - 1) / round * round;
-    const uint32_t base = a.group_first[g] + atomicAdd(&a.group_count[g], n);
-    CellItem it;
-    it.t_a = (uint32_t)t_a;
-    it.t_b = (uint32_t)t_b;
-    it.task_begin = a.groups[g].task_begin;
-    it.lo_shift = (uint32_t)t_cell - a.cell_lo_begin[cell0 + j];
-    it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (a.groups[g].task_count - 1u) << 24;
-    it.group = g;
-    it.block = block;
-    it.cell_scale = a.q8_scale ? a.q8_scale[cell0 + j] : 0.f;
-    it.hi_shift = (uint32_t)t_cell - a.cell_hi_begin[cell0 + j];
-    it.pad1 = 0u;
-    for (uint32_t i = 0; i < n; ++i) {
-        const int64_t b = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, b + per);
-        it.t_begin = (uint32_t)b;
-        it.t_end = (uint32_t)e;
-        a.items[base + i] = it;   // (group_first reserves tiles / seg_tiles + 1 >= n entries for every cell of the group)
+// The work items of one pass (PassSetupKernel, phase 3): every (task group, cell) block with something left to run, its tile range cut into
+// equal pieces of at most seg_tiles row tiles (bounded pieces keep the persistent workgroups of FilterKernelCells balanced to the end of the
+// launch; blocks without work never reach them), one list per task group.  Order of the lists is irrelevant for the result.
+// ---- one launch per pass (round 4): what SplitMergeKernel + NeedKernel + FilterItemsKernel did in three --------------------------------------
+// One workgroup per TASK GROUP (<= 256 tasks of one shard):
+//   phase 1  (a thread per task) the pieces of the task's split bucket of the PREVIOUS pass are merged into its list (SplitMergeKernel's
+//            job; the pass's statistics ride along), the task's k-th distance tau is taken — capped by the query's merge bound —, its
+//            bf16 threshold U is written and its candidate counter zeroed;
+//   phase 2  (a thread per (task, cell) pair, tau from LDS) the cell test of NeedKernel: the group's need mask per cell in LDS, the 8-bit
+//            pass's per-(task, cell) thresholds to the table;
+//   phase 3  (a thread per cell) the group's work items for FilterKernelCells (FilterItemsKernel's job), counted in LDS — one workgroup
+//            owns the group's list, so no global atomics — and the group's item count / claim cursor.
+// Nothing here can change a result: the lists are exact at any time, and which cells / candidates a pass looks at only has to be a
+// superset of what the k-th distances require (a merge bound that another group lowers while this one reads it is merely looser).
+struct PassSetupArgs {
+    NeedArgs need;
+    CellFilterArgs filt;
+    RescoreArgs merge;        // the previous pass's buckets (cand_cnt, cand_cap, parts, split_min, split lists), lists, query_tau, statistics
+    uint32_t merge_splits;    // 1: the previous launch was a bucket re-scoring whose heavy buckets were split (RescoreKernel, parts > 1)
+};
+constexpr int kSetupThreads = 256;
+static inline size_t PassSetupLdsBytes(uint32_t kmax) { return ((size_t)kmax + kGTasks + 8) * sizeof(uint32_t); }
+
+// the pieces of task t's split bucket -> its list (the body of SplitMergeKernel's loop): all 64 lanes of a wavefront; returns the list's k-th distance
+__device__ __forceinline__ float MergeSplitPieces(const RescoreArgs& a, uint32_t t, uint32_t n_parts, int lane) {
+    const uint32_t k = a.k;
+    const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
+    const uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
+    float ld_ = INFINITY;
+    uint32_t lr_ = kNoId;
+    if (lane < (int)k) {
+        ld_ = pd[lane];
+        lr_ = pr[lane];
+    }
+    for (uint32_t p = 1; p < n_parts; ++p) {
+        float cd_l = INFINITY;
+        uint32_t cr_l = kNoId;
+        if (lane < (int)k) {
+            cd_l = pd[(size_t)p * k + lane];
+            cr_l = pr[(size_t)p * k + lane];
+        }
+        for (uint32_t e = 0; e < k; ++e) {
+            const float cd = __shfl(cd_l, e);
+            const uint32_t cr = __shfl(cr_l, e);
+            const float td = __shfl(ld_, k - 1);
+            const uint32_t tr = __shfl(lr_, k - 1);
+            if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
+            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+            ListInsertF(ld_, lr_, cd, cr, k, lane);
+        }
+    }
+    if (lane < (int)k) {
+        a.list_dist[(size_t)t * k + lane] = ld_;
+        a.list_row[(size_t)t * k + lane] = lr_;
+    }
+    if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
+    return __shfl(ld_, k - 1);
+}
+
+template <int METRIC>
+static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetupArgs A) {
+    extern __shared__ uint32_t psm[];
+    const NeedArgs& a = A.need;
+    const CellFilterArgs& f = A.filt;
+    const uint32_t g = blockIdx.x;
+    const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count, b = a.groups[g].shard;
+    const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
+    uint32_t* s_misc = psm;                                             // [0] items of the group, [1] overflowed buckets, [2..3] candidates (u64, 8-byte aligned)
+    float* s_tau = reinterpret_cast<float*>(psm + 8);                   // [kGTasks] tau of the group's tasks (capped by the merge bound); NaN = dirty task
+    uint32_t* s_need = psm + 8 + kGTasks;                               // [kmax] the group's need mask per cell
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t j = tid; j < K; j += kSetupThreads) s_need[j] = 0u;
+    if (tid < 8) s_misc[tid] = 0u;
+    __syncthreads();
+
+    // ---- phase 1: thread tl <-> task task_begin + tl (kGTasks == kSetupThreads)
+    {
+        const uint32_t tl = (uint32_t)tid, t = task_begin + tl;
+        const bool real = tl < task_count;
+        float tau = INFINITY;
+        uint32_t parts_l = 0;
+        if (real) {
+            if (A.merge_splits) {
+                const uint32_t cnt = A.merge.cand_cnt[t];
+                if (cnt != 0u) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(s_misc + 2), (unsigned long long)cnt);
+                    if (cnt > A.merge.cand_cap) atomicAdd(&s_misc[1], 1u);
+                    else parts_l = min(A.merge.parts, (cnt + A.merge.split_min - 1) / A.merge.split_min);
+                }
+            }
+            tau = a.list_dist[(size_t)t * a.k + a.k - 1];
+        }
+        // the split buckets among this wavefront's 64 tasks, one after the other with all lanes
+        unsigned long long todo = __ballot(parts_l > 1u);
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t ti = task_begin + (uint32_t)(tid - lane + i);
+            const float kth = MergeSplitPieces(A.merge, ti, (uint32_t)__shfl((int)parts_l, i), lane);
+            if (lane == i) tau = kth;
+        }
+        if (real) {
+            if (a.query_tau) tau = fminf(tau, OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
+            const bool dirty = a.dirty_flag && a.dirty_flag[t] != 0u;
+            a.task_U[t] = dirty ? INFINITY : ThresholdOf<METRIC>((double)tau, a.task_nq[a.task_src[t]], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
+            a.cand_cnt[t] = 0;
+            s_tau[tl] = dirty ? __uint_as_float(0x7FC00000u) : tau;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the cell tests (NeedKernel), cells fastest: a task's table row is read coalesced
+    const uint32_t pairs = task_count * K;
+    for (uint32_t i = (uint32_t)tid; i < pairs; i += kSetupThreads) {
+        const uint32_t tl = i / K, j = i - tl * K, t = task_begin + tl;
+        const uint32_t src = a.task_src[t];
+        const float tau_f = s_tau[tl];
+        const bool dirty = tau_f != tau_f;
+        const double tau = (double)tau_f;
+        bool need;
+        if (dirty || (a.head && a.nearest[src] != j)) {
+            need = false;
+        } else if (!(tau < (double)INFINITY)) {
+            need = true;
+        } else {
+            const double dd = (double)a.d;
+            const double s = (dd + 64.0) * 0x1p-22;
+            const double D = (double)a.cell_dist[(size_t)src * a.kmax + j];
+            const double r = (double)a.radius[cell0 + j];
+            if (METRIC == GPANN_METRIC_L2) {
+                const double g1 = (dd + 32.0) * 0x1p-23;
+                const double lb = sqrt(fmax(D, 0.0)) * (1.0 - s) - r;
+                need = !(lb > 0.0 && lb * lb > tau * (1.0 + 2.0 * g1) * (1.0 + s) + 1e-30);
+            } else {
+                const double nq = a.task_nq[src] * (1.0 + 1e-6), nc = (double)a.cell_cnorm[cell0 + j];
+                const double R = a.shard_rmax[b];
+                const double qn = sqrt(nq);
+                const double dot_ub = 0.5 * (nq + nc - D) + s * (nq + nc + fabs(D));
+                const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + fabs(tau) * 0x1p-22;
+                need = dot_ub + qn * r * (1.0 + s) >= 1.0 - tau - e1 - s;
+            }
+        }
+        if (need) atomicOr(&s_need[j], 1u << (tl >> 5));
+        if (a.q8_B)   // every (task, cell) slot of the table in every 8-bit pass: the threshold, or "nothing passes"
+            a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + tl] =
+                need ? Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
+                                           (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j],
+                                           a.cell_l1 ? (double)a.cell_l1[(size_t)src * a.kmax + j] : -1.0)
+                     : INFINITY;
+    }
+    __syncthreads();
+
+    // ---- phase 3: the group's work items (FilterItemsKernel), a thread per cell
+    for (uint32_t j = (uint32_t)tid; j < K; j += kSetupThreads) {
+        const uint32_t block = g * a.kmax + j;
+        const uint32_t mask = s_need[j];
+        a.need[block] = mask;   // (later passes read it as their done mask)
+        if (mask == 0) continue;
+        const uint32_t d0 = (f.done0 ? f.done0[block] : 0u) | (f.done0b ? f.done0b[block] : 0u);
+        const uint32_t d1 = f.done1 ? f.done1[block] : 0u;
+        const int64_t t_cell = (int64_t)f.cell_tile_begin[cell0 + j];
+        const int64_t t_cell_end = (int64_t)f.cell_tile_begin[cell0 + j + 1];
+        const int64_t t_a = min(t_cell_end, t_cell + (int64_t)f.head_tiles);
+        const int64_t t_b = min(t_cell_end, max(t_a, t_cell + (t_cell_end - t_cell + f.sample_div - 1) / f.sample_div));
+        const int64_t t_pass_end = f.pass == 0 ? t_a : (f.pass == 1 ? t_b : t_cell_end);
+        const int64_t t_first = (mask & ~d0) ? t_cell : ((mask & ~d1) ? t_a : t_b);
+        if (t_first >= t_pass_end) continue;
+        const int64_t range = t_pass_end - t_first;
+        const uint32_t n = (uint32_t)((range + f.seg_tiles - 1) / f.seg_tiles);
+        const int64_t round = (int64_t)f.round_tiles;
+        const int64_t per = ((range + n - 1) / n + round - 1) / round * round;
+        const uint32_t base = f.group_first[g] + atomicAdd(&s_misc[0], n);
+        CellItem it;
+        it.t_a = (uint32_t)t_a;
+        it.t_b = (uint32_t)t_b;
+        it.task_begin = task_begin;
+        it.lo_shift = (uint32_t)t_cell - f.cell_lo_begin[cell0 + j];
+        it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (task_count - 1u) << 24;
+        it.group = g;
+        it.block = block;
+        it.cell_scale = f.q8_scale ? f.q8_scale[cell0 + j] : 0.f;
+        it.hi_shift = (uint32_t)t_cell - f.cell_hi_begin[cell0 + j];
+        it.pad1 = 0u;
+        for (uint32_t i = 0; i < n; ++i) {
+            const int64_t bb = min(t_pass_end, t_first + (int64_t)i * per), e = min(t_pass_end, bb + per);
+            it.t_begin = (uint32_t)bb;
+            it.t_end = (uint32_t)e;
+            f.items[base + i] = it;   // (group_first reserves tiles / seg_tiles + 1 >= n entries for every cell of the group)
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        f.group_count[g] = s_misc[0];
+        f.group_cursor[g] = 0u;
+        if (A.merge_splits && A.merge.stat_overflowed) {
+            const unsigned long long total = *reinterpret_cast<unsigned long long*>(s_misc + 2);
+            if (total) atomicAdd(A.merge.stat_candidates, total);
+            if (s_misc[1]) atomicAdd(A.merge.stat_overflowed, s_misc[1]);
+        }
+        if (g == 0 && f.pass == 2 && f.work) f.work[3] = f.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
     }
 }
 
@@ -661,7 +787,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
                 const char* base = lane_q8 + (size_t)(T + tw) * (KS * 1024);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) Ah[tw][ks].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + ks * 1024));
-                if (METRIC == GPANN_METRIC_L2) nrm[tw] = a.plane_norm[(size_t)(T + tw) * kGTileRows + c];
+                if (METRIC == GPANN_METRIC_L2) nrm[tw] = a.q8_norm[(size_t)(T + tw) * kGTileRows + c];
                 nmax[tw] = a.tile_bound[T + tw];   // (inner product: .x is 0)
             }
             return;

@@ -231,6 +231,12 @@ struct RescoreArgs {
     uint32_t seed_first_slot_of;
     uint32_t seed_catch_up;             // second seed launch: the tasks of queries that still have no bound are seeded after all
     const uint32_t* task_out;           // [tasks] slot index q * nprobe + j of every task
+    // SEED mode, every task seeded (seed_first_slot_of == 0): the task's first bf16 threshold U (ThresholdKernel's job) is written at the end of
+    // its seed evaluation — the shard-sample pass follows without a launch in between
+    float* seed_task_U;                 // [tasks] or null
+    const double* task_nq;              // [tasks] |q|^2 (through task_src)
+    const double* shard_rmax;           // [S]
+    uint32_t seed_hi_only;
 };
 
 __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd, uint32_t cr, uint32_t k, int lane) {
@@ -500,6 +506,10 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     }
     // the query's merge bound: the smallest k-th distance among its tasks' lists (a list that is not full yet has +inf there)
     if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
+    if (!RANGED) {
+        if (seed && a.seed_task_U && lane == (int)k - 1)   // (the lane that holds the k-th entry)
+            a.seed_task_U[t] = ThresholdOf<METRIC>((double)ld_, a.task_nq[a.task_src[t]], a.shard_rmax[a.task_shard[t]], (double)a.d, a.seed_hi_only != 0);
+    }
     return;
     } while (RANGED);   // items
 }
@@ -508,11 +518,11 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
 // lists — all grown from the task's list, so an entry of that list can be in several: duplicates are dropped by row — into the task's list.
 // It also keeps the pass's statistics (what OverflowCountKernel did in a launch of its own): buckets that overflowed, candidates in total.
 constexpr uint32_t kSplitMergeTasksPerWave = 8;   // (a wavefront per task: at C3, 40 000 wavefronts of which most return at once, the four launches were 0.30 ms of a 2.8 ms scan)
-static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) {
+__device__ __forceinline__ void SplitMergeBody(const RescoreArgs& a, uint32_t block) {   // (all 256 threads of the workgroup)
     __shared__ unsigned long long s_total;
     __shared__ uint32_t s_overflowed;
     const int lane = threadIdx.x & 63;
-    const uint32_t t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSplitMergeTasksPerWave;   // this wavefront's tasks: t0 .. t0 + 7, lane i looks at task t0 + i
+    const uint32_t t0 = (block * 4 + (threadIdx.x >> 6)) * kSplitMergeTasksPerWave;   // this wavefront's tasks: t0 .. t0 + 7, lane i looks at task t0 + i
     if (threadIdx.x == 0) {
         s_total = 0ull;
         s_overflowed = 0u;
@@ -568,14 +578,15 @@ static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) {
         if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
     }
 }
+static __global__ void __launch_bounds__(256) SplitMergeKernel(RescoreArgs a) { SplitMergeBody(a, blockIdx.x); }
 
 // The dirty tasks' lists: one wavefront per dirty task merges the range_segs partial lists RescoreKernel's RANGE mode left (ascending
 // (dist, row), disjoint row ranges) into the task's list — which then is the exact top-k of the whole shard, whatever the passes did.
-static __global__ void __launch_bounds__(64) DirtyMergeKernel(RescoreArgs a) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void DirtyMergeBody(const RescoreArgs& a, uint32_t index, int lane) {   // (one wavefront)
     const uint32_t n_dirty = min(*a.dirty_count, a.dirty_cap);
-    if (blockIdx.x >= n_dirty) return;
-    const uint32_t t = a.dirty_list[blockIdx.x].x, k = a.k;
+    if (index >= n_dirty) return;
+    const uint32_t dirty_index = index;
+    const uint32_t t = a.dirty_list[dirty_index].x, k = a.k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
     // 64 segments at a time: every lane looks at the FIRST (smallest) entry of one partial list; only the lists whose first entry still beats
@@ -585,14 +596,14 @@ static __global__ void __launch_bounds__(64) DirtyMergeKernel(RescoreArgs a) {
         float fd = INFINITY;
         uint32_t fr = kNoId;
         if (sg_l < a.range_segs) {
-            fd = a.part_dist[((size_t)blockIdx.x * a.range_segs + sg_l) * k];
-            fr = a.part_row[((size_t)blockIdx.x * a.range_segs + sg_l) * k];
+            fd = a.part_dist[((size_t)dirty_index * a.range_segs + sg_l) * k];
+            fr = a.part_row[((size_t)dirty_index * a.range_segs + sg_l) * k];
         }
         unsigned long long todo = __ballot(PairLess(fd, fr, __shfl(ld_, k - 1), __shfl(lr_, k - 1)));
         while (todo) {
             const uint32_t sg = sg0 + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            const size_t base = ((size_t)blockIdx.x * a.range_segs + sg) * k;
+            const size_t base = ((size_t)dirty_index * a.range_segs + sg) * k;
             float cd_l = INFINITY;
             uint32_t cr_l = kNoId;
             if (lane < (int)k) {
@@ -614,6 +625,13 @@ static __global__ void __launch_bounds__(64) DirtyMergeKernel(RescoreArgs a) {
         a.list_row[(size_t)t * k + lane] = lr_;
     }
     if (a.query_tau && lane == (int)k - 1 && ld_ < INFINITY) atomicMin(&a.query_tau[a.task_query[t]], OrderedKey(ld_));
+}
+static __global__ void __launch_bounds__(64) DirtyMergeKernel(RescoreArgs a) { DirtyMergeBody(a, blockIdx.x, (int)threadIdx.x); }
+// After the last pass, in one launch: the pieces of the split buckets into their lists (blocks below merge_blocks) and the dirty tasks' partial
+// lists into theirs (wavefront 0 of the blocks behind them; a dirty task has no bucket: its last passes gave it none).
+static __global__ void __launch_bounds__(256) FinalMergeKernel(RescoreArgs a, uint32_t merge_blocks) {
+    if (blockIdx.x < merge_blocks) SplitMergeBody(a, blockIdx.x);
+    else if (threadIdx.x < 64) DirtyMergeBody(a, blockIdx.x - merge_blocks, (int)threadIdx.x);
 }
 
 // final lists -> caller arrays: out[task_out[t]][i] = (dist, permutation[row], row)

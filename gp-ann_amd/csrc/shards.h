@@ -139,6 +139,10 @@ struct gpann_shards {
         uint32_t q8_ks = 0;                        // k-steps of 32 dimensions = ceil(d / 32)
         float* d_q8_scale = nullptr;               // [n_cells] quantisation step of the cell: max |p~_i - c^_i| / 127, rounded up
         double* d_q8_cnorm = nullptr;              // [n_cells] |c^|^2
+        // Squared L2 (round 4): the 8-bit passes' own norm words, -|p~|^2/2 + c^.e per plane row (e = p~ - c^ - s P': the row's quantisation error,
+        // known at store build), so that the only unknown part of q~.e is (q~ - c^).e, bounded by (s/2) |q~ - c^|_1 — the query in the frame of the
+        // CELL, 2-3x smaller than (s/2) |q~|_1 — without a per-cell query image (scan_cells.h, Q8Threshold).  [(cell tiles + 2) * 32], -inf on padding.
+        float* q8_norm = nullptr;
         float2* d_tile_bound = nullptr;            // [cell tiles + 2] (max over the tile's rows of plane_norm = -min |p~|^2 / 2, 127 max_row sum |P'|): cells.hip, TileBoundKernel
         // squared L2 only: the planes, their norms, the shards' max norms and the query images are taken around the store's mean row
         // `mu` ([ld] device, pad zero; nullptr = not centred: inner-product stores)
@@ -150,15 +154,36 @@ struct gpann_shards {
 
     // per-call workspace, grown on demand and reused
     gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8, ws_split;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of a call, [3] its last staged upload
-    bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
-    hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
-                                                                                          // and of the rest pass's filter launch alone
-    int filter_passes_timed = 0;
+    // Per-call host state, TWO sets (round 4): a call issued with GPANN_SCAN_DEFER returns once its work is enqueued, and the NEXT call may be
+    // planned, staged and enqueued behind it before gpann_scan_finish completes the first — the host-side planning of batch i + 1 then runs under
+    // the kernels of batch i.  `cur` is the slot of the most recent call.
+    struct CallState {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of the call, [3] the end of its enqueued device work
+        bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
+        hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
+                                                                                              // and of the rest pass's filter launch alone
+        int filter_passes_timed = 0;
+        gpann::ScanPlan plan;
+        gpann::PinnedStage stage;
+        uint32_t* pin_words = nullptr;   // pinned [16]: the filtered pipeline's counters land here (overflow / dirty words [0..3], work counters [4..11])
+        // what the completion of the call (CompleteCall: at once, or in gpann_scan_finish) needs to know
+        bool pending = false;            // enqueued, not completed yet
+        bool filtered = false;           // the filtered pipeline ran (its counters are on their way to pin_words)
+        uint32_t dirty_cap = 0;
+        const float* d_queries = nullptr;   // the device queries the kernels read (for the exact redo of an overflowed call)
+        uint32_t nq = 0, k = 0, nprobe = 0, T = 0;
+        int flags = 0;
+        void* stream = nullptr;
+        float* out_dist = nullptr;       // the call's DEVICE result arrays
+        uint32_t* out_ids = nullptr;
+        uint32_t* out_rows = nullptr;
+        float* host_dist = nullptr;      // host destinations of a call without GPANN_OUTPUT_ON_DEVICE (null: none)
+        uint32_t* host_ids = nullptr;
+        uint32_t* host_rows = nullptr;
+    } cs[2];
+    int cur = 0;
     gpann_scan_stats stats{};
-    gpann::ScanPlan plan;
-    gpann::PinnedStage stage;
-    gpann::DeviceBuffer ws_stage_dev;   // device mirror of `stage`: the call's small arrays arrive in it with one copy (scan.hip UploadBatch)
+    gpann::DeviceBuffer ws_stage_dev;   // device mirror of the calls' pinned `stage`s (uploads are stream-ordered: one mirror serves both slots): the call's small arrays arrive in it with one copy (scan.hip UploadBatch)
 };
 
 namespace gpann {

@@ -130,8 +130,11 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     TRY_OR_FAIL(hipMalloc(&s->d_offsets, (S + 1) * sizeof(int64_t)));
     TRY_OR_FAIL(hipMemcpy(s->d_offsets, s->offsets.data(), (S + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     if (rows) TRY_OR_FAIL(hipMemcpy(s->permutation, ids_concat, rows * sizeof(uint32_t), hipMemcpyHostToDevice));
-    for (auto& e : s->ev) TRY_OR_FAIL(hipEventCreate(&e));
-    for (auto& e : s->ev_filter) TRY_OR_FAIL(hipEventCreate(&e));
+    for (auto& c : s->cs) {
+        for (auto& e : c.ev) TRY_OR_FAIL(hipEventCreate(&e));
+        for (auto& e : c.ev_filter) TRY_OR_FAIL(hipEventCreate(&e));
+        TRY_OR_FAIL(hipHostMalloc(reinterpret_cast<void**>(&c.pin_words), 64, hipHostMallocDefault));
+    }
 
     if (rows) {
         if (flags & GPANN_POINTS_ON_DEVICE) {
@@ -265,11 +268,14 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     s->ws_partials.Release();
     s->ws_out.Release();
     s->ws_misc.Release();
-    s->stage.Release();
-    for (auto& e : s->ev)
-        if (e) (void)hipEventDestroy(e);
-    for (auto& e : s->ev_filter)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& c : s->cs) {
+        c.stage.Release();
+        if (c.pin_words) (void)hipHostFree(c.pin_words);
+        for (auto& e : c.ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : c.ev_filter)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete s;
     return GPANN_OK;
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1
-QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN, SCAN_FOR_MERGE = 1, 2, 4, 8, 16, 32
+QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN, SCAN_FOR_MERGE, SCAN_DEFER = 1, 2, 4, 8, 16, 32, 64
 MAX_K = 64
 NO_ID = np.uint32(0xFFFFFFFF)
 
@@ -28,7 +28,7 @@ _i64p = C.POINTER(C.c_int64)
 EXPORTS = [
     "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_build_filter", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
-    "gpann_scan_last_stats", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_query_batch_top", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
+    "gpann_scan_last_stats", "gpann_scan_finish", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_query_batch_top", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
 ]
 
@@ -90,6 +90,7 @@ def lib():
     L.gpann_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, _f32p]
     L.gpann_scan_last_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats)]
+    L.gpann_scan_finish.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.gpann_shards_set_scan_mode.argtypes = [C.c_void_p, C.c_int]
     L.gpann_router_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, C.c_int,
                                       C.POINTER(C.c_void_p)]
@@ -231,15 +232,24 @@ class Shards:
             return ids, dist, rows, ms.value
         return ids, dist, ms.value
 
-    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False, for_merge=False):
-        """Same with queries and outputs resident on the device (raw pointers); asynchronous unless timed."""
+    def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False, for_merge=False,
+                            defer=False, host_out=False):
+        """Same with queries resident on the device (raw pointer) and the outputs on the device (raw pointers) or — host_out — in host
+        arrays given by address (pinned ones for an asynchronous copy); asynchronous unless timed.  defer: GPANN_SCAN_DEFER — the call only
+        enqueues its work and finish() completes it; one more call may be issued before that."""
         probes = _np(probes, np.int32)
         stride = probes.shape[1]
         ms = C.c_float(0)
+        flags = QUERIES_ON_DEVICE | (0 if host_out else OUTPUT_ON_DEVICE) | (AUX_PASS if aux else 0) | (SCAN_FOR_MERGE if for_merge else 0) | (SCAN_DEFER if defer else 0)
         _check(lib().gpann_scan_buckets(self.h, C.c_void_p(int(queries_ptr)), nq, k, probes.ctypes.data_as(_i32p), stride, nprobe,
                                         C.c_void_p(int(out_ids_ptr)), C.c_void_p(int(out_dist_ptr)) if out_dist_ptr else None, None,
-                                        QUERIES_ON_DEVICE | OUTPUT_ON_DEVICE | (AUX_PASS if aux else 0) | (SCAN_FOR_MERGE if for_merge else 0), C.c_void_p(stream or 0),
-                                        C.byref(ms) if timed else None))
+                                        flags, C.c_void_p(stream or 0), C.byref(ms) if (timed and not defer) else None))
+        return ms.value
+
+    def finish(self):
+        """completes the oldest deferred scan call (gpann_scan_finish); returns its kernel time in ms"""
+        ms = C.c_float(0)
+        _check(lib().gpann_scan_finish(self.h, C.byref(ms)))
         return ms.value
 
     def scan_merged(self, queries, k, probes, nprobe, stream=None):

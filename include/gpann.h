@@ -60,7 +60,7 @@ enum {
                                           bf16 planes); for stores that only feed training / partitioning.  Scans on it are exact-mode */
     GPANN_AUX_PASS = 1 << 3,           /* profiling label: run the identical scan kernel under a second symbol name so that
                                           auxiliary passes (ground truth) stay out of the hot path's per-kernel statistics */
-    GPANN_SCAN_FOR_MERGE = 1 << 5      /* gpann_scan_buckets: the caller only merges the slots of a query (DedupNeighbors,
+    GPANN_SCAN_FOR_MERGE = 1 << 5,     /* gpann_scan_buckets: the caller only merges the slots of a query (DedupNeighbors,
                                           small_scale_queries.cpp:15-23, or one TopN over them, inverted_index.h:43-60).  Slot j of query q then
                                           holds the reference's per-slot list TRUNCATED after its last entry with distance <= tau_q, where
                                           tau_q = min over the query's slots of the slot's k-th distance (+inf for a slot with < k rows);
@@ -69,6 +69,15 @@ enum {
                                           among the first k of the merge: the merged result is bit-identical to the one over the full lists.
                                           In filter mode tau_q bounds every shard of the query, not only the one that produced it — rows and
                                           cells beyond it are never evaluated. */
+    GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
+                                          arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
+                                          with the plain exact scan should the data have defeated the filter, statistics, timing).  ONE further
+                                          call may be issued on the handle before the finish: its host-side planning and uploads then run while
+                                          the device works on the first (a call issued with two unfinished calls outstanding completes the older
+                                          one itself).  Contract until the finish: the same `stream` for the calls, device queries in the layout the
+                                          kernels read in place (GPANN_QUERIES_ON_DEVICE, d % 4 == 0, 16-byte aligned — otherwise the call simply
+                                          completes before it returns), queries and output arrays left alone (device outputs: not reused by the
+                                          next call). */
 };
 
 #define GPANN_MAX_K 64u                 /* top-k lists are held one entry per wavefront lane */
@@ -122,6 +131,9 @@ gpann_status gpann_shards_export_range(const gpann_shards* s, uint64_t row_begin
 gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
                                 uint32_t probe_stride, uint32_t nprobe, uint32_t* out_ids, float* out_dist, uint32_t* out_rows,
                                 int flags, void* stream, float* elapsed_ms);
+/* Completes the oldest gpann_scan_buckets call issued with GPANN_SCAN_DEFER (no-op if there is none): on return its results are in place —
+ * in the host arrays of a call without GPANN_OUTPUT_ON_DEVICE — gpann_scan_last_stats describes it and *elapsed_ms (may be NULL) is its kernel time. */
+gpann_status gpann_scan_finish(gpann_shards* s, float* elapsed_ms);
 
 /* Batched InvertedIndex::Query: ONE top-k over the union of the first nprobe probed shards (no dedupe), [nq][k]. */
 gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,

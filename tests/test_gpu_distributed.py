@@ -82,6 +82,47 @@ def _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank=False, **e
                 GPANN_DIST_DEVICE=dev, GPANN_DIST_OUT=out, GPANN_DIST_REPS="2", GPANN_ROUTER_VERIFY="1", GPANN_ROUTER_STRICT="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
 
 
+def _join_ranks(procs, tag, limit_s=240.0):
+    """waits for the rank processes; a rank that ends with an error (or the time limit) ends the others too — they would otherwise sit in
+    the rendezvous / a collective until THEIR limits — and the test fails with every rank's output"""
+    import tempfile
+    import threading
+    import time
+    outs = [None] * len(procs)
+
+    def drain(i):
+        outs[i] = procs[i].communicate()
+    threads = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(len(procs))]
+    for t in threads:
+        t.start()
+    t0 = time.time()
+    failed = None
+    while any(t.is_alive() for t in threads):
+        time.sleep(0.05)
+        bad = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() - t0 > limit_s:
+            failed = f"rank(s) {bad} ended with an error" if bad else f"no completion within {limit_s:.0f} s"
+            time.sleep(2.0)   # (the others may be about to notice by themselves: their messages are worth having)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+    for t in threads:
+        t.join(30)
+    if failed is None and all(p.returncode == 0 for p in procs):
+        return outs
+    report = f"[{tag}] {failed or 'a rank failed'}; return codes {[p.returncode for p in procs]}\n"
+    for i, o in enumerate(outs):
+        so, se = o if o else ("", "")
+        report += f"--- rank {i} stdout tail:\n{so[-1500:]}\n--- rank {i} stderr tail:\n{se[-3000:]}\n"
+    try:   # kept for the record of rare events (tools/stress_suite_context.sh collects gpurun_out)
+        with open(os.path.join(ROOT, "gpurun_out", f"distributed_failure_{tag}_{os.getpid()}.txt"), "w") as fh:
+            fh.write(report)
+    except OSError:
+        pass
+    pytest.fail(report)
+
+
 def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False):
     f = data["files"]
     out = str(data["tmp"] / f"out_{tag}.bin")
@@ -92,9 +133,7 @@ def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False):
         env = _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank)
         procs.append(subprocess.Popen([DB, f["points"], f["queries"], f["gt"], str(data["k"]), f["part"], router], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, so[-2000:] + se[-2000:]
+    outs = _join_ranks(procs, tag)
     raw = np.fromfile(out, np.uint32)
     nq, k = int(raw[0]), int(raw[1])
     assert (nq, k) == (data["nq"], data["k"])

@@ -164,3 +164,84 @@ def test_split_buckets_give_the_same_lists(orc, gp, monkeypatch, parts, split_mi
     for metric in (0, 1):
         st = _check(orc, gp, pts, clusters, queries, probes, 1, k, metric, expect_filtered=None)
         assert st["filtered"] == 1 and st["filter_candidates"] > 64 * nq, st   # buckets heavy enough to be split
+
+
+def _hip():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")   # the runtime libgpann_hip.so is linked against (device buffers, pinned arrays and a stream without torch)
+
+    def ok(rc):
+        assert rc == 0, f"hip error {rc}"
+    return C, hip, ok
+
+
+@pytest.mark.parametrize("mode", ["filter", "exact", "overflow"])
+def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
+    """GPANN_SCAN_DEFER (include/gpann.h): a call only enqueues its work, the NEXT call is planned and enqueued behind it, gpann_scan_finish
+    completes them oldest first.  Results (pinned host arrays) and statistics of every call equal the plain call's and the oracle's —
+    `overflow`: the first batch floods its buckets with tied rows, so its filtered attempt is redone with the exact scan AT ITS FINISH, after the
+    second batch has already been enqueued behind it."""
+    C, hip, ok = _hip()
+    rng = np.random.default_rng(77)
+    n, d, nq, k, nprobe = 30000, 16, 96, 10, 1
+    pts = make_mixture(orc, n, d, n_centers=4)
+    if mode == "overflow":
+        pts[2000:] = pts[2000]
+    clusters = [np.arange(n, dtype=np.uint32)]
+    batches = [make_mixture(orc, nq, d, seed=556 + i, n_centers=4) for i in range(3)]
+    if mode == "overflow":
+        batches[0][:40] = pts[2000]   # 40 tasks tie with tens of thousands of rows: more dirty tasks than the pipeline redoes itself
+    probes = np.zeros((nq, nprobe), np.int32)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(0 if mode == "exact" else 1)
+    ivf = orc.ivf_build(pts, clusters)
+    st = C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(st)))
+    q_dev, h_ids, h_dist = [], [], []
+    nb = nq * nprobe * k * 4
+    for q in batches:
+        p = C.c_void_p()
+        ok(hip.hipMalloc(C.byref(p), C.c_size_t(q.nbytes)))
+        ok(hip.hipMemcpy(p, q.ctypes.data_as(C.c_void_p), C.c_size_t(q.nbytes), 1))
+        q_dev.append(p)
+        for lst in (h_ids, h_dist):
+            h = C.c_void_p()
+            ok(hip.hipHostMalloc(C.byref(h), C.c_size_t(nb), 0))
+            lst.append(h)
+    ok(hip.hipDeviceSynchronize())
+
+    def host_view(h, dtype):
+        return np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_uint32)), shape=(nq * nprobe * k,)).view(dtype).reshape(nq, nprobe, k)
+
+    # batch 0 and 1 enqueued back to back, then: finish(0), enqueue 2, finish(1), finish(2)
+    shards.scan_buckets_device(q_dev[0].value, nq, k, probes, nprobe, h_ids[0].value, h_dist[0].value, st.value, defer=True, host_out=True)
+    shards.scan_buckets_device(q_dev[1].value, nq, k, probes, nprobe, h_ids[1].value, h_dist[1].value, st.value, defer=True, host_out=True)
+    stats = []
+    shards.finish()
+    stats.append(shards.stats())
+    shards.scan_buckets_device(q_dev[2].value, nq, k, probes, nprobe, h_ids[2].value, h_dist[2].value, st.value, defer=True, host_out=True)
+    shards.finish()
+    stats.append(shards.stats())
+    shards.finish()
+    stats.append(shards.stats())
+    shards.finish()   # nothing outstanding: a no-op
+    for i, q in enumerate(batches):
+        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, q, k, probes, nprobe, 0, nthreads=4)
+        assert np.array_equal(host_view(h_ids[i], np.uint32), wi), (mode, i)
+        assert np.array_equal(host_view(h_dist[i], np.uint32), wd.view(np.uint32)), (mode, i)
+        assert stats[i]["tasks"] == nq
+    if mode == "filter":
+        assert all(s_["filtered"] == 1 for s_ in stats), stats
+    if mode == "exact":
+        assert all(s_["filtered"] == 0 for s_ in stats), stats
+    if mode == "overflow":
+        assert stats[0]["filtered"] == 0, stats   # (the other batches may or may not get by with a few dirty tasks: their results are checked above)
+    # a plain (synchronous) call right after deferred ones
+    ids, dist, _ = shards.scan_buckets(batches[1], k, probes, nprobe)
+    assert np.array_equal(ids, host_view(h_ids[1], np.uint32)) and np.array_equal(dist.view(np.uint32), host_view(h_dist[1], np.uint32))
+    for p in q_dev:
+        ok(hip.hipFree(p))
+    for h in h_ids + h_dist:
+        ok(hip.hipHostFree(h))
+    ok(hip.hipStreamDestroy(st))
+    shards.close()

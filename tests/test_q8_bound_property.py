@@ -28,7 +28,7 @@ def up32(x):
     return y if float(y) >= x else np.nextafter(y, f32(np.inf))
 
 
-def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius):
+def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius, l1_table=-1.0):
     """scan_cells.h Q8Threshold, line by line (double arithmetic)"""
     if not tau < np.inf:
         return f32(-np.inf)
@@ -44,8 +44,10 @@ def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius):
     cn = np.sqrt(nc)
     e_tab = 0.5 * ((d + 8.0) * 2.0 ** -23 * abs(D_table) + 2.0 ** -21 * (qn + cn) * np.sqrt(abs(D_table)) + 2.0 ** -40 * (nq + nc))
     r_eff = radius + 2.0 ** -23 * (R + cn)          # |p~ - c^| <= |p - c| + the rounding of the centred coordinates
-    E = 0.5 * s_c * (1.0 + 1e-6) * q1 + tscale / 508.0 * (1.0 + 1e-6) * (np.sqrt(d) * r_eff + 0.5 * d * s_c)
-    e_fp = 2.0 ** -21 * (qn * (r_eff + np.sqrt(d) * s_c) + 0.5 * R * R + 1.0)
+    # the own norm words of the 8-bit plane (squared L2): only (q~ - c^).e is unknown, |.| <= (s/2) |q~ - c^|_1
+    q1_eff = l1_table * (1.0 + (d + 8.0) * 2.0 ** -24) + 2.0 ** -23 * np.sqrt(d) * (qn + cn) if l1_table >= 0.0 else q1
+    E = 0.5 * s_c * (1.0 + 1e-6) * q1_eff + tscale / 508.0 * (1.0 + 1e-6) * (np.sqrt(d) * r_eff + 0.5 * d * s_c)
+    e_fp = 2.0 ** -21 * (qn * (r_eff + np.sqrt(d) * s_c) + 0.5 * R * R + cn * np.sqrt(d) * s_c + 1.0)
     Bd0 = Ub - qc - E - e_tab - e_fp
     Bd = Bd0 - 1024.0 * s_c * tscale / 254.0 * (1.0 + 1e-6) - 2.0 ** -22 * abs(Bd0)
     Bf = f32(Bd)
@@ -64,9 +66,11 @@ def make_cell(rng, n, d, centre_offset, sigma, outliers):
     return pts
 
 
-@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("metric,cell_frame", [(0, True), (0, False), (1, False)])
 @pytest.mark.parametrize("case", ["plain", "offset", "outliers", "tiny", "huge", "degenerate", "degenerate_ulp"])
-def test_rows_within_tau_pass_the_8_bit_test(metric, case):
+def test_rows_within_tau_pass_the_8_bit_test(metric, cell_frame, case):
+    """cell_frame (squared L2, the default store layout since round 4): the plane's own norm words -|p~|^2/2 + c^.e (cells.hip CellQ8NormKernel) with
+    the error term (s/2) |q~ - c^|_1 from the fp32 table of |q - c|_1 (CellDistKernel<true>); else the plain norm words with (s/2) |q~|_1"""
     cases = ["plain", "offset", "outliers", "tiny", "huge", "degenerate", "degenerate_ulp"]
     rng = np.random.default_rng(1000 * metric + cases.index(case))
     d, n, nq = 48, 640, 24
@@ -97,6 +101,9 @@ def test_rows_within_tau_pass_the_8_bit_test(metric, case):
     s_c = up32(max(float(np.abs(res).max()) * (1.0 + 1e-6) / 127.0, 1e-30))
     Pq = np.clip(np.rint((pt.astype(np.float64) - ct.astype(np.float64)) / float(s_c)), -127, 127).astype(np.int64)
     nhn = (-0.5 * (pt.astype(np.float64) ** 2).sum(axis=1)).astype(f32) if metric == 0 else np.zeros(n, f32)
+    if cell_frame:   # CellQ8NormKernel: -|p~|^2/2 + c^.e per row, e = (p~ - c^) - s P' (double), one rounding to a float
+        e_q = (pt.astype(np.float64) - ct.astype(np.float64)) - float(s_c) * Pq
+        nhn = (-0.5 * (pt.astype(np.float64) ** 2).sum(axis=1) + e_q @ ct.astype(np.float64)).astype(f32)
     # CellRadiusKernel: max |p - c| in the ORIGINAL coordinates (double), x (1 + 1e-6), rounded up to a float
     radius = float(up32(float(np.sqrt(((pts.astype(np.float64) - c.astype(np.float64)) ** 2).sum(axis=1)).max()) * (1.0 + 1e-6)))
     R = float(np.sqrt((((store - mu).astype(f32).astype(np.float64)) ** 2).sum(axis=1)).max()) * (1.0 + 1e-12)
@@ -114,12 +121,13 @@ def test_rows_within_tau_pass_the_8_bit_test(metric, case):
             L = np.clip(np.rint((u - H) * 254.0), -127, 127).astype(np.int64)
             H = H.astype(np.int64)
             E = np_ref.dist_many(pts, q, metric)                                    # canonical binary32 distances
-            D_table = f32(0.0)
-            for x in range(d):                                                      # CellDistKernel: plain fp32 sum of squared fp32 differences
+            D_table, L1_table = f32(0.0), f32(0.0)
+            for x in range(d):                                                      # CellDistKernel: plain fp32 sums of the squared / absolute fp32 differences
                 df = f32(q[x] - c[x])
                 D_table = f32(D_table + f32(df * df))
+                L1_table = f32(L1_table + np.abs(df))
             for tau in (float(np.sort(E)[9]), float(np.sort(E)[0]), float(np.sort(E)[n // 2]), float(np.sort(E)[9]) * 1.5 + (1e-9 if degenerate else 0.0)):
-                B = q8_threshold(metric, tau, nqd, q1, float(t_q), R, float(d), float(D_table), nc, float(s_c), radius)
+                B = q8_threshold(metric, tau, nqd, q1, float(t_q), R, float(d), float(D_table), nc, float(s_c), radius, float(L1_table) if cell_frame else -1.0)
                 h = Pq @ H
                 l = Pq @ L
                 assert np.abs(h).max() < 2 ** 22 and np.abs(l).max() < 2 ** 22
