@@ -529,19 +529,77 @@ def main():
     #    (probe lists through pinned host arrays) leaves the critical path.  GPANN_BENCH_ROUTE_AHEAD=0: strictly one batch at a time.
     merger = concurrent.futures.ThreadPoolExecutor(1)
     route_ahead = (not multi) and os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0"
+    # (one rank, round 4) ... and the SCAN of batch i + 1 is planned, staged and enqueued behind batch i before batch i is waited for
+    # (GPANN_SCAN_DEFER / gpann_scan_finish, include/gpann.h): the host side of a scan call — task lists, group tables, the uploads, ~35 launches —
+    # runs under the previous batch's kernels instead of between two batches.  GPANN_BENCH_SCAN_AHEAD=0: the scan call completes before it returns.
+    scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
     if route_ahead:
         r_stream = torch.cuda.Stream(device=dev)
-        r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(2)]
+        r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
         router_pool = concurrent.futures.ThreadPoolExecutor(1)
         def route_job(j):
-            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j & 1],
+            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j % 3],
                                              want_min_dist=False, n_top=None if nprobe == S else nprobe)
             return pr, r_ms, router.stats()
+
+    def scan_begin(pr, buf):
+        """enqueue the scan of one batch (deferred call): the per-slot lists travel to the pinned host buffers `buf` behind the kernels"""
+        key = (nq, nprobe, buf)
+        if key not in host_out:
+            host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory())
+        hd, hi = host_out[key]
+        shards.scan_buckets_device(queries.data_ptr(), nq, k, np.ascontiguousarray(pr[:, :nprobe]), nprobe, hi.data_ptr(), hd.data_ptr(), stream, for_merge=merge_bound,
+                                   defer=True, host_out=True)
+
+    def scan_finish(buf):
+        ms = shards.finish()
+        hd, hi = host_out[(nq, nprobe, buf)]
+        return hd.numpy(), hi.numpy().view(np.uint32), ms
 
     def run_steps(count, record):
         """count steps back to back; returns the last merged lists"""
         pending = None
         md = mi = None
+        def note(t_step, r_ms, s_ms, rst):
+            if record is None:
+                return
+            nonlocal_stats = shards.stats()
+            step_wall_ms.append(round(1e3 * (time.perf_counter() - t_step), 3))
+            scan_ms.append(nonlocal_stats["scan_ms"])
+            filter_ms.append(nonlocal_stats["filter_ms"])
+            rest_ms.append(nonlocal_stats["filter_rest_ms"])
+            router_ms.append(r_ms)
+            router_bound_ms.append(rst["last_bound_ms"])
+            algo_bytes.append(nonlocal_stats["algorithmic_bytes"])
+            record["stats"] = nonlocal_stats
+            record["router_bound_flops"] = rst["last_bound_flops"]
+        if scan_ahead and count:
+            # routes run two batches ahead of the batch being completed, scans one
+            routes = {0: router_pool.submit(route_job, 0)}
+            if count > 1:
+                routes[1] = router_pool.submit(route_job, 1)
+            info = {}
+            pr, r_ms, rst = routes.pop(0).result()
+            info[0] = (r_ms, rst)
+            scan_begin(pr, 0)
+            t_step = time.perf_counter()
+            for it in range(count):
+                if pending is not None:   # the merge of batch it - 1 (submitted a whole batch ago): its host buffers are handed to batch it + 1 next
+                    md, mi, _ = pending.result()
+                    pending = None
+                if it + 1 < count:
+                    pr, r_ms, rst = routes.pop(it + 1).result()
+                    info[it + 1] = (r_ms, rst)
+                    if it + 2 < count:
+                        routes[it + 2] = router_pool.submit(route_job, it + 2)
+                    scan_begin(pr, (it + 1) & 1)     # (batch it + 1 queued behind batch it, which the GPU is still working on)
+                sd, si, s_ms = scan_finish(it & 1)
+                pending = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
+                note(t_step, info[it][0], s_ms, info.pop(it)[1])
+                t_step = time.perf_counter()
+            if pending is not None:
+                md, mi, _ = pending.result()
+            return md, mi
         nxt = router_pool.submit(route_job, 0) if route_ahead and count else None
         for it in range(count):
             t_step = time.perf_counter()
@@ -556,17 +614,7 @@ def main():
             if pending is not None:
                 md, mi, _ = pending.result()
             pending = fut
-            if record is not None:
-                nonlocal_stats = shards.stats()
-                step_wall_ms.append(round(1e3 * (time.perf_counter() - t_step), 3))
-                scan_ms.append(nonlocal_stats["scan_ms"])
-                filter_ms.append(nonlocal_stats["filter_ms"])
-                rest_ms.append(nonlocal_stats["filter_rest_ms"])
-                router_ms.append(r_ms)
-                router_bound_ms.append(rst["last_bound_ms"])
-                algo_bytes.append(nonlocal_stats["algorithmic_bytes"])
-                record["stats"] = nonlocal_stats
-                record["router_bound_flops"] = rst["last_bound_flops"]
+            note(t_step, r_ms, s_ms, rst)
         if pending is not None:
             md, mi, _ = pending.result()
         return md, mi
@@ -694,7 +742,9 @@ def main():
     result["hbm_resident_GB"] = hbm_resident_gb
     result["config"]["slot_lists"] = ("cut at the query's merge bound (GPANN_SCAN_FOR_MERGE): the merged neighbours are bit-identical to the merge of the "
                                       "complete QueryBucket lists" if merge_bound else "complete QueryBucket lists")
-    result["config"]["pipeline"] = ("batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned"
+    result["config"]["pipeline"] = (("batches overlap: batch i+2 is routed (second stream), the scan of batch i+1 is planned and enqueued behind batch i (deferred "
+                                     "scan call) and batch i-1 is merged on the host while batch i is scanned" if scan_ahead else
+                                     "batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned")
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
     result["detail"] = {"merge": {"slot_entries": slot_entries, "duplicate_ids_dropped": dup_ids,
                                   "note": "DedupNeighbors over the per-slot lists of the last timed step: entries whose id also came back from another probed shard"},

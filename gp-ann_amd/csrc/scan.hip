@@ -708,13 +708,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     GPANN_REQUIRE(items_cap < 0xFFFFFFFFull, "too many filter work items");
     group_first[G] = (uint32_t)items_cap;
     const size_t gtab_words = ((size_t)3 * G + 1 + 3) / 4 * 4;   // group_first [G+1] | group_count [G] | group_cursor [G], 16-byte multiple
-    GPANN_TRY(s->ws_need.Reserve(4 * need_words * 4 + (size_t)G * sizeof(CellGroup) + 64 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
+    const size_t ticket_words = 0;
+    GPANN_TRY(s->ws_need.Reserve((4 * need_words + ticket_words) * 4 + (size_t)G * sizeof(CellGroup) + 64 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
     need_pass[0] = s->ws_need.as<uint32_t>();
     need_pass[1] = need_pass[0] + need_words;
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
-    CellGroup* d_groups_own = reinterpret_cast<CellGroup*>(done_head + need_words);
+    uint32_t* d_tickets = done_head + need_words;      // (zeroed with the masks)
+    CellGroup* d_groups_own = reinterpret_cast<CellGroup*>(d_tickets + ticket_words);
     unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups_own + G);   // [0..2] work counters (scan_cells.h), [3] = [1] before the rest pass
     uint32_t* d_group_first_own = reinterpret_cast<uint32_t*>(d_work + 4);
     uint32_t* d_group_count = d_group_first_own + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
@@ -823,10 +825,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     size_t q8_B_words = 0;
     if (use_q8) {
         const size_t img8 = (size_t)G * QT8 * KS8 * 2048, b_words = (size_t)G * kmax * 32u * QT8;
-        GPANN_TRY(s->ws_q8.Reserve(img8 + b_words * 4 + 256));
+        // (one threshold table PER 8-bit pass, both set to +inf — "this task does not need this cell" — by FilterInitKernel below: a pass's set-up
+        // launch then writes the few needed (task, cell) slots only.  With one table every slot had to be rewritten in every pass: 20 000 scattered
+        // 4-byte stores per task group)
+        GPANN_TRY(s->ws_q8.Reserve(img8 + 2 * b_words * 4 + 256));
         q8_image = s->ws_q8.as<char>();
         q8_B = reinterpret_cast<float*>(q8_image + img8);
-        q8_B_words = b_words;   // (set to +inf — "this task does not need this cell" — by FilterInitKernel below)
+        q8_B_words = b_words;
         switch (KS8) {
 #define GPANN_IMAGE8(KS_)                                                                                                                                   \
     case KS_:                                                                                                                                               \
@@ -847,7 +852,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ia.zero[1] = d_dirty_flag;             // [T]
         ia.zero_words[1] = T;
         ia.zero[2] = need_pass[0];             // the passes' need / done masks
-        ia.zero_words[2] = 4 * (uint64_t)need_words;
+        ia.zero_words[2] = 4 * (uint64_t)need_words + ticket_words;
         ia.zero[4] = reinterpret_cast<uint32_t*>(d_work);   // work counters (4 x u64)
         ia.zero_words[4] = 8;
         ia.zero[3] = cand_cnt;                 // [T]
@@ -855,12 +860,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ia.query_tau = d_query_tau;
         ia.nq = nq;
         ia.inf_floats = reinterpret_cast<uint32_t*>(q8_B);
-        ia.inf_words = q8_B_words;
+        ia.inf_words = 2 * q8_B_words;
         ia.fill_dist = out.dist;   // unused slots (skipped probes, shards with < k rows) read as (+inf, NO_ID): FillKernel's job, in this launch
         ia.fill_ids = out.ids;
         ia.fill_rows = out.rows;
         ia.fill_n = (uint64_t)nq * nprobe_of_call * k;
-        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(ia.zero_words[2], q8_B_words), T), ia.fill_n);
+        const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(ia.zero_words[2], 2 * q8_B_words), T), ia.fill_n);
         hipLaunchKernelGGL(FilterInitKernel, dim3((uint32_t)std::min<uint64_t>(2048, (most + 255) / 256)), dim3(256), 0, st, ia);
         GPANN_HIP_TRY(hipGetLastError());
     }
@@ -1158,7 +1163,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         na.hi_only = hi_pass ? 1u : 0u;
         na.head = pass == 0 ? 1u : 0u;
         na.need = need_pass[pass];
-        na.q8_B = q8_pass ? q8_B : nullptr;
+        float* const pass_B = q8_pass ? q8_B + (pass == 2 ? q8_B_words : 0) : nullptr;   // (this pass's own table)
+        na.q8_B = pass_B;
+        fa.q8_B = pass_B;
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
         fa.round_tiles = q8_pass ? q8_waves * (pass == 2 ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
@@ -1174,8 +1181,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             ps.merge.parts = split_parts;
             ps.merge_splits = buckets_pending ? 1u : 0u;
             const size_t slds = PassSetupLdsBytes(kmax);
-            if (l2) hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_L2>, dim3(G), dim3(kSetupThreads), slds, st, ps);
-            else hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_MIPS>, dim3(G), dim3(kSetupThreads), slds, st, ps);
+            if (l2) hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_L2>, dim3(kSetupChunks, G), dim3(kSetupThreads), slds, st, ps);
+            else hipLaunchKernelGGL(PassSetupKernel<GPANN_METRIC_MIPS>, dim3(kSetupChunks, G), dim3(kSetupThreads), slds, st, ps);
+            hipLaunchKernelGGL(PassItemsKernel, dim3(G), dim3(kItemsThreads), 0, st, ps);
             buckets_pending = false;
         }
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it (FilterItemsKernel keeps the count, work[3]), and its begin / end
@@ -1186,7 +1194,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             // (measurement aid, WRONG RESULTS: GPANN_DEBUG_Q8_NO_CAND=1 raises every threshold to +inf after the items are built — the launch streams
             // and multiplies the same tiles but finds no candidate: what the candidate hand-off costs)
             if (EnvU32("GPANN_DEBUG_Q8_NO_CAND", 0) != 0)
-                GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q8_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
+                GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pass_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             void* kargs8[] = {&f8};

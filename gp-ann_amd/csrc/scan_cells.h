@@ -64,7 +64,7 @@ struct CellDistArgs {
 
 // 64 tasks x 64 cells per pass of the cell loop; squared L2 distance in plain fp32 (bounds carry their own slack)
 template <bool WITH_L1>
-static __global__ void __launch_bounds__(256, WITH_L1 ? 2 : 3) CellDistKernel(CellDistArgs a) {
+static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) {
     constexpr int kStride = 36;
     __shared__ float sC[64 * kStride];
     __shared__ float sQ[64 * kStride];
@@ -418,35 +418,66 @@ struct PassSetupArgs {
     RescoreArgs merge;        // the previous pass's buckets (cand_cnt, cand_cap, parts, split_min, split lists), lists, query_tau, statistics
     uint32_t merge_splits;    // 1: the previous launch was a bucket re-scoring whose heavy buckets were split (RescoreKernel, parts > 1)
 };
-constexpr int kSetupThreads = 256;
+constexpr int kSetupThreads = 1024;   // (40 task groups at the NS workload: the launch lives on threads per group — 256 threads took 78 rounds of the cell loop)
 static inline size_t PassSetupLdsBytes(uint32_t kmax) { return ((size_t)kmax + kGTasks + 8) * sizeof(uint32_t); }
 
-// the pieces of task t's split bucket -> its list (the body of SplitMergeKernel's loop): all 64 lanes of a wavefront; returns the list's k-th distance
+// the pieces of task t's split bucket -> its list (the body of SplitMergeKernel's loop): all 64 lanes of a wavefront; returns the list's k-th distance.
+// For k <= 16 every piece is fetched up front — lanes 16 q .. 16 q + k - 1 hold piece q (pieces 4 .. 7 in a second register): one memory latency
+// per task instead of one per piece (a wavefront of PassSetupKernel merges its tasks one after the other).
 __device__ __forceinline__ float MergeSplitPieces(const RescoreArgs& a, uint32_t t, uint32_t n_parts, int lane) {
     const uint32_t k = a.k;
     const float* pd = a.split_dist + ((size_t)t * a.parts) * k;
     const uint32_t* pr = a.split_row + ((size_t)t * a.parts) * k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
-    if (lane < (int)k) {
-        ld_ = pd[lane];
-        lr_ = pr[lane];
-    }
-    for (uint32_t p = 1; p < n_parts; ++p) {
-        float cd_l = INFINITY;
-        uint32_t cr_l = kNoId;
-        if (lane < (int)k) {
-            cd_l = pd[(size_t)p * k + lane];
-            cr_l = pr[(size_t)p * k + lane];
+    if (k <= 16 && n_parts <= 8) {
+        const uint32_t q = (uint32_t)lane >> 4, e_l = (uint32_t)lane & 15u;
+        float d0 = INFINITY, d1 = INFINITY;
+        uint32_t r0 = kNoId, r1 = kNoId;
+        if (e_l < k && q < n_parts) {
+            d0 = pd[(size_t)q * k + e_l];
+            r0 = pr[(size_t)q * k + e_l];
         }
-        for (uint32_t e = 0; e < k; ++e) {
-            const float cd = __shfl(cd_l, e);
-            const uint32_t cr = __shfl(cr_l, e);
-            const float td = __shfl(ld_, k - 1);
-            const uint32_t tr = __shfl(lr_, k - 1);
-            if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
-            if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
-            ListInsertF(ld_, lr_, cd, cr, k, lane);
+        if (e_l < k && q + 4 < n_parts) {
+            d1 = pd[(size_t)(q + 4) * k + e_l];
+            r1 = pr[(size_t)(q + 4) * k + e_l];
+        }
+        // piece 0 is the starting list: entry e of it sits in lane e already
+        ld_ = lane < (int)k ? d0 : INFINITY;
+        lr_ = lane < (int)k ? r0 : kNoId;
+        for (uint32_t p = 1; p < n_parts; ++p) {
+            for (uint32_t e = 0; e < k; ++e) {
+                const int src = (int)(16u * (p & 3u) + e);
+                const float cd = p < 4 ? __shfl(d0, src) : __shfl(d1, src);
+                const uint32_t cr = p < 4 ? __shfl(r0, src) : __shfl(r1, src);
+                const float td = __shfl(ld_, k - 1);
+                const uint32_t tr = __shfl(lr_, k - 1);
+                if (!PairLess(cd, cr, td, tr)) break;   // (ascending: nothing after it fits either)
+                if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+                ListInsertF(ld_, lr_, cd, cr, k, lane);
+            }
+        }
+    } else {
+        if (lane < (int)k) {
+            ld_ = pd[lane];
+            lr_ = pr[lane];
+        }
+        for (uint32_t p = 1; p < n_parts; ++p) {
+            float cd_l = INFINITY;
+            uint32_t cr_l = kNoId;
+            if (lane < (int)k) {
+                cd_l = pd[(size_t)p * k + lane];
+                cr_l = pr[(size_t)p * k + lane];
+            }
+            for (uint32_t e = 0; e < k; ++e) {
+                const float cd = __shfl(cd_l, e);
+                const uint32_t cr = __shfl(cr_l, e);
+                const float td = __shfl(ld_, k - 1);
+                const uint32_t tr = __shfl(lr_, k - 1);
+                if (!PairLess(cd, cr, td, tr)) break;
+                if (__ballot(lane < (int)k && lr_ == cr) != 0ull) continue;
+                ListInsertF(ld_, lr_, cd, cr, k, lane);
+            }
         }
     }
     if (lane < (int)k) {
@@ -457,49 +488,67 @@ __device__ __forceinline__ float MergeSplitPieces(const RescoreArgs& a, uint32_t
     return __shfl(ld_, k - 1);
 }
 
+// Grid: (kSetupChunks, task groups).  Workgroup (p, g) owns the tasks [64 p, 64 p + 64) of group g — two query tiles — for phases 1 and 2
+// (with ONE workgroup per group the launch ran on 40 of the 256 CUs at the NS workload and its chains of dependent loads, 20 rounds of
+// the cell loop deep, took 0.10 - 0.15 ms); the group's need masks are OR-ed together in global memory with device-scope atomics, and
+// PassItemsKernel — the next launch — runs phase 3 per group.
+constexpr uint32_t kSetupChunkTasks = 64;
+constexpr uint32_t kSetupChunks = kGTasks / kSetupChunkTasks;
 template <int METRIC>
 static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetupArgs A) {
     extern __shared__ uint32_t psm[];
     const NeedArgs& a = A.need;
     const CellFilterArgs& f = A.filt;
-    const uint32_t g = blockIdx.x;
-    const uint32_t task_begin = a.groups[g].task_begin, task_count = a.groups[g].task_count, b = a.groups[g].shard;
+    const uint32_t g = blockIdx.y, chunk = blockIdx.x;
+    const uint32_t group_task_begin = a.groups[g].task_begin, group_task_count = a.groups[g].task_count, b = a.groups[g].shard;
+    const uint32_t n_chunks = (group_task_count + kSetupChunkTasks - 1) / kSetupChunkTasks;
+    if (chunk >= n_chunks) return;
+    const uint32_t task_begin = group_task_begin + chunk * kSetupChunkTasks, task_count = min(kSetupChunkTasks, group_task_count - chunk * kSetupChunkTasks);
     const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
-    uint32_t* s_misc = psm;                                             // [0] items of the group, [1] overflowed buckets, [2..3] candidates (u64, 8-byte aligned)
-    float* s_tau = reinterpret_cast<float*>(psm + 8);                   // [kGTasks] tau of the group's tasks (capped by the merge bound); NaN = dirty task
-    uint32_t* s_need = psm + 8 + kGTasks;                               // [kmax] the group's need mask per cell
+    uint32_t* s_misc = psm;                                             // [0] items of the group, [1] overflowed buckets, [2..3] candidates (u64, 8-byte aligned), [4] last arrival
+    float* s_tau = reinterpret_cast<float*>(psm + 8);                   // [kGTasks] tau of the chunk's tasks (capped by the merge bound); NaN = dirty task
+    uint32_t* s_need = psm + 8 + kGTasks;                               // [kmax] the chunk's need mask per cell (bits of the GROUP's query tiles)
     const int tid = threadIdx.x, lane = tid & 63;
     for (uint32_t j = tid; j < K; j += kSetupThreads) s_need[j] = 0u;
     if (tid < 8) s_misc[tid] = 0u;
     __syncthreads();
 
-    // ---- phase 1: thread tl <-> task task_begin + tl (kGTasks == kSetupThreads)
-    {
+    // ---- phase 1a: thread tl <-> task task_begin + tl (the first wavefront): its bucket's statistics, how many pieces the bucket was split into
+    uint32_t* s_parts = reinterpret_cast<uint32_t*>(s_tau);   // (the words of s_tau hold the piece counts until the merges are done)
+    if (tid < (int)kSetupChunkTasks) {
         const uint32_t tl = (uint32_t)tid, t = task_begin + tl;
-        const bool real = tl < task_count;
-        float tau = INFINITY;
         uint32_t parts_l = 0;
-        if (real) {
-            if (A.merge_splits) {
-                const uint32_t cnt = A.merge.cand_cnt[t];
-                if (cnt != 0u) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(s_misc + 2), (unsigned long long)cnt);
-                    if (cnt > A.merge.cand_cap) atomicAdd(&s_misc[1], 1u);
-                    else parts_l = min(A.merge.parts, (cnt + A.merge.split_min - 1) / A.merge.split_min);
-                }
+        if (tl < task_count && A.merge_splits) {
+            const uint32_t cnt = A.merge.cand_cnt[t];
+            if (cnt != 0u) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(s_misc + 2), (unsigned long long)cnt);
+                if (cnt > A.merge.cand_cap) atomicAdd(&s_misc[1], 1u);
+                else parts_l = min(A.merge.parts, (cnt + A.merge.split_min - 1) / A.merge.split_min);
             }
-            tau = a.list_dist[(size_t)t * a.k + a.k - 1];
         }
-        // the split buckets among this wavefront's 64 tasks, one after the other with all lanes
-        unsigned long long todo = __ballot(parts_l > 1u);
+        s_parts[tl] = parts_l;
+    }
+    __syncthreads();
+    // ---- phase 1b: the split buckets, spread over the wavefronts of the workgroup (a wavefront per task, one after the other)
+    {
+        const int wave = tid >> 6;
+        constexpr int n_waves = kSetupThreads / 64;
+        const uint32_t p = (uint32_t)lane < task_count ? s_parts[lane] : 0u;
+        unsigned long long todo = __ballot(p > 1u);
+        uint32_t seen = 0;
         while (todo) {
             const int i = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const uint32_t ti = task_begin + (uint32_t)(tid - lane + i);
-            const float kth = MergeSplitPieces(A.merge, ti, (uint32_t)__shfl((int)parts_l, i), lane);
-            if (lane == i) tau = kth;
+            if ((int)(seen++ % (uint32_t)n_waves) != wave) continue;
+            (void)MergeSplitPieces(A.merge, task_begin + (uint32_t)i, (uint32_t)__shfl((int)p, i), lane);
         }
-        if (real) {
+    }
+    __syncthreads();   // (the merged lists are read back below by other threads of the workgroup: written through to L2, and nobody on this CU has read them before)
+    // ---- phase 1c: thread tl <-> task: tau (capped by the merge bound), the bf16 threshold, the candidate counter back to zero
+    if (tid < (int)kSetupChunkTasks) {
+        const uint32_t tl = (uint32_t)tid, t = task_begin + tl;
+        if (tl < task_count) {
+            float tau = __builtin_nontemporal_load(&a.list_dist[(size_t)t * a.k + a.k - 1]);
             if (a.query_tau) tau = fminf(tau, OrderedKeyToFloat(a.query_tau[a.task_query[t]]));
             const bool dirty = a.dirty_flag && a.dirty_flag[t] != 0u;
             a.task_U[t] = dirty ? INFINITY : ThresholdOf<METRIC>((double)tau, a.task_nq[a.task_src[t]], a.shard_rmax[b], (double)a.d, a.hi_only != 0);
@@ -509,10 +558,12 @@ static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetu
     }
     __syncthreads();
 
-    // ---- phase 2: the cell tests (NeedKernel), cells fastest: a task's table row is read coalesced
+    // ---- phase 2: the cell tests (NeedKernel), cells fastest: a task's row of the distance table is read coalesced.  The 8-bit pass's
+    //      threshold table is this pass's own and arrives filled with +inf (FilterInitKernel): only the needed slots are written
     const uint32_t pairs = task_count * K;
     for (uint32_t i = (uint32_t)tid; i < pairs; i += kSetupThreads) {
         const uint32_t tl = i / K, j = i - tl * K, t = task_begin + tl;
+        const uint32_t tg = chunk * kSetupChunkTasks + tl;   // the task's number in its GROUP (its query tile: tg >> 5)
         const uint32_t src = a.task_src[t];
         const float tau_f = s_tau[tl];
         const bool dirty = tau_f != tau_f;
@@ -540,21 +591,44 @@ static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetu
                 need = dot_ub + qn * r * (1.0 + s) >= 1.0 - tau - e1 - s;
             }
         }
-        if (need) atomicOr(&s_need[j], 1u << (tl >> 5));
-        if (a.q8_B)   // every (task, cell) slot of the table in every 8-bit pass: the threshold, or "nothing passes"
-            a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + tl] =
-                need ? Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
-                                           (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j],
-                                           a.cell_l1 ? (double)a.cell_l1[(size_t)src * a.kmax + j] : -1.0)
-                     : INFINITY;
+        if (need) {
+            atomicOr(&s_need[j], 1u << (tg >> 5));
+            if (a.q8_B)
+                a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + tg] =
+                    Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
+                                        (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j],
+                                        a.cell_l1 ? (double)a.cell_l1[(size_t)src * a.kmax + j] : -1.0);
+        }
     }
     __syncthreads();
+    // the chunk's bits join the group's masks (device-scope atomics: the chunks of a group run on any CU of any XCD); the statistics ride along
+    for (uint32_t j = (uint32_t)tid; j < K; j += kSetupThreads)
+        if (s_need[j] != 0u) atomicOr(&a.need[(size_t)g * a.kmax + j], s_need[j]);
+    if (tid == 0 && A.merge_splits && A.merge.stat_overflowed) {
+        const unsigned long long total = *reinterpret_cast<unsigned long long*>(s_misc + 2);
+        if (total) atomicAdd(A.merge.stat_candidates, total);
+        if (s_misc[1]) atomicAdd(A.merge.stat_overflowed, s_misc[1]);
+    }
+}
 
-    // ---- phase 3: the group's work items (FilterItemsKernel), a thread per cell
-    for (uint32_t j = (uint32_t)tid; j < K; j += kSetupThreads) {
+// phase 3, a launch of its own (one workgroup per task group): the group's work items from the need masks the chunks have OR-ed together.
+// (Run by the last chunk of a group to arrive — a ticket per group behind a device-scope fence — the set-up launch took twice as long: on this
+// multi-XCD part an agent-scope release / acquire writes back and invalidates an XCD's whole L2.  The kernel boundary is the cheap fence.)
+constexpr int kItemsThreads = 256;
+static __global__ void __launch_bounds__(kItemsThreads) PassItemsKernel(PassSetupArgs A) {
+    __shared__ uint32_t s_items;
+    const NeedArgs& a = A.need;
+    const CellFilterArgs& f = A.filt;
+    const uint32_t g = blockIdx.x;
+    const uint32_t group_task_begin = a.groups[g].task_begin, group_task_count = a.groups[g].task_count, b = a.groups[g].shard;
+    const uint32_t cell0 = a.shard_cell_begin[b], K = a.shard_cell_begin[b + 1] - cell0;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_items = 0u;
+    __syncthreads();
+    uint32_t* s_misc = &s_items;
+    for (uint32_t j = (uint32_t)tid; j < K; j += kItemsThreads) {
         const uint32_t block = g * a.kmax + j;
-        const uint32_t mask = s_need[j];
-        a.need[block] = mask;   // (later passes read it as their done mask)
+        const uint32_t mask = a.need[block];   // (later passes read it as their done mask)
         if (mask == 0) continue;
         const uint32_t d0 = (f.done0 ? f.done0[block] : 0u) | (f.done0b ? f.done0b[block] : 0u);
         const uint32_t d1 = f.done1 ? f.done1[block] : 0u;
@@ -573,9 +647,9 @@ static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetu
         CellItem it;
         it.t_a = (uint32_t)t_a;
         it.t_b = (uint32_t)t_b;
-        it.task_begin = task_begin;
+        it.task_begin = group_task_begin;
         it.lo_shift = (uint32_t)t_cell - f.cell_lo_begin[cell0 + j];
-        it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (task_count - 1u) << 24;
+        it.acts = (mask & ~d0) | (mask & ~d1) << 8 | mask << 16 | (group_task_count - 1u) << 24;
         it.group = g;
         it.block = block;
         it.cell_scale = f.q8_scale ? f.q8_scale[cell0 + j] : 0.f;
@@ -592,11 +666,6 @@ static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetu
     if (tid == 0) {
         f.group_count[g] = s_misc[0];
         f.group_cursor[g] = 0u;
-        if (A.merge_splits && A.merge.stat_overflowed) {
-            const unsigned long long total = *reinterpret_cast<unsigned long long*>(s_misc + 2);
-            if (total) atomicAdd(A.merge.stat_candidates, total);
-            if (s_misc[1]) atomicAdd(A.merge.stat_overflowed, s_misc[1]);
-        }
         if (g == 0 && f.pass == 2 && f.work) f.work[3] = f.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
     }
 }

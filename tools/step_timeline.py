@@ -2,7 +2,7 @@
 """GPU-side timeline of the last timed steps of a bench.py run from a rocprofv3 --kernel-trace CSV: per kernel of a step its start offset,
 duration and the idle gap before it (the gaps are what the host side — Python, ctypes, plan building, synchronous copies — costs).
 
-usage: python tools/step_timeline.py <kernel_trace.csv> [steps=3] [anchor-kernel-substring=RouterBoundKernel<0, 8, 1>]
+usage: python tools/step_timeline.py <kernel_trace.csv> [steps=3] [anchor-kernel-substring=BoundInitKernel]
 A step starts at the first kernel of the router (the anchor) and ends before the next anchor."""
 import csv
 import re
@@ -10,7 +10,7 @@ import sys
 
 path = sys.argv[1]
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-anchor = sys.argv[3] if len(sys.argv) > 3 else "FillMinBitsKernel"
+anchor = sys.argv[3] if len(sys.argv) > 3 else "BoundInitKernel"   # (rounds 1-3: FillMinBitsKernel)
 rows = [r for r in csv.DictReader(open(path))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
