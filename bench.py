@@ -179,8 +179,17 @@ def main():
         _live_comm.append(comm)
         if comm.world != args.gpus or comm.rank != rank:
             raise SystemExit(f"communicator has {comm.world} ranks (this is rank {comm.rank}), --gpus {args.gpus}")
+        # a second communicator for the ROUTING exchange of the timed loop (round 4): batch i + 1 is routed, its probe lists all-gathered and
+        # waited for on a second stream by a second thread while batch i is scanned — collectives of one communicator must be issued in one
+        # order by one thread at a time, so the route-ahead thread gets its own (bootstrap port: the first communicator's + 1)
+        comm_r = None
+        if os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0":
+            base_port = int(os.environ.get("GPANN_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+            comm_r = gcomm.Comm(gcomm.RCCL if args.backend == "rccl" else gcomm.TCP, rank=rank, world=world, addr=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                port=base_port + 1, device=local_rank, timeout_s=int(os.environ.get("GPANN_COMM_TIMEOUT", "600")))
+            _live_comm.append(comm_r)
     else:
-        comm = None
+        comm = comm_r = None
     on_dev = args.backend == "rccl"
     stream = torch.cuda.current_stream().cuda_stream
     n, d, nq, S, k = args.n, args.d, args.nq, args.shards, args.k
@@ -404,42 +413,49 @@ def main():
 
     probes_top = {}   # pinned [nq][n_top] arrays
 
-    def route(n_top=None):
+    def route(n_top=None, j=0, st=None, cm=None):
         """KMeansTreeRouter::Query for the whole batch.  n_top: only the first n_top shards of every order come back (the timed steps
         probe nprobe shards; the sweep before them needs the whole order).  N > 1: the router is replicated, every rank routes its slice
-        of the queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered."""
+        of the queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered — on stream `st` through communicator `cm` into buffer
+        set `j` (the timed loop's route-ahead thread passes its own of each)."""
+        st = stream if st is None else st
+        cm = comm if cm is None else cm
         if not multi:   # (one reusable host array for the probe lists; min_dist itself is not needed here)
             buf = probes_buf
             if n_top is not None and n_top < S:
                 if n_top not in probes_top:
                     probes_top[n_top] = torch.empty((nq, n_top), dtype=torch.int32).pin_memory().numpy()
                 buf = probes_top[n_top]
-            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, stream, on_device=True, nq=nq, out_probes=buf,
+            pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, st, on_device=True, nq=nq, out_probes=buf,
                                              want_min_dist=False, n_top=None if buf is probes_buf else n_top)
             return pr, r_ms
         lo = min(nq, rank * chunk_q)
         hi = min(nq, lo + chunk_q)
         r_ms = 0.0
-        route_mine[:] = -1
+        mine_t, all_t, dev_mine, dev_all = route_sets[j]
+        mine, allp = mine_t.numpy(), all_t.numpy()
+        mine[:] = -1
         if hi > lo:
-            _, _, r_ms = router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo,
-                                            out_probes=route_mine[:hi - lo], want_min_dist=False)
+            _, _, r_ms = router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, st, on_device=True, nq=hi - lo,
+                                            out_probes=mine[:hi - lo], want_min_dist=False)
         if on_dev:   # all-gather of the probe lists over RCCL on this stream
-            route_dev_mine.copy_(route_mine_t, non_blocking=True)
-            comm.allgather(route_dev_mine.data_ptr(), route_dev_all.data_ptr(), route_mine.nbytes, stream)
-            route_all_t.copy_(route_dev_all, non_blocking=True)
-            comm.wait(stream, COMM_WAIT_S)
+            with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)) if st != stream else contextlib.nullcontext():
+                dev_mine.copy_(mine_t, non_blocking=True)
+                cm.allgather(dev_mine.data_ptr(), dev_all.data_ptr(), mine.nbytes, st)
+                all_t.copy_(dev_all, non_blocking=True)
+            cm.wait(st, COMM_WAIT_S)
         else:
-            comm.allgather(route_mine, route_all, route_mine.nbytes)
-        return route_all.reshape(-1, S)[:nq], r_ms
+            cm.allgather(mine, allp, mine.nbytes)
+        return allp.reshape(-1, S)[:nq], r_ms
 
     if multi:
-        route_mine_t = torch.empty((chunk_q, S), dtype=torch.int32).pin_memory()
-        route_all_t = torch.empty((world, chunk_q, S), dtype=torch.int32).pin_memory()
-        route_mine, route_all = route_mine_t.numpy(), route_all_t.numpy()
-        if on_dev:
-            route_dev_mine = torch.empty((chunk_q, S), dtype=torch.int32, device=dev)
-            route_dev_all = torch.empty((world, chunk_q, S), dtype=torch.int32, device=dev)
+        def _route_set():
+            mine_t = torch.empty((chunk_q, S), dtype=torch.int32).pin_memory()
+            all_t = torch.empty((world, chunk_q, S), dtype=torch.int32).pin_memory()
+            dm = torch.empty((chunk_q, S), dtype=torch.int32, device=dev) if on_dev else None
+            da = torch.empty((world, chunk_q, S), dtype=torch.int32, device=dev) if on_dev else None
+            return mine_t, all_t, dm, da
+        route_sets = [_route_set() for _ in range(3)]   # [0]: the calls outside the timed loop; [1], [2]: the route-ahead thread, alternating
 
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
@@ -528,16 +544,21 @@ def main():
     #    kernels fill what the scan leaves idle (its host-side planning, the tail of its launches) and the router -> scan hand-over
     #    (probe lists through pinned host arrays) leaves the critical path.  GPANN_BENCH_ROUTE_AHEAD=0: strictly one batch at a time.
     merger = concurrent.futures.ThreadPoolExecutor(1)
-    route_ahead = (not multi) and os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0"
+    # (several ranks, round 4: the same with the slice routing + the probe all-gather + its wait on the second stream, through the second communicator)
+    route_ahead = os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0" and (not multi or comm_r is not None)
     # (one rank, round 4) ... and the SCAN of batch i + 1 is planned, staged and enqueued behind batch i before batch i is waited for
     # (GPANN_SCAN_DEFER / gpann_scan_finish, include/gpann.h): the host side of a scan call — task lists, group tables, the uploads, ~35 launches —
     # runs under the previous batch's kernels instead of between two batches.  GPANN_BENCH_SCAN_AHEAD=0: the scan call completes before it returns.
-    scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
+    scan_ahead = route_ahead and not multi and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
     if route_ahead:
         r_stream = torch.cuda.Stream(device=dev)
         r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
         router_pool = concurrent.futures.ThreadPoolExecutor(1)
         def route_job(j):
+            if multi:   # my slice, the all-gather of the probe lists and its wait: all on the second stream, buffer sets 1 / 2 alternating
+                torch.cuda.set_device(local_rank)
+                pr, r_ms = route(j=1 + (j & 1), st=r_stream.cuda_stream, cm=comm_r)
+                return pr, r_ms, router.stats()
             pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j % 3],
                                              want_min_dist=False, n_top=None if nprobe == S else nprobe)
             return pr, r_ms, router.stats()
@@ -746,6 +767,9 @@ def main():
                                      "scan call) and batch i-1 is merged on the host while batch i is scanned" if scan_ahead else
                                      "batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned")
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
+    if multi and route_ahead:
+        result["config"]["pipeline"] = ("batches overlap: every rank routes its slice of batch i+1 and the probe lists are all-gathered (second stream, second "
+                                        "communicator) while batch i is scanned and its slot lists are exchanged; batch i-1 is merged on the host")
     result["detail"] = {"merge": {"slot_entries": slot_entries, "duplicate_ids_dropped": dup_ids,
                                   "note": "DedupNeighbors over the per-slot lists of the last timed step: entries whose id also came back from another probed shard"},
                         "scan_mode": args.scan_mode, "filtered": filtered, "recall_curve": recall_curve, "router_ms": float(np.mean(router_ms)), "step_wall_ms": step_wall_ms,
@@ -826,6 +850,8 @@ def main():
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     if multi:
         comm.barrier()
+        if comm_r is not None:
+            comm_r.close()
         comm.close()
 
 
@@ -898,13 +924,25 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             od = torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)
             hbuf = [(torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory()) for _ in range(2)]
             lo, hi = min(nq, r * chunk_q), min(nq, (r + 1) * chunk_q)
-            route_buf = torch.empty((max(hi - lo, 1), S), dtype=torch.int32).pin_memory().numpy()
+            route_bufs = [torch.empty((max(hi - lo, 1), S), dtype=torch.int32).pin_memory().numpy() for _ in range(2)]
             merger = concurrent.futures.ThreadPoolExecutor(1)
+            router_pool = concurrent.futures.ThreadPoolExecutor(1)
+            r_stream = torch.cuda.Stream(device=dev)
             tasks_rows = [0.0]
+            route_ahead = os.environ.get("GPANN_BENCH_ROUTE_AHEAD", "1") != "0"
 
-            def one(i):
-                if hi > lo:   # this rank's share of the routing
-                    router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, stream, on_device=True, nq=hi - lo, out_probes=route_buf[:hi - lo], want_min_dist=False)
+            def route_share(j, st):   # this rank's share of the routing of batch j
+                if hi > lo:
+                    router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, st, on_device=True, nq=hi - lo, out_probes=route_bufs[j & 1][:hi - lo], want_min_dist=False)
+                return True
+
+            def one(i, routed):
+                """like the real loop of a rank: batch i + 1 is routed on a second stream by a second thread while batch i is scanned"""
+                if routed is not None:
+                    routed.result()
+                else:
+                    route_share(i, stream)
+                nxt = router_pool.submit(route_share, i + 1, r_stream.cuda_stream) if route_ahead else None
                 lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
                 sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, timed=True, for_merge=merge_bound)
                 hd, hi_ = hbuf[i & 1]
@@ -912,32 +950,31 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 hi_.copy_(oi, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 tasks_rows[0] = float(sh.stats()["pairs"])
-                return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k)
+                return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k), nxt
 
-            pending = None
-            for i in range(max(2, args.warmup)):
-                f = one(i)
-                if pending is not None:
-                    pending.result()
-                pending = f
-            pending.result()
-            torch.cuda.synchronize()
+            def loop(count):
+                pending, routed = None, (router_pool.submit(route_share, 0, r_stream.cuda_stream) if route_ahead else None)
+                for i in range(count):
+                    f, routed = one(i, routed)
+                    if pending is not None:
+                        pending.result()
+                    pending = f
+                pending.result()
+                if routed is not None:
+                    routed.result()
+                torch.cuda.synchronize()
+
+            loop(max(2, args.warmup))
             steps = max(5, args.steps // 2)
             t0 = time.perf_counter()
-            pending = None
-            for i in range(steps):
-                f = one(i)
-                if pending is not None:
-                    pending.result()
-                pending = f
-            pending.result()
-            torch.cuda.synchronize()
+            loop(steps)
             ms = 1000.0 * (time.perf_counter() - t0) / steps
             st = sh.stats()
             ranks.append({"rank": r, "shards": len(mine), "rows": int(sum(int(counts[b]) for b in mine)), "ms_per_step": ms, "scan_kernels_ms": st["scan_ms"],
                           "rest_pass_ms": st["filter_rest_ms"], "task_rows": tasks_rows[0], "store_build_s": build_s})
             log(f"emulated world {W} rank {r}: {len(mine)} shards, {ranks[-1]['rows']} rows, {ms:.3f} ms/step (scan kernels {st['scan_ms']:.3f})")
             merger.shutdown()
+            router_pool.shutdown()
             sh.close()
             del oi, od, hbuf
             torch.cuda.empty_cache()

@@ -1,6 +1,8 @@
 // core.cpp — host mirror: containers and conversions (reference src/defs.{h,cpp}), TopN (src/topn.h), the canonical
 // host distance functions (src/dist.cpp), binary point / ground-truth files (src/points_io.cpp) and the text formats for
 // partitions and clusters (src/metis_io.cpp).  New code; behaviour follows the cited lines.
+#include <atomic>
+
 #include "gpann_host.h"
 #include "host_util.h"
 
@@ -30,6 +32,9 @@ void SetDevice(int device) { g_device = device; }
 int Device() { return g_device; }
 void SetNumThreads(int n) { g_threads = n; }
 void SetFilteredScan(bool on) { g_filtered = on; }
+static std::atomic<bool> g_coalesce{true};
+void SetCoalescing(bool on) { g_coalesce = on; }
+bool Coalescing() { return g_coalesce; }
 bool FilteredScan() { return g_filtered; }
 int NumThreads() {
     if (g_threads > 0) return g_threads;

@@ -124,6 +124,11 @@ bool FilteredScan();
 // (router_host.cpp).  Both build the same tree, bit for bit.
 void SetDeviceTraining(bool on);
 bool DeviceTraining();
+// Concurrent one-query calls — KMeansTreeRouter::Query, InvertedIndex::Query / QueryBucket, the way the reference's callers issue them from
+// up to 32 threads (routes.cpp:194-200, shard_searches.cpp:48) — are coalesced into device batches: whoever finds no batch in flight runs
+// everything that has queued up as ONE launch sequence.  Default on; off = every call a batch of one behind the handle's lock.
+void SetCoalescing(bool on);
+bool Coalescing();
 }   // namespace gpann_host
 
 // --------------------------------------------------------------------------------------------- src/points_io.h:5-11
@@ -248,6 +253,7 @@ struct InvertedIndex {
 private:
     gpann_shards* shards_ = nullptr;
     bool mips_ = false;
+    size_t d_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------------- src/recall.h

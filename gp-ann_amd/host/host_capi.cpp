@@ -1,6 +1,10 @@
 // host_capi.cpp — a small extern "C" surface over the C++ host mirror so that Python (tests, bench.py) can drive the
 // host-side pieces that have no device counterpart: router training, k-means, the text/binary file formats.
+#include <chrono>
 #include <cstring>
+#include <limits>
+#include <mutex>
+#include <stdexcept>
 
 #include "gpann_host.h"
 #include "host_util.h"
@@ -184,6 +188,104 @@ int gpann_host_ground_truth_roundtrip(const char* path, const float* dist, const
                 out_ids[(size_t)q * k + j] = back[q][j].second;
             }
         }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// ---- the reference's calling pattern, for tests and the benchmark of the coalescing queue: `threads` host threads, each calling the
+//      one-query interface for its share of the queries (routes.cpp:194-200, shard_searches.cpp:48), with the queue on or off
+void gpann_host_router_queue_counters(uint64_t* batches, uint64_t* requests);
+void gpann_host_scan_queue_counters(uint64_t* batches, uint64_t* requests);
+
+// tree: the flat arrays of gpann_router_create.  out_probes [nq][S].  Returns 0 / -1; *seconds = wall time of the query loop, *batches = device batches it took
+int gpann_host_router_query_threads(uint32_t d, int mips, uint32_t S, uint32_t n_nodes, const int32_t* node_shard, const uint32_t* node_cent_first,
+                                    const uint32_t* node_child_first, const uint32_t* node_child_count, const uint32_t* shard_root, const float* centroids,
+                                    const float* queries, uint32_t nq, int budget, int threads, int coalesce, int32_t* out_probes, double* seconds, uint64_t* batches) {
+    try {
+        gpann_host::SetMetricMIPS(mips != 0);
+        KMeansTreeRouter::Flat f;
+        f.d = d;
+        f.S = S;
+        f.mips = mips != 0;
+        f.node_shard.assign(node_shard, node_shard + n_nodes);
+        f.node_cent_first.assign(node_cent_first, node_cent_first + n_nodes + 1);
+        f.node_child_first.assign(node_child_first, node_child_first + n_nodes);
+        f.node_child_count.assign(node_child_count, node_child_count + n_nodes);
+        f.shard_root.assign(shard_root, shard_root + S);
+        f.centroids.assign(centroids, centroids + (size_t)f.node_cent_first.back() * d);
+        KMeansTreeRouter router;
+        router.LoadFlat(std::move(f));
+        std::vector<float> q(queries, queries + (size_t)nq * d);
+        (void)router.Query(q.data(), budget);   // (the upload and the first call's workspace growth stay out of the clock)
+        const bool before = gpann_host::Coalescing();
+        gpann_host::SetCoalescing(coalesce != 0);
+        uint64_t b0 = 0, r0 = 0, b1 = 0, r1 = 0;
+        gpann_host_router_queue_counters(&b0, &r0);
+        std::string err;
+        std::mutex err_mutex;
+        const auto t0 = std::chrono::steady_clock::now();
+        gpann_host::ParallelFor(0, nq, threads, [&](size_t i) {
+            try {
+                const std::vector<int> p = router.Query(&q[i * d], budget);
+                for (uint32_t b = 0; b < S; ++b) out_probes[i * S + b] = p[b];
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(err_mutex);
+                err = e.what();
+            }
+        });
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        gpann_host_router_queue_counters(&b1, &r1);
+        *batches = coalesce ? b1 - b0 : nq;
+        gpann_host::SetCoalescing(before);
+        if (!err.empty()) throw std::runtime_error(err);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// InvertedIndex::QueryBucket(Q, k, probes[q]) from `threads` host threads, one call per query: out_ids / out_dist [nq][k]
+int gpann_host_index_query_bucket_threads(const float* points, uint64_t n, uint32_t d, int mips, const uint32_t* ids, const uint64_t* offsets, uint32_t S,
+                                          const float* queries, uint32_t nq, uint32_t k, const int32_t* bucket, int threads, int coalesce, uint32_t* out_ids,
+                                          float* out_dist, double* seconds, uint64_t* batches) {
+    try {
+        gpann_host::SetMetricMIPS(mips != 0);
+        PointSet ps;
+        ps.n = n;
+        ps.d = d;
+        ps.coordinates.assign(points, points + n * d);
+        Clusters clusters = FromCsr(ids, offsets, S);
+        InvertedIndex index(ps, clusters);
+        std::vector<float> q(queries, queries + (size_t)nq * d);
+        (void)index.QueryBucket(q.data(), (int)k, bucket[0]);
+        const bool before = gpann_host::Coalescing();
+        gpann_host::SetCoalescing(coalesce != 0);
+        uint64_t b0 = 0, r0 = 0, b1 = 0, r1 = 0;
+        gpann_host_scan_queue_counters(&b0, &r0);
+        std::string err;
+        std::mutex err_mutex;
+        const auto t0 = std::chrono::steady_clock::now();
+        gpann_host::ParallelFor(0, nq, threads, [&](size_t i) {
+            try {
+                const NNVec r = index.QueryBucket(&q[i * d], (int)k, bucket[i]);
+                for (uint32_t x = 0; x < k; ++x) {
+                    out_dist[i * k + x] = x < r.size() ? r[x].first : std::numeric_limits<float>::infinity();
+                    out_ids[i * k + x] = x < r.size() ? r[x].second : 0xFFFFFFFFu;
+                }
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(err_mutex);
+                err = e.what();
+            }
+        });
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        gpann_host_scan_queue_counters(&b1, &r1);
+        *batches = coalesce ? b1 - b0 : nq;
+        gpann_host::SetCoalescing(before);
+        if (!err.empty()) throw std::runtime_error(err);
         return 0;
     } catch (const std::exception& e) {
         g_err = e.what();

@@ -2,7 +2,10 @@
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
 #include <cstddef>
+#include <exception>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +44,65 @@ void ParallelFor(size_t begin, size_t end, int threads, Body body) {
     run();
     for (auto& t : pool) t.join();
 }
+
+// Group commit for the reference's one-query-per-call interfaces (KMeansTreeRouter::Query, InvertedIndex::Query / QueryBucket): the
+// reference's callers issue them from up to 32 threads at once (routes.cpp:194-200, small_scale_queries.cpp:114-116), and on the GPU a
+// batch of one costs a whole launch sequence.  Concurrent callers Submit() their request; whoever finds no batch in flight becomes the
+// leader of the next one, takes EVERYTHING that has queued up — its own request included —, runs it as one device batch and wakes the
+// owners; callers that arrive meanwhile form the following batch.  A single caller pays one mutex round trip; nothing waits on a timer.
+// Req needs the members `bool done` and `std::exception_ptr error`.
+template <typename Req>
+class Coalescer {
+public:
+    template <typename RunBatch>
+    void Submit(Req& req, RunBatch run) {
+        std::unique_lock<std::mutex> lk(m_);
+        req.done = false;
+        req.error = nullptr;
+        queue_.push_back(&req);
+        for (;;) {
+            if (req.done) break;
+            if (!leader_) {   // (no batch in flight and this request not served: it is in the queue — this thread leads the next batch)
+                leader_ = true;
+                std::vector<Req*> batch;
+                batch.swap(queue_);
+                lk.unlock();
+                std::exception_ptr err;
+                try {
+                    run(batch);
+                } catch (...) {
+                    err = std::current_exception();
+                }
+                lk.lock();
+                for (Req* r : batch) {
+                    if (err && !r->error) r->error = err;
+                    r->done = true;
+                }
+                leader_ = false;
+                ++batches_;
+                requests_ += batch.size();
+                cv_.notify_all();
+                continue;
+            }
+            cv_.wait(lk);
+        }
+        lk.unlock();
+        if (req.error) std::rethrow_exception(req.error);
+    }
+    // batches run / requests served so far (a test hook: requests / batches = the mean batch size)
+    void Counters(uint64_t* batches, uint64_t* requests) {
+        std::lock_guard<std::mutex> lk(m_);
+        *batches = batches_;
+        *requests = requests_;
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<Req*> queue_;
+    bool leader_ = false;
+    uint64_t batches_ = 0, requests_ = 0;
+};
 
 // throws std::runtime_error carrying gpann_last_error() unless status == GPANN_OK (the reference reports internal
 // failures with exceptions, SURVEY.md §8b "Errors")

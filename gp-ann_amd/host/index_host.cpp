@@ -2,6 +2,7 @@
 // (src/recall.h), DedupNeighbors (small_scale_queries.cpp:15-23) and RunInShardSearches + ShardSearch (src/shard_searches.*).
 // All scans run on the GPU through the C-ABI of libgpann_hip.so.
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <limits>
 #include <sstream>
@@ -61,6 +62,7 @@ InvertedIndex::InvertedIndex(PointSet& points, const Clusters& clusters) {
                               csr.offsets.data(), (uint32_t)clusters.size(), gpann_host::Device(), 0, &shards_),
           "gpann_shards_create");
     Check(gpann_shards_set_scan_mode(shards_, gpann_host::FilteredScan() ? 1 : 0), "gpann_shards_set_scan_mode");
+    d_ = points.d;
 }
 
 InvertedIndex::~InvertedIndex() {
@@ -110,24 +112,104 @@ std::vector<NNVec> InvertedIndex::QueryBatch(PointSet& queries, int k, const std
     return out;
 }
 
-// inverted_index.h:43-60 — one query = a batch of one (correct; use QueryBatch for throughput)
+// inverted_index.h:43-75 — Query (one TopN over the probed shards) and QueryBucket (one shard).  The reference's callers run them from many
+// threads, one query per call (shard_searches.cpp:48, small_scale_queries.cpp:149-155): concurrent calls are coalesced into device batches
+// (host_util.h Coalescer) — per (store, kind, k) one scan call over everything that queued up while the previous batch ran; a query's probe
+// list is padded with -1 (= skip) to the longest of its batch.  Results are those of a batch of one (the batch entry points are row-independent).
+namespace {
+struct ScanReq {
+    const float* Q = nullptr;
+    gpann_shards* handle = nullptr;
+    uint32_t d = 0, k = 0;
+    bool merged = false;               // InvertedIndex::Query (gpann_scan_merged) / QueryBucket (gpann_scan_buckets, one slot)
+    std::vector<int32_t> probes;
+    std::vector<uint32_t> ids;
+    std::vector<float> dist;
+    bool done = false;
+    std::exception_ptr error;
+};
+gpann_host::Coalescer<ScanReq>& ScanQueue() {
+    static gpann_host::Coalescer<ScanReq>* q = new gpann_host::Coalescer<ScanReq>();
+    return *q;
+}
+void RunScanBatch(std::vector<ScanReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<ScanReq*> group;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->handle == batch[i]->handle && batch[j]->merged == batch[i]->merged && batch[j]->k == batch[i]->k) {
+                taken[j] = 1;
+                group.push_back(batch[j]);
+            }
+        const uint32_t n = (uint32_t)group.size(), d = group[0]->d, k = group[0]->k;
+        uint32_t np = 0;
+        for (ScanReq* r : group) np = std::max<uint32_t>(np, (uint32_t)r->probes.size());
+        std::vector<float> q((size_t)n * d);
+        std::vector<int32_t> probes((size_t)n * std::max(np, 1u), -1);
+        for (uint32_t x = 0; x < n; ++x) {
+            std::memcpy(&q[(size_t)x * d], group[x]->Q, (size_t)d * sizeof(float));
+            std::copy(group[x]->probes.begin(), group[x]->probes.end(), probes.begin() + (size_t)x * np);
+        }
+        std::vector<uint32_t> ids((size_t)n * k);
+        std::vector<float> dist((size_t)n * k);
+        try {
+            if (group[0]->merged)
+                Check(gpann_scan_merged(group[0]->handle, q.data(), n, k, probes.data(), np, np, ids.data(), dist.data(), 0, nullptr, nullptr), "gpann_scan_merged");
+            else
+                Check(gpann_scan_buckets(group[0]->handle, q.data(), n, k, probes.data(), 1, 1, ids.data(), dist.data(), nullptr, 0, nullptr, nullptr), "gpann_scan_buckets");
+            for (uint32_t x = 0; x < n; ++x) {
+                group[x]->ids.assign(ids.begin() + (size_t)x * k, ids.begin() + (size_t)(x + 1) * k);
+                group[x]->dist.assign(dist.begin() + (size_t)x * k, dist.begin() + (size_t)(x + 1) * k);
+            }
+        } catch (...) {
+            for (ScanReq* r : group) r->error = std::current_exception();
+        }
+    }
+}
+}   // namespace
+
+extern "C" void gpann_host_scan_queue_counters(uint64_t* batches, uint64_t* requests) { ScanQueue().Counters(batches, requests); }
+
 NNVec InvertedIndex::Query(float* Q, int k, const std::vector<int>& buckets_to_probe, size_t num_buckets_to_probe) {
     std::vector<int32_t> probes(buckets_to_probe.begin(), buckets_to_probe.begin() + num_buckets_to_probe);
-    std::vector<uint32_t> ids(k);
-    std::vector<float> dist(k);
-    Check(gpann_scan_merged(shards_, Q, 1, (uint32_t)k, probes.data(), (uint32_t)probes.size(), (uint32_t)probes.size(), ids.data(), dist.data(), 0, nullptr,
-                            nullptr),
-          "gpann_scan_merged");
-    return SlotToNNVec(dist.data(), ids.data(), (uint32_t)k);
+    if (!gpann_host::Coalescing() || probes.empty()) {
+        std::vector<uint32_t> ids(k);
+        std::vector<float> dist(k);
+        Check(gpann_scan_merged(shards_, Q, 1, (uint32_t)k, probes.data(), (uint32_t)probes.size(), (uint32_t)probes.size(), ids.data(), dist.data(), 0, nullptr,
+                                nullptr),
+              "gpann_scan_merged");
+        return SlotToNNVec(dist.data(), ids.data(), (uint32_t)k);
+    }
+    ScanReq req;
+    req.Q = Q;
+    req.handle = shards_;
+    req.d = (uint32_t)d_;
+    req.k = (uint32_t)k;
+    req.merged = true;
+    req.probes = std::move(probes);
+    ScanQueue().Submit(req, RunScanBatch);
+    return SlotToNNVec(req.dist.data(), req.ids.data(), (uint32_t)k);
 }
 
 // inverted_index.h:62-75
 NNVec InvertedIndex::QueryBucket(float* Q, int k, int bucket) {
-    int32_t probe = bucket;
-    std::vector<uint32_t> ids(k);
-    std::vector<float> dist(k);
-    Check(gpann_scan_buckets(shards_, Q, 1, (uint32_t)k, &probe, 1, 1, ids.data(), dist.data(), nullptr, 0, nullptr, nullptr), "gpann_scan_buckets");
-    return SlotToNNVec(dist.data(), ids.data(), (uint32_t)k);
+    if (!gpann_host::Coalescing()) {
+        int32_t probe = bucket;
+        std::vector<uint32_t> ids(k);
+        std::vector<float> dist(k);
+        Check(gpann_scan_buckets(shards_, Q, 1, (uint32_t)k, &probe, 1, 1, ids.data(), dist.data(), nullptr, 0, nullptr, nullptr), "gpann_scan_buckets");
+        return SlotToNNVec(dist.data(), ids.data(), (uint32_t)k);
+    }
+    ScanReq req;
+    req.Q = Q;
+    req.handle = shards_;
+    req.d = (uint32_t)d_;
+    req.k = (uint32_t)k;
+    req.merged = false;
+    req.probes.assign(1, (int32_t)bucket);
+    ScanQueue().Submit(req, RunScanBatch);
+    return SlotToNNVec(req.dist.data(), req.ids.data(), (uint32_t)k);
 }
 
 // ================================================================================================== recall.h

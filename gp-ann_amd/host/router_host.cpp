@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <limits>
 #include <numeric>
 #include <random>
@@ -350,6 +351,8 @@ void KMeansTreeRouter::TrainOnHost(PointSet& points, const Clusters& clusters, K
 }
 
 void KMeansTreeRouter::EnsureOnDevice() {
+    static std::mutex upload_mutex;   // (the reference's callers run Query from many threads: the first of them uploads the tree)
+    std::lock_guard<std::mutex> lk(upload_mutex);
     if (device_router_) return;
     if (tree_.S == 0) throw std::runtime_error("KMeansTreeRouter: Query before Train");
     gpann_host::Check(gpann_router_create(tree_.d, tree_.mips ? GPANN_METRIC_MIPS : GPANN_METRIC_L2, tree_.S, (uint32_t)tree_.node_shard.size(),
@@ -375,11 +378,64 @@ void KMeansTreeRouter::MinDistBatch(const float* Q, size_t nq, int budget, float
     gpann_host::Check(gpann_router_query_batch(device_router_, Q, (uint32_t)nq, budget, nullptr, out, 0, nullptr, nullptr), "gpann_router_query_batch");
 }
 
+// kmeans_tree_router.cpp:93-130.  The reference's callers run this from up to 32 threads, one query per call (routes.cpp:194-200): concurrent
+// calls are coalesced into device batches (host_util.h Coalescer) — per (router, budget) one gpann_router_query_batch over everything that
+// queued up while the previous batch ran.  result = what a batch of one returns (the batch entry points are row-independent).
+namespace {
+struct RouterQueryReq {
+    const float* Q = nullptr;
+    int budget = 0;
+    gpann_router* handle = nullptr;
+    uint32_t d = 0, S = 0;
+    std::vector<int32_t> probes;
+    bool done = false;
+    std::exception_ptr error;
+};
+gpann_host::Coalescer<RouterQueryReq>& RouterQueue() {
+    static gpann_host::Coalescer<RouterQueryReq>* q = new gpann_host::Coalescer<RouterQueryReq>();   // (never destroyed: callers may outlive static destruction order)
+    return *q;
+}
+void RunRouterBatch(std::vector<RouterQueryReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<RouterQueryReq*> group;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->handle == batch[i]->handle && batch[j]->budget == batch[i]->budget) {
+                taken[j] = 1;
+                group.push_back(batch[j]);
+            }
+        const uint32_t n = (uint32_t)group.size(), d = group[0]->d, S = group[0]->S;
+        std::vector<float> q((size_t)n * d);
+        for (uint32_t x = 0; x < n; ++x) std::memcpy(&q[(size_t)x * d], group[x]->Q, (size_t)d * sizeof(float));
+        std::vector<int32_t> probes((size_t)n * S);
+        try {
+            gpann_host::Check(gpann_router_query_batch(group[0]->handle, q.data(), n, group[0]->budget, probes.data(), nullptr, 0, nullptr, nullptr), "gpann_router_query_batch");
+            for (uint32_t x = 0; x < n; ++x) group[x]->probes.assign(probes.begin() + (size_t)x * S, probes.begin() + (size_t)(x + 1) * S);
+        } catch (...) {
+            for (RouterQueryReq* r : group) r->error = std::current_exception();
+        }
+    }
+}
+}   // namespace
+
+extern "C" void gpann_host_router_queue_counters(uint64_t* batches, uint64_t* requests) { RouterQueue().Counters(batches, requests); }
+
 std::vector<int> KMeansTreeRouter::Query(float* Q, int budget) {
     EnsureOnDevice();
-    std::vector<int32_t> probes(tree_.S);
-    gpann_host::Check(gpann_router_query_batch(device_router_, Q, 1, budget, probes.data(), nullptr, 0, nullptr, nullptr), "gpann_router_query_batch");
-    return std::vector<int>(probes.begin(), probes.end());
+    if (!gpann_host::Coalescing()) {   // one query = a batch of one behind the handle's lock
+        std::vector<int32_t> probes(tree_.S);
+        gpann_host::Check(gpann_router_query_batch(device_router_, Q, 1, budget, probes.data(), nullptr, 0, nullptr, nullptr), "gpann_router_query_batch");
+        return std::vector<int>(probes.begin(), probes.end());
+    }
+    RouterQueryReq req;
+    req.Q = Q;
+    req.budget = budget;
+    req.handle = device_router_;
+    req.d = tree_.d;
+    req.S = tree_.S;
+    RouterQueue().Submit(req, RunRouterBatch);
+    return std::vector<int>(req.probes.begin(), req.probes.end());
 }
 
 std::vector<KMeansTreeRouter::FrequencyQueryData> KMeansTreeRouter::FrequencyQueryBatch(PointSet& queries, int budget, int num_voting_neighbors) {

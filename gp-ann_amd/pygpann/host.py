@@ -34,6 +34,10 @@ def lib():
         L.gpann_host_ground_truth_roundtrip.argtypes = [C.c_char_p, _f32p, _u32p, C.c_uint32, C.c_uint32, _f32p, _u32p]
         L.gpann_host_distance.restype = C.c_float
         L.gpann_host_distance.argtypes = [_f32p, _f32p, C.c_uint32]
+        L.gpann_host_router_query_threads.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, _f32p, C.c_uint32, C.c_int,
+                                                      C.c_int, C.c_int, _i32p, C.POINTER(C.c_double), _u64p]
+        L.gpann_host_index_query_bucket_threads.argtypes = [_f32p, C.c_uint64, C.c_uint32, C.c_int, _u32p, _u64p, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, _i32p,
+                                                            C.c_int, C.c_int, _u32p, _f32p, C.POINTER(C.c_double), _u64p]
         _lib = L
     return _lib
 
@@ -65,6 +69,46 @@ def train_router(points, clusters, num_centroids=64, min_cluster_size=250, budge
         return f
     finally:
         lib().gpann_host_router_free(h)
+
+
+def router_query_threads(tree, queries, budget, threads, coalesce, mips=False):
+    """The reference's calling pattern on the host mirror (needs a GPU): `threads` host threads, each calling KMeansTreeRouter::Query(Q, budget)
+    for its share of the queries, one query per call (routes.cpp:194-200) — with the mirror's coalescing queue on or off.
+    Returns (probes [nq][S], seconds of the query loop, device batches it took)."""
+    queries = np.ascontiguousarray(queries, np.float32)
+    nq, d = queries.shape
+    S = int(tree["S"])
+    cents = np.ascontiguousarray(tree["centroids"], np.float32)
+    probes = np.empty((nq, S), np.int32)
+    sec, batches = C.c_double(0), C.c_uint64(0)
+    arr = {k_: np.ascontiguousarray(tree[k_]) for k_ in ("node_shard", "node_cent_first", "node_child_first", "node_child_count", "shard_root")}
+    rc = lib().gpann_host_router_query_threads(d, int(mips), S, len(arr["node_shard"]), arr["node_shard"].astype(np.int32).ctypes.data_as(_i32p),
+                                               arr["node_cent_first"].astype(np.uint32).ctypes.data_as(_u32p), arr["node_child_first"].astype(np.uint32).ctypes.data_as(_u32p),
+                                               arr["node_child_count"].astype(np.uint32).ctypes.data_as(_u32p), arr["shard_root"].astype(np.uint32).ctypes.data_as(_u32p),
+                                               cents.ctypes.data_as(_f32p), queries.ctypes.data_as(_f32p), nq, int(budget), int(threads), int(bool(coalesce)),
+                                               probes.ctypes.data_as(_i32p), C.byref(sec), C.byref(batches))
+    if rc != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return probes, sec.value, batches.value
+
+
+def index_query_bucket_threads(points, clusters, queries, k, buckets, threads, coalesce, mips=False):
+    """InvertedIndex::QueryBucket(Q, k, buckets[q]) from `threads` host threads, one call per query (shard_searches.cpp:48) — coalescing queue on or
+    off.  Returns (ids [nq][k], dist [nq][k], seconds, device batches)."""
+    points = np.ascontiguousarray(points, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    buckets = np.ascontiguousarray(buckets, np.int32)
+    ids_csr, offs = clusters_to_csr(clusters)
+    nq, d = queries.shape
+    ids = np.empty((nq, k), np.uint32)
+    dist = np.empty((nq, k), np.float32)
+    sec, batches = C.c_double(0), C.c_uint64(0)
+    rc = lib().gpann_host_index_query_bucket_threads(points.ctypes.data_as(_f32p), points.shape[0], d, int(mips), ids_csr.ctypes.data_as(_u32p), offs.ctypes.data_as(_u64p),
+                                                     len(clusters), queries.ctypes.data_as(_f32p), nq, int(k), buckets.ctypes.data_as(_i32p), int(threads),
+                                                     int(bool(coalesce)), ids.ctypes.data_as(_u32p), dist.ctypes.data_as(_f32p), C.byref(sec), C.byref(batches))
+    if rc != 0:
+        raise RuntimeError(lib().gpann_host_last_error().decode())
+    return ids, dist, sec.value, batches.value
 
 
 def kmeans(points, k, seed, mips=False, threads=0):

@@ -50,3 +50,38 @@ def test_concurrent_calls_on_one_handle_return_the_serial_results(orc, gp):
     st = router.stats()
     assert st["verify_failures"] == 0 and st["bound_selfcheck"] == 0
     shards.close()
+
+
+def test_one_query_calls_from_many_threads_are_coalesced(orc, gp):
+    """The reference's callers issue KMeansTreeRouter::Query / InvertedIndex::QueryBucket one query per call from up to 32 threads
+    (routes.cpp:194-200, shard_searches.cpp:48).  The host mirror coalesces concurrent calls into device batches (host_util.h Coalescer):
+    same results as the calls one by one and as the batch entry points, far fewer device batches than calls."""
+    from pygpann import host
+    rng = np.random.default_rng(41)
+    n, d, S, nq, k = 30000, 32, 4, 1500, 10
+    pts = make_mixture(orc, n, d, n_centers=16)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
+    tree = orc.kmtr_train(pts, clusters, 32, 200, 4000, 0, nthreads=4)
+    flat = tree.flat()
+    router = gp.Router(flat, 0)
+    want_p, _, _ = router.query_batch(queries, 10 ** 6)
+    p_on, s_on, b_on = host.router_query_threads(flat, queries, 10 ** 6, 32, True)
+    p_off, s_off, b_off = host.router_query_threads(flat, queries[:300], 10 ** 6, 32, False)
+    assert np.array_equal(p_on, want_p) and np.array_equal(p_off, want_p[:300])
+    assert b_off == 300 and b_on < nq / 4, (b_on, b_off)          # (32 callers in flight: batches of up to 32)
+    rate_on, rate_off = nq / s_on, 300 / s_off
+    print(f"router: {rate_on:.0f} calls/s coalesced ({nq / b_on:.1f} per batch) vs {rate_off:.0f} one by one: {rate_on / rate_off:.1f}x")
+    assert rate_on > 2.0 * rate_off
+    # QueryBucket: every query against its nearest shard
+    buckets = want_p[:, 0].astype(np.int32)
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, want_p, 1, 0, nthreads=4)
+    i_on, d_on, s_on, b_on = host.index_query_bucket_threads(pts, clusters, queries, k, buckets, 32, True)
+    i_off, d_off, s_off, b_off = host.index_query_bucket_threads(pts, clusters, queries[:300], k, buckets[:300], 32, False)
+    assert np.array_equal(i_on, wi[:, 0]) and np.array_equal(d_on.view(np.uint32), wd[:, 0].view(np.uint32))
+    assert np.array_equal(i_off, wi[:300, 0]) and np.array_equal(d_off.view(np.uint32), wd[:300, 0].view(np.uint32))
+    assert b_on < nq / 4
+    rate_on, rate_off = nq / s_on, 300 / s_off
+    print(f"QueryBucket: {rate_on:.0f} calls/s coalesced ({nq / b_on:.1f} per batch) vs {rate_off:.0f} one by one: {rate_on / rate_off:.1f}x")
+    assert rate_on > 2.0 * rate_off
