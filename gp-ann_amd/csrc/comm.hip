@@ -188,7 +188,17 @@ int ConnectTo(const char* addr, int port, int timeout_s) {
     int fd = -1;
     while (std::chrono::steady_clock::now() < deadline) {
         fd = ::socket(AF_INET, SOCK_STREAM, 0);
-        if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+        if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+            // A connect() to a local port nobody listens on yet can CONNECT TO ITSELF when the kernel happens to pick that very port as the
+            // source port (TCP simultaneous open; the bootstrap port often lies in the ephemeral range): the socket then looks connected, rank 0
+            // can no longer bind the port ("Address already in use") and every rank waits for the others until its timeout.  Seen twice in
+            // 110 three-rank runs on one box (round 4, tools/stress_suite_context.sh).  Such a socket is dropped and the connect repeated.
+            sockaddr_in self{}, peer{};
+            socklen_t ls = sizeof self, lp = sizeof peer;
+            const bool self_connected = ::getsockname(fd, reinterpret_cast<sockaddr*>(&self), &ls) == 0 && ::getpeername(fd, reinterpret_cast<sockaddr*>(&peer), &lp) == 0 &&
+                                        self.sin_port == peer.sin_port && self.sin_addr.s_addr == peer.sin_addr.s_addr;
+            if (!self_connected) break;
+        }
         if (fd >= 0) ::close(fd);
         fd = -1;
         std::this_thread::sleep_for(std::chrono::milliseconds(50));   // rank 0 may not be listening yet

@@ -682,7 +682,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const uint32_t G = (uint32_t)groups.size();
     const size_t need_words = (size_t)G * kmax;
     // (the 8-bit passes of a squared-L2 store whose plane has its own norm words bound the quantisation error in the frame of the cell: |q - c|_1 per (task, cell))
-    const bool cell_l1 = use_q8 && C.q8_norm != nullptr;
+    // (GPANN_FILTER_Q8_L1=0: no table — |q - c|_1 <= sqrt(d) |q - c|_2 from the table of squared distances instead, ~25 % looser)
+    const bool cell_l1 = use_q8 && C.q8_norm != nullptr && EnvU32("GPANN_FILTER_Q8_L1", 1) != 0;
     GPANN_TRY(s->ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 * (cell_l1 ? 2 : 1) + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     double* d_task_nq = s->ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
     double* d_task_q1 = d_task_nq + T;              // |q~|_1 (old order) ...
@@ -936,6 +937,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     na.task_tscale = d_task_tscale;
     na.group_tasks = 32u * QT8;
     na.cell_l1 = cell_l1_tab;
+    na.q8_own_norm = (use_q8 && C.q8_norm != nullptr) ? 1u : 0u;
     th.task_src = d_task_src;
     na.tasks = T;
     na.kmax = kmax;
@@ -1168,7 +1170,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.q8_B = pass_B;
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
-        fa.round_tiles = q8_pass ? q8_waves * (pass == 2 ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
+        // (the 8-bit sample pass: one row tile per unit of work by default — GPANN_FILTER_SAMPLE_UNIT=2: the rest pass's kernel, two tiles per unit)
+        const bool sample_wide = q8_pass && pass == 1 && EnvU32("GPANN_FILTER_SAMPLE_UNIT", 1) >= 2 && q8_unit_tiles >= 2;
+        fa.round_tiles = q8_pass ? q8_waves * ((pass == 2 || sample_wide) ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
@@ -1198,7 +1202,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             void* kargs8[] = {&f8};
-            GPANN_HIP_TRY(hipLaunchKernel(pass == 2 ? fn_q8 : fn_q8_sample, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
+            GPANN_HIP_TRY(hipLaunchKernel((pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
             if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));

@@ -284,6 +284,7 @@ struct NeedArgs {
     const float* task_tscale;           // [tasks] query quantisation step (through task_src)
     uint32_t group_tasks;
     const float* cell_l1;               // [tasks][kmax] |q - c|_1 (CellDistKernel<true>; squared L2 stores whose 8-bit plane has its own norm words), or null
+    uint32_t q8_own_norm;               // the 8-bit plane has its own norm words (shards.h q8_norm): without cell_l1 the error term comes from Cauchy-Schwarz
 };
 
 // The threshold of the 8-bit pass for task t and cell j (derivation in DESIGN.md §3.1c).  With p~ = c^ + s P' + e (|e_i| <= s/2) and
@@ -322,7 +323,11 @@ __device__ __forceinline__ float Q8Threshold(double tau, double nq, double q1, d
     // is in the row's word and only (q~ - c^).e is left: <= (s/2) |q~ - c^|_1, the query seen from the CELL — 2-3x smaller for a query inside its
     // cluster.  |q~ - c^|_1 <= l1_table (1 + (d + 8) 2^-24) + 2^-23 sqrt(d) (|q~| + |c^|): the table is a plain fp32 sum of d fp32 terms
     // |q_i - c_i| in the ORIGINAL coordinates, the second term the rounding of the centred ones.
-    const double q1_eff = l1_table >= 0.0 ? l1_table * (1.0 + (dd + 8.0) * 0x1p-24) + 0x1p-23 * sqrt(dd) * (qn + cn) : q1;
+    // (l1_table == -2: own norm words but no table of |q - c|_1 — Cauchy-Schwarz on the table of squared distances, |q - c|_1 <= sqrt(d) |q - c|_2,
+    // whose fp32 error (d + 2) 2^-24 D is covered by the factor; about a quarter looser than the exact sum for Gaussian residuals)
+    const double q1_eff = l1_table >= 0.0    ? l1_table * (1.0 + (dd + 8.0) * 0x1p-24) + 0x1p-23 * sqrt(dd) * (qn + cn)
+                          : l1_table == -2.0 ? sqrt(dd * fabs(D_table)) * (1.0 + (dd + 8.0) * 0x1p-24) + 0x1p-23 * sqrt(dd) * (qn + cn)
+                                             : q1;
     const double E = 0.5 * s_c * (1.0 + 1e-6) * q1_eff + tscale / 508.0 * (1.0 + 1e-6) * (sqrt(dd) * r_eff + 0.5 * dd * s_c);
     // fp32 evaluation of (float)I * (s t_q / 254) + nhn: four roundings of magnitudes <= |q~| (r + sqrt(d) s) and R^2 / 2 (the own norm
     // words add |c^.e| <= |c^| sqrt(d) s / 2 to the word's magnitude)
@@ -597,7 +602,7 @@ static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetu
                 a.q8_B[((size_t)g * a.kmax + j) * a.group_tasks + tg] =
                     Q8Threshold<METRIC>(tau, a.task_nq[src], a.task_q1[src], (double)a.task_tscale[src], a.shard_rmax[b], (double)a.d,
                                         (double)a.cell_dist[(size_t)src * a.kmax + j], a.q8_cnorm[cell0 + j], (double)a.q8_scale[cell0 + j], (double)a.radius[cell0 + j],
-                                        a.cell_l1 ? (double)a.cell_l1[(size_t)src * a.kmax + j] : -1.0);
+                                        a.cell_l1 ? (double)a.cell_l1[(size_t)src * a.kmax + j] : (a.q8_own_norm ? -2.0 : -1.0));
         }
     }
     __syncthreads();

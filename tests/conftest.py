@@ -39,6 +39,36 @@ def gp():
     return pygpann
 
 
+def free_port(span=2):
+    """`span` consecutive free TCP ports on 127.0.0.1 BELOW the kernel's ephemeral range; returns the first.  (A port from bind(0) lies inside
+    the ephemeral range: a rank that connects to it before rank 0 listens can be handed that very port as its SOURCE port and connect to itself —
+    rank 0 then fails with "Address already in use" and the others wait for their timeouts: 2 of 110 three-rank runs on one box in round 4.)"""
+    import random
+    import socket
+    lo_eph = 32768
+    try:
+        lo_eph = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError):
+        pass
+    hi = max(12000, min(lo_eph, 32768) - span - 1)
+    rng = random.Random(os.getpid() * 1000003 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        p = rng.randrange(11000, hi)
+        socks = []
+        try:
+            for i in range(span):
+                s = socket.socket()
+                socks.append(s)
+                s.bind(("127.0.0.1", p + i))
+            return p
+        except OSError:
+            continue
+        finally:
+            for s in socks:
+                s.close()
+    raise RuntimeError("no free ports")
+
+
 def make_mixture(orc, n, d, seed=555, n_centers=16, sigma=0.35, center_seed=7):
     return orc.synth_rows(seed, center_seed, n_centers, sigma, 0, n, d, nthreads=4)
 

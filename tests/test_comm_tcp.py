@@ -13,11 +13,8 @@ from conftest import ROOT, random_clusters
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from conftest import free_port   # (below the ephemeral range: see there)
+    return free_port(2)
 
 
 def _worker(rank, world, port, out_dir):

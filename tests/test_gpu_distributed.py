@@ -19,21 +19,9 @@ DB = os.path.join(ROOT, "gp-ann_amd", "bin", "DistributedBench")
 
 
 def _free_port():
-    """a free MASTER_PORT whose successor — the exchange library's default GPANN_COMM_PORT — is free as well"""
-    for _ in range(50):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        p = s.getsockname()[1]
-        s2 = socket.socket()
-        try:
-            s2.bind(("127.0.0.1", p + 1))
-            return p
-        except OSError:
-            continue
-        finally:
-            s2.close()
-            s.close()
-    raise RuntimeError("no pair of free ports")
+    """a free MASTER_PORT whose successors — the exchange library's default GPANN_COMM_PORT and the second communicator's — are free as well"""
+    from conftest import free_port
+    return free_port(3)
 
 
 @pytest.fixture(scope="module")

@@ -18,11 +18,8 @@ NO_ID = 0xFFFFFFFF
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from conftest import free_port   # (below the ephemeral range: see there)
+    return free_port(2)
 
 
 def _cut_at_merge_bound(d, i):

@@ -45,7 +45,12 @@ def q8_threshold(metric, tau, nq, q1, tscale, R, d, D_table, nc, s_c, radius, l1
     e_tab = 0.5 * ((d + 8.0) * 2.0 ** -23 * abs(D_table) + 2.0 ** -21 * (qn + cn) * np.sqrt(abs(D_table)) + 2.0 ** -40 * (nq + nc))
     r_eff = radius + 2.0 ** -23 * (R + cn)          # |p~ - c^| <= |p - c| + the rounding of the centred coordinates
     # the own norm words of the 8-bit plane (squared L2): only (q~ - c^).e is unknown, |.| <= (s/2) |q~ - c^|_1
-    q1_eff = l1_table * (1.0 + (d + 8.0) * 2.0 ** -24) + 2.0 ** -23 * np.sqrt(d) * (qn + cn) if l1_table >= 0.0 else q1
+    if l1_table >= 0.0:
+        q1_eff = l1_table * (1.0 + (d + 8.0) * 2.0 ** -24) + 2.0 ** -23 * np.sqrt(d) * (qn + cn)
+    elif l1_table == -2.0:   # own norm words, no |q - c|_1 table: Cauchy-Schwarz on the squared distance
+        q1_eff = np.sqrt(d * abs(D_table)) * (1.0 + (d + 8.0) * 2.0 ** -24) + 2.0 ** -23 * np.sqrt(d) * (qn + cn)
+    else:
+        q1_eff = q1
     E = 0.5 * s_c * (1.0 + 1e-6) * q1_eff + tscale / 508.0 * (1.0 + 1e-6) * (np.sqrt(d) * r_eff + 0.5 * d * s_c)
     e_fp = 2.0 ** -21 * (qn * (r_eff + np.sqrt(d) * s_c) + 0.5 * R * R + cn * np.sqrt(d) * s_c + 1.0)
     Bd0 = Ub - qc - E - e_tab - e_fp
@@ -66,7 +71,7 @@ def make_cell(rng, n, d, centre_offset, sigma, outliers):
     return pts
 
 
-@pytest.mark.parametrize("metric,cell_frame", [(0, True), (0, False), (1, False)])
+@pytest.mark.parametrize("metric,cell_frame", [(0, True), (0, "cs"), (0, False), (1, False)])
 @pytest.mark.parametrize("case", ["plain", "offset", "outliers", "tiny", "huge", "degenerate", "degenerate_ulp"])
 def test_rows_within_tau_pass_the_8_bit_test(metric, cell_frame, case):
     """cell_frame (squared L2, the default store layout since round 4): the plane's own norm words -|p~|^2/2 + c^.e (cells.hip CellQ8NormKernel) with
@@ -127,7 +132,8 @@ def test_rows_within_tau_pass_the_8_bit_test(metric, cell_frame, case):
                 D_table = f32(D_table + f32(df * df))
                 L1_table = f32(L1_table + np.abs(df))
             for tau in (float(np.sort(E)[9]), float(np.sort(E)[0]), float(np.sort(E)[n // 2]), float(np.sort(E)[9]) * 1.5 + (1e-9 if degenerate else 0.0)):
-                B = q8_threshold(metric, tau, nqd, q1, float(t_q), R, float(d), float(D_table), nc, float(s_c), radius, float(L1_table) if cell_frame else -1.0)
+                B = q8_threshold(metric, tau, nqd, q1, float(t_q), R, float(d), float(D_table), nc, float(s_c), radius,
+                                 -2.0 if cell_frame == "cs" else (float(L1_table) if cell_frame else -1.0))
                 h = Pq @ H
                 l = Pq @ L
                 assert np.abs(h).max() < 2 ** 22 and np.abs(l).max() < 2 ** 22
