@@ -940,7 +940,10 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             holders = [{int(owner[b])} for b in range(S)]
         chunk_q = (nq + W - 1) // W
         ranks = []
+        only = os.environ.get("GPANN_BENCH_EMULATE_RANKS")   # (profiling aid: "0" or "0,3": only these ranks of every world)
         for r in range(W):
+            if only and str(r) not in only.split(","):
+                continue
             mine = [b for b in range(S) if r in holders[b]]
             cl = [clusters[b] if b in mine else np.zeros(0, np.uint32) for b in range(S)]
             t_b = time.time()

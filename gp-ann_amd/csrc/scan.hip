@@ -776,8 +776,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     cd.ld = s->ld;
     cd.out_l1 = cell_l1_tab;
     auto cell_table = [&](bool with_qnorm) -> gpann_status {
-        if (cell_l1) hipLaunchKernelGGL(CellDistKernel<true>, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
-        else hipLaunchKernelGGL(CellDistKernel<false>, dim3((uint32_t)dtiles.size()), dim3(256), 0, st, cd);
+        const dim3 cgrid((uint32_t)dtiles.size(), std::max<uint32_t>(1, (kmax + 63) / 64));
+        if (cell_l1) hipLaunchKernelGGL(CellDistKernel<true>, cgrid, dim3(256), 0, st, cd);
+        else hipLaunchKernelGGL(CellDistKernel<false>, cgrid, dim3(256), 0, st, cd);
         hipLaunchKernelGGL(NearestCellKernel, dim3((T + 15) / 16), dim3(256), 0, st, cell_dist, ta.shard, C.d_shard_cell_begin, d_queries, ta.query, T, kmax,
                            s->d, s->ld, d_nearest, with_qnorm ? d_task_nq : nullptr, C.d_mu, use_q8 ? d_task_q1 : nullptr, use_q8 ? d_task_tscale : nullptr);
         GPANN_HIP_TRY(hipGetLastError());

@@ -78,7 +78,9 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
     const float* qrow0 = a.queries + (size_t)a.task_query[first + min((uint32_t)st_row0, count - 1)] * ld;
     const float* qrow1 = a.queries + (size_t)a.task_query[first + min((uint32_t)st_row1, count - 1)] * ld;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t ct = 0; ct < K; ct += 64) {
+    // grid.y = cell tiles of 64 (a workgroup per (task tile, cell tile): a rank of an 8-GPU run has ~20 task tiles — with the cell loop inside
+    // the workgroup the launch ran on 20 CUs for 0.18 ms)
+    for (uint32_t ct = 64u * blockIdx.y; ct < K; ct += 64u * gridDim.y) {
         const float* crow0 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row0, K - 1)) * ld;
         const float* crow1 = a.center + (size_t)(cell0 + min(ct + (uint32_t)st_row1, K - 1)) * ld;
         float acc[4][4], acc1[WITH_L1 ? 4 : 1][WITH_L1 ? 4 : 1];
@@ -493,11 +495,11 @@ __device__ __forceinline__ float MergeSplitPieces(const RescoreArgs& a, uint32_t
     return __shfl(ld_, k - 1);
 }
 
-// Grid: (kSetupChunks, task groups).  Workgroup (p, g) owns the tasks [64 p, 64 p + 64) of group g — two query tiles — for phases 1 and 2
+// Grid: (kSetupChunks, task groups).  Workgroup (p, g) owns the tasks [32 p, 32 p + 32) of group g — one query tile — for phases 1 and 2
 // (with ONE workgroup per group the launch ran on 40 of the 256 CUs at the NS workload and its chains of dependent loads, 20 rounds of
 // the cell loop deep, took 0.10 - 0.15 ms); the group's need masks are OR-ed together in global memory with device-scope atomics, and
 // PassItemsKernel — the next launch — runs phase 3 per group.
-constexpr uint32_t kSetupChunkTasks = 64;
+constexpr uint32_t kSetupChunkTasks = 32;   // (one query tile per workgroup: 64 was measured no faster at 10k tasks and 1.5x slower at 1 250 — a rank of an 8-GPU run)
 constexpr uint32_t kSetupChunks = kGTasks / kSetupChunkTasks;
 template <int METRIC>
 static __global__ void __launch_bounds__(kSetupThreads) PassSetupKernel(PassSetupArgs A) {

@@ -1,7 +1,9 @@
 // host_util.h — internal helpers of the host mirror (not part of the mirrored interface).
 #pragma once
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <exception>
@@ -49,7 +51,9 @@ void ParallelFor(size_t begin, size_t end, int threads, Body body) {
 // reference's callers issue them from up to 32 threads at once (routes.cpp:194-200, small_scale_queries.cpp:114-116), and on the GPU a
 // batch of one costs a whole launch sequence.  Concurrent callers Submit() their request; whoever finds no batch in flight becomes the
 // leader of the next one, takes EVERYTHING that has queued up — its own request included —, runs it as one device batch and wakes the
-// owners; callers that arrive meanwhile form the following batch.  A single caller pays one mutex round trip; nothing waits on a timer.
+// owners; callers that arrive meanwhile form the following batch.  A single caller pays one mutex round trip and never waits; with several
+// callers a leader gives the callers of the previous batches up to 50 us to come back with their next query (else T callers settle into
+// two alternating half-size batches).
 // Req needs the members `bool done` and `std::exception_ptr error`.
 template <typename Req>
 class Coalescer {
@@ -60,10 +64,20 @@ public:
         req.done = false;
         req.error = nullptr;
         queue_.push_back(&req);
+        if (gathering_) cv_.notify_all();   // (a leader is giving its batch a moment to fill up)
         for (;;) {
             if (req.done) break;
             if (!leader_) {   // (no batch in flight and this request not served: it is in the queue — this thread leads the next batch)
                 leader_ = true;
+                // Callers that were served by the batch before are on their way back with their next query: in the steady state of T callers
+                // the batches would alternate between two halves of them.  When the last two batches together were larger than what has queued
+                // up, the leader gives the others up to 50 us (a fraction of a launch sequence) to arrive.
+                const size_t expect = std::min<size_t>(last_batch_ + before_last_, 4096);
+                if ((last_batch_ > 1 || before_last_ > 1) && expect > queue_.size()) {   // (a lone caller — batches of one — never waits)
+                    gathering_ = true;
+                    cv_.wait_for(lk, std::chrono::microseconds(50), [&] { return queue_.size() >= expect; });
+                    gathering_ = false;
+                }
                 std::vector<Req*> batch;
                 batch.swap(queue_);
                 lk.unlock();
@@ -81,6 +95,8 @@ public:
                 leader_ = false;
                 ++batches_;
                 requests_ += batch.size();
+                before_last_ = last_batch_;
+                last_batch_ = batch.size();
                 cv_.notify_all();
                 continue;
             }
@@ -100,7 +116,8 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::vector<Req*> queue_;
-    bool leader_ = false;
+    bool leader_ = false, gathering_ = false;
+    size_t last_batch_ = 0, before_last_ = 0;   // sizes of the two most recent batches
     uint64_t batches_ = 0, requests_ = 0;
 };
 
