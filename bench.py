@@ -553,7 +553,9 @@ def main():
     # (one rank, round 4) ... and the SCAN of batch i + 1 is planned, staged and enqueued behind batch i before batch i is waited for
     # (GPANN_SCAN_DEFER / gpann_scan_finish, include/gpann.h): the host side of a scan call — task lists, group tables, the uploads, ~35 launches —
     # runs under the previous batch's kernels instead of between two batches.  GPANN_BENCH_SCAN_AHEAD=0: the scan call completes before it returns.
-    scan_ahead = route_ahead and not multi and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
+    # (several ranks: the scan is deferred the same way — into device arrays, two sets — and the exchange of batch i's slot lists (gather_slots,
+    # the copies to the host) runs on a THIRD stream once its scan has been completed, next to the scan of batch i + 1)
+    scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
     if route_ahead:
         r_stream = torch.cuda.Stream(device=dev)
         r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
@@ -567,9 +569,19 @@ def main():
                                              want_min_dist=False, n_top=None if nprobe == S else nprobe)
             return pr, r_ms, router.stats()
 
+    x_stream = torch.cuda.Stream(device=dev) if multi else None
+    dev_sets = {}
+
     def scan_begin(pr, buf):
         """enqueue the scan of one batch (deferred call): the per-slot lists travel to the pinned host buffers `buf` behind the kernels"""
         key = (nq, nprobe, buf)
+        if multi:   # this rank's slots into device arrays of set `buf`; the exchange follows in scan_finish
+            lp = gcomm.mask_probes_replicated(pr, nprobe, rep_begin, rep_rank, rank) if placement else gcomm.mask_probes(pr, nprobe, owner, rank)
+            if buf not in dev_sets:
+                dev_sets[buf] = (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev))
+            oi, od = dev_sets[buf]
+            shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, for_merge=merge_bound, defer=True)
+            return
         if key not in host_out:
             host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory())
         hd, hi = host_out[key]
@@ -578,6 +590,31 @@ def main():
 
     def scan_finish(buf):
         ms = shards.finish()
+        if multi:   # the batch's scan is complete (an overflowed filter call redone): its slot lists are exchanged on the third stream
+            key = (nq, nprobe, buf)
+            n_slots = nq * nprobe * k
+            if key not in host_out:
+                host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory(),
+                                 torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev),
+                                 torch.empty(comm.gather_slots_scratch(n_slots), dtype=torch.uint8, device=dev if on_dev else "cpu"))
+            hd, hi, gd, gi, scratch = host_out[key]
+            oi, od = dev_sets[buf]
+            with torch.cuda.stream(x_stream):
+                if on_dev:
+                    comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(),
+                                      stream=x_stream.cuda_stream)
+                    hd.copy_(gd, non_blocking=True)
+                    hi.copy_(gi, non_blocking=True)
+                else:
+                    hd.copy_(od, non_blocking=True)
+                    hi.copy_(oi, non_blocking=True)
+            if on_dev:
+                comm.wait(x_stream.cuda_stream, COMM_WAIT_S)
+            else:
+                x_stream.synchronize()
+                sd_, si_ = hd.numpy().copy(), hi.numpy().view(np.uint32).copy()
+                comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
+            return hd.numpy(), hi.numpy().view(np.uint32), ms
         hd, hi = host_out[(nq, nprobe, buf)]
         return hd.numpy(), hi.numpy().view(np.uint32), ms
 
@@ -772,7 +809,10 @@ def main():
                                      "batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned")
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
     if multi and route_ahead:
-        result["config"]["pipeline"] = ("batches overlap: every rank routes its slice of batch i+1 and the probe lists are all-gathered (second stream, second "
+        result["config"]["pipeline"] = ("batches overlap: every rank routes its slice of batch i+2 and the probe lists are all-gathered (second stream, second "
+                                        "communicator), the scan of batch i+1 is planned and enqueued behind batch i (deferred scan call), the slot lists of batch i "
+                                        "are exchanged on a third stream once its scan is complete; batch i-1 is merged on the host" if scan_ahead else
+                                        "batches overlap: every rank routes its slice of batch i+1 and the probe lists are all-gathered (second stream, second "
                                         "communicator) while batch i is scanned and its slot lists are exchanged; batch i-1 is merged on the host")
     result["detail"] = {"merge": {"slot_entries": slot_entries, "duplicate_ids_dropped": dup_ids,
                                   "note": "DedupNeighbors over the per-slot lists of the last timed step: entries whose id also came back from another probed shard"},
@@ -893,7 +933,8 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
     nq, d, S, k = args.nq, args.d, args.shards, args.k
     metric = args.metric_id
     out = {"note": "per-rank steps of a W-GPU run executed one rank at a time on ONE GPU (same placement, same kernels, same host code); "
-                   "predicted_qps = nq / (max over ranks of ms_per_step + exchange_ms); exchange_ms = the step's three collectives timed through "
+                   "predicted_qps = nq / predicted_ms_per_step (see `model` per world; `..._exchange_in_series` = the rounds 2-3 model: slowest rank + exchange + wire); "
+                   "exchange_ms = the step's collectives timed through "
                    "RCCL with ONE rank on this GPU (launch + kernel cost, no wire) + wire_ms_estimate (bytes / 50 GB/s per xGMI link direction, "
                    "ring of W - 1 steps); NOT a measurement on W GPUs",
            "one_gpu_ms_per_step": one_gpu_ms, "worlds": []}
@@ -968,8 +1009,12 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                     router.query_batch(queries.data_ptr() + lo * d * 4, args.search_budget, st, on_device=True, nq=hi - lo, out_probes=route_bufs[j & 1][:hi - lo], want_min_dist=False)
                 return True
 
+            scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
+            x_stream = torch.cuda.Stream(device=dev)
+            dsets = [(oi, od), (torch.empty_like(oi), torch.empty_like(od))]
+
             def one(i, routed):
-                """like the real loop of a rank: batch i + 1 is routed on a second stream by a second thread while batch i is scanned"""
+                """like the real loop of a rank with GPANN_BENCH_SCAN_AHEAD=0: batch i + 1 is routed on a second stream by a second thread while batch i is scanned"""
                 if routed is not None:
                     routed.result()
                 else:
@@ -984,7 +1029,41 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 tasks_rows[0] = float(sh.stats()["pairs"])
                 return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k), nxt
 
+            def begin(i, routed):
+                """the real loop's scan_begin: the routing of batch i has arrived (batch i + 1 goes to the router thread), the scan is planned and ENQUEUED (deferred call)"""
+                routed.result()
+                nxt = router_pool.submit(route_share, i + 1, r_stream.cuda_stream)
+                lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
+                di, dd = dsets[i & 1]
+                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), stream, for_merge=merge_bound, defer=True)
+                return nxt
+
+            def finish(i):
+                """the real loop's scan_finish: the scan of batch i is completed; its lists leave on the third stream (where the real loop runs gather_slots first)"""
+                sh.finish()
+                di, dd = dsets[i & 1]
+                hd, hi_ = hbuf[i & 1]
+                with torch.cuda.stream(x_stream):
+                    hd.copy_(dd, non_blocking=True)
+                    hi_.copy_(di, non_blocking=True)
+                x_stream.synchronize()
+                tasks_rows[0] = float(sh.stats()["pairs"])
+                return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k)
+
             def loop(count):
+                if scan_ahead:
+                    pending = None
+                    nxt = begin(0, router_pool.submit(route_share, 0, r_stream.cuda_stream))
+                    for i in range(count):
+                        if pending is not None:
+                            pending.result()
+                        if i + 1 < count:
+                            nxt = begin(i + 1, nxt)
+                        pending = finish(i)
+                    pending.result()
+                    nxt.result()
+                    torch.cuda.synchronize()
+                    return
                 pending, routed = None, (router_pool.submit(route_share, 0, r_stream.cuda_stream) if route_ahead else None)
                 for i in range(count):
                     f, routed = one(i, routed)
@@ -1008,16 +1087,27 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             merger.shutdown()
             router_pool.shutdown()
             sh.close()
-            del oi, od, hbuf
+            del oi, od, hbuf, dsets
             torch.cuda.empty_cache()
         worst = max(x["ms_per_step"] for x in ranks)
-        # wire time of the collectives on W GPUs: ring all-gather, (W - 1) steps of one rank's block over one xGMI link direction (~50 GB/s achievable)
-        wire_bytes = (W - 1) * (chunk_q * S * 4 + 2 * nq * nprobe * k * 4) + queries.numel() * 4
+        # wire time of a STEP's collectives on W GPUs: ring all-gather, (W - 1) steps of one rank's block over one xGMI link direction (~50 GB/s achievable):
+        # the probe lists and the per-slot (dist, id) lists.  (The query block is broadcast once per block of batches, not per step: the timed loop's
+        # queries are resident — rounds 2-3 charged its 5 MB to every step.)
+        wire_bytes = (W - 1) * (chunk_q * S * 4 + 2 * nq * nprobe * k * 4)
         wire_ms = 1000.0 * wire_bytes / 50e9
-        total = worst + (exch_ms or 0.0) + wire_ms
+        serial = worst + (exch_ms or 0.0) + wire_ms
+        # The pipelined loop (GPANN_BENCH_SCAN_AHEAD, the default) exchanges batch i's lists on a third stream while batch i + 1 is scanned and routes batch
+        # i + 2 on a second: the exchange sits beside the scan, not behind it — a step then takes what the slower of the two takes: the rank's own step (GPU
+        # and host work, measured above WITH the deferred scans) or its host-side chain plan + enqueue (measured: the one-rank scan call's host time) + exchange.
+        host_chain = 0.35 + (exch_ms or 0.0) + wire_ms   # (0.35 ms: mask + plan + staging + ~30 launches of a scan call, bench.py's own trace)
+        pipelined = max(worst, host_chain) if os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0" else serial
+        total = pipelined
         out["worlds"].append({"world": W, "ranks": ranks, "max_ms_per_step": worst, "mean_ms_per_step": float(np.mean([x["ms_per_step"] for x in ranks])),
                               "wire_ms_estimate": wire_ms, "predicted_ms_per_step": total, "predicted_qps": 1000.0 * nq / total,
                               "predicted_speedup_over_one_gpu": one_gpu_ms / total,
+                              "predicted_ms_per_step_exchange_in_series": serial, "predicted_speedup_exchange_in_series": one_gpu_ms / serial,
+                              "model": "max(slowest rank's step, host chain + exchange): the exchange of batch i runs beside the scan of batch i + 1 (third stream)"
+                                       if total is pipelined and pipelined != serial else "slowest rank's step + exchange + wire",
                               "replicas": int(sum(len(h) for h in holders) - S)})
         log(f"emulated world {W}: max {worst:.3f} ms/step -> predicted {1000.0 * nq / total:.0f} QPS ({one_gpu_ms / total:.2f}x one GPU)")
     return out
@@ -1145,38 +1235,40 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
         return time.perf_counter() - t0, md, mi
 
     everything = np.arange(len(qidx))
-    dt, cd, ci = run(orc, everything, cores)
+    # the reference's own thread cap (routes.cpp:194: 32 workers) on the WHOLE sample — on a 256-thread host it is the faster setting (the per-query
+    # streams of 256 threads thrash the memory system) and it is the leg whose neighbours are compared with the GPU's; all hardware threads, and the
+    # flags upstream ships, on an eighth of the sample each (until round 3 they ran on all of it: three minutes of a default run)
+    t32 = min(32, cores)
+    dt32, cd, ci = run(orc, everything, t32)
     # parity of the timed GPU path with the CPU path on the sample: ids and distance bits
     cd, ci = np.asarray(cd).reshape(len(qidx), k), np.asarray(ci).reshape(len(qidx), k)
     match = bool(np.array_equal(ci, gpu_ids[qidx]) and np.array_equal(cd.view(np.uint32), np.ascontiguousarray(gpu_dist[qidx]).view(np.uint32)))
-    # the reference's own thread cap, on a quarter of the sample
-    t32 = min(32, cores)
-    sub = everything[:max(1, len(qidx) // 4)]
-    dt32, _, _ = run(orc, sub, t32)
-    # the same sample with the flags upstream ships (-O3 -march=native -ffast-math, CMakeLists.txt:15): not the parity oracle
+    sub = everything[:max(1, len(qidx) // 8)]
+    dt, _, _ = run(orc, sub, cores)
+    # the same sub-sample with the flags upstream ships (-O3 -march=native -ffast-math, CMakeLists.txt:15): not the parity oracle
     # (results may differ in the last bits), reported so the strict flags do not flatter the GPU
     fast = None
     try:
-        dtf, _, _ = run(pyoracle.Oracle("refflags"), everything, cores)
-        fast = len(qidx) / dtf
+        dtf, _, _ = run(pyoracle.Oracle("refflags"), sub, cores)
+        fast = len(sub) / dtf
     except Exception:
         pass
     # `value` = the better of the two thread counts (on a 256-thread host the reference's own cap of 32 workers is the faster setting: the
     # per-query streams of 256 threads thrash the memory system); both are reported
-    v_all, v_32 = len(qidx) / dt, len(sub) / dt32
+    v_all, v_32 = len(sub) / dt, len(qidx) / dt32
     return {"value": max(v_all, v_32), "unit": "queries/s", "cores": cores if v_all >= v_32 else t32, "kind": "port", "cpu_model": cpu_model(),
             "value_all_threads": v_all, "threads_all": cores,
             "value_reference_flags": fast, "value_32_threads": v_32, "threads_32": t32, "results_match_gpu": match,
-            "sample_queries": int(len(qidx)), "sample_pairs": pairs, "sample_GBps": pairs * d * 4 / dt / 1e9,
+            "sample_queries": int(len(qidx)), "sample_pairs": pairs, "sample_GBps": pairs * d * 4 / dt32 / 1e9,
             "sample_rows_per_query": sample_rows_per_query, "batch_rows_per_query": batch_rows_per_query,
             "value_scaled_to_batch": max(v_all, v_32) * sample_rows_per_query / max(batch_rows_per_query, 1.0),
             "sample_choice": "shards in a fixed pseudo-random order (seed 12345) until enough queries fall entirely into them: size-representative; "
                              "value_scaled_to_batch = value x sample_rows_per_query / batch_rows_per_query (the CPU path's time is proportional to the rows it streams)",
             "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
-                      f"{pairs:.3g} (query,row) pairs = {pairs * d * 4 / 1e9:.0f} GB streamed in {dt:.1f}s on {cores} threads (rows first-touched by {touchers} "
-                      f"threads in interleaved 2 MiB blocks); strict build (-O2, no fast-math/FMA/AVX); value_32_threads: {len(sub)} of them on "
-                      f"{t32} threads in {dt32:.1f}s; value_reference_flags: -O3 -march=native -ffast-math on {cores} threads",
-            "seconds": dt}
+                      f"{pairs:.3g} (query,row) pairs = {pairs * d * 4 / 1e9:.0f} GB streamed in {dt32:.1f}s on {t32} threads — the reference's own cap — (rows "
+                      f"first-touched by {touchers} threads in interleaved 2 MiB blocks); strict build (-O2, no fast-math/FMA/AVX); value_all_threads: {len(sub)} of "
+                      f"them on {cores} threads in {dt:.1f}s; value_reference_flags: those {len(sub)} with -O3 -march=native -ffast-math on {cores} threads",
+            "seconds": dt32}
 
 
 if __name__ == "__main__":

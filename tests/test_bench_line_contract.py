@@ -1,4 +1,5 @@
-"""The committed bench lines (profiles/r03/bench_*.json, each the single JSON line `python bench.py ...` printed on an MI355X) carry every field of the
+"""SCHEMA check of committed artefacts (not behavioural coverage: tests/test_gpu_bench_line.py runs bench.py itself on a GPU and validates the line it prints).
+The committed bench lines (profiles/r03|r04/bench_*.json, each the single JSON line `python bench.py ...` printed on an MI355X) carry every field of the
 measurement contract: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
 config.workload, the `roofline` object (bound, achieved, peak, unit, frac, traffic) and — where the CPU leg ran — `cpu_baseline`; and the self-checks
 of the run (filter mode == exact mode, GPU == CPU oracle) are recorded as true."""
@@ -10,14 +11,14 @@ import pytest
 
 from conftest import ROOT
 
-FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench_*.json")))
+FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "bench_*.json")))
 
 
 def _line(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(os.path.dirname(f)) + "/" + os.path.basename(f) for f in FILES])
 def test_bench_line_has_the_contract_fields(path):
     j = _line(path)
     if "bench_line" in j:          # (scale_emulated-style wrappers keep the line inside)
@@ -43,8 +44,12 @@ def test_bench_line_has_the_contract_fields(path):
         assert c["kind"] in ("port", "reference") and c["results_match_gpu"] is True
 
 
-def test_the_default_line_is_the_metric_workload():
-    j = _line(os.path.join(ROOT, "profiles", "r03", "bench_ns_default.json"))
+@pytest.mark.parametrize("rnd", ["r03", "r04"])
+def test_the_default_line_is_the_metric_workload(rnd):
+    path = os.path.join(ROOT, "profiles", rnd, "bench_ns_default.json")
+    if not os.path.exists(path):
+        pytest.skip(f"no {rnd} default line committed yet")
+    j = _line(path)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert j["metric"].startswith("QPS @ recall@10") and "QPS" in base["metric"]
     cfg = j["config"]

@@ -175,7 +175,7 @@ def _hip():
     return C, hip, ok
 
 
-@pytest.mark.parametrize("mode", ["filter", "exact", "overflow"])
+@pytest.mark.parametrize("mode", ["filter", "exact", "overflow", "filter_ip_2probes"])
 def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
     """GPANN_SCAN_DEFER (include/gpann.h): a call only enqueues its work, the NEXT call is planned and enqueued behind it, gpann_scan_finish
     completes them oldest first.  Results (pinned host arrays) and statistics of every call equal the plain call's and the oracle's —
@@ -183,16 +183,18 @@ def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
     second batch has already been enqueued behind it."""
     C, hip, ok = _hip()
     rng = np.random.default_rng(77)
-    n, d, nq, k, nprobe = 30000, 16, 96, 10, 1
+    two = mode == "filter_ip_2probes"          # inner product, three shards, two probes per query, lists cut at the merge bound
+    metric = 1 if two else 0
+    n, d, nq, k, nprobe = 30000, 16, 96, 10, (2 if two else 1)
     pts = make_mixture(orc, n, d, n_centers=4)
     if mode == "overflow":
         pts[2000:] = pts[2000]
-    clusters = [np.arange(n, dtype=np.uint32)]
+    clusters = random_clusters(rng, n, 3) if two else [np.arange(n, dtype=np.uint32)]
     batches = [make_mixture(orc, nq, d, seed=556 + i, n_centers=4) for i in range(3)]
     if mode == "overflow":
         batches[0][:40] = pts[2000]   # 40 tasks tie with tens of thousands of rows: more dirty tasks than the pipeline redoes itself
-    probes = np.zeros((nq, nprobe), np.int32)
-    shards = gp.Shards(pts, clusters, 0, 0)
+    probes = np.stack([rng.permutation(3)[:nprobe] for _ in range(nq)]).astype(np.int32) if two else np.zeros((nq, nprobe), np.int32)
+    shards = gp.Shards(pts, clusters, metric, 0)
     shards.set_scan_mode(0 if mode == "exact" else 1)
     ivf = orc.ivf_build(pts, clusters)
     st = C.c_void_p()
@@ -214,30 +216,36 @@ def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
         return np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_uint32)), shape=(nq * nprobe * k,)).view(dtype).reshape(nq, nprobe, k)
 
     # batch 0 and 1 enqueued back to back, then: finish(0), enqueue 2, finish(1), finish(2)
-    shards.scan_buckets_device(q_dev[0].value, nq, k, probes, nprobe, h_ids[0].value, h_dist[0].value, st.value, defer=True, host_out=True)
-    shards.scan_buckets_device(q_dev[1].value, nq, k, probes, nprobe, h_ids[1].value, h_dist[1].value, st.value, defer=True, host_out=True)
+    shards.scan_buckets_device(q_dev[0].value, nq, k, probes, nprobe, h_ids[0].value, h_dist[0].value, st.value, defer=True, host_out=True, for_merge=two)
+    shards.scan_buckets_device(q_dev[1].value, nq, k, probes, nprobe, h_ids[1].value, h_dist[1].value, st.value, defer=True, host_out=True, for_merge=two)
     stats = []
     shards.finish()
     stats.append(shards.stats())
-    shards.scan_buckets_device(q_dev[2].value, nq, k, probes, nprobe, h_ids[2].value, h_dist[2].value, st.value, defer=True, host_out=True)
+    shards.scan_buckets_device(q_dev[2].value, nq, k, probes, nprobe, h_ids[2].value, h_dist[2].value, st.value, defer=True, host_out=True, for_merge=two)
     shards.finish()
     stats.append(shards.stats())
     shards.finish()
     stats.append(shards.stats())
     shards.finish()   # nothing outstanding: a no-op
     for i, q in enumerate(batches):
-        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, q, k, probes, nprobe, 0, nthreads=4)
+        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, q, k, probes, nprobe, metric, nthreads=4)
+        if two:   # GPANN_SCAN_FOR_MERGE: every slot cut after its last entry within the query's merge bound (include/gpann.h)
+            tau = wd[:, :, -1].min(axis=1)
+            cut = ~(wd <= tau[:, None, None])
+            wd, wi = wd.copy(), wi.copy()
+            wd[cut] = np.inf
+            wi[cut] = 0xFFFFFFFF
         assert np.array_equal(host_view(h_ids[i], np.uint32), wi), (mode, i)
         assert np.array_equal(host_view(h_dist[i], np.uint32), wd.view(np.uint32)), (mode, i)
-        assert stats[i]["tasks"] == nq
-    if mode == "filter":
+        assert stats[i]["tasks"] == nq * nprobe
+    if mode in ("filter", "filter_ip_2probes"):
         assert all(s_["filtered"] == 1 for s_ in stats), stats
     if mode == "exact":
         assert all(s_["filtered"] == 0 for s_ in stats), stats
     if mode == "overflow":
         assert stats[0]["filtered"] == 0, stats   # (the other batches may or may not get by with a few dirty tasks: their results are checked above)
     # a plain (synchronous) call right after deferred ones
-    ids, dist, _ = shards.scan_buckets(batches[1], k, probes, nprobe)
+    ids, dist, _ = shards.scan_buckets(batches[1], k, probes, nprobe, for_merge=two)
     assert np.array_equal(ids, host_view(h_ids[1], np.uint32)) and np.array_equal(dist.view(np.uint32), host_view(h_dist[1], np.uint32))
     for p in q_dev:
         ok(hip.hipFree(p))
