@@ -1002,16 +1002,28 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         // 255 x 12582912 x s0 — Q8Threshold's e_bias covers the roundings at that magnitude)
         const float s0 = cell_scale * U[q0], b0 = BIAS ? __builtin_fmaf(kBias255, s0, Bq[Q8 ? q0 : 0]) : Bq[Q8 ? q0 : 0];
         uint32_t neg = 0;
+        // two accumulators per instruction: v_pk_fma_f32 / v_pk_add_f32 on register pairs (the matrix instruction's 16 result registers are
+        // consecutive) — 40 vector instructions per product instead of 64 (each element the same IEEE operation as before: same bits)
+        const f32x2 k254 = {254.0f, 254.0f}, s02 = {s0, s0}, b02 = {b0, b0};
 #pragma unroll
         for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
             const float4 n = METRIC == GPANN_METRIC_L2 ? *reinterpret_cast<const float4*>(norms + 8 * gg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float nn[4] = {n.x, n.y, n.z, n.w};
 #pragma unroll
-            for (int i = 3; i >= 0; --i) {
-                const int r = 4 * gg + i;
-                const float fv = BIAS ? __builtin_fmaf(__int_as_float(h0[r]), 254.0f, __int_as_float(l0[r])) : __builtin_fmaf((float)h0[r], 254.0f, (float)l0[r]);
-                const float x = __builtin_fmaf(fv, s0, nn[i]) - b0;
-                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x), 31);   // neg = neg << 1 | sign(x)
+            for (int p = 1; p >= 0; --p) {
+                const int r = 4 * gg + 2 * p;
+                f32x2 hv, lv;
+                if (BIAS) {
+                    hv = f32x2{__int_as_float(h0[r]), __int_as_float(h0[r + 1])};
+                    lv = f32x2{__int_as_float(l0[r]), __int_as_float(l0[r + 1])};
+                } else {
+                    hv = f32x2{(float)h0[r], (float)h0[r + 1]};
+                    lv = f32x2{(float)l0[r], (float)l0[r + 1]};
+                }
+                const f32x2 nv = p ? f32x2{n.z, n.w} : f32x2{n.x, n.y};
+                const f32x2 fv = __builtin_elementwise_fma(hv, k254, lv);
+                const f32x2 x = __builtin_elementwise_fma(fv, s02, nv) - b02;
+                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x.y), 31);   // neg = neg << 1 | sign(x): accumulator r + 1, then r
+                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(x.x), 31);
             }
         }
         // (a NaN — a padding row's -inf norm against a -inf threshold — may read as a candidate: padding rows are dropped at the flush)
