@@ -1964,7 +1964,7 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     BoundArgs ba;
     float* thr = nullptr;
     const bool defer = may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK") &&
-                       !std::getenv("GPANN_ROUTER_PROBE");
+                       !std::getenv("GPANN_ROUTER_PROBE") && !std::getenv("GPANN_ROUTER_FORCE_EVIDENCE");
     GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr, /*convert_minima=*/defer));
     if (defer) {
         // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
@@ -2016,6 +2016,10 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     }
     if (std::getenv("GPANN_ROUTER_VERIFY")) GPANN_TRY(VerifyBound(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
     if (std::getenv("GPANN_ROUTER_PROBE")) GPANN_TRY(ProbeBoundDeterminism(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
+    if (std::getenv("GPANN_ROUTER_FORCE_EVIDENCE")) {   // test hook: the evidence machinery on a healthy block (its report then says: nothing differs)
+        size_t bad = 0;
+        GPANN_TRY(BoundEvidence(r, da, nb, st, ba, thr, caller_queries, caller_on_device, "forced (GPANN_ROUTER_FORCE_EVIDENCE, a test hook)", &bad));
+    }
     hipLaunchKernelGGL(MinBitsToFloatKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
     GPANN_HIP_TRY(hipGetLastError());
     *settled = true;

@@ -306,3 +306,61 @@ def test_shipping_configuration_of_the_bound_path(orc, gp, metric, d, S, num_cen
         assert st["bound_calls"] == 2 and st["verified"] == 0, st
         assert st["bound_selfcheck"] == 0 and st["bound_overflow"] == 0 and st["verify_failures"] == 0, st
         router.close()
+
+
+def test_bound_evidence_dump_and_determinism_probe(orc, gp, monkeypatch, tmp_path):
+    """The diagnostics of the bound path: GPANN_ROUTER_PROBE runs every block twice and compares every bit; an event would
+    leave BoundEvidence — text + a binary dump of both runs' arrays and the canonical minima.  GPANN_ROUTER_FORCE_EVIDENCE (a test hook) writes
+    that evidence for a healthy block: the dump must parse, its two runs must agree bit for bit and equal the canonical minima."""
+    import glob
+    import struct
+    report = str(tmp_path / "verify_report.txt")
+    monkeypatch.setenv("GPANN_VERIFY_REPORT", report)
+    monkeypatch.setenv("GPANN_ROUTER_PROBE", "1")
+    monkeypatch.setenv("GPANN_ROUTER_FORCE_EVIDENCE", "1")
+    d, S, metric = 32, 5, 0
+    pts, clusters, tree = _tree(orc, 20000, d, S, metric, 16, 40, 4000, seed=91)
+    queries = make_mixture(orc, 200, d, seed=556, n_centers=24)       # the shape of the reference driver's call in the drop-in test
+    want_p, want_md = tree.query_batch(queries, 10 ** 6, nthreads=4)
+    router = gp.Router(tree.flat(), metric, 0)
+    p, md, _ = router.query_batch(queries, 10 ** 6)
+    assert np.array_equal(md.view(np.uint32), want_md.view(np.uint32)) and np.array_equal(p, want_p)
+    st = router.stats()
+    assert st["probed"] >= 1 and st["probe_failures"] == 0 and st["verify_failures"] == 0 and st["bound_selfcheck"] == 0, st
+    text = open(report).read()
+    assert "EVIDENCE" in text and "forced" in text and " 0 of " in text, text[:600]
+    dumps = glob.glob(report + ".*.bin")
+    assert len(dumps) >= 1
+    raw = open(dumps[0], "rb").read()
+    assert raw[:8] == b"GPANNBD1"
+    nb, S_, d_, ld, n_seg, cand_cap, metric_, plane_ks = struct.unpack_from("<8I", raw, 8)
+    (C,) = struct.unpack_from("<Q", raw, 40)
+    counters1 = struct.unpack_from("<8I", raw, 48)
+    counters2 = struct.unpack_from("<8I", raw, 80)
+    n_cand1, n_cand2 = struct.unpack_from("<2I", raw, 112)
+    assert (nb, S_, d_, metric_) == (200, S, d, metric) and C == tree.flat()["centroids"].shape[0]
+    off = 120
+    nb_s = nb * S_
+
+    def take(n_words, dtype):
+        nonlocal off
+        a = np.frombuffer(raw, dtype, n_words, off)
+        off += 4 * n_words
+        return a
+    runs = []
+    for n_cand in (n_cand1, n_cand2):
+        max_bits, thr, min_bits, q = take(nb_s, np.uint32), take(nb_s, np.uint32), take(nb_s, np.uint32), take(nb * ld, np.float32)
+        cand = take(2 * n_cand, np.uint32).reshape(-1, 2)
+        runs.append((max_bits, thr, min_bits, q, cand))
+    want = take(nb_s, np.uint32)
+    assert off == len(raw)
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)                                   # maxima, thresholds, minima, staged queries: bit-equal between the runs
+    def cand_set(c):
+        v = c[c[:, 0] != 0xFFFFFFFF]
+        return np.sort(v[:, 0].astype(np.uint64) << np.uint64(32) | v[:, 1].astype(np.uint64))
+    assert np.array_equal(cand_set(runs[0][4]), cand_set(runs[1][4]))   # the candidate SETS (slot order is not defined)
+    assert np.array_equal(runs[0][2], want)                           # the minima equal the canonical evaluation's (ordered bits)
+    assert counters1[1] == 0 and counters1[4] == 0 and counters2[1] == 0
+    assert np.array_equal(runs[0][3].reshape(nb, ld)[:, :d], queries)
+    router.close()
