@@ -67,7 +67,8 @@ struct gpann_router {
     hipEvent_t ev_bound[2] = {nullptr, nullptr};   // around the two RouterBoundKernel launches of the most recent bound block
     double stat_bound_ms = 0.0, stat_bound_flops = 0.0;   // accumulated over the blocks of the most recent call
     uint32_t max_depth = 0;              // deepest non-root level (roots = 0)
-    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi;
+    gpann::DeviceBuffer ws_queries, ws_heap, ws_out, ws_dense, ws_redo, ws_pi, ws_frame;
+    uint64_t stat_table_blocks = 0, stat_table_queries = 0, stat_table_band_nodes = 0, stat_table_exact = 0, stat_table_band_overflow = 0, stat_table_rescans = 0;
     float* pinned_min = nullptr;         // pinned staging for min_dist (a pageable D2H copy costs several times more)
     size_t pinned_floats = 0;
     int32_t* pinned_probes = nullptr;    // pinned staging for the device-sorted probe lists + one tie flag per query
@@ -1129,6 +1130,383 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
     }
 }
 
+// ---- bounded threshold replay: the same result from a table the MATRIX CORES wrote ------------------------------------------------
+// The table above costs nq x C canonical evaluations on the vector ALUs (12.5 of the 26 ms of a step on the 139k-centroid NS tree).  Here
+// the table holds  D~ = base - 2 acc  from RouterBoundKernel<.., PASS 3> (bf16 hi/lo products, router_bound.h), and every query knows eps
+// with |D~(c) - E(c)| <= eps for the canonical float distance E of EVERY centroid (BoundFrameKernel).  Then pi~ (from D~) is within eps of
+// pi for every node, and the cut-off x~* the radix select finds on pi~ within eps of x* (shifting every value by <= eps shifts the
+// weighted quantile by <= eps).  So
+//     pi~ < x~* - 2 eps  =>  pi < x*   visited, whatever the exact values are;      pi~ > x~* + 2 eps  =>  pi > x*   not visited
+// and only the BAND in between (a few dozen of 31k nodes) needs exact keys: the canonical distance of the band nodes' path centroids
+// (those that can be the path's maximum), then x*, the weight below it and the cut-off group exactly as RouterThresholdReplayKernel
+// computes them — on the band entries, which hold every node with pi == x* and every child of one that can enter the group's frontier.
+// The per-shard minima are bounded the same way: the minimiser of E over the visited centroids of a shard has D~ <= min D~ + 2 eps, so
+// those candidates (one or two per shard) get the canonical evaluation and the minimum of THOSE is the walk's min_dist.
+// Everything consumed downstream (min_dist, and through it the probe order) is therefore a canonical value of the reference's sequence;
+// the matrix cores only decide which pairs are worth evaluating.  A band that does not fit its LDS list, a non-finite eps and the
+// equal-key cases of the threshold replay mark the query: it gets an exact table row and the real queue (HostReplayMarked).
+struct BoundedTable {
+    const float* table;          // [nq][table_ld]
+    uint64_t table_ld;
+    const float* eps;            // [nq]
+    const float* centroids;      // [C][ld]
+    const float* queries;        // [nq][ld]
+    const uint32_t* cent_shard;  // [C]
+    uint32_t d, ld;
+    uint32_t band_cap;           // band entries per wavefront (LDS: 3 words each)
+    uint32_t* stats;             // [0] band nodes, [1] canonical evaluations, [2] queries whose band overflowed, [3] shard ranges scanned twice
+};
+constexpr uint32_t kBandNodeBits = 22;   // a band entry: node | size << 22
+
+template <int METRIC>
+__global__ void __launch_bounds__(64 * kRWaves) RouterBoundedReplayKernel(ReplayArgs a, ThresholdTree t, BoundedTable bt) {
+    extern __shared__ uint32_t bdsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = a.S, n_nodes = a.n_nodes, C = a.C, cap = bt.band_cap;
+    const size_t per_wave = ((size_t)256 + S + 3 * (size_t)cap + 3) & ~(size_t)3;
+    uint32_t* hist = bdsm + (size_t)wave * per_wave;
+    uint32_t* sMinOrd = hist + 256;
+    uint32_t* bnode = sMinOrd + S;   // after the band: the candidate list of the minima (3 * cap entries)
+    uint32_t* bkey = bnode + cap;
+    uint32_t* bpi = bkey + cap;
+    const uint32_t slot = blockIdx.x * kRWaves + wave, n_slots = gridDim.x * kRWaves;
+    uint32_t* pi = t.pi + (size_t)slot * n_nodes;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const uint32_t node_mask = (1u << kBandNodeBits) - 1u;
+
+    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+        const float* D = bt.table + (size_t)q * bt.table_ld;
+        const float* qrow = bt.queries + (size_t)q * bt.ld;
+        const float eps = bt.eps[q], eps2 = 2.f * eps;
+        for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
+        uint32_t n_exact = 0, n_band = 0, n_rescan = 0;
+        bool redo = !(eps < INFINITY), band_over = false;
+
+        // ---- 1. pi~ (as RouterThresholdReplayKernel, from the bounded table)
+        for (uint32_t u0 = lane; u0 < n_nodes && !t.visit_all; u0 += 64 * kBatch) {
+            uint32_t cidx[kBatch][kPathMax];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const uint32_t u = u0 + 64u * k;
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j) cidx[k][j] = u < n_nodes ? t.path_cent[(size_t)u * kPathMax + j] : kNoCent;
+            }
+            float val[kBatch][kPathMax];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j) val[k][j] = D[cidx[k][j] != kNoCent ? cidx[k][j] : 0u];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const uint32_t u = u0 + 64u * k;
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < kPathMax; ++j)
+                    if (cidx[k][j] != kNoCent) m = max(m, OrderedBits(val[k][j]));
+                if (u < n_nodes) pi[u] = m;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 2. x~*: the radix select of RouterThresholdReplayKernel on pi~
+        const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
+        bool all = t.visit_all != 0;
+        uint32_t lo = 1;          // visited <=> pi word < lo (roots are 0; visited band nodes are set to 0, the others to ~0)
+        if (budget_left > 0 && !all && !redo) {
+            const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
+            uint32_t prefix = 0, prefix_mask = 0, w_lt = 0;
+            for (int pass = 0; pass < 4 && !all; ++pass) {
+                const int shift = 24 - 8 * pass;
+                for (int b = lane; b < 256; b += 64) hist[b] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t u0 = lane; u0 < n_nodes; u0 += 64 * kBatch) {
+                    uint32_t p[kBatch], sz[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const uint32_t u = min(u0 + 64u * k, n_nodes - 1);
+                        p[k] = u0 + 64u * k < n_nodes ? pi[u] : 0u;
+                        sz[k] = a.node_cent_first[u + 1] - a.node_cent_first[u];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (p[k] != 0 && (p[k] & prefix_mask) == prefix) atomicAdd(&hist[(p[k] >> shift) & 255u], sz[k]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const uint32_t mine = h0 + h1 + h2 + h3;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const uint32_t before = w_lt + incl - mine;
+                const unsigned long long hit = __ballot(before + mine >= need);
+                if (hit == 0) {
+                    all = true;   // (only possible in pass 0) the whole tree is visited
+                } else {
+                    const int l = __builtin_ctzll(hit);
+                    uint32_t bin = 0, excl = 0;
+                    if (lane == l) {
+                        uint32_t c = before;
+                        if (c + h0 >= need) { bin = 0; excl = c; }
+                        else if ((c += h0) + h1 >= need) { bin = 1; excl = c; }
+                        else if ((c += h1) + h2 >= need) { bin = 2; excl = c; }
+                        else { c += h2; bin = 3; excl = c; }
+                    }
+                    bin = (uint32_t)__shfl((int)bin, l) + 4u * (uint32_t)l;
+                    w_lt = (uint32_t)__shfl((int)excl, l);
+                    prefix |= bin << shift;
+                    prefix_mask |= 255u << shift;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!all) {
+                // ---- 2b. the band  [x~* - 2 eps, x~* + 2 eps]  (one more ulp on either side) and the weight surely below it
+                const float xf = FromOrderedBits(prefix);
+                uint32_t lo_b = OrderedBits(xf - eps2), hi_b = OrderedBits(xf + eps2);
+                lo_b = lo_b > 2u ? lo_b - 1u : 1u;
+                hi_b = hi_b < 0xFFFFFFFEu ? hi_b + 1u : 0xFFFFFFFEu;
+                uint32_t w_in = 0;
+                for (uint32_t base = 0; base < n_nodes; base += 64 * kBatch) {
+                    uint32_t p[kBatch], sz[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const uint32_t u = min(base + lane + 64u * k, n_nodes - 1);
+                        p[k] = base + lane + 64u * k < n_nodes ? pi[u] : 0u;
+                        sz[k] = a.node_cent_first[u + 1] - a.node_cent_first[u];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        if (p[k] != 0 && p[k] < lo_b) w_in += sz[k];
+                        const bool inb = p[k] != 0 && p[k] >= lo_b && p[k] <= hi_b;
+                        const unsigned long long m = __ballot(inb);
+                        const uint32_t add = (uint32_t)__popcll(m);
+                        if (add == 0) continue;
+                        if (n_band + add > cap) {
+                            band_over = true;
+                        } else {
+                            if (inb) bnode[n_band + (uint32_t)__popcll(m & lanes_below)] = (base + lane + 64u * k) | (sz[k] << kBandNodeBits);
+                            n_band += add;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) w_in += __shfl_xor(w_in, o);
+                __builtin_amdgcn_wave_barrier();
+                if (band_over) redo = true;
+
+                // ---- 3. canonical keys of the band: the node's own key, and every key on its path that can be the path's maximum
+                for (uint32_t i0 = 0; i0 < n_band && !redo; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < n_band) {
+                        const uint32_t u = bnode[i] & node_mask;
+                        const float cut = FromOrderedBits(pi[u]) - eps2;
+                        uint32_t key = 0, m = 0;
+                        for (int j = 0; j < kPathMax; ++j) {
+                            const uint32_t c = t.path_cent[(size_t)u * kPathMax + j];
+                            if (c == kNoCent) break;
+                            if (j == 0 || D[c] >= cut) {
+                                const uint32_t bits = OrderedBits(ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d));
+                                if (j == 0) key = bits;
+                                m = max(m, bits);
+                                ++n_exact;
+                            }
+                        }
+                        bkey[i] = key;
+                        bpi[i] = m;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+
+                // ---- 3b. x*: the smallest exact pi in the band at which the accumulated sizes reach the budget left after the roots
+                uint32_t xs = 0xFFFFFFFFu;
+                for (uint32_t i0 = 0; i0 < n_band && !redo; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const uint32_t mine = i < n_band ? bpi[i] : 0xFFFFFFFFu;
+                    uint32_t cum = w_in;
+                    for (uint32_t j = 0; j < n_band; ++j) cum += bpi[j] <= mine ? bnode[j] >> kBandNodeBits : 0u;
+                    if (i < n_band && cum >= need) xs = min(xs, mine);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) xs = min(xs, (uint32_t)__shfl_xor((int)xs, o));
+                if (xs == 0xFFFFFFFFu) redo = true;   // (cannot happen while eps holds: x* lies in the band)
+                if (!redo) {
+                    uint32_t below = 0, n_bottle = 0, iw = 0;
+                    for (uint32_t i = lane; i < n_band; i += 64) {
+                        const uint32_t v = bpi[i];
+                        if (v < xs) below += bnode[i] >> kBandNodeBits;
+                        if (v == xs && bkey[i] == xs) {
+                            ++n_bottle;
+                            iw = i;
+                        }
+                    }
+                    const unsigned long long have = __ballot(n_bottle != 0);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        below += __shfl_xor(below, o);
+                        n_bottle += __shfl_xor(n_bottle, o);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // states from here on: 0 visited, 1 in the group pi == x* (waiting), 2 not visited, 3 in the group's frontier
+                    for (uint32_t i = lane; i < n_band; i += 64) {
+                        const uint32_t v = bpi[i];
+                        bpi[i] = v < xs ? 0u : (v == xs ? 1u : 2u);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- 3c. the cut-off group (RouterThresholdReplayKernel step 3 on the band entries)
+                    int64_t budget_in = (int64_t)need - (int64_t)(w_in + below);   // > 0
+                    if (n_bottle != 1) {
+                        redo = true;
+                    } else {
+                        uint32_t cur = (uint32_t)__shfl((int)iw, __builtin_ctzll(have));
+                        while (true) {
+                            if (lane == 0) bpi[cur] = 0u;
+                            const uint32_t packed = bnode[cur];
+                            const uint32_t node = packed & node_mask;
+                            budget_in -= (int64_t)(packed >> kBandNodeBits);
+                            __builtin_amdgcn_wave_barrier();
+                            if (budget_in <= 0) break;
+                            // its children with smaller keys join the frontier (a child with pi == x* is in the band)
+                            const uint32_t n_child = a.node_child_count[node], child_first = a.node_child_first[node];
+                            for (uint32_t i = lane; i < n_band && n_child != 0; i += 64) {
+                                const uint32_t u = bnode[i] & node_mask;
+                                if (bpi[i] == 1u && u >= child_first && u < child_first + n_child && bkey[i] < xs) bpi[i] = 3u;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            uint32_t best = 0xFFFFFFFFu, best_at = 0;
+                            for (uint32_t i = lane; i < n_band; i += 64) {
+                                if (bpi[i] == 3u && bkey[i] < best) {
+                                    best = bkey[i];
+                                    best_at = i;
+                                }
+                            }
+                            uint32_t mn = best;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                            if (mn == 0xFFFFFFFFu) break;   // the frontier is empty
+                            uint32_t n_min = 0;
+                            for (uint32_t i = lane; i < n_band; i += 64) n_min += (bpi[i] == 3u && bkey[i] == mn) ? 1u : 0u;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) n_min += __shfl_xor(n_min, o);
+                            if (n_min != 1) {   // equal keys inside the cut-off group
+                                redo = true;
+                                break;
+                            }
+                            cur = (uint32_t)__shfl((int)best_at, __builtin_ctzll(__ballot(best == mn)));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!redo) {
+                        for (uint32_t i = lane; i < n_band; i += 64) pi[bnode[i] & node_mask] = bpi[i] == 0u ? 0u : 0xFFFFFFFFu;
+                        lo = lo_b;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+
+        if (redo) {
+            if (lane == 0) {
+                a.redo[q] = 1;
+                atomicAdd(a.redo_count, 1u);
+            }
+        } else {
+            // ---- 4. per-shard minima: the two smallest D~ per lane; centroids within 2 eps of the shard's smallest D~ are the candidates
+            uint32_t* cand = bnode;
+            const uint32_t cand_cap = 3 * cap;
+            uint32_t n_cand = 0;
+            auto flush = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i0 = 0; i0 < n_cand; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < n_cand) {
+                        const uint32_t c = cand[i];
+                        const float e = ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d);
+                        atomicMin(&sMinOrd[bt.cent_shard[c]], OrderedBits(e));
+                        ++n_exact;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                n_cand = 0;
+            };
+            auto append = [&](bool take, uint32_t c) {
+                const unsigned long long m = __ballot(take);
+                if (m == 0) return;
+                const uint32_t add = (uint32_t)__popcll(m);
+                if (n_cand + add > cand_cap) flush();
+                if (take) cand[n_cand + (uint32_t)__popcll(m & lanes_below)] = c;
+                n_cand += add;
+            };
+            for (uint32_t b = 0; b < S; ++b) {
+                const uint32_t c0 = a.node_cent_first[a.shard_root[b]];
+                const uint32_t c1 = b + 1 < S ? a.node_cent_first[a.shard_root[b + 1]] : C;
+                float v1 = FLT_MAX, v2 = FLT_MAX;
+                uint32_t i1 = 0;
+                for (uint32_t cb = c0 + lane; cb < c1; cb += 64 * kBatch) {
+                    uint32_t node[kBatch];
+                    float dv[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const uint32_t c = min(cb + 64u * k, c1 - 1);
+                        node[k] = t.cent_node[c];
+                        dv[k] = D[c];
+                    }
+                    uint32_t pv[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) pv[k] = pi[node[k]];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (cb + 64u * k < c1 && (all || pv[k] < lo)) {
+                            if (dv[k] < v1) {
+                                v2 = v1;
+                                v1 = dv[k];
+                                i1 = cb + 64u * k;
+                            } else if (dv[k] < v2) {
+                                v2 = dv[k];
+                            }
+                        }
+                }
+                float mn = v1;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+                if (!(mn < FLT_MAX)) continue;   // no visited centroid (a shard without centroids)
+                const float thr = mn + eps2;
+                if (__any(v2 <= thr)) {   // a lane holds more than one candidate: every visited centroid of the shard within the margin
+                    ++n_rescan;
+                    for (uint32_t cb = c0; cb < c1; cb += 64) {
+                        const uint32_t c = cb + lane;
+                        bool take = false;
+                        if (c < c1) {
+                            const uint32_t pv = pi[t.cent_node[c]];
+                            take = (all || pv < lo) && D[c] <= thr;
+                        }
+                        append(take, c);
+                    }
+                } else {
+                    append(v1 <= thr, i1);
+                }
+            }
+            flush();
+            for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
+            if (lane == 0) a.redo[q] = 0;
+        }
+        if (lane == 0 && bt.stats) {
+            atomicAdd(bt.stats + 0, n_band);
+            if (band_over) atomicAdd(bt.stats + 2, 1u);
+            atomicAdd(bt.stats + 3, n_rescan);
+        }
+        {
+            uint32_t ne = n_exact;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+            if (lane == 0 && bt.stats) atomicAdd(bt.stats + 1, ne);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // kmeans_tree_router.cpp:93-130 with distance() replaced by the table: one wavefront per query.
 template <bool LDS_HEAP>
 __global__ void __launch_bounds__(64 * kRWaves) RouterReplayKernel(ReplayArgs a) {
@@ -1418,6 +1796,12 @@ gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* o
     out->last_bound_flops = r->stat_bound_flops;
     out->probed = r->stat_probed;
     out->probe_failures = r->stat_probe_failures;
+    out->table_blocks = r->stat_table_blocks;
+    out->table_queries = r->stat_table_queries;
+    out->table_band_nodes = r->stat_table_band_nodes;
+    out->table_exact = r->stat_table_exact;
+    out->table_band_overflow = r->stat_table_band_overflow;
+    out->table_rescans = r->stat_table_rescans;
     return GPANN_OK;
 }
 
@@ -1448,6 +1832,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     r->ws_dense.Release();
     r->ws_redo.Release();
     r->ws_pi.Release();
+    r->ws_frame.Release();
     r->ws_bound.Release();
     r->ws_verify.Release();
     r->ws_host_redo.Release();
@@ -1522,8 +1907,11 @@ void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, floa
 
 // Replays the marked queries of a block on the host.  `flags` [nb] (device): 1 = marked.  Returns false (nothing done) if the rows do not
 // fit the staging budget — the caller then runs the device heap kernel as before.
+// `exact_for` (the bounded replay, whose table is not exact): the marked queries' rows are evaluated canonically here (DenseDistKernel on
+// the gathered queries) instead of being gathered from `d_table`.
 gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint32_t* d_flags, uint32_t nb, uint32_t marked, int32_t budget, float* d_min_dist,
-                              float* d_rec_dist, int32_t* d_rec_shard, uint32_t* d_rec_count, uint64_t rec_cap, hipStream_t st, bool* done) {
+                              float* d_rec_dist, int32_t* d_rec_shard, uint32_t* d_rec_count, uint64_t rec_cap, hipStream_t st, bool* done,
+                              const DenseArgs* exact_for = nullptr) {
     *done = false;
     const uint64_t C = r->n_centroids;
     const uint32_t S = r->S;
@@ -1542,9 +1930,11 @@ gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint3
         return GPANN_OK;
     }
     // device: [list m] [rows m x C]; host (pinned): rows m x C | min_dist m x S | records
-    GPANN_TRY(r->ws_host_redo.Reserve((size_t)m * 4 + (size_t)m * row_floats * 4 + 64));
+    const size_t qpack_floats = exact_for ? (((size_t)m + 63) & ~(size_t)63) * exact_for->ld : 0;
+    GPANN_TRY(r->ws_host_redo.Reserve((size_t)((m + 15) & ~15u) * 4 + (size_t)m * row_floats * 4 + qpack_floats * 4 + 64));
     uint32_t* d_list = r->ws_host_redo.as<uint32_t>();
     float* d_rows = reinterpret_cast<float*>(d_list + ((m + 15) & ~15u));
+    float* d_qpack = d_rows + (size_t)m * row_floats;
     if (r->pinned_redo_floats < (size_t)m * row_floats) {
         if (r->pinned_redo) (void)hipHostFree(r->pinned_redo);
         r->pinned_redo = nullptr;
@@ -1558,7 +1948,20 @@ gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint3
     int32_t* h_rec_shard = reinterpret_cast<int32_t*>(h_rec_dist + (rec ? (size_t)m * rec_cap : 0));
     uint32_t* h_rec_count = reinterpret_cast<uint32_t*>(h_rec_shard + (rec ? (size_t)m * rec_cap : 0));
     GPANN_HIP_TRY(hipMemcpyAsync(d_list, list.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(GatherRowsF32Kernel, dim3((uint32_t)std::min<uint64_t>(4096, ((uint64_t)m * C + 255) / 256)), dim3(256), 0, st, d_table, d_list, m, C, d_rows);
+    if (exact_for) {
+        hipLaunchKernelGGL(GatherRowsF32Kernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)m * exact_for->ld + 255) / 256)), dim3(256), 0, st, exact_for->queries,
+                           d_list, m, (uint64_t)exact_for->ld, d_qpack);
+        DenseArgs da = *exact_for;
+        da.queries = d_qpack;
+        da.out = d_rows;
+        da.nq = m;
+        const dim3 dgrid((uint32_t)((C + 63) / 64), (m + 63) / 64);
+        const size_t dlds = (size_t)2 * 64 * (kRDC + 4) * sizeof(float);
+        if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, false>), dgrid, dim3(256), dlds, st, da);
+        else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, false>), dgrid, dim3(256), dlds, st, da);
+    } else {
+        hipLaunchKernelGGL(GatherRowsF32Kernel, dim3((uint32_t)std::min<uint64_t>(4096, ((uint64_t)m * C + 255) / 256)), dim3(256), 0, st, d_table, d_list, m, C, d_rows);
+    }
     GPANN_HIP_TRY(hipGetLastError());
     GPANN_HIP_TRY(hipMemcpyAsync(h_rows, d_rows, (size_t)m * C * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
@@ -2056,6 +2459,42 @@ gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
 
 // Stages the queries, sizes the queue workspace and launches the walk for queries [0, nq); min_dist lands in r->ws_out.
 // rec_* (device, optional) receive every evaluated (distance, shard) pair.
+// The bounded replay's table for a block of queries: BoundFrameKernel (row bases, eps) + RouterBoundKernel<.., PASS 3> (router_bound.h).
+gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t nb, hipStream_t st, float* table, uint64_t table_ld, float* base, float* eps) {
+    BoundArgs ba{};
+    ba.queries = d_queries;
+    ba.cent_planes = r->cent_planes;
+    ba.cent_nhn = r->cent_nhn;
+    ba.cent_shard = r->cent_shard;
+    ba.nq = nb;
+    ba.C = (uint32_t)r->n_centroids;
+    ba.S = r->S;
+    ba.ld = r->ld;
+    ba.mu = r->cent_mu;
+    ba.plane_ks = r->plane_ks;
+    ba.table = table;
+    ba.table_ld = table_ld;
+    ba.table_base = base;
+    const bool l2 = r->metric == GPANN_METRIC_L2, ks16 = r->d > 128, ks4 = r->d <= 64;
+    const uint32_t group_q = ks16 ? 128u : 256u;
+    const uint32_t groups = (nb + group_q - 1) / group_q;
+    const uint32_t n_tiles = (uint32_t)((r->n_centroids + kGTileRows - 1) / kGTileRows);
+    // (several rounds of workgroups are fine here: a workgroup's share is hundreds of tiles)
+    ba.n_seg = std::max(1u, std::min((n_tiles + 63) / 64, std::max(1u, 2u * (uint32_t)r->num_cus / groups)));
+    if (l2) hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps);
+    else hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps);
+    GPANN_HIP_TRY(hipGetLastError());
+    const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
+    const void* f3 = l2 ? (ks16 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 16, 3> : ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, 3> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, 3>)
+                        : (ks16 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 16, 3> : ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 4, 3> : (const void*)RouterBoundKernel<GPANN_METRIC_MIPS, 8, 3>);
+    GPANN_HIP_TRY(hipFuncSetAttribute(f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+    void* kargs[] = {&ba};
+    GPANN_HIP_TRY(hipEventRecord(r->ev_bound[0], st));
+    GPANN_HIP_TRY(hipLaunchKernel(f3, dim3(ba.n_seg, groups), dim3(512), kargs, blds, st));
+    GPANN_HIP_TRY(hipEventRecord(r->ev_bound[1], st));
+    return GPANN_OK;
+}
+
 gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int flags, hipStream_t st, float* rec_dist,
                         int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap) {
     const uint32_t S = r->S, ld = r->ld;
@@ -2090,8 +2529,6 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     if (force && std::string(force) == "dense" && C * 4 * 64 <= dense_cap) dense = budget > 0;
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
     if (dense) {
-        const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (C * 4) / 64 * 64));
-        GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * C * 4, 256)));
         const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
         const bool force_heap = rmode && std::string(rmode) == "heap";
         const bool all_roots_open = (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min;
@@ -2106,6 +2543,16 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                                   budget < 0x7FFFFFFF;
         // every node is visited iff the budget left after the roots exceeds all non-root sizes together, i.e. budget > C
         const bool min_only = all_roots_open && (uint64_t)budget > C && rec_dist == nullptr && !force_heap;
+        // the threshold replay on a table the matrix cores wrote, canonical evaluation of the cut-off band only (RouterBoundedReplayKernel)
+        const char* tmode = std::getenv("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
+        const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
+        const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && rec_dist == nullptr && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
+                             !r->canonical_once && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits));
+        const uint64_t row_floats = bounded ? table_ld : C;
+        const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (row_floats * 4) / 64 * 64));
+        GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * row_floats * 4, 256)));
+        uint32_t band_cap = 512;
+        if (const char* e = std::getenv("GPANN_ROUTER_BAND_CAP")) band_cap = (uint32_t)std::min(4096, std::max(64, std::atoi(e)));
         for (uint32_t q0 = 0; q0 < nq; q0 += q_block) {
             const uint32_t nb = std::min(q_block, nq - q0);
             DenseArgs da;
@@ -2139,9 +2586,21 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 GPANN_HIP_TRY(hipGetLastError());
                 continue;
             }
-            if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, false>), dgrid, dim3(256), dlds, st, da);
-            else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, false>), dgrid, dim3(256), dlds, st, da);
-            GPANN_HIP_TRY(hipGetLastError());
+            auto canonical_table = [&]() -> gpann_status {
+                if (r->metric == GPANN_METRIC_L2) hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_L2, false>), dgrid, dim3(256), dlds, st, da);
+                else hipLaunchKernelGGL((DenseDistKernel<GPANN_METRIC_MIPS, false>), dgrid, dim3(256), dlds, st, da);
+                GPANN_HIP_TRY(hipGetLastError());
+                return GPANN_OK;
+            };
+            float *frame_base = nullptr, *frame_eps = nullptr;
+            if (bounded) {
+                GPANN_TRY(r->ws_frame.Reserve((size_t)2 * nb * 4 + 64));
+                frame_base = r->ws_frame.as<float>();
+                frame_eps = frame_base + nb;
+                GPANN_TRY(EnqueueBoundTable(r, da.queries, nb, st, da.out, table_ld, frame_base, frame_eps));
+            } else {
+                GPANN_TRY(canonical_table());
+            }
 
             const size_t base_floats = (size_t)64 + S;
             const bool lds_heap = ((((base_floats + 2 * cap) + 3) & ~(size_t)3) * kRWaves * sizeof(float)) <= 40 * 1024;
@@ -2178,10 +2637,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             ra.sort_n = sort_n;
             ra.n_nodes = r->n_nodes;
             if (sorted_ok || threshold_ok) {
-                GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 16));
+                GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 32));
                 ra.redo = r->ws_redo.as<uint32_t>();
-                ra.redo_count = ra.redo + nb;
-                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 4, st));
+                ra.redo_count = ra.redo + nb;   // (+ 1..4: the bounded replay's counters)
+                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 20, st));
             }
             if (sorted_ok) {
                 const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
@@ -2205,9 +2664,28 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 tt.cent_node = r->cent_node;
                 tt.pi = r->ws_pi.as<uint32_t>();
                 tt.visit_all = (uint64_t)budget > C ? 1u : 0u;   // then budget_left exceeds the sizes of all non-root nodes together
-                if (t_lds > 48 * 1024)
-                    GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterThresholdReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t_lds));
-                hipLaunchKernelGGL(RouterThresholdReplayKernel, dim3(t_grid), dim3(64 * kRWaves), t_lds, st, ra, tt);
+                if (bounded) {
+                    BoundedTable bt;
+                    bt.table = da.out;
+                    bt.table_ld = table_ld;
+                    bt.eps = frame_eps;
+                    bt.centroids = r->centroids;
+                    bt.queries = da.queries;
+                    bt.cent_shard = r->cent_shard;
+                    bt.d = r->d;
+                    bt.ld = ld;
+                    bt.band_cap = band_cap;
+                    bt.stats = ra.redo_count + 1;
+                    const size_t b_lds = ((((size_t)256 + S + 3 * (size_t)band_cap) + 3) & ~(size_t)3) * kRWaves * sizeof(uint32_t);
+                    const void* fb = r->metric == GPANN_METRIC_L2 ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS>;
+                    if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+                    void* kargs[] = {&ra, &tt, &bt};
+                    GPANN_HIP_TRY(hipLaunchKernel(fb, dim3(t_grid), dim3(64 * kRWaves), kargs, b_lds, st));
+                } else {
+                    if (t_lds > 48 * 1024)
+                        GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterThresholdReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t_lds));
+                    hipLaunchKernelGGL(RouterThresholdReplayKernel, dim3(t_grid), dim3(64 * kRWaves), t_lds, st, ra, tt);
+                }
                 GPANN_HIP_TRY(hipGetLastError());
                 ra.only_redo = 1;
             }
@@ -2216,10 +2694,26 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             uint32_t hgrid = grid;
             uint32_t marked = 0;
             if (ra.only_redo) {
-                GPANN_HIP_TRY(hipMemcpyAsync(&marked, ra.redo_count, 4, hipMemcpyDeviceToHost, st));
+                uint32_t words[5] = {0, 0, 0, 0, 0};
+                GPANN_HIP_TRY(hipMemcpyAsync(words, ra.redo_count, sizeof(words), hipMemcpyDeviceToHost, st));
                 GPANN_HIP_TRY(hipStreamSynchronize(st));
+                marked = words[0];
                 need_heap = marked != 0;
                 r->stat_heap_redo += marked;
+                if (bounded) {
+                    ++r->stat_table_blocks;
+                    r->stat_table_queries += nb;
+                    r->stat_table_band_nodes += words[1];
+                    r->stat_table_exact += words[2];
+                    r->stat_table_band_overflow += words[3];
+                    r->stat_table_rescans += words[4];
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, r->ev_bound[0], r->ev_bound[1]) == hipSuccess) r->stat_bound_ms += ms;
+                    r->stat_bound_flops += 3.0 * 2.0 * (double)nb * (double)C * (double)r->d;
+                    if (std::getenv("GPANN_ROUTER_DEBUG"))
+                        fprintf(stderr, "[gpann router] bounded table: %u queries x %llu centroids in %.3f ms; band %.1f nodes, %.1f canonical evaluations per query, %u band overflows, %u rescans\n",
+                                nb, (unsigned long long)C, ms, (double)words[1] / nb, (double)words[2] / nb, words[3], words[4]);
+                }
                 if (std::getenv("GPANN_ROUTER_DEBUG"))
                     fprintf(stderr, "[gpann router] %s replay: %u of %u queries need the real priority queue\n", sorted_ok ? "sorted" : "threshold", marked, nb);
                 hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
@@ -2229,9 +2723,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 // stays for batches whose marked rows would not fit the staging budget
                 bool done = false;
                 GPANN_TRY(HostReplayMarked(r, ra.dense, ra.redo, nb, marked, budget, ra.out_min_dist, ra.rec_dist, ra.rec_shard,
-                                           ra.rec_count, ra.rec_cap, st, &done));
+                                           ra.rec_count, ra.rec_cap, st, &done, bounded ? &da : nullptr));
                 need_heap = !done;
             }
+            if (need_heap && bounded) GPANN_TRY(canonical_table());   // (the device queue walks canonical values: the block's table once more, on the vector ALUs)
             if (need_heap) {
                 if (lds_heap) hipLaunchKernelGGL(RouterReplayKernel<true>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);
                 else hipLaunchKernelGGL(RouterReplayKernel<false>, dim3(hgrid), dim3(64 * kRWaves), lds, st, ra);

@@ -33,6 +33,9 @@ struct BoundArgs {
     uint32_t nq, C, S, ld, n_seg;
     uint32_t plane_ks;            // k-steps (16 dimensions each) per plane of a centroid tile: 8 (d <= 128) or 16 (d <= 256); a tile = 2 planes of plane_ks KiB
     const float* mu;              // squared L2: the centre the centroid planes were built around ([ld]); nullptr = not centred
+    float* table;                 // PASS 3: [nq][table_ld] approximate distances  base[q] - (L2: 2, MIPS: 1) * acc  (router.hip, bounded replay)
+    uint64_t table_ld;            //         row stride in floats: a multiple of kGTileRows, >= C
+    const float* table_base;      //         [nq]  L2: |q - mu|^2 (float), MIPS: 1
 };
 
 __device__ __forceinline__ uint32_t OrderedBitsB(float f) {
@@ -94,9 +97,13 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
         chunk_used += need;
     };
     uint32_t cur_shard = 0xFFFFFFFFu;
-    float run[QT];   // pass 1: running max of the current shard; pass 2: its threshold
+    float run[QT];   // pass 1: running max of the current shard; pass 2: its threshold; pass 3: the query's table base
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) run[qt] = PASS == 1 ? -INFINITY : INFINITY;
+    if (PASS == 3) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) run[qt] = a.table_base[q_base + min(32u * qt + c, q_count - 1)];
+    }
     auto flush = [&]() {
         if (PASS != 1 || cur_shard == 0xFFFFFFFFu) return;
 #pragma unroll
@@ -124,9 +131,13 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
             if (h == 0) wave_norms[c] = nrm;
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t shard_first = a.cent_shard[min(c0, a.C - 1)], shard_last = a.cent_shard[min(c0 + 31u, a.C - 1)];
+        uint32_t shard_first = 0, shard_last = 0;
+        if (PASS != 3) {
+            shard_first = a.cent_shard[min(c0, a.C - 1)];
+            shard_last = a.cent_shard[min(c0 + 31u, a.C - 1)];
+        }
         const bool one_shard = shard_first == shard_last && c0 + 31u < a.C;
-        if (one_shard && shard_first != cur_shard) {
+        if (PASS != 3 && one_shard && shard_first != cur_shard) {
             flush();
             cur_shard = shard_first;
             if (PASS == 2) {
@@ -171,6 +182,24 @@ __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
                 const int qt = 2 * qp + e;
                 const uint32_t ql = 32u * qt + c;
                 const bool q_ok = ql < q_count;
+                if (PASS == 3) {   // the table: 32 consecutive distances of a query's row per tile, 16 bytes per lane and store
+                    if (q_ok) {
+                        float* row = a.table + (size_t)(q_base + ql) * a.table_ld + c0 + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float4 v;
+                            if (METRIC == GPANN_METRIC_L2) {
+                                v.x = run[qt] - 2.f * acc[e][4 * g + 0]; v.y = run[qt] - 2.f * acc[e][4 * g + 1];
+                                v.z = run[qt] - 2.f * acc[e][4 * g + 2]; v.w = run[qt] - 2.f * acc[e][4 * g + 3];
+                            } else {
+                                v.x = run[qt] - acc[e][4 * g + 0]; v.y = run[qt] - acc[e][4 * g + 1];
+                                v.z = run[qt] - acc[e][4 * g + 2]; v.w = run[qt] - acc[e][4 * g + 3];
+                            }
+                            *reinterpret_cast<float4*>(row + 8 * g) = v;
+                        }
+                    }
+                    continue;
+                }
                 const size_t qrow = (size_t)(q_base + min(ql, q_count - 1)) * a.S;
                 if (one_shard) {
                     float m = acc[e][0];
@@ -259,6 +288,43 @@ __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, co
         thr[(size_t)q * S + b] = tf;
         if (shard_has_cent[b] != 0u && (mb == 0u || !(fabsf(tf) < INFINITY))) atomicAdd(bad_pairs, 1u);
     }
+}
+
+// The bounded replay's frame of a query (router.hip): the base of its table row (PASS 3 writes  base - 2 acc  /  base - acc) and eps[q], a
+// bound on |table value - canonical distance| for EVERY centroid:
+//   L2:   |(nq - 2 acc) - D| <= e2 = c2 (R + qn)^2 as above; nq as a float and the rounding of the subtraction add <= 2^-22 (R + qn)^2;
+//         the canonical float sequence is within g1 D <= g1 (R + qn)^2 of D
+//   MIPS: |acc - q.c| <= e2', the canonical 1 - q.c within e1 (as above), the rounding of 1 - acc <= 2^-23 (1 + qn R)
+// times (1 + 2^-6): the consumers add and subtract multiples of eps in float.
+template <int METRIC>
+__global__ void __launch_bounds__(64) BoundFrameKernel(const float* queries, uint32_t d, uint32_t ld, double cent_rmax, const float* mu, float* base, float* eps) {
+    const uint32_t q = blockIdx.x;
+    const float* row = queries + (size_t)q * ld;
+    double nq = 0.0;
+    for (uint32_t i = threadIdx.x; i < d; i += 64) {
+        const float v = mu ? row[i] - mu[i] : row[i];
+        nq += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nq += __shfl_xor(nq, o);
+    if (threadIdx.x != 0) return;
+    const double qn = sqrt(nq) * (1.0 + 1e-12), R = cent_rmax, dd = (double)d;
+    double e;
+    if (METRIC == GPANN_METRIC_L2) {
+        const double g1 = (dd + 32.0) * 0x1p-23;
+        const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20 + 0x1p-21 + 0x1p-22;
+        e = (c2 + g1) * (R + qn) * (R + qn);
+        base[q] = (float)nq;
+    } else {
+        const double e1 = (dd + 4.0) * 0x1p-23 * (qn * R + 1.0) + (1.0 + qn * R) * 0x1p-22;
+        const double e2 = (4.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24) * qn * R;
+        e = e1 + e2 + 0x1p-23 * (1.0 + qn * R);
+        base[q] = 1.0f;
+    }
+    e = e * (1.0 + 0x1p-6) + 1e-30;
+    float ef = (float)e;
+    if ((double)ef < e) ef = nextafterf(ef, INFINITY);
+    eps[q] = ef;
 }
 
 // canonical distance of every candidate pair -> min per (query, shard)

@@ -50,7 +50,8 @@ class ScanStats(C.Structure):
 
 class RouterStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("bound_calls", "bound_selfcheck", "bound_overflow", "verified", "verify_failures", "host_sorted", "heap_redo")] + \
-               [("last_bound_ms", C.c_double), ("last_bound_flops", C.c_double), ("probed", C.c_uint64), ("probe_failures", C.c_uint64)]
+               [("last_bound_ms", C.c_double), ("last_bound_flops", C.c_double), ("probed", C.c_uint64), ("probe_failures", C.c_uint64)] + \
+               [(n, C.c_uint64) for n in ("table_blocks", "table_queries", "table_band_nodes", "table_exact", "table_band_overflow", "table_rescans")]
 
 
 def build(force=False):

@@ -239,6 +239,14 @@ typedef struct gpann_router_stats {
     double last_bound_flops;    /* most recent call: matrix-core flops of those launches, 2 passes x 3 bf16 products x 2 nq C d */
     uint64_t probed;            /* GPANN_ROUTER_PROBE=1 (debugging aid): blocks whose bound pipeline was run twice on the same inputs ... */
     uint64_t probe_failures;    /* ... and whose two runs differed in any bit (maxima, thresholds, candidate set, minima): GPANN_ERR_INTERNAL */
+    /* the bounded replay (search budget inside the tree): distance table from the matrix cores, canonical evaluation of the cut-off band and
+     * of the per-shard minimum candidates only; last_bound_ms / last_bound_flops then describe its table launches */
+    uint64_t table_blocks;         /* query blocks answered through it */
+    uint64_t table_queries;        /* ... queries in those blocks */
+    uint64_t table_band_nodes;     /* ... tree nodes inside the cut-off band (they got canonical keys) */
+    uint64_t table_exact;          /* ... canonical distance evaluations (band keys + minimum candidates) */
+    uint64_t table_band_overflow;  /* ... queries whose band did not fit (replayed on a canonical row, counted in heap_redo too) */
+    uint64_t table_rescans;        /* ... (query, shard) ranges read twice because one lane held two minimum candidates */
 } gpann_router_stats;
 gpann_status gpann_router_get_stats(const gpann_router* r, gpann_router_stats* out);
 

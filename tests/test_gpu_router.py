@@ -364,3 +364,68 @@ def test_bound_evidence_dump_and_determinism_probe(orc, gp, monkeypatch, tmp_pat
     assert counters1[1] == 0 and counters1[4] == 0 and counters2[1] == 0
     assert np.array_equal(runs[0][3].reshape(nb, ld)[:, :d], queries)
     router.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d,S,num_centroids,n", [(16, 6, 6, 30000), (100, 9, 8, 40000), (128, 12, 16, 60000), (200, 5, 6, 24000)])
+def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S, num_centroids, n, monkeypatch):
+    """search budgets that stop the walk inside a multi-level tree: the distance table comes from the matrix cores (RouterBoundKernel pass 3)
+    and only the cut-off band and the per-shard minimum candidates get the canonical evaluation (RouterBoundedReplayKernel) — min_dist bits
+    and probes must equal the oracle's and those of the canonical table; a band that does not fit goes to the real queue on a canonical row"""
+    pts, clusters, tree = _tree(orc, n, d, S, metric, num_centroids, 12, n // 6, seed=5)
+    f = tree.flat()
+    C = int(f["node_cent_first"][-1])
+    assert int((f["node_child_count"] > 0).sum()) > S + 5 and C > 1200
+    queries = make_mixture(orc, 257, d, seed=557, n_centers=24)
+    router = gp.Router(f, metric, 0)
+    depth = np.zeros(len(f["node_shard"]), np.int64)   # (nodes are numbered parents first)
+    for u in range(len(depth)):
+        depth[f["node_child_first"][u]:f["node_child_first"][u] + f["node_child_count"][u]] = depth[u] + 1
+    expect_table = depth.max() <= 6                      # kPathMax: deeper trees (inner-product k-means can be very lopsided) keep the queue
+    assert expect_table or metric == 1
+    for budget in (C // 5, C // 3, C // 2, (3 * C) // 4, C - 1):
+        wp, wm = tree.query_batch(queries, budget, nthreads=8)
+        before = router.stats()
+        probes, md, _ = router.query_batch(queries, budget)
+        st = router.stats()
+        if expect_table:
+            assert st["table_blocks"] == before["table_blocks"] + 1 and st["table_queries"] == before["table_queries"] + len(queries), st
+            assert st["table_band_overflow"] == before["table_band_overflow"], st
+            assert st["table_exact"] > before["table_exact"]
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), budget
+        assert np.array_equal(probes, wp), budget
+        monkeypatch.setenv("GPANN_ROUTER_BOUND_TABLE", "0")
+        p0, m0, _ = router.query_batch(queries, budget)
+        assert router.stats()["table_blocks"] == st["table_blocks"]
+        monkeypatch.delenv("GPANN_ROUTER_BOUND_TABLE")
+        assert np.array_equal(m0.view(np.uint32), md.view(np.uint32)) and np.array_equal(p0, probes), budget
+    # a tiny band list: overflowing queries are marked and replayed on canonical rows — same bits
+    monkeypatch.setenv("GPANN_ROUTER_BAND_CAP", "64")
+    before = router.stats()
+    budget = C // 2
+    probes, md, _ = router.query_batch(queries, budget)
+    wp, wm = tree.query_batch(queries, budget, nthreads=8)
+    assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+    # ... and with the device queue instead of the host's
+    monkeypatch.setenv("GPANN_ROUTER_HOST_REDO", "0")
+    probes, md, _ = router.query_batch(queries, budget)
+    assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+
+
+def test_bounded_table_replay_with_duplicate_points(orc, gp):
+    """equal keys everywhere: every ambiguous query of the bounded replay must reach the real queue with canonical values"""
+    n, d, S = 12000, 8, 4
+    rng = np.random.default_rng(8)
+    base = make_mixture(orc, 50, d, n_centers=4)
+    pts = base[rng.integers(0, 50, size=n)] + (rng.integers(0, 3, size=(n, 1)) * np.float32(0.25)).astype(np.float32)
+    clusters = random_clusters(rng, n, S)
+    tree = orc.kmtr_train(pts, clusters, num_centroids=5, min_cluster_size=10, budget=3000, metric=0, nthreads=4)
+    f = tree.flat()
+    C = int(f["node_cent_first"][-1])
+    queries = np.concatenate([base[rng.integers(0, 50, size=150)], make_mixture(orc, 50, d, seed=9, n_centers=4)])
+    router = gp.Router(f, 0, 0)
+    for budget in (C // 3, C // 2, C - 3):
+        probes, md, _ = router.query_batch(queries, budget)
+        wp, wm = tree.query_batch(queries, budget, nthreads=4)
+        assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp), budget
+    assert router.stats()["table_blocks"] == 3
