@@ -53,6 +53,8 @@ struct gpann_router {
     uint32_t* shard_root = nullptr;
     uint32_t* path_cent = nullptr;       // [n_nodes][kPathMax] centroids whose distances are the keys on the path root -> node (threshold replay)
     uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
+    uint8_t* cent_node8 = nullptr;       // ... as cent_block_node[c >> 8] + cent_node8[c] (ThresholdTree)
+    uint32_t* cent_block_node = nullptr;
     uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
     uint32_t* shard_has_cent = nullptr;  // [S] 1 if the shard has at least one centroid (its min_dist cannot stay at FLT_MAX after a full visit)
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
@@ -97,7 +99,13 @@ namespace gpann {
 class HostPool {
 public:
     static HostPool& Get() {
-        static HostPool* pool = new HostPool();   // intentionally never destroyed (no join during static destruction)
+        static HostPool* pool = new HostPool(31);   // intentionally never destroyed (no join during static destruction)
+        return *pool;
+    }
+    // for the walks of the marked queries of a deep-tree batch (HostReplayMarked): ~70 of 10 000 queries, a 1-2 ms walk each, one chunk
+    // each — on the 32 threads above they took three rounds.  (A pool of its own: the short merges and sorts do not wake 128 threads.)
+    static HostPool& Wide() {
+        static HostPool* pool = new HostPool(127);
         return *pool;
     }
     // runs fn(chunk) for chunk in [0, n_chunks) on the pool and the calling thread; returns when all are done
@@ -130,9 +138,9 @@ private:
         uint32_t n_chunks = 0, pending = 0;                  // pending: guarded by m_
         std::atomic<uint32_t> next{0};
     };
-    HostPool() {
+    explicit HostPool(unsigned max_workers) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n = std::min(31u, hw > 1 ? hw - 1 : 0u);
+        const unsigned n = std::min(max_workers, hw > 1 ? hw - 1 : 0u);
         for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { Loop(); });
         for (auto& t : workers_) t.detach();
     }
@@ -862,6 +870,10 @@ struct ThresholdTree {
     const uint32_t* cent_node;   // [C]
     uint32_t* pi;                // [slots][n_nodes] scratch
     uint32_t visit_all;          // the budget exceeds the tree: every node is visited, steps 1-3 are skipped
+    // cent_node in a quarter of the bytes (the bounded replay streams it next to the table row): node(c) = cent_block_node[c >> 8] + cent_node8[c]
+    // (every node has a centroid, so the 256 centroids of a block belong to at most 256 consecutive nodes)
+    const uint8_t* cent_node8;        // [C + 4]
+    const uint32_t* cent_block_node;  // [(C >> 8) + 2]
 };
 
 __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(ReplayArgs a, ThresholdTree t) {
@@ -1134,10 +1146,10 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
 // The table above costs nq x C canonical evaluations on the vector ALUs (12.5 of the 26 ms of a step on the 139k-centroid NS tree).  Here
 // the table holds  D~ = base - 2 acc  from RouterBoundKernel<.., PASS 3> (bf16 hi/lo products, router_bound.h), and every query knows eps
 // with |D~(c) - E(c)| <= eps for the canonical float distance E of EVERY centroid (BoundFrameKernel).  Then pi~ (from D~) is within eps of
-// pi for every node, and the cut-off x~* the radix select finds on pi~ within eps of x* (shifting every value by <= eps shifts the
-// weighted quantile by <= eps).  So
+// pi for every node, and the cut-off x~* of the pi~ values within eps of x* (shifting every value by <= eps shifts the weighted quantile
+// by <= eps).  So
 //     pi~ < x~* - 2 eps  =>  pi < x*   visited, whatever the exact values are;      pi~ > x~* + 2 eps  =>  pi > x*   not visited
-// and only the BAND in between (a few dozen of 31k nodes) needs exact keys: the canonical distance of the band nodes' path centroids
+// and only the BAND in between (about a hundred of 31k nodes) needs exact keys: the canonical distance of the band nodes' path centroids
 // (those that can be the path's maximum), then x*, the weight below it and the cut-off group exactly as RouterThresholdReplayKernel
 // computes them — on the band entries, which hold every node with pi == x* and every child of one that can enter the group's frontier.
 // The per-shard minima are bounded the same way: the minimiser of E over the visited centroids of a shard has D~ <= min D~ + 2 eps, so
@@ -1145,278 +1157,346 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(Repl
 // Everything consumed downstream (min_dist, and through it the probe order) is therefore a canonical value of the reference's sequence;
 // the matrix cores only decide which pairs are worth evaluating.  A band that does not fit its LDS list, a non-finite eps and the
 // equal-key cases of the threshold replay mark the query: it gets an exact table row and the real queue (HostReplayMarked).
+//
+// One WORKGROUP per query.  pi~ is kept as a bin number g = 1 + floor((pi~ - h_lo) h_scale) in [1, 2^20] (0: a root) — monotone in pi~,
+// 2^20 bins over the interval that holds every table value of the query (BoundFrameKernel) — and all of the above is done in bin space:
+// x~* is found as the bin G that holds the weighted quantile (two 1024-bin histograms in LDS: g >> 10, then g & 1023 inside the coarse bin;
+// the first is filled while pi~ is computed), the band is  |g - G| <= k  with k = ceil(2 eps h_scale) + 2 bins (pi~ within 2 eps of ANY value of
+// bin G lies inside), surely visited is g < G - k.  The visited set becomes a bitmap over the nodes in LDS, so the pass over the query's
+// table row (the minima) reads two coalesced streams — the row and cent_node — and nothing that depends on them.
 struct BoundedTable {
     const float* table;          // [nq][table_ld]
     uint64_t table_ld;
     const float* eps;            // [nq]
+    const float* h_lo;           // [nq]
+    const float* h_scale;        // [nq]
     const float* centroids;      // [C][ld]
     const float* queries;        // [nq][ld]
     const uint32_t* cent_shard;  // [C]
     uint32_t d, ld;
-    uint32_t band_cap;           // band entries per wavefront (LDS: 3 words each)
+    uint32_t band_cap;           // band entries per query (LDS: 3 words each)
     uint32_t* stats;             // [0] band nodes, [1] canonical evaluations, [2] queries whose band overflowed, [3] shard ranges scanned twice
+    uint32_t* ticket;            // zeroed: the next unclaimed query
 };
 constexpr uint32_t kBandNodeBits = 22;   // a band entry: node | size << 22
+constexpr int kBWaves = 4;               // wavefronts per workgroup (= per query) of RouterBoundedReplayKernel
+constexpr uint32_t kBinMax = 1u << 20;
+
+__device__ __forceinline__ uint32_t BinOf(float v, float h_lo, float h_scale) {
+    const float x = fmaxf((v - h_lo) * h_scale, 0.f);   // (NaN -> 0)
+    return 1u + min((uint32_t)fminf(x, 1048575.f), kBinMax - 1u);
+}
+
+// exclusive prefix of `mine` over the workgroup's threads (kBWaves wavefronts); `red` = kBWaves words of LDS; returns the workgroup total in `total`
+__device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t mine, uint32_t* red, int lane, int wave, uint32_t& total) {
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < kBWaves; ++w) {
+        const uint32_t v = red[w];
+        if (w < wave) before += v;
+        total += v;
+    }
+    return before + incl - mine;
+}
 
 template <int METRIC>
-__global__ void __launch_bounds__(64 * kRWaves) RouterBoundedReplayKernel(ReplayArgs a, ThresholdTree t, BoundedTable bt) {
+__global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(ReplayArgs a, ThresholdTree t, BoundedTable bt) {
     extern __shared__ uint32_t bdsm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kT = 64 * kBWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t S = a.S, n_nodes = a.n_nodes, C = a.C, cap = bt.band_cap;
-    const size_t per_wave = ((size_t)256 + S + 3 * (size_t)cap + 3) & ~(size_t)3;
-    uint32_t* hist = bdsm + (size_t)wave * per_wave;
-    uint32_t* sMinOrd = hist + 256;
-    uint32_t* bnode = sMinOrd + S;   // after the band: the candidate list of the minima (3 * cap entries)
+    uint32_t* hist = bdsm;                               // 1024
+    uint32_t* sMinOrd = hist + 1024;                     // S
+    uint32_t* bnode = sMinOrd + ((S + 3u) & ~3u);        // band entries; afterwards the candidate lists of the minima (3 * cap words)
     uint32_t* bkey = bnode + cap;
     uint32_t* bpi = bkey + cap;
-    const uint32_t slot = blockIdx.x * kRWaves + wave, n_slots = gridDim.x * kRWaves;
-    uint32_t* pi = t.pi + (size_t)slot * n_nodes;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    uint32_t* bitmap = bpi + cap;                        // visited nodes
+    const uint32_t bm_words = (n_nodes + 31u) / 32u;
+    uint32_t* sh = bitmap + ((bm_words + 3u) & ~3u);     // 32 words of scalars
+    uint32_t* red = sh + 24;
+    enum { N_BAND = 0, W_IN, XS, BELOW, N_BOTTLE, IW, REDO, OVER, SEL_BIN, SEL_BEFORE, SEL_ALL, N_EXACT, N_RESCAN, N_CAND /* .. + kBWaves */ };
+    uint32_t* g_of = t.pi + (size_t)blockIdx.x * n_nodes;
     const uint32_t node_mask = (1u << kBandNodeBits) - 1u;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-    for (uint32_t q = slot; q < a.nq; q += n_slots) {
+    for (;;) {
+        // (queries are claimed one at a time: their cost varies, and the launch is exactly one resident round of workgroups)
+        __syncthreads();
+        if (tid == 0) sh[31] = atomicAdd(bt.ticket, 1u);
+        __syncthreads();
+        const uint32_t q = sh[31];
+        if (q >= a.nq) break;
         const float* D = bt.table + (size_t)q * bt.table_ld;
         const float* qrow = bt.queries + (size_t)q * bt.ld;
-        const float eps = bt.eps[q], eps2 = 2.f * eps;
-        for (uint32_t b = lane; b < S; b += 64) sMinOrd[b] = OrderedBits(FLT_MAX);
-        uint32_t n_exact = 0, n_band = 0, n_rescan = 0;
-        bool redo = !(eps < INFINITY), band_over = false;
-
-        // ---- 1. pi~ (as RouterThresholdReplayKernel, from the bounded table)
-        for (uint32_t u0 = lane; u0 < n_nodes && !t.visit_all; u0 += 64 * kBatch) {
-            uint32_t cidx[kBatch][kPathMax];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const uint32_t u = u0 + 64u * k;
-#pragma unroll
-                for (int j = 0; j < kPathMax; ++j) cidx[k][j] = u < n_nodes ? t.path_cent[(size_t)u * kPathMax + j] : kNoCent;
-            }
-            float val[kBatch][kPathMax];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k)
-#pragma unroll
-                for (int j = 0; j < kPathMax; ++j) val[k][j] = D[cidx[k][j] != kNoCent ? cidx[k][j] : 0u];
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const uint32_t u = u0 + 64u * k;
-                uint32_t m = 0;
-#pragma unroll
-                for (int j = 0; j < kPathMax; ++j)
-                    if (cidx[k][j] != kNoCent) m = max(m, OrderedBits(val[k][j]));
-                if (u < n_nodes) pi[u] = m;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 2. x~*: the radix select of RouterThresholdReplayKernel on pi~
+        const float eps = bt.eps[q], eps2 = 2.f * eps, h_lo = bt.h_lo[q], h_scale = bt.h_scale[q];
+        const bool frame_ok = eps < INFINITY && h_scale > 0.f && h_scale < INFINITY && fabsf(h_lo) < INFINITY;
+        const uint32_t k_bins = (uint32_t)fminf(eps2 * h_scale, 1048575.f) + 3u;
+        for (uint32_t i = tid; i < 1024; i += kT) hist[i] = 0;
+        for (uint32_t b = tid; b < S; b += kT) sMinOrd[b] = OrderedBits(FLT_MAX);
+        if (tid < 24 + kBWaves) sh[tid] = tid == XS ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
         const int64_t budget_left = (int64_t)a.budget - (int64_t)a.root_total;
         bool all = t.visit_all != 0;
-        uint32_t lo = 1;          // visited <=> pi word < lo (roots are 0; visited band nodes are set to 0, the others to ~0)
-        if (budget_left > 0 && !all && !redo) {
-            const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
-            uint32_t prefix = 0, prefix_mask = 0, w_lt = 0;
-            for (int pass = 0; pass < 4 && !all; ++pass) {
-                const int shift = 24 - 8 * pass;
-                for (int b = lane; b < 256; b += 64) hist[b] = 0;
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t u0 = lane; u0 < n_nodes; u0 += 64 * kBatch) {
-                    uint32_t p[kBatch], sz[kBatch];
-#pragma unroll
-                    for (int k = 0; k < kBatch; ++k) {
-                        const uint32_t u = min(u0 + 64u * k, n_nodes - 1);
-                        p[k] = u0 + 64u * k < n_nodes ? pi[u] : 0u;
-                        sz[k] = a.node_cent_first[u + 1] - a.node_cent_first[u];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kBatch; ++k)
-                        if (p[k] != 0 && (p[k] & prefix_mask) == prefix) atomicAdd(&hist[(p[k] >> shift) & 255u], sz[k]);
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                const uint32_t mine = h0 + h1 + h2 + h3;
-                uint32_t incl = mine;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
-                const uint32_t before = w_lt + incl - mine;
-                const unsigned long long hit = __ballot(before + mine >= need);
-                if (hit == 0) {
-                    all = true;   // (only possible in pass 0) the whole tree is visited
-                } else {
-                    const int l = __builtin_ctzll(hit);
-                    uint32_t bin = 0, excl = 0;
-                    if (lane == l) {
-                        uint32_t c = before;
-                        if (c + h0 >= need) { bin = 0; excl = c; }
-                        else if ((c += h0) + h1 >= need) { bin = 1; excl = c; }
-                        else if ((c += h1) + h2 >= need) { bin = 2; excl = c; }
-                        else { c += h2; bin = 3; excl = c; }
-                    }
-                    bin = (uint32_t)__shfl((int)bin, l) + 4u * (uint32_t)l;
-                    w_lt = (uint32_t)__shfl((int)excl, l);
-                    prefix |= bin << shift;
-                    prefix_mask |= 255u << shift;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (!all) {
-                // ---- 2b. the band  [x~* - 2 eps, x~* + 2 eps]  (one more ulp on either side) and the weight surely below it
-                const float xf = FromOrderedBits(prefix);
-                uint32_t lo_b = OrderedBits(xf - eps2), hi_b = OrderedBits(xf + eps2);
-                lo_b = lo_b > 2u ? lo_b - 1u : 1u;
-                hi_b = hi_b < 0xFFFFFFFEu ? hi_b + 1u : 0xFFFFFFFEu;
-                uint32_t w_in = 0;
-                for (uint32_t base = 0; base < n_nodes; base += 64 * kBatch) {
-                    uint32_t p[kBatch], sz[kBatch];
-#pragma unroll
-                    for (int k = 0; k < kBatch; ++k) {
-                        const uint32_t u = min(base + lane + 64u * k, n_nodes - 1);
-                        p[k] = base + lane + 64u * k < n_nodes ? pi[u] : 0u;
-                        sz[k] = a.node_cent_first[u + 1] - a.node_cent_first[u];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kBatch; ++k) {
-                        if (p[k] != 0 && p[k] < lo_b) w_in += sz[k];
-                        const bool inb = p[k] != 0 && p[k] >= lo_b && p[k] <= hi_b;
-                        const unsigned long long m = __ballot(inb);
-                        const uint32_t add = (uint32_t)__popcll(m);
-                        if (add == 0) continue;
-                        if (n_band + add > cap) {
-                            band_over = true;
-                        } else {
-                            if (inb) bnode[n_band + (uint32_t)__popcll(m & lanes_below)] = (base + lane + 64u * k) | (sz[k] << kBandNodeBits);
-                            n_band += add;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) w_in += __shfl_xor(w_in, o);
-                __builtin_amdgcn_wave_barrier();
-                if (band_over) redo = true;
+        const bool roots_only = budget_left <= 0;
+        uint32_t n_exact = 0;
+        bool redo = !frame_ok;
+        unsigned long long tk[6];
+        tk[0] = wall_clock64();
 
-                // ---- 3. canonical keys of the band: the node's own key, and every key on its path that can be the path's maximum
-                for (uint32_t i0 = 0; i0 < n_band && !redo; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    if (i < n_band) {
-                        const uint32_t u = bnode[i] & node_mask;
-                        const float cut = FromOrderedBits(pi[u]) - eps2;
-                        uint32_t key = 0, m = 0;
-                        for (int j = 0; j < kPathMax; ++j) {
-                            const uint32_t c = t.path_cent[(size_t)u * kPathMax + j];
-                            if (c == kNoCent) break;
-                            if (j == 0 || D[c] >= cut) {
-                                const uint32_t bits = OrderedBits(ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d));
-                                if (j == 0) key = bits;
-                                m = max(m, bits);
-                                ++n_exact;
-                            }
-                        }
-                        bkey[i] = key;
-                        bpi[i] = m;
-                    }
+        // ---- 1. g = bin of pi~ for every node (kBatch nodes per thread and trip in flight) + the coarse histogram of the node sizes
+        if (!all && !roots_only && !redo) {
+            for (uint32_t u0 = tid; u0 < n_nodes; u0 += kT * 2) {
+                uint32_t cidx[2][kPathMax], sz[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t u = u0 + (uint32_t)kT * k;
+#pragma unroll
+                    for (int j = 0; j < kPathMax; ++j) cidx[k][j] = u < n_nodes ? t.path_cent[(size_t)u * kPathMax + j] : kNoCent;
+                    const uint32_t uc = min(u, n_nodes - 1);
+                    sz[k] = a.node_cent_first[uc + 1] - a.node_cent_first[uc];
                 }
-                __builtin_amdgcn_wave_barrier();
-
-                // ---- 3b. x*: the smallest exact pi in the band at which the accumulated sizes reach the budget left after the roots
-                uint32_t xs = 0xFFFFFFFFu;
-                for (uint32_t i0 = 0; i0 < n_band && !redo; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const uint32_t mine = i < n_band ? bpi[i] : 0xFFFFFFFFu;
-                    uint32_t cum = w_in;
-                    for (uint32_t j = 0; j < n_band; ++j) cum += bpi[j] <= mine ? bnode[j] >> kBandNodeBits : 0u;
-                    if (i < n_band && cum >= need) xs = min(xs, mine);
-                }
+                float val[2][kPathMax];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) xs = min(xs, (uint32_t)__shfl_xor((int)xs, o));
-                if (xs == 0xFFFFFFFFu) redo = true;   // (cannot happen while eps holds: x* lies in the band)
-                if (!redo) {
-                    uint32_t below = 0, n_bottle = 0, iw = 0;
-                    for (uint32_t i = lane; i < n_band; i += 64) {
-                        const uint32_t v = bpi[i];
-                        if (v < xs) below += bnode[i] >> kBandNodeBits;
-                        if (v == xs && bkey[i] == xs) {
-                            ++n_bottle;
-                            iw = i;
-                        }
-                    }
-                    const unsigned long long have = __ballot(n_bottle != 0);
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        below += __shfl_xor(below, o);
-                        n_bottle += __shfl_xor(n_bottle, o);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    // states from here on: 0 visited, 1 in the group pi == x* (waiting), 2 not visited, 3 in the group's frontier
-                    for (uint32_t i = lane; i < n_band; i += 64) {
-                        const uint32_t v = bpi[i];
-                        bpi[i] = v < xs ? 0u : (v == xs ? 1u : 2u);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    // ---- 3c. the cut-off group (RouterThresholdReplayKernel step 3 on the band entries)
-                    int64_t budget_in = (int64_t)need - (int64_t)(w_in + below);   // > 0
-                    if (n_bottle != 1) {
-                        redo = true;
-                    } else {
-                        uint32_t cur = (uint32_t)__shfl((int)iw, __builtin_ctzll(have));
-                        while (true) {
-                            if (lane == 0) bpi[cur] = 0u;
-                            const uint32_t packed = bnode[cur];
-                            const uint32_t node = packed & node_mask;
-                            budget_in -= (int64_t)(packed >> kBandNodeBits);
-                            __builtin_amdgcn_wave_barrier();
-                            if (budget_in <= 0) break;
-                            // its children with smaller keys join the frontier (a child with pi == x* is in the band)
-                            const uint32_t n_child = a.node_child_count[node], child_first = a.node_child_first[node];
-                            for (uint32_t i = lane; i < n_band && n_child != 0; i += 64) {
-                                const uint32_t u = bnode[i] & node_mask;
-                                if (bpi[i] == 1u && u >= child_first && u < child_first + n_child && bkey[i] < xs) bpi[i] = 3u;
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                            uint32_t best = 0xFFFFFFFFu, best_at = 0;
-                            for (uint32_t i = lane; i < n_band; i += 64) {
-                                if (bpi[i] == 3u && bkey[i] < best) {
-                                    best = bkey[i];
-                                    best_at = i;
-                                }
-                            }
-                            uint32_t mn = best;
+                    for (int j = 0; j < kPathMax; ++j) val[k][j] = D[cidx[k][j] != kNoCent ? cidx[k][j] : 0u];
 #pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-                            if (mn == 0xFFFFFFFFu) break;   // the frontier is empty
-                            uint32_t n_min = 0;
-                            for (uint32_t i = lane; i < n_band; i += 64) n_min += (bpi[i] == 3u && bkey[i] == mn) ? 1u : 0u;
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t u = u0 + (uint32_t)kT * k;
+                    uint32_t g = 0;
 #pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) n_min += __shfl_xor(n_min, o);
-                            if (n_min != 1) {   // equal keys inside the cut-off group
-                                redo = true;
-                                break;
-                            }
-                            cur = (uint32_t)__shfl((int)best_at, __builtin_ctzll(__ballot(best == mn)));
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (!redo) {
-                        for (uint32_t i = lane; i < n_band; i += 64) pi[bnode[i] & node_mask] = bpi[i] == 0u ? 0u : 0xFFFFFFFFu;
-                        lo = lo_b;
+                    for (int j = 0; j < kPathMax; ++j)
+                        if (cidx[k][j] != kNoCent) g = max(g, BinOf(val[k][j], h_lo, h_scale));
+                    if (u < n_nodes) {
+                        g_of[u] = g;
+                        if (g != 0) atomicAdd(&hist[(g - 1u) >> 10], sz[k]);
                     }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        __syncthreads();
+        tk[1] = wall_clock64();
+
+        // ---- 2. the bin G of x~*: coarse bin, then the fine bin inside it
+        uint32_t lo_g = 1, hi_g = 0;   // surely visited <=> g < lo_g; the band: lo_g <= g <= hi_g
+        if (!all && !roots_only && !redo) {
+            const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
+            uint32_t need_in = need, G = 0;
+            for (int level = 0; level < 2 && !all; ++level) {
+                const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const uint32_t mine = h0 + h1 + h2 + h3;
+                uint32_t total = 0;
+                const uint32_t before = BlockExclusiveScan(mine, red, lane, wave, total);
+                if (before < need_in && before + mine >= need_in) {
+                    uint32_t c = before, bin;
+                    if (c + h0 >= need_in) bin = 0;
+                    else if ((c += h0) + h1 >= need_in) bin = 1;
+                    else if ((c += h1) + h2 >= need_in) bin = 2;
+                    else { c += h2; bin = 3; }
+                    sh[SEL_BIN] = 4u * (uint32_t)tid + bin;
+                    sh[SEL_BEFORE] = c;
+                }
+                if (tid == 0 && total < need_in) sh[SEL_ALL] = 1u;   // (level 0 only) the whole tree is visited
+                __syncthreads();
+                all = sh[SEL_ALL] != 0u;
+                const uint32_t bin = sh[SEL_BIN];
+                need_in -= sh[SEL_BEFORE];
+                G = (G << 10) | bin;
+                __syncthreads();
+                if (level == 0 && !all) {   // the fine histogram of the coarse bin's nodes
+                    for (uint32_t i = tid; i < 1024; i += kT) hist[i] = 0;
+                    __syncthreads();
+                    for (uint32_t u0 = tid; u0 < n_nodes; u0 += kT * kBatch) {
+                        uint32_t g[kBatch];
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k) g[k] = u0 + (uint32_t)kT * k < n_nodes ? g_of[u0 + (uint32_t)kT * k] : 0u;
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k)
+                            if (g[k] != 0 && ((g[k] - 1u) >> 10) == bin) {
+                                const uint32_t u = u0 + (uint32_t)kT * k;
+                                atomicAdd(&hist[(g[k] - 1u) & 1023u], a.node_cent_first[u + 1] - a.node_cent_first[u]);
+                            }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (!all) {
+                G += 1u;   // (bins are numbered from 1)
+                lo_g = G > k_bins + 1u ? G - k_bins : 1u;
+                hi_g = G + k_bins;
+            }
+        }
+
+        tk[2] = wall_clock64();
+        // ---- 3. one pass over the nodes: the bitmap of the surely visited, the weight of the surely visited non-roots, the band list
+        if (all) {
+            for (uint32_t i = tid; i < bm_words; i += kT) bitmap[i] = 0xFFFFFFFFu;
+        } else if (!redo) {
+            uint32_t w_in = 0;
+            for (uint32_t base0 = 0; base0 < n_nodes; base0 += kT * kBatch) {
+                uint32_t gk[kBatch], sk[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const uint32_t u = base0 + (uint32_t)kT * k + tid;
+                    const uint32_t uc = min(u, n_nodes - 1);
+                    gk[k] = roots_only ? (u < n_nodes && t.path_cent[(size_t)u * kPathMax] == kNoCent ? 0u : 0xFFFFFFFFu) : (u < n_nodes ? g_of[u] : 0xFFFFFFFFu);
+                    sk[k] = a.node_cent_first[uc + 1] - a.node_cent_first[uc];
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const uint32_t base = base0 + (uint32_t)kT * k, u = base + tid, g = gk[k];
+                    const bool vis = g < lo_g;
+                    const unsigned long long m = __ballot(vis);
+                    if (lane == 0 && base + 64u * wave < n_nodes) {
+                        bitmap[(base >> 5) + 2u * wave] = (uint32_t)m;
+                        if ((base >> 5) + 2u * wave + 1u < bm_words) bitmap[(base >> 5) + 2u * wave + 1u] = (uint32_t)(m >> 32);
+                    }
+                    if (g != 0 && g <= hi_g && u < n_nodes) {
+                        if (vis) {
+                            w_in += sk[k];
+                        } else {
+                            const uint32_t at = atomicAdd(&sh[N_BAND], 1u);
+                            if (at < cap) bnode[at] = u | (sk[k] << kBandNodeBits);
+                            else sh[OVER] = 1u;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w_in += __shfl_xor(w_in, o);
+            if (lane == 0) atomicAdd(&sh[W_IN], w_in);
+        }
+        __syncthreads();
+        const uint32_t n_band = min(sh[N_BAND], cap);
+        const bool band_over = sh[OVER] != 0u;
+        if (band_over) redo = true;
+        tk[3] = wall_clock64();
+
+        if (!all && !roots_only && !redo) {
+            const uint32_t need = (uint32_t)min(budget_left, (int64_t)0x7FFFFFFF);
+            const uint32_t w_in = sh[W_IN];
+            // ---- 4. canonical keys of the band: the node's own key, and every key on its path that can be the path's maximum
+            for (uint32_t i = tid; i < n_band; i += kT) {
+                const uint32_t u = bnode[i] & node_mask;
+                const uint32_t gu = g_of[u];
+                uint32_t key = 0, m = 0;
+                for (int j = 0; j < kPathMax; ++j) {
+                    const uint32_t c = t.path_cent[(size_t)u * kPathMax + j];
+                    if (c == kNoCent) break;
+                    if (j == 0 || BinOf(D[c], h_lo, h_scale) + k_bins >= gu) {
+                        const uint32_t bits = OrderedBits(ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d));
+                        if (j == 0) key = bits;
+                        m = max(m, bits);
+                        ++n_exact;
+                    }
+                }
+                bkey[i] = key;
+                bpi[i] = m;
+            }
+            __syncthreads();
+            // ---- 4b. x*: the smallest exact pi in the band at which the accumulated sizes reach the budget left after the roots
+            for (uint32_t i = tid; i < n_band; i += kT) {
+                const uint32_t mine = bpi[i];
+                uint32_t cum = w_in;
+                for (uint32_t j = 0; j < n_band; ++j) cum += bpi[j] <= mine ? bnode[j] >> kBandNodeBits : 0u;
+                if (cum >= need) atomicMin(&sh[XS], mine);
+            }
+            __syncthreads();
+            const uint32_t xs = sh[XS];
+            if (xs == 0xFFFFFFFFu) redo = true;   // (cannot happen while eps holds: x* lies in the band)
+            if (!redo) {
+                for (uint32_t i = tid; i < n_band; i += kT) {
+                    const uint32_t v = bpi[i];
+                    if (v < xs) atomicAdd(&sh[BELOW], bnode[i] >> kBandNodeBits);
+                    if (v == xs && bkey[i] == xs) {
+                        atomicAdd(&sh[N_BOTTLE], 1u);
+                        sh[IW] = i;
+                    }
+                }
+                __syncthreads();
+                // states from here on: 0 visited, 1 in the group pi == x* (waiting), 2 not visited, 3 in the group's frontier
+                for (uint32_t i = tid; i < n_band; i += kT) {
+                    const uint32_t v = bpi[i];
+                    bpi[i] = v < xs ? 0u : (v == xs ? 1u : 2u);
+                }
+                __syncthreads();
+                // ---- 4c. the cut-off group (RouterThresholdReplayKernel step 3 on the band entries): wavefront 0
+                if (wave == 0) {
+                    int64_t budget_in = (int64_t)need - (int64_t)(w_in + sh[BELOW]);   // > 0
+                    bool bad = sh[N_BOTTLE] != 1u;
+                    uint32_t cur = sh[IW];
+                    while (!bad) {
+                        if (lane == 0) bpi[cur] = 0u;
+                        const uint32_t packed = bnode[cur];
+                        const uint32_t node = packed & node_mask;
+                        budget_in -= (int64_t)(packed >> kBandNodeBits);
+                        __builtin_amdgcn_wave_barrier();
+                        if (budget_in <= 0) break;
+                        // its children with smaller keys join the frontier (a child with pi == x* is in the band)
+                        const uint32_t n_child = a.node_child_count[node], child_first = a.node_child_first[node];
+                        for (uint32_t i = lane; i < n_band && n_child != 0; i += 64) {
+                            const uint32_t u = bnode[i] & node_mask;
+                            if (bpi[i] == 1u && u >= child_first && u < child_first + n_child && bkey[i] < xs) bpi[i] = 3u;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        uint32_t best = 0xFFFFFFFFu, best_at = 0;
+                        for (uint32_t i = lane; i < n_band; i += 64) {
+                            if (bpi[i] == 3u && bkey[i] < best) {
+                                best = bkey[i];
+                                best_at = i;
+                            }
+                        }
+                        uint32_t mn = best;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                        if (mn == 0xFFFFFFFFu) break;   // the frontier is empty
+                        uint32_t n_min = 0;
+                        for (uint32_t i = lane; i < n_band; i += 64) n_min += (bpi[i] == 3u && bkey[i] == mn) ? 1u : 0u;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) n_min += __shfl_xor(n_min, o);
+                        if (n_min != 1) {   // equal keys inside the cut-off group
+                            bad = true;
+                            break;
+                        }
+                        cur = (uint32_t)__shfl((int)best_at, __builtin_ctzll(__ballot(best == mn)));
+                    }
+                    if (bad && lane == 0) sh[REDO] = 1u;
+                }
+                __syncthreads();
+                if (sh[REDO] != 0u) redo = true;
+                if (!redo) {
+                    for (uint32_t i = tid; i < n_band; i += kT)
+                        if (bpi[i] == 0u) {
+                            const uint32_t u = bnode[i] & node_mask;
+                            atomicOr(&bitmap[u >> 5], 1u << (u & 31u));
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        tk[4] = wall_clock64();
 
         if (redo) {
-            if (lane == 0) {
+            if (tid == 0) {
                 a.redo[q] = 1;
                 atomicAdd(a.redo_count, 1u);
             }
         } else {
-            // ---- 4. per-shard minima: the two smallest D~ per lane; centroids within 2 eps of the shard's smallest D~ are the candidates
-            uint32_t* cand = bnode;
-            const uint32_t cand_cap = 3 * cap;
-            uint32_t n_cand = 0;
+            // ---- 5. per-shard minima, a wavefront per shard: the two smallest D~ per lane; centroids within 2 eps of the shard's smallest
+            //      D~ are the candidates (their own list per wavefront)
+            const uint32_t cand_cap = 3u * cap / kBWaves;
+            uint32_t* cand = bnode + (size_t)wave * cand_cap;
+            uint32_t n_cand = 0, n_rescan = 0;
             auto flush = [&]() {
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t i0 = 0; i0 < n_cand; i0 += 64) {
@@ -1439,34 +1519,41 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterBoundedReplayKernel(Replay
                 if (take) cand[n_cand + (uint32_t)__popcll(m & lanes_below)] = c;
                 n_cand += add;
             };
-            for (uint32_t b = 0; b < S; ++b) {
+            for (uint32_t b = wave; b < S; b += kBWaves) {
                 const uint32_t c0 = a.node_cent_first[a.shard_root[b]];
                 const uint32_t c1 = b + 1 < S ? a.node_cent_first[a.shard_root[b + 1]] : C;
                 float v1 = FLT_MAX, v2 = FLT_MAX;
                 uint32_t i1 = 0;
-                for (uint32_t cb = c0 + lane; cb < c1; cb += 64 * kBatch) {
-                    uint32_t node[kBatch];
-                    float dv[kBatch];
+                // (16-byte loads: four consecutive centroids per lane, two trips in flight — the row is 16-byte aligned and padded to table_ld,
+                //  cent_node is padded by four entries)
+                for (uint32_t cb = (c0 & ~3u) + 4u * lane; cb < c1; cb += 256 * 2) {
+                    uint32_t nd8[2], nb[2];
+                    float4 dq[2];
 #pragma unroll
-                    for (int k = 0; k < kBatch; ++k) {
-                        const uint32_t c = min(cb + 64u * k, c1 - 1);
-                        node[k] = t.cent_node[c];
-                        dv[k] = D[c];
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t c = min(cb + 256u * k, (c1 - 1) & ~3u);
+                        nd8[k] = *reinterpret_cast<const uint32_t*>(t.cent_node8 + c);
+                        nb[k] = t.cent_block_node[c >> 8];
+                        dq[k] = *reinterpret_cast<const float4*>(D + c);
                     }
-                    uint32_t pv[kBatch];
 #pragma unroll
-                    for (int k = 0; k < kBatch; ++k) pv[k] = pi[node[k]];
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t node[4] = {nb[k] + (nd8[k] & 255u), nb[k] + ((nd8[k] >> 8) & 255u), nb[k] + ((nd8[k] >> 16) & 255u), nb[k] + (nd8[k] >> 24)};
+                        const float dv[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
 #pragma unroll
-                    for (int k = 0; k < kBatch; ++k)
-                        if (cb + 64u * k < c1 && (all || pv[k] < lo)) {
-                            if (dv[k] < v1) {
-                                v2 = v1;
-                                v1 = dv[k];
-                                i1 = cb + 64u * k;
-                            } else if (dv[k] < v2) {
-                                v2 = dv[k];
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t c = cb + 256u * k + e;
+                            if (c >= c0 && c < c1 && ((bitmap[node[e] >> 5] >> (node[e] & 31u)) & 1u)) {
+                                if (dv[e] < v1) {
+                                    v2 = v1;
+                                    v1 = dv[e];
+                                    i1 = c;
+                                } else if (dv[e] < v2) {
+                                    v2 = dv[e];
+                                }
                             }
                         }
+                    }
                 }
                 float mn = v1;
 #pragma unroll
@@ -1479,8 +1566,8 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterBoundedReplayKernel(Replay
                         const uint32_t c = cb + lane;
                         bool take = false;
                         if (c < c1) {
-                            const uint32_t pv = pi[t.cent_node[c]];
-                            take = (all || pv < lo) && D[c] <= thr;
+                            const uint32_t node = t.cent_node[c];
+                            take = ((bitmap[node >> 5] >> (node & 31u)) & 1u) && D[c] <= thr;
                         }
                         append(take, c);
                     }
@@ -1489,21 +1576,27 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterBoundedReplayKernel(Replay
                 }
             }
             flush();
-            for (uint32_t b = lane; b < S; b += 64) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
-            if (lane == 0) a.redo[q] = 0;
-        }
-        if (lane == 0 && bt.stats) {
-            atomicAdd(bt.stats + 0, n_band);
-            if (band_over) atomicAdd(bt.stats + 2, 1u);
-            atomicAdd(bt.stats + 3, n_rescan);
+            if (lane == 0 && n_rescan) atomicAdd(&sh[N_RESCAN], n_rescan);
+            __syncthreads();
+            for (uint32_t b = tid; b < S; b += kT) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
+            if (tid == 0) a.redo[q] = 0;
         }
         {
             uint32_t ne = n_exact;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
-            if (lane == 0 && bt.stats) atomicAdd(bt.stats + 1, ne);
+            if (lane == 0 && ne) atomicAdd(&sh[N_EXACT], ne);
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (tid == 0 && bt.stats) {
+            atomicAdd(bt.stats + 0, n_band);
+            atomicAdd(bt.stats + 1, sh[N_EXACT]);
+            if (band_over) atomicAdd(bt.stats + 2, 1u);
+            atomicAdd(bt.stats + 3, sh[N_RESCAN]);
+            tk[5] = wall_clock64();   // (100 MHz ticks per phase, summed over the queries: GPANN_ROUTER_DEBUG prints them)
+            for (int i = 0; i < 5; ++i) atomicAdd(bt.stats + 4 + i, (uint32_t)(tk[i + 1] - tk[i]));
+        }
+        __syncthreads();
     }
 }
 
@@ -1694,7 +1787,7 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
                 parent[node_child_first[u] + i] = u;
                 key_cent[node_child_first[u] + i] = node_cent_first[u] + i;
             }
-        std::vector<uint32_t> path((size_t)n_nodes * kPathMax, kNoCent), cent_node(std::max<size_t>(nc, 1), 0);
+        std::vector<uint32_t> path((size_t)n_nodes * kPathMax, kNoCent), cent_node(std::max<size_t>(nc, 1) + 4, 0);   // (+ 4: 16-byte loads)
         for (uint32_t u = 0; u < n_nodes; ++u) {
             uint32_t v = u, len = 0;
             while (parent[v] != kNoCent && len <= n_nodes) {   // (len bound: malformed input must not hang)
@@ -1713,8 +1806,8 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         TRY_OR_FAIL(hipMemcpy(r->cent_shard, cent_shard.data(), cent_shard.size() * 4, hipMemcpyHostToDevice));
         {
             std::vector<uint32_t> has(S, 0);
-            for (uint32_t b : cent_shard)
-                if (b < S) has[b] = 1;
+            for (size_t c = 0; c < std::max<size_t>(nc, 1); ++c)
+                if (cent_shard[c] < S) has[cent_shard[c]] = 1;
             TRY_OR_FAIL(hipMalloc(&r->shard_has_cent, (size_t)S * 4));
             TRY_OR_FAIL(hipMemcpy(r->shard_has_cent, has.data(), (size_t)S * 4, hipMemcpyHostToDevice));
         }
@@ -1765,6 +1858,24 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             }
         }
         TRY_OR_FAIL(hipMalloc(&r->cent_node, cent_node.size() * 4));
+        {
+            std::vector<uint8_t> n8(cent_node.size(), 0);
+            std::vector<uint32_t> bn((nc >> 8) + 2, 0);
+            for (size_t c = 0; c < nc; ++c) {
+                if ((c & 255u) == 0) bn[c >> 8] = cent_node[c];
+                n8[c] = (uint8_t)(cent_node[c] - bn[c >> 8]);
+                if (cent_node[c] - bn[c >> 8] > 255u) {   // (a node without centroids in between: cannot happen for trees the trainer builds)
+                    n8.clear();
+                    break;
+                }
+            }
+            if (!n8.empty()) {
+                TRY_OR_FAIL(hipMalloc(&r->cent_node8, n8.size()));
+                TRY_OR_FAIL(hipMalloc(&r->cent_block_node, bn.size() * 4));
+                TRY_OR_FAIL(hipMemcpy(r->cent_node8, n8.data(), n8.size(), hipMemcpyHostToDevice));
+                TRY_OR_FAIL(hipMemcpy(r->cent_block_node, bn.data(), bn.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
         TRY_OR_FAIL(hipMemcpy(r->path_cent, path.data(), path.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_FAIL(hipMemcpy(r->cent_node, cent_node.data(), cent_node.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1824,7 +1935,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn, (void*)r->cent_mu})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn, (void*)r->cent_mu, (void*)r->cent_node8, (void*)r->cent_block_node})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -1965,8 +2076,8 @@ gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint3
     GPANN_HIP_TRY(hipGetLastError());
     GPANN_HIP_TRY(hipMemcpyAsync(h_rows, d_rows, (size_t)m * C * 4, hipMemcpyDeviceToHost, st));
     GPANN_HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t chunks = std::min<uint32_t>(m, 64);
-    HostPool::Get().Run(chunks, [&](uint32_t c) {
+    const uint32_t chunks = m;
+    HostPool::Wide().Run(chunks, [&](uint32_t c) {
         for (uint32_t i = (uint32_t)((uint64_t)m * c / chunks); i < (uint32_t)((uint64_t)m * (c + 1) / chunks); ++i)
             HostWalkOnTable(r, h_rows + (size_t)i * C, budget, h_min + (size_t)i * S, rec ? h_rec_dist + (size_t)i * rec_cap : nullptr,
                             rec ? h_rec_shard + (size_t)i * rec_cap : nullptr, rec ? h_rec_count + i : nullptr, rec_cap);
@@ -2461,6 +2572,9 @@ gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
 // rec_* (device, optional) receive every evaluated (distance, shard) pair.
 // The bounded replay's table for a block of queries: BoundFrameKernel (row bases, eps) + RouterBoundKernel<.., PASS 3> (router_bound.h).
 gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t nb, hipStream_t st, float* table, uint64_t table_ld, float* base, float* eps) {
+    float *h_lo = eps + nb, *h_scale = eps + 2 * (size_t)nb;   // (the frame: four arrays of nb floats, base first)
+    double eps_scale = 1.0;
+    if (const char* e = std::getenv("GPANN_ROUTER_EPS_SCALE")) eps_scale = std::max(1.0, std::atof(e));   // test knob: a wider band, the same bits
     BoundArgs ba{};
     ba.queries = d_queries;
     ba.cent_planes = r->cent_planes;
@@ -2481,8 +2595,8 @@ gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t
     const uint32_t n_tiles = (uint32_t)((r->n_centroids + kGTileRows - 1) / kGTileRows);
     // (several rounds of workgroups are fine here: a workgroup's share is hundreds of tiles)
     ba.n_seg = std::max(1u, std::min((n_tiles + 63) / 64, std::max(1u, 2u * (uint32_t)r->num_cus / groups)));
-    if (l2) hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps);
-    else hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps);
+    if (l2) hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_L2>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps, h_lo, h_scale, eps_scale);
+    else hipLaunchKernelGGL(BoundFrameKernel<GPANN_METRIC_MIPS>, dim3(nb), dim3(64), 0, st, d_queries, r->d, r->ld, r->cent_rmax, r->cent_mu, base, eps, h_lo, h_scale, eps_scale);
     GPANN_HIP_TRY(hipGetLastError());
     const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
     const void* f3 = l2 ? (ks16 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 16, 3> : ks4 ? (const void*)RouterBoundKernel<GPANN_METRIC_L2, 4, 3> : (const void*)RouterBoundKernel<GPANN_METRIC_L2, 8, 3>)
@@ -2547,12 +2661,13 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const char* tmode = std::getenv("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
         const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
         const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && rec_dist == nullptr && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
-                             !r->canonical_once && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits));
+                             !r->canonical_once && r->cent_node8 != nullptr && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
+                             ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
         const uint64_t row_floats = bounded ? table_ld : C;
         const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (row_floats * 4) / 64 * 64));
         GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * row_floats * 4, 256)));
         uint32_t band_cap = 512;
-        if (const char* e = std::getenv("GPANN_ROUTER_BAND_CAP")) band_cap = (uint32_t)std::min(4096, std::max(64, std::atoi(e)));
+        if (const char* e = std::getenv("GPANN_ROUTER_BAND_CAP")) band_cap = (uint32_t)std::min(4096, std::max(96, std::atoi(e)));
         for (uint32_t q0 = 0; q0 < nq; q0 += q_block) {
             const uint32_t nb = std::min(q_block, nq - q0);
             DenseArgs da;
@@ -2594,7 +2709,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             };
             float *frame_base = nullptr, *frame_eps = nullptr;
             if (bounded) {
-                GPANN_TRY(r->ws_frame.Reserve((size_t)2 * nb * 4 + 64));
+                GPANN_TRY(r->ws_frame.Reserve((size_t)4 * nb * 4 + 64));
                 frame_base = r->ws_frame.as<float>();
                 frame_eps = frame_base + nb;
                 GPANN_TRY(EnqueueBoundTable(r, da.queries, nb, st, da.out, table_ld, frame_base, frame_eps));
@@ -2637,10 +2752,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             ra.sort_n = sort_n;
             ra.n_nodes = r->n_nodes;
             if (sorted_ok || threshold_ok) {
-                GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 32));
+                GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 64));
                 ra.redo = r->ws_redo.as<uint32_t>();
                 ra.redo_count = ra.redo + nb;   // (+ 1..4: the bounded replay's counters)
-                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 20, st));
+                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 48, st));
             }
             if (sorted_ok) {
                 const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
@@ -2658,17 +2773,31 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 const uint64_t t_fit = std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)kRWaves * r->n_nodes * 4));
                 const uint32_t t_grid = (uint32_t)std::min<uint64_t>((nb + kRWaves - 1) / kRWaves,
                                                                      std::max<uint64_t>((uint64_t)prop.multiProcessorCount * t_bpc, std::min<uint64_t>(t_fit, 1u << 20)));
-                GPANN_TRY(r->ws_pi.Reserve((size_t)t_grid * kRWaves * r->n_nodes * 4));
+                // (the bounded replay: a workgroup per query; 1024 + S + 3 band_cap + n_nodes / 32 + 32 words of LDS)
+                const size_t b_lds = ((size_t)1024 + ((S + 3u) & ~3u) + 3 * (size_t)band_cap + (((r->n_nodes + 31u) / 32u + 3u) & ~3u) + 32) * sizeof(uint32_t);
+                uint32_t b_grid = 1;
+                if (bounded) {   // exactly the workgroups that are resident together (registers: 4 per CU today)
+                    const void* fb = r->metric == GPANN_METRIC_L2 ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS>;
+                    if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
+                    int per_cu = 0;
+                    GPANN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fb, 64 * kBWaves, b_lds));
+                    b_grid = std::min<uint32_t>(nb, (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, per_cu));
+                }
+                GPANN_TRY(r->ws_pi.Reserve(bounded ? (size_t)b_grid * r->n_nodes * 4 : (size_t)t_grid * kRWaves * r->n_nodes * 4));
                 ThresholdTree tt;
                 tt.path_cent = r->path_cent;
                 tt.cent_node = r->cent_node;
                 tt.pi = r->ws_pi.as<uint32_t>();
+                tt.cent_node8 = r->cent_node8;
+                tt.cent_block_node = r->cent_block_node;
                 tt.visit_all = (uint64_t)budget > C ? 1u : 0u;   // then budget_left exceeds the sizes of all non-root nodes together
                 if (bounded) {
                     BoundedTable bt;
                     bt.table = da.out;
                     bt.table_ld = table_ld;
                     bt.eps = frame_eps;
+                    bt.h_lo = frame_eps + nb;
+                    bt.h_scale = frame_eps + 2 * (size_t)nb;
                     bt.centroids = r->centroids;
                     bt.queries = da.queries;
                     bt.cent_shard = r->cent_shard;
@@ -2676,11 +2805,11 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     bt.ld = ld;
                     bt.band_cap = band_cap;
                     bt.stats = ra.redo_count + 1;
-                    const size_t b_lds = ((((size_t)256 + S + 3 * (size_t)band_cap) + 3) & ~(size_t)3) * kRWaves * sizeof(uint32_t);
+                    bt.ticket = ra.redo_count + 10;
                     const void* fb = r->metric == GPANN_METRIC_L2 ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS>;
                     if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
                     void* kargs[] = {&ra, &tt, &bt};
-                    GPANN_HIP_TRY(hipLaunchKernel(fb, dim3(t_grid), dim3(64 * kRWaves), kargs, b_lds, st));
+                    GPANN_HIP_TRY(hipLaunchKernel(fb, dim3(b_grid), dim3(64 * kBWaves), kargs, b_lds, st));
                 } else {
                     if (t_lds > 48 * 1024)
                         GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RouterThresholdReplayKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t_lds));
@@ -2694,7 +2823,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             uint32_t hgrid = grid;
             uint32_t marked = 0;
             if (ra.only_redo) {
-                uint32_t words[5] = {0, 0, 0, 0, 0};
+                uint32_t words[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 GPANN_HIP_TRY(hipMemcpyAsync(words, ra.redo_count, sizeof(words), hipMemcpyDeviceToHost, st));
                 GPANN_HIP_TRY(hipStreamSynchronize(st));
                 marked = words[0];
@@ -2713,6 +2842,9 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     if (std::getenv("GPANN_ROUTER_DEBUG"))
                         fprintf(stderr, "[gpann router] bounded table: %u queries x %llu centroids in %.3f ms; band %.1f nodes, %.1f canonical evaluations per query, %u band overflows, %u rescans\n",
                                 nb, (unsigned long long)C, ms, (double)words[1] / nb, (double)words[2] / nb, words[3], words[4]);
+                    if (std::getenv("GPANN_ROUTER_DEBUG"))
+                        fprintf(stderr, "[gpann router] bounded replay, us per query: bins %.1f, select %.1f, band pass %.1f, band keys + group %.1f, minima %.1f\n",
+                                words[5] / 100.0 / nb, words[6] / 100.0 / nb, words[7] / 100.0 / nb, words[8] / 100.0 / nb, words[9] / 100.0 / nb);
                 }
                 if (std::getenv("GPANN_ROUTER_DEBUG"))
                     fprintf(stderr, "[gpann router] %s replay: %u of %u queries need the real priority queue\n", sorted_ok ? "sorted" : "threshold", marked, nb);

@@ -295,9 +295,11 @@ __global__ void __launch_bounds__(64) BoundMarginKernel(const float* queries, co
 //   L2:   |(nq - 2 acc) - D| <= e2 = c2 (R + qn)^2 as above; nq as a float and the rounding of the subtraction add <= 2^-22 (R + qn)^2;
 //         the canonical float sequence is within g1 D <= g1 (R + qn)^2 of D
 //   MIPS: |acc - q.c| <= e2', the canonical 1 - q.c within e1 (as above), the rounding of 1 - acc <= 2^-23 (1 + qn R)
-// times (1 + 2^-6): the consumers add and subtract multiples of eps in float.
+// times (1 + 2^-6): the consumers add and subtract multiples of eps in float.  h_lo / h_scale: the interval that holds every table value
+// of the query, cut into 2^20 bins.
 template <int METRIC>
-__global__ void __launch_bounds__(64) BoundFrameKernel(const float* queries, uint32_t d, uint32_t ld, double cent_rmax, const float* mu, float* base, float* eps) {
+__global__ void __launch_bounds__(64) BoundFrameKernel(const float* queries, uint32_t d, uint32_t ld, double cent_rmax, const float* mu, float* base, float* eps,
+                                                       float* h_lo, float* h_scale, double eps_scale) {
     const uint32_t q = blockIdx.x;
     const float* row = queries + (size_t)q * ld;
     double nq = 0.0;
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(64) BoundFrameKernel(const float* queries, uin
     for (int o = 32; o > 0; o >>= 1) nq += __shfl_xor(nq, o);
     if (threadIdx.x != 0) return;
     const double qn = sqrt(nq) * (1.0 + 1e-12), R = cent_rmax, dd = (double)d;
-    double e;
+    double e, lo, span;   // every table value of the query lies in [lo + e, lo + span - e]
     if (METRIC == GPANN_METRIC_L2) {
         const double g1 = (dd + 32.0) * 0x1p-23;
         const double c2 = 2.0 * 0x1p-16 + 8.0 * (dd + 16.0) * 0x1p-24 + 0x1p-20 + 0x1p-21 + 0x1p-22;
@@ -321,10 +323,20 @@ __global__ void __launch_bounds__(64) BoundFrameKernel(const float* queries, uin
         e = e1 + e2 + 0x1p-23 * (1.0 + qn * R);
         base[q] = 1.0f;
     }
-    e = e * (1.0 + 0x1p-6) + 1e-30;
+    e = e * (1.0 + 0x1p-6) * eps_scale + 1e-30;   // (eps_scale >= 1: a test knob — a wider band must give the same bits)
     float ef = (float)e;
     if ((double)ef < e) ef = nextafterf(ef, INFINITY);
     eps[q] = ef;
+    if (METRIC == GPANN_METRIC_L2) {
+        lo = -2.0 * e;
+        span = (R + qn) * (R + qn) + 4.0 * e;
+    } else {
+        lo = 1.0 - qn * R - 2.0 * e;
+        span = 2.0 * qn * R + 4.0 * e;
+    }
+    // the bins of the bounded replay (router.hip, BinOf): 2^20 over the span
+    h_lo[q] = (float)lo;
+    h_scale[q] = (float)(1048574.0 / span);
 }
 
 // canonical distance of every candidate pair -> min per (query, shard)

@@ -399,12 +399,24 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
         assert router.stats()["table_blocks"] == st["table_blocks"]
         monkeypatch.delenv("GPANN_ROUTER_BOUND_TABLE")
         assert np.array_equal(m0.view(np.uint32), md.view(np.uint32)) and np.array_equal(p0, probes), budget
-    # a tiny band list: overflowing queries are marked and replayed on canonical rows — same bits
-    monkeypatch.setenv("GPANN_ROUTER_BAND_CAP", "64")
-    before = router.stats()
+    if not expect_table:
+        return
+    # a 30 times wider band (the error bound inflated): many more canonical evaluations, the same bits
     budget = C // 2
-    probes, md, _ = router.query_batch(queries, budget)
     wp, wm = tree.query_batch(queries, budget, nthreads=8)
+    monkeypatch.setenv("GPANN_ROUTER_EPS_SCALE", "30")
+    before = router.stats()
+    probes, md, _ = router.query_batch(queries, budget)
+    st = router.stats()
+    assert st["table_band_nodes"] - before["table_band_nodes"] > 3 * before["table_band_nodes"] / 5 / 2, (before, st)
+    assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
+    # ... and with a tiny band list on top: overflowing queries are marked and replayed on canonical rows — same bits
+    monkeypatch.setenv("GPANN_ROUTER_EPS_SCALE", "300")
+    monkeypatch.setenv("GPANN_ROUTER_BAND_CAP", "96")
+    before = router.stats()
+    probes, md, _ = router.query_batch(queries, budget)
+    st = router.stats()
+    assert st["table_band_overflow"] > before["table_band_overflow"], st
     assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
     # ... and with the device queue instead of the host's
     monkeypatch.setenv("GPANN_ROUTER_HOST_REDO", "0")
