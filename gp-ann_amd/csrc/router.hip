@@ -55,6 +55,9 @@ struct gpann_router {
     uint32_t* cent_node = nullptr;       // [n_centroids] node of every centroid
     uint8_t* cent_node8 = nullptr;       // ... as cent_block_node[c >> 8] + cent_node8[c] (ThresholdTree)
     uint32_t* cent_block_node = nullptr;
+    uint32_t *lvl_node = nullptr, *lvl_parent = nullptr, *lvl_key = nullptr;   // the nodes level by level (ThresholdTree)
+    uint32_t lvl_first[8] = {};   // (kPathMax + 2)
+    uint32_t n_levels = 0;
     uint32_t* cent_shard = nullptr;      // [n_centroids] shard of every centroid
     uint32_t* shard_has_cent = nullptr;  // [S] 1 if the shard has at least one centroid (its min_dist cannot stay at FLT_MAX after a full visit)
     char* cent_planes = nullptr;         // optional (d <= 128, finite centroids): bf16 planes of the centroids for RouterBoundKernel
@@ -861,6 +864,7 @@ __global__ void __launch_bounds__(64 * kRWaves) RouterSortedReplayKernel(ReplayA
 // Equal keys make the order libstdc++'s business only if they sit in the cut-off group (two bottlenecks, or equal minima in
 // the group's frontier); those queries are marked in `redo` and replayed by RouterReplayKernel with the real heap.
 constexpr int kPathMax = 6;
+static_assert(kPathMax + 2 == 8, "gpann_router::lvl_first");
 constexpr int kBatch = 4;   // independent loop trips a lane of RouterThresholdReplayKernel keeps in flight
 constexpr uint32_t kFrontCap = 512;
 constexpr uint32_t kNoCent = 0xFFFFFFFFu;
@@ -874,6 +878,13 @@ struct ThresholdTree {
     // (every node has a centroid, so the 256 centroids of a block belong to at most 256 consecutive nodes)
     const uint8_t* cent_node8;        // [C + 4]
     const uint32_t* cent_block_node;  // [(C >> 8) + 2]
+    // the nodes level by level (roots = level 0), ascending node ids inside a level: pi(u) = max(pi(parent), key(u)) needs one table value
+    // per node when the parents' level is done — the path table costs six gathers per node, and the texture addresser was the busiest unit
+    const uint32_t* lvl_node;     // [n_nodes]
+    const uint32_t* lvl_parent;   // [n_nodes] (roots: kNoCent)
+    const uint32_t* lvl_key;      // [n_nodes] the centroid whose distance is the node's key (roots: kNoCent)
+    uint32_t lvl_first[kPathMax + 2];   // level l = entries lvl_first[l] .. lvl_first[l + 1]
+    uint32_t n_levels;
 };
 
 __global__ void __launch_bounds__(64 * kRWaves) RouterThresholdReplayKernel(ReplayArgs a, ThresholdTree t) {
@@ -1253,35 +1264,37 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
         unsigned long long tk[6];
         tk[0] = wall_clock64();
 
-        // ---- 1. g = bin of pi~ for every node (kBatch nodes per thread and trip in flight) + the coarse histogram of the node sizes
+        // ---- 1. g = bin of pi~ for every node, level by level: g(u) = max(g(parent), bin(D~[key(u)])); + the coarse histogram of the node sizes
         if (!all && !roots_only && !redo) {
-            for (uint32_t u0 = tid; u0 < n_nodes; u0 += kT * 2) {
-                uint32_t cidx[2][kPathMax], sz[2];
+            for (uint32_t i = tid; i < t.lvl_first[1]; i += kT) g_of[t.lvl_node[i]] = 0u;
+            for (uint32_t L = 1; L < t.n_levels; ++L) {
+                const uint32_t l_end = t.lvl_first[L + 1];
+                for (uint32_t i0 = t.lvl_first[L] + tid; i0 < l_end; i0 += kT * kBatch) {
+                    uint32_t u[kBatch], par[kBatch], kc[kBatch];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t u = u0 + (uint32_t)kT * k;
-#pragma unroll
-                    for (int j = 0; j < kPathMax; ++j) cidx[k][j] = u < n_nodes ? t.path_cent[(size_t)u * kPathMax + j] : kNoCent;
-                    const uint32_t uc = min(u, n_nodes - 1);
-                    sz[k] = a.node_cent_first[uc + 1] - a.node_cent_first[uc];
-                }
-                float val[2][kPathMax];
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int j = 0; j < kPathMax; ++j) val[k][j] = D[cidx[k][j] != kNoCent ? cidx[k][j] : 0u];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t u = u0 + (uint32_t)kT * k;
-                    uint32_t g = 0;
-#pragma unroll
-                    for (int j = 0; j < kPathMax; ++j)
-                        if (cidx[k][j] != kNoCent) g = max(g, BinOf(val[k][j], h_lo, h_scale));
-                    if (u < n_nodes) {
-                        g_of[u] = g;
-                        if (g != 0) atomicAdd(&hist[(g - 1u) >> 10], sz[k]);
+                    for (int k = 0; k < kBatch; ++k) {
+                        const uint32_t i = min(i0 + (uint32_t)kT * k, l_end - 1);
+                        u[k] = t.lvl_node[i];
+                        par[k] = t.lvl_parent[i];
+                        kc[k] = t.lvl_key[i];
                     }
+                    float dk[kBatch];
+                    uint32_t gp[kBatch], sz[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        dk[k] = D[kc[k]];
+                        gp[k] = L > 1 ? g_of[par[k]] : 0u;
+                        sz[k] = a.node_cent_first[u[k] + 1] - a.node_cent_first[u[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (i0 + (uint32_t)kT * k < l_end) {
+                            const uint32_t g = max(gp[k], BinOf(dk[k], h_lo, h_scale));
+                            g_of[u[k]] = g;
+                            atomicAdd(&hist[(g - 1u) >> 10], sz[k]);
+                        }
                 }
+                __syncthreads();   // (the next level reads this level's bins)
             }
         }
         __syncthreads();
@@ -1524,26 +1537,30 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
                 const uint32_t c1 = b + 1 < S ? a.node_cent_first[a.shard_root[b + 1]] : C;
                 float v1 = FLT_MAX, v2 = FLT_MAX;
                 uint32_t i1 = 0;
-                // (16-byte loads: four consecutive centroids per lane, two trips in flight — the row is 16-byte aligned and padded to table_ld,
+                // (16-byte loads: four consecutive centroids per lane, kM trips in flight — the row is 16-byte aligned and padded to table_ld,
                 //  cent_node is padded by four entries)
-                for (uint32_t cb = (c0 & ~3u) + 4u * lane; cb < c1; cb += 256 * 2) {
-                    uint32_t nd8[2], nb[2];
-                    float4 dq[2];
+                constexpr int kM = 4;   // 16-byte trips in flight per lane
+                for (uint32_t cb = (c0 & ~3u) + 4u * lane; cb < c1; cb += 256 * kM) {
+                    uint32_t nd8[kM], nb[kM];
+                    float4 dq[kM];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
+                    for (int k = 0; k < kM; ++k) {
                         const uint32_t c = min(cb + 256u * k, (c1 - 1) & ~3u);
                         nd8[k] = *reinterpret_cast<const uint32_t*>(t.cent_node8 + c);
                         nb[k] = t.cent_block_node[c >> 8];
                         dq[k] = *reinterpret_cast<const float4*>(D + c);
                     }
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
+                    for (int k = 0; k < kM; ++k) {
+                        // (only values below the lane's second smallest matter — after the first trips hardly any: the node, the bitmap and the range
+                        //  are looked at for those only; the arithmetic of this loop was half of the kernel's time)
+                        if (!(fminf(fminf(dq[k].x, dq[k].y), fminf(dq[k].z, dq[k].w)) < v2)) continue;
                         const uint32_t node[4] = {nb[k] + (nd8[k] & 255u), nb[k] + ((nd8[k] >> 8) & 255u), nb[k] + ((nd8[k] >> 16) & 255u), nb[k] + (nd8[k] >> 24)};
                         const float dv[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t c = cb + 256u * k + e;
-                            if (c >= c0 && c < c1 && ((bitmap[node[e] >> 5] >> (node[e] & 31u)) & 1u)) {
+                            if (dv[e] < v2 && c >= c0 && c < c1 && ((bitmap[node[e] >> 5] >> (node[e] & 31u)) & 1u)) {
                                 if (dv[e] < v1) {
                                     v2 = v1;
                                     v1 = dv[e];
@@ -1800,6 +1817,29 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
             for (uint32_t c = node_cent_first[u]; c < node_cent_first[u + 1]; ++c) cent_node[c] = u;
         }
         TRY_OR_FAIL(hipMalloc(&r->path_cent, path.size() * 4));
+        {   // the nodes level by level (ThresholdTree::lvl_*), for trees the threshold replays take (depth <= kPathMax)
+            const uint32_t n_levels = std::min<uint32_t>(r->max_depth, (uint32_t)kPathMax) + 1;
+            std::vector<uint32_t> first(kPathMax + 2, 0), order(n_nodes), lp(n_nodes), lk(n_nodes);
+            for (uint32_t u = 0; u < n_nodes; ++u)
+                if (depth[u] < n_levels) ++first[depth[u] + 1];
+            for (int l = 0; l <= kPathMax; ++l) first[l + 1] += first[l];
+            std::vector<uint32_t> at(first.begin(), first.end() - 1);
+            for (uint32_t u = 0; u < n_nodes; ++u)
+                if (depth[u] < n_levels) {
+                    const uint32_t i = at[depth[u]]++;
+                    order[i] = u;
+                    lp[i] = parent[u];
+                    lk[i] = key_cent[u];
+                }
+            for (int l = 0; l < kPathMax + 2; ++l) r->lvl_first[l] = first[std::min<int>(l, (int)n_levels)];
+            r->n_levels = n_levels;
+            TRY_OR_FAIL(hipMalloc(&r->lvl_node, (size_t)n_nodes * 4));
+            TRY_OR_FAIL(hipMalloc(&r->lvl_parent, (size_t)n_nodes * 4));
+            TRY_OR_FAIL(hipMalloc(&r->lvl_key, (size_t)n_nodes * 4));
+            TRY_OR_FAIL(hipMemcpy(r->lvl_node, order.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice));
+            TRY_OR_FAIL(hipMemcpy(r->lvl_parent, lp.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice));
+            TRY_OR_FAIL(hipMemcpy(r->lvl_key, lk.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice));
+        }
         std::vector<uint32_t> cent_shard(cent_node.size(), 0);
         for (size_t c = 0; c < nc; ++c) cent_shard[c] = (uint32_t)node_shard[cent_node[c]];
         TRY_OR_FAIL(hipMalloc(&r->cent_shard, cent_shard.size() * 4));
@@ -1935,7 +1975,7 @@ gpann_status gpann_router_destroy(gpann_router* r) {
     if (!r) return GPANN_OK;
     (void)hipSetDevice(r->device);
     for (void* p : {(void*)r->centroids, (void*)r->node_shard, (void*)r->node_cent_first, (void*)r->node_child_first,
-                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn, (void*)r->cent_mu, (void*)r->cent_node8, (void*)r->cent_block_node})
+                    (void*)r->node_child_count, (void*)r->shard_root, (void*)r->path_cent, (void*)r->cent_node, (void*)r->cent_shard, (void*)r->shard_has_cent, (void*)r->cent_planes, (void*)r->cent_nhn, (void*)r->cent_mu, (void*)r->cent_node8, (void*)r->cent_block_node, (void*)r->lvl_node, (void*)r->lvl_parent, (void*)r->lvl_key})
         if (p) (void)hipFree(p);
     r->ws_queries.Release();
     r->ws_heap.Release();
@@ -2790,6 +2830,11 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 tt.pi = r->ws_pi.as<uint32_t>();
                 tt.cent_node8 = r->cent_node8;
                 tt.cent_block_node = r->cent_block_node;
+                tt.lvl_node = r->lvl_node;
+                tt.lvl_parent = r->lvl_parent;
+                tt.lvl_key = r->lvl_key;
+                for (int l = 0; l < kPathMax + 2; ++l) tt.lvl_first[l] = r->lvl_first[l];
+                tt.n_levels = r->n_levels;
                 tt.visit_all = (uint64_t)budget > C ? 1u : 0u;   // then budget_left exceeds the sizes of all non-root nodes together
                 if (bounded) {
                     BoundedTable bt;

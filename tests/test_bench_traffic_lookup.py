@@ -22,7 +22,7 @@ def _bench():
 def test_traffic_of_the_ns_rest_pass_comes_from_the_newest_round():
     b = _bench()
     traffic, src = b.lookup_traffic(100_000_000, 128, 40, 1, "FilterKernelCells<", {"": 1}, largest_launch=True)
-    assert src is not None and src.startswith("profiles/r03/"), src
+    assert src is not None and src.startswith("profiles/r04/"), src
     # the rest pass reads about one int8 plane + norm word per row of the store: 100M x 132 B, give or take the pruned / repeated cells
     assert 10e9 < traffic < 15e9, traffic
     # and it is only reported for a run whose rest pass has to read the same bytes
@@ -43,6 +43,6 @@ def test_a_pass_taken_on_other_bytes_is_not_reported():
     round-2 files carry no such figure (taken before the guard existed, on a layout with different bytes per row) and must not be used"""
     b = _bench()
     traffic, src = b.lookup_traffic(10_000_000, 96, 16, 4, "FilterKernelCells<", {"": 1}, largest_launch=True, kernel_bytes=15.9e9)
-    assert traffic is None or src.startswith("profiles/r03/"), (traffic, src)
+    assert traffic is None or src.startswith("profiles/r04/"), (traffic, src)
     if traffic is None:
         assert src is None or src.startswith("stale: "), src
