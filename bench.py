@@ -531,6 +531,26 @@ def main():
             trial = comm.max_double(trial)
         candidates.append(dict(index_budget=index_budget, router=router, tree=tree, train_s=router_train_s, nprobe=nprobe, recall_curve=recall_curve,
                                trial_ms=1000.0 * trial, probes=probes.copy()))
+        if os.environ.get("GPANN_BENCH_FREQUENCY") == "1" and not multi:
+            # KMeansTreeRouter::FrequencyQuery (500 votes, the reference's default) on the same batch: the bounded replay against the canonical table
+            hq = queries.cpu().numpy()
+            fq = {}
+            outs = {}
+            for name, env in (("bounded", None), ("canonical_table", "0")):
+                if env is None:
+                    os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+                else:
+                    os.environ["GPANN_ROUTER_BOUND_TABLE"] = env
+                outs[name] = router.frequency_query_batch(hq, args.search_budget, 500)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    router.frequency_query_batch(hq, args.search_budget, 500)
+                fq[name + "_ms"] = 1000.0 * (time.perf_counter() - t0) / 2
+            os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+            a_, b_ = outs["bounded"], outs["canonical_table"]
+            fq["identical"] = bool(all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a_[:4], b_[:4])))
+            candidates[-1]["frequency_query"] = fq
+            log(f"index budget {index_budget}: FrequencyQuery(500 votes) {fq}")
         log(f"index budget {index_budget}: {candidates[-1]['trial_ms']:.2f} ms per step")
     del gt_slot_d, gt_slot_i
     best = min(candidates, key=lambda c: c["trial_ms"])
@@ -820,7 +840,7 @@ def main():
                         "scan_kernels_ms": float(np.mean(scan_ms)), "filter_kernels_ms": float(np.mean(filter_ms)), "merge_kernel_ms": stats["merge_ms"],
                         "units": stats["units"], "tasks": stats["tasks"], "pairs": stats["pairs"], "exact_pairs_padded": stats["padded_pairs"],
                         "router_train_s": router_train_s, "router_index_budget": best["index_budget"],
-                        "router_configs": [{kk: c[kk] for kk in ("index_budget", "nprobe", "trial_ms", "train_s", "recall_curve")} | {"centroids": int(c["tree"]["centroids"].shape[0]), "nodes": int(len(c["tree"]["node_shard"]))} for c in candidates],
+                        "router_configs": [{kk: c[kk] for kk in ("index_budget", "nprobe", "trial_ms", "train_s", "recall_curve", "frequency_query") if kk in c} | {"centroids": int(c["tree"]["centroids"].shape[0]), "nodes": int(len(c["tree"]["node_shard"]))} for c in candidates],
                         "router_nodes": int(len(tree["node_shard"])),
                         "router_centroids": int(tree["centroids"].shape[0]), "setup_s": time.time() - t_setup}
 

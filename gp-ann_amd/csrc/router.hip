@@ -1188,6 +1188,7 @@ struct BoundedTable {
     uint32_t band_cap;           // band entries per query (LDS: 3 words each)
     uint32_t* stats;             // [0] band nodes, [1] canonical evaluations, [2] queries whose band overflowed, [3] shard ranges scanned twice
     uint32_t* ticket;            // zeroed: the next unclaimed query
+    uint32_t rec_keep;           // FrequencyQuery (ReplayArgs::rec_dist != nullptr): records are needed for the rec_keep smallest pairs only
 };
 constexpr uint32_t kBandNodeBits = 22;   // a band entry: node | size << 22
 constexpr int kBWaves = 4;               // wavefronts per workgroup (= per query) of RouterBoundedReplayKernel
@@ -1220,7 +1221,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t mine, uint32_t* 
     return before + incl - mine;
 }
 
-template <int METRIC>
+template <int METRIC, bool REC>
 __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(ReplayArgs a, ThresholdTree t, BoundedTable bt) {
     extern __shared__ uint32_t bdsm[];
     constexpr int kT = 64 * kBWaves;
@@ -1235,7 +1236,7 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
     const uint32_t bm_words = (n_nodes + 31u) / 32u;
     uint32_t* sh = bitmap + ((bm_words + 3u) & ~3u);     // 32 words of scalars
     uint32_t* red = sh + 24;
-    enum { N_BAND = 0, W_IN, XS, BELOW, N_BOTTLE, IW, REDO, OVER, SEL_BIN, SEL_BEFORE, SEL_ALL, N_EXACT, N_RESCAN, N_CAND /* .. + kBWaves */ };
+    enum { N_BAND = 0, W_IN, XS, BELOW, N_BOTTLE, IW, REDO, OVER, SEL_BIN, SEL_BEFORE, SEL_ALL, N_EXACT, N_RESCAN, N_REC, F_ALL };
     uint32_t* g_of = t.pi + (size_t)blockIdx.x * n_nodes;
     const uint32_t node_mask = (1u << kBandNodeBits) - 1u;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1510,15 +1511,29 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
             const uint32_t cand_cap = 3u * cap / kBWaves;
             uint32_t* cand = bnode + (size_t)wave * cand_cap;
             uint32_t n_cand = 0, n_rescan = 0;
+            bool recording = false;   // FrequencyQuery's records instead of the minima (REC)
             auto flush = [&]() {
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t i0 = 0; i0 < n_cand; i0 += 64) {
                     const uint32_t i = i0 + lane;
+                    float e = 0.f;
+                    uint32_t shard = 0;
                     if (i < n_cand) {
                         const uint32_t c = cand[i];
-                        const float e = ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d);
-                        atomicMin(&sMinOrd[bt.cent_shard[c]], OrderedBits(e));
+                        e = ExactDistanceVec4<METRIC>(bt.centroids + (size_t)c * bt.ld, qrow, bt.d);
+                        shard = bt.cent_shard[c];
+                        if (!REC || !recording) atomicMin(&sMinOrd[shard], OrderedBits(e));
                         ++n_exact;
+                    }
+                    if (REC && recording) {
+                        const uint32_t cnt = min(64u, n_cand - i0);
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(&sh[N_REC], cnt);
+                        at = (uint32_t)__shfl((int)at, 0) + (uint32_t)lane;
+                        if (i < n_cand && at < a.rec_cap) {
+                            a.rec_dist[(size_t)q * a.rec_cap + at] = e;
+                            a.rec_shard[(size_t)q * a.rec_cap + at] = (int32_t)shard;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1597,6 +1612,77 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
             __syncthreads();
             for (uint32_t b = tid; b < S; b += kT) a.out_min_dist[(size_t)q * S + b] = FromOrderedBits(sMinOrd[b]);
             if (tid == 0) a.redo[q] = 0;
+
+            // ---- 6. FrequencyQuery (kmeans_tree_router.cpp:132-172): the rec_keep smallest (distance, shard) pairs over the visited centroids.
+            //      The V-th smallest table value lies in bin G_t (two histograms of the visited centroids' bins, as for x~*); every pair that can
+            //      be among the V smallest canonical ones has its table value within 2 eps of it, i.e. a bin <= G_t + k: those (V + a few dozen)
+            //      get the canonical evaluation and are the records VoteSelectKernel selects from.  (All visited centroids if there are <= V.)
+            if constexpr (REC) {
+                const uint32_t V = max(bt.rec_keep, 1u);
+                recording = true;
+                uint32_t need_in = V, Gt = 0;
+                bool take_all = false;
+                // f(c, D~[c]) for every visited centroid c; uniform trip count (the functors vote across the wavefront)
+                auto for_visited = [&](auto&& f) {
+                    for (uint32_t base = 0; base < C; base += 4u * kT * 2) {
+                        uint32_t nd8[2], nbk[2];
+                        float4 dq[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const uint32_t c = min(base + 4u * kT * k + 4u * tid, (C - 1) & ~3u);
+                            nd8[k] = *reinterpret_cast<const uint32_t*>(t.cent_node8 + c);
+                            nbk[k] = t.cent_block_node[c >> 8];
+                            dq[k] = *reinterpret_cast<const float4*>(D + c);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float dv[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t c = base + 4u * kT * k + 4u * tid + e;
+                                const uint32_t node = nbk[k] + ((nd8[k] >> (8 * e)) & 255u);
+                                f(c, dv[e], c < C && ((bitmap[min(node, n_nodes - 1) >> 5] >> (node & 31u)) & 1u));
+                            }
+                        }
+                    }
+                };
+                for (int level = 0; level < 2 && !take_all; ++level) {
+                    for (uint32_t i = tid; i < 1024; i += kT) hist[i] = 0;
+                    __syncthreads();
+                    const uint32_t coarse = Gt;
+                    for_visited([&](uint32_t, float dv, bool vis) {
+                        if (!vis) return;
+                        const uint32_t g = BinOf(dv, h_lo, h_scale) - 1u;
+                        if (level == 0) atomicAdd(&hist[g >> 10], 1u);
+                        else if ((g >> 10) == coarse) atomicAdd(&hist[g & 1023u], 1u);
+                    });
+                    __syncthreads();
+                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                    const uint32_t mine = h0 + h1 + h2 + h3;
+                    uint32_t total = 0;
+                    const uint32_t before = BlockExclusiveScan(mine, red, lane, wave, total);
+                    if (before < need_in && before + mine >= need_in) {
+                        uint32_t c = before, bin;
+                        if (c + h0 >= need_in) bin = 0;
+                        else if ((c += h0) + h1 >= need_in) bin = 1;
+                        else if ((c += h1) + h2 >= need_in) bin = 2;
+                        else { c += h2; bin = 3; }
+                        sh[SEL_BIN] = 4u * (uint32_t)tid + bin;
+                        sh[SEL_BEFORE] = c;
+                    }
+                    if (tid == 0 && total < need_in) sh[F_ALL] = 1u;   // fewer visited centroids than votes: all of them
+                    __syncthreads();
+                    take_all = sh[F_ALL] != 0u;
+                    need_in -= sh[SEL_BEFORE];
+                    Gt = (Gt << 10) | sh[SEL_BIN];
+                    __syncthreads();
+                }
+                const uint32_t g_max = take_all ? 0xFFFFFFFFu : Gt + 1u + k_bins;   // (bins are numbered from 1)
+                for_visited([&](uint32_t c, float dv, bool vis) { append(vis && BinOf(dv, h_lo, h_scale) <= g_max, c); });
+                flush();
+                __syncthreads();
+                if (tid == 0) a.rec_count[q] = (uint32_t)min((uint64_t)sh[N_REC], a.rec_cap);
+            }
         }
         {
             uint32_t ne = n_exact;
@@ -2610,6 +2696,11 @@ gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
 
 // Stages the queries, sizes the queue workspace and launches the walk for queries [0, nq); min_dist lands in r->ws_out.
 // rec_* (device, optional) receive every evaluated (distance, shard) pair.
+const void* BoundedReplayFn(int metric, bool rec) {
+    if (metric == GPANN_METRIC_L2) return rec ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2, true> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2, false>;
+    return rec ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS, true> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS, false>;
+}
+
 // The bounded replay's table for a block of queries: BoundFrameKernel (row bases, eps) + RouterBoundKernel<.., PASS 3> (router_bound.h).
 gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t nb, hipStream_t st, float* table, uint64_t table_ld, float* base, float* eps) {
     float *h_lo = eps + nb, *h_scale = eps + 2 * (size_t)nb;   // (the frame: four arrays of nb floats, base first)
@@ -2649,8 +2740,10 @@ gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t
     return GPANN_OK;
 }
 
+// rec_keep (FrequencyQuery with a device-side selection): only the rec_keep smallest pairs of every query will be looked at — the bounded replay
+// then records just the pairs that can be among them; 0 = every evaluated pair is needed.
 gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int flags, hipStream_t st, float* rec_dist,
-                        int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap) {
+                        int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap, uint32_t rec_keep = 0) {
     const uint32_t S = r->S, ld = r->ld;
     const size_t qbytes = (size_t)nq * ld * sizeof(float);
     r->stat_bound_ms = r->stat_bound_flops = 0.0;
@@ -2700,7 +2793,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         // the threshold replay on a table the matrix cores wrote, canonical evaluation of the cut-off band only (RouterBoundedReplayKernel)
         const char* tmode = std::getenv("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
         const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
-        const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && rec_dist == nullptr && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
+        const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && (rec_dist == nullptr || rec_keep > 0) && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
                              !r->canonical_once && r->cent_node8 != nullptr && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
                              ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
         const uint64_t row_floats = bounded ? table_ld : C;
@@ -2817,7 +2910,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 const size_t b_lds = ((size_t)1024 + ((S + 3u) & ~3u) + 3 * (size_t)band_cap + (((r->n_nodes + 31u) / 32u + 3u) & ~3u) + 32) * sizeof(uint32_t);
                 uint32_t b_grid = 1;
                 if (bounded) {   // exactly the workgroups that are resident together (registers: 4 per CU today)
-                    const void* fb = r->metric == GPANN_METRIC_L2 ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS>;
+                    const void* fb = BoundedReplayFn(r->metric, rec_dist != nullptr);
                     if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
                     int per_cu = 0;
                     GPANN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fb, 64 * kBWaves, b_lds));
@@ -2851,7 +2944,8 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     bt.band_cap = band_cap;
                     bt.stats = ra.redo_count + 1;
                     bt.ticket = ra.redo_count + 10;
-                    const void* fb = r->metric == GPANN_METRIC_L2 ? (const void*)RouterBoundedReplayKernel<GPANN_METRIC_L2> : (const void*)RouterBoundedReplayKernel<GPANN_METRIC_MIPS>;
+                    bt.rec_keep = rec_keep;
+                    const void* fb = BoundedReplayFn(r->metric, rec_dist != nullptr);
                     if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
                     void* kargs[] = {&ra, &tt, &bt};
                     GPANN_HIP_TRY(hipLaunchKernel(fb, dim3(b_grid), dim3(64 * kBWaves), kargs, b_lds, st));
@@ -3190,7 +3284,7 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     gpann_status status = GPANN_OK;
     for (uint32_t q0 = 0; q0 < nq && status == GPANN_OK; q0 += batch) {
         const uint32_t m = std::min(batch, nq - q0);
-        status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap);
+        status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap, device_select ? num_voting : 0u);
         if (status != GPANN_OK) break;
         hipError_t e = hipMemcpyAsync(out_min_dist + (size_t)q0 * S, r->ws_out.ptr, (size_t)m * S * 4, hipMemcpyDeviceToHost, st);
         if (device_select) {

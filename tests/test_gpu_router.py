@@ -401,6 +401,16 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
         assert np.array_equal(m0.view(np.uint32), md.view(np.uint32)) and np.array_equal(p0, probes), budget
     if not expect_table:
         return
+    # FrequencyQuery through the same path: only the pairs within the error of the num_voting-th smallest table value are evaluated
+    for budget, votes in ((C // 2, 500), (C // 3, 7), (C // 5, 2048)):   # (the last: fewer visited centroids than votes)
+        before = router.stats()
+        md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, votes)
+        st = router.stats()
+        assert st["table_blocks"] == before["table_blocks"] + 1, (budget, votes, st)
+        for q in range(0, len(queries), 5):
+            wmd, wnd, wns = tree.frequency_query(queries[q], budget, votes)
+            assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32)), (budget, votes, q)
+            assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (budget, votes, q)
     # a 30 times wider band (the error bound inflated): many more canonical evaluations, the same bits
     budget = C // 2
     wp, wm = tree.query_batch(queries, budget, nthreads=8)
