@@ -1049,18 +1049,26 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 tasks_rows[0] = float(sh.stats()["pairs"])
                 return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k), nxt
 
+            host_t = np.zeros(6)   # GPANN_BENCH_TRACE: where the main thread's time goes (wait for the routing, mask, enqueue, finish, copies, merge wait)
+
             def begin(i, routed):
                 """the real loop's scan_begin: the routing of batch i has arrived (batch i + 1 goes to the router thread), the scan is planned and ENQUEUED (deferred call)"""
+                t_a = time.perf_counter()
                 routed.result()
                 nxt = router_pool.submit(route_share, i + 1, r_stream.cuda_stream)
+                t_b = time.perf_counter()
                 lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
+                t_c = time.perf_counter()
                 di, dd = dsets[i & 1]
                 sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), stream, for_merge=merge_bound, defer=True)
+                host_t[:3] += (t_b - t_a, t_c - t_b, time.perf_counter() - t_c)
                 return nxt
 
             def finish(i):
                 """the real loop's scan_finish: the scan of batch i is completed; its lists leave on the third stream (where the real loop runs gather_slots first)"""
+                t_a = time.perf_counter()
                 sh.finish()
+                t_b = time.perf_counter()
                 di, dd = dsets[i & 1]
                 hd, hi_ = hbuf[i & 1]
                 with torch.cuda.stream(x_stream):
@@ -1068,6 +1076,7 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                     hi_.copy_(di, non_blocking=True)
                 x_stream.synchronize()
                 tasks_rows[0] = float(sh.stats()["pairs"])
+                host_t[3:5] += (t_b - t_a, time.perf_counter() - t_b)
                 return merger.submit(pygpann.merge_dedup, hd.numpy(), hi_.numpy().view(np.uint32), nprobe, k)
 
             def loop(count):
@@ -1076,7 +1085,9 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                     nxt = begin(0, router_pool.submit(route_share, 0, r_stream.cuda_stream))
                     for i in range(count):
                         if pending is not None:
+                            t_a = time.perf_counter()
                             pending.result()
+                            host_t[5] += time.perf_counter() - t_a
                         if i + 1 < count:
                             nxt = begin(i + 1, nxt)
                         pending = finish(i)
@@ -1104,6 +1115,10 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             ranks.append({"rank": r, "shards": len(mine), "rows": int(sum(int(counts[b]) for b in mine)), "ms_per_step": ms, "scan_kernels_ms": st["scan_ms"],
                           "rest_pass_ms": st["filter_rest_ms"], "task_rows": tasks_rows[0], "store_build_s": build_s})
             log(f"emulated world {W} rank {r}: {len(mine)} shards, {ranks[-1]['rows']} rows, {ms:.3f} ms/step (scan kernels {st['scan_ms']:.3f})")
+            if os.environ.get("GPANN_BENCH_TRACE") == "1" and scan_ahead:
+                n_it = max(1, steps + max(2, args.warmup))
+                log("   main thread, ms per step: wait for the routing %.3f, mask %.3f, plan + enqueue %.3f, finish %.3f, copies + sync %.3f, wait for the merge %.3f"
+                    % tuple(1000.0 * host_t / n_it))
             merger.shutdown()
             router_pool.shutdown()
             sh.close()

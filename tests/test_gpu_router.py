@@ -451,3 +451,26 @@ def test_bounded_table_replay_with_duplicate_points(orc, gp):
         wp, wm = tree.query_batch(queries, budget, nthreads=4)
         assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp), budget
     assert router.stats()["table_blocks"] == 3
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_bounded_table_replay_budget_and_batch_edges(orc, gp, metric):
+    """the bounded replay at its edges: budgets around the roots' total (nothing / almost nothing below the roots is visited), budgets C - 1 and C
+    (the last one visits everything: no cut-off), batches of 1, 31, 33 and 300 queries (partly filled query tiles), one query twice in a batch"""
+    pts, clusters, tree = _tree(orc, 36000, 48, 7, metric, 8, 12, 6000, seed=11)
+    f = tree.flat()
+    C = int(f["node_cent_first"][-1])
+    roots = f["shard_root"]
+    root_sizes = (f["node_cent_first"][roots + 1] - f["node_cent_first"][roots]).astype(np.int64)
+    root_total, root_min = int(root_sizes.sum()), int(root_sizes.min())
+    queries = make_mixture(orc, 300, 48, seed=558, n_centers=24)
+    queries[7] = queries[3]
+    router = gp.Router(f, metric, 0)
+    for budget in (root_total - root_min + 1, root_total, root_total + 1, root_total + 2, root_total + 40, C - 1, C):
+        for nq in (1, 31, 33, 300):
+            probes, md, _ = router.query_batch(queries[:nq], budget)
+            wp, wm = tree.query_batch(queries[:nq], budget, nthreads=4)
+            assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), (budget, nq)
+            assert np.array_equal(probes, wp), (budget, nq)
+    st = router.stats()
+    assert st["verify_failures"] == 0 and st["bound_selfcheck"] == 0, st
