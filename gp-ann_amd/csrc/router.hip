@@ -1681,7 +1681,10 @@ __global__ void __launch_bounds__(64 * kBWaves, 5) RouterBoundedReplayKernel(Rep
                 for_visited([&](uint32_t c, float dv, bool vis) { append(vis && BinOf(dv, h_lo, h_scale) <= g_max, c); });
                 flush();
                 __syncthreads();
-                if (tid == 0) a.rec_count[q] = (uint32_t)min((uint64_t)sh[N_REC], a.rec_cap);
+                if (tid == 0) {
+                    a.rec_count[q] = (uint32_t)min((uint64_t)sh[N_REC], a.rec_cap);
+                    if ((uint64_t)sh[N_REC] > a.rec_cap && bt.stats) atomicAdd(bt.stats + 10, 1u);   // (records lost: the caller repeats the block with room for all)
+                }
             }
         }
         {
@@ -2110,8 +2113,10 @@ __global__ void ScatterRowsF32Kernel(const float* packed, const uint32_t* rows, 
 }
 
 // kmeans_tree_router.cpp:93-123 on a row of exact distances (D[c] = distance(centroid c, Q)); records as FrequencyQuery sees them (:155)
+// select_smallest: the caller will only look at the smallest pairs (FrequencyQuery's votes, <= rec_cap of them) and rec_cap may be smaller than the
+// number of evaluated pairs: the rec_cap lexicographically smallest (distance, shard) pairs are kept instead of the first rec_cap.
 void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, float* min_dist, float* rec_dist, int32_t* rec_shard, uint32_t* rec_count,
-                     uint64_t rec_cap) {
+                     uint64_t rec_cap, bool select_smallest = false) {
     struct PQEntry {
         float dist;
         uint32_t node;
@@ -2122,6 +2127,7 @@ void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, floa
     for (uint32_t b = 0; b < S; ++b) min_dist[b] = std::numeric_limits<float>::max();
     for (uint32_t b = 0; b < S; ++b) pq.push(PQEntry{std::numeric_limits<float>::lowest(), r->h_shard_root[b]});
     uint64_t n_rec = 0;
+    std::vector<std::pair<float, int32_t>> all;
     while (!pq.empty() && budget > 0) {
         const PQEntry top = pq.top();
         pq.pop();
@@ -2131,12 +2137,24 @@ void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, floa
         for (uint32_t i = 0; i < n; ++i) {
             const float dist = D[first + i];
             min_dist[shard] = std::min(min_dist[shard], dist);
-            if (rec_dist && n_rec < rec_cap) {
+            if (rec_dist && select_smallest) {
+                all.emplace_back(dist, (int32_t)shard);
+            } else if (rec_dist && n_rec < rec_cap) {
                 rec_dist[n_rec] = dist;
                 rec_shard[n_rec] = (int32_t)shard;
             }
             ++n_rec;
             if (i < r->h_node_child_count[top.node]) pq.push(PQEntry{dist, r->h_node_child_first[top.node] + i});
+        }
+    }
+    if (rec_dist && select_smallest) {
+        if (all.size() > rec_cap) {
+            std::nth_element(all.begin(), all.begin() + (ptrdiff_t)rec_cap, all.end());
+            all.resize(rec_cap);
+        }
+        for (size_t i = 0; i < all.size(); ++i) {
+            rec_dist[i] = all[i].first;
+            rec_shard[i] = all[i].second;
         }
     }
     if (rec_count) *rec_count = (uint32_t)std::min<uint64_t>(n_rec, rec_cap);
@@ -2148,7 +2166,7 @@ void HostWalkOnTable(const gpann_router* r, const float* D, int32_t budget, floa
 // the gathered queries) instead of being gathered from `d_table`.
 gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint32_t* d_flags, uint32_t nb, uint32_t marked, int32_t budget, float* d_min_dist,
                               float* d_rec_dist, int32_t* d_rec_shard, uint32_t* d_rec_count, uint64_t rec_cap, hipStream_t st, bool* done,
-                              const DenseArgs* exact_for = nullptr) {
+                              const DenseArgs* exact_for = nullptr, bool select_smallest = false) {
     *done = false;
     const uint64_t C = r->n_centroids;
     const uint32_t S = r->S;
@@ -2206,7 +2224,7 @@ gpann_status HostReplayMarked(gpann_router* r, const float* d_table, const uint3
     HostPool::Wide().Run(chunks, [&](uint32_t c) {
         for (uint32_t i = (uint32_t)((uint64_t)m * c / chunks); i < (uint32_t)((uint64_t)m * (c + 1) / chunks); ++i)
             HostWalkOnTable(r, h_rows + (size_t)i * C, budget, h_min + (size_t)i * S, rec ? h_rec_dist + (size_t)i * rec_cap : nullptr,
-                            rec ? h_rec_shard + (size_t)i * rec_cap : nullptr, rec ? h_rec_count + i : nullptr, rec_cap);
+                            rec ? h_rec_shard + (size_t)i * rec_cap : nullptr, rec ? h_rec_count + i : nullptr, rec_cap, select_smallest);
     });
     // results back: min_dist rows (and the records) of the marked queries
     float* d_min_packed = d_rows;   // (the table rows are no longer needed)
@@ -2743,7 +2761,10 @@ gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t
 // rec_keep (FrequencyQuery with a device-side selection): only the rec_keep smallest pairs of every query will be looked at — the bounded replay
 // then records just the pairs that can be among them; 0 = every evaluated pair is needed.
 gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, int flags, hipStream_t st, float* rec_dist,
-                        int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap, uint32_t rec_keep = 0) {
+                        int32_t* rec_shard, uint32_t* rec_count, uint64_t rec_cap, uint32_t rec_keep = 0, bool rec_small = false, bool* rec_truncated = nullptr) {
+    // rec_small: rec_cap holds the pairs that can be among the rec_keep smallest, not every evaluated pair (the bounded replay records only
+    // those; the host's walks of the marked queries keep their rec_cap smallest).  *rec_truncated = some query's records did not fit, or the
+    // call would have taken a path that records in evaluation order: the caller repeats it with room for every evaluated pair.
     const uint32_t S = r->S, ld = r->ld;
     const size_t qbytes = (size_t)nq * ld * sizeof(float);
     r->stat_bound_ms = r->stat_bound_flops = 0.0;
@@ -2774,6 +2795,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     bool dense = budget > 0 && C <= dense_factor * (uint64_t)budget && C < 0xFFFFFFFFull && C * 4 * 64 <= dense_cap;
     if (force && std::string(force) == "walk") dense = false;
     if (force && std::string(force) == "dense" && C * 4 * 64 <= dense_cap) dense = budget > 0;
+    if (rec_small && !dense) {
+        if (rec_truncated) *rec_truncated = true;
+        return GPANN_OK;
+    }
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
     if (dense) {
         const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
@@ -2796,6 +2821,10 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && (rec_dist == nullptr || rec_keep > 0) && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
                              !r->canonical_once && r->cent_node8 != nullptr && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
                              ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
+        if (rec_small && !bounded) {
+            if (rec_truncated) *rec_truncated = true;
+            return GPANN_OK;
+        }
         const uint64_t row_floats = bounded ? table_ld : C;
         const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (row_floats * 4) / 64 * 64));
         GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * row_floats * 4, 256)));
@@ -2888,7 +2917,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 64));
                 ra.redo = r->ws_redo.as<uint32_t>();
                 ra.redo_count = ra.redo + nb;   // (+ 1..4: the bounded replay's counters)
-                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 48, st));
+                GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 56, st));
             }
             if (sorted_ok) {
                 const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
@@ -2943,7 +2972,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     bt.ld = ld;
                     bt.band_cap = band_cap;
                     bt.stats = ra.redo_count + 1;
-                    bt.ticket = ra.redo_count + 10;
+                    bt.ticket = ra.redo_count + 12;
                     bt.rec_keep = rec_keep;
                     const void* fb = BoundedReplayFn(r->metric, rec_dist != nullptr);
                     if (b_lds > 48 * 1024) GPANN_HIP_TRY(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_lds));
@@ -2962,7 +2991,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             uint32_t hgrid = grid;
             uint32_t marked = 0;
             if (ra.only_redo) {
-                uint32_t words[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t words[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 GPANN_HIP_TRY(hipMemcpyAsync(words, ra.redo_count, sizeof(words), hipMemcpyDeviceToHost, st));
                 GPANN_HIP_TRY(hipStreamSynchronize(st));
                 marked = words[0];
@@ -2975,6 +3004,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     r->stat_table_exact += words[2];
                     r->stat_table_band_overflow += words[3];
                     r->stat_table_rescans += words[4];
+                    if (rec_dist && words[11] != 0 && rec_truncated) *rec_truncated = true;
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, r->ev_bound[0], r->ev_bound[1]) == hipSuccess) r->stat_bound_ms += ms;
                     r->stat_bound_flops += 3.0 * 2.0 * (double)nb * (double)C * (double)r->d;
@@ -2994,8 +3024,12 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 // stays for batches whose marked rows would not fit the staging budget
                 bool done = false;
                 GPANN_TRY(HostReplayMarked(r, ra.dense, ra.redo, nb, marked, budget, ra.out_min_dist, ra.rec_dist, ra.rec_shard,
-                                           ra.rec_count, ra.rec_cap, st, &done, bounded ? &da : nullptr));
+                                           ra.rec_count, ra.rec_cap, st, &done, bounded ? &da : nullptr, rec_small));
                 need_heap = !done;
+            }
+            if (need_heap && rec_small) {   // (the device queue records in evaluation order)
+                if (rec_truncated) *rec_truncated = true;
+                return GPANN_OK;
             }
             if (need_heap && bounded) GPANN_TRY(canonical_table());   // (the device queue walks canonical values: the block's table once more, on the vector ALUs)
             if (need_heap) {
@@ -3245,6 +3279,10 @@ static gpann_status QueryBatchTopImpl(gpann_router* r, const float* queries, uin
 // (distance, shard) pairs over ALL evaluated centroids (TopN, then FrequencyQueryData::Init sorts them ascending).
 // The walk kernel records every evaluated pair; the selection of the num_voting smallest is done here on the host
 // (order-independent: the result is the set of lexicographically smallest pairs).
+static gpann_status FrequencyQueryAttempt(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t num_voting, float* out_min_dist,
+                                          float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count, int flags, void* stream, float* elapsed_ms,
+                                          uint64_t rec_cap, bool rec_small, bool* truncated);
+
 gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t num_voting,
                                                 float* out_min_dist, float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count,
                                                 int flags, void* stream, float* elapsed_ms) {
@@ -3254,12 +3292,31 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     GPANN_TRY(EnsureDevice(r->device));
     if (elapsed_ms) *elapsed_ms = 0.f;
     if (nq == 0) return GPANN_OK;
+    // a walk evaluates at most budget + (largest node - 1) centroids after the budget check, and never more than the tree holds
+    uint64_t rec_cap = std::min<uint64_t>(r->n_centroids, (uint64_t)std::max(budget, 0) + r->max_node);
+    rec_cap = std::max<uint64_t>(rec_cap, 1);
+    // The bounded replay records only the pairs that can be among the num_voting smallest (num_voting + a few dozen): room for 4 x num_voting
+    // (>= num_voting + 4096) per query lets the whole batch run in one block instead of blocks sized for every evaluated pair (50 000 per query
+    // on the NS trees: 8 blocks of 1310 queries).  A query whose records do not fit, or a tree / budget the bounded replay does not take,
+    // repeats the call the old way.
+    uint64_t small_cap = std::max<uint64_t>(4ull * num_voting, (uint64_t)num_voting + 4096);
+    const char* small_env = std::getenv("GPANN_ROUTER_FREQ_SMALL");   // "0": never; n > 1 (tests): n records per query (at least num_voting)
+    if (small_env && std::atoll(small_env) > 1) small_cap = std::max<uint64_t>((uint64_t)std::atoll(small_env), num_voting);
+    if (num_voting >= 1 && num_voting <= 2048 && small_cap < rec_cap && !(small_env && small_env[0] == '0')) {
+        bool truncated = false;
+        const gpann_status s1 = FrequencyQueryAttempt(r, queries, nq, budget, num_voting, out_min_dist, out_nn_dist, out_nn_shard, out_nn_count, flags, stream, elapsed_ms,
+                                                      small_cap, true, &truncated);
+        if (s1 != GPANN_OK || !truncated) return s1;
+    }
+    bool unused = false;
+    return FrequencyQueryAttempt(r, queries, nq, budget, num_voting, out_min_dist, out_nn_dist, out_nn_shard, out_nn_count, flags, stream, elapsed_ms, rec_cap, false, &unused);
+}
+
+static gpann_status FrequencyQueryAttempt(gpann_router* r, const float* queries, uint32_t nq, int32_t budget, uint32_t num_voting, float* out_min_dist,
+                                          float* out_nn_dist, uint32_t* out_nn_shard, uint32_t* out_nn_count, int flags, void* stream, float* elapsed_ms,
+                                          uint64_t rec_cap, bool rec_small, bool* truncated) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t S = r->S;
-    // a walk evaluates at most budget + (largest node - 1) centroids after the budget check, and never more than the tree holds
-    const uint32_t max_node = r->max_node;
-    uint64_t rec_cap = std::min<uint64_t>(r->n_centroids, (uint64_t)std::max(budget, 0) + max_node);
-    rec_cap = std::max<uint64_t>(rec_cap, 1);
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (512ull << 20) / (rec_cap * 8)));
     DeviceBuffer rec;
     GPANN_TRY(rec.Reserve((size_t)batch * rec_cap * 8 + (size_t)batch * 4));
@@ -3284,8 +3341,10 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     gpann_status status = GPANN_OK;
     for (uint32_t q0 = 0; q0 < nq && status == GPANN_OK; q0 += batch) {
         const uint32_t m = std::min(batch, nq - q0);
-        status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap, device_select ? num_voting : 0u);
+        status = LaunchWalk(r, queries + (size_t)q0 * qstride, m, budget, flags, st, d_rec_dist, d_rec_shard, d_rec_count, rec_cap, device_select ? num_voting : 0u,
+                            rec_small, truncated);
         if (status != GPANN_OK) break;
+        if (rec_small && *truncated) break;   // (the caller repeats the call with room for every evaluated pair)
         hipError_t e = hipMemcpyAsync(out_min_dist + (size_t)q0 * S, r->ws_out.ptr, (size_t)m * S * 4, hipMemcpyDeviceToHost, st);
         if (device_select) {
             // the votes are selected on the device; only [m][num_voting] pairs travel

@@ -411,6 +411,15 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
             wmd, wnd, wns = tree.frequency_query(queries[q], budget, votes)
             assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32)), (budget, votes, q)
             assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (budget, votes, q)
+    # ... with room for few records per query (what the full-size trees get: the batch in one block): enough room, and too little (the call is repeated)
+    for cap, votes in (("600", 500), ("56", 50), ("8", 7)):
+        monkeypatch.setenv("GPANN_ROUTER_FREQ_SMALL", cap)
+        md, nd, ns, nc, _ = router.frequency_query_batch(queries, C // 2, votes)
+        for q in range(0, len(queries), 7):
+            wmd, wnd, wns = tree.frequency_query(queries[q], C // 2, votes)
+            assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32)), (cap, votes, q)
+            assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (cap, votes, q)
+    monkeypatch.delenv("GPANN_ROUTER_FREQ_SMALL")
     # a 30 times wider band (the error bound inflated): many more canonical evaluations, the same bits
     budget = C // 2
     wp, wm = tree.query_batch(queries, budget, nthreads=8)
