@@ -9,8 +9,10 @@
 // Additive environment knobs: GPANN_COMM_BACKEND=rccl|tcp (default rccl; tcp = exchange over host sockets, e.g. several ranks on one
 // GPU), GPANN_DIST_PROBES (default 2, distributed_query_benchmark.h:35), GPANN_DIST_REPS (timed repetitions, default 1),
 // GPANN_DIST_ROUTER_BUDGET (index size when the router file does not exist yet, default points / shards),
-// GPANN_DIST_OUT (rank 0 writes the merged neighbours of all queries there: u32 nq, u32 k, ids, distances — the ground-truth layout).
+// GPANN_DIST_OUT (rank 0 writes the merged neighbours of all queries there: u32 nq, u32 k, ids, distances — the ground-truth layout),
+// GPANN_DIST_PIPELINE=<batches> (after the reference's protocol: the block as a stream of batches through the three-stage pipeline).
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <numeric>
 
@@ -87,6 +89,35 @@ int main(int argc, const char* argv[]) {
         std::sort(times.begin(), times.end());
         const double max_elapsed = times[times.size() / 2];
 
+        // GPANN_DIST_PIPELINE=<batches>: the same block as a STREAM of batches through the three-stage pipeline (ProcessQueryStream) — what a
+        // serving loop does; the reference's protocol above times one batch at a time.  A second communicator (the first one's port + 1) carries the
+        // route-ahead thread's all-gathers.
+        double stream_per_batch = 0.0;
+        int stream_batches = std::max(0, EnvInt("GPANN_DIST_PIPELINE", 0));
+        bool stream_identical = true;
+        if (stream_batches > 0) {
+            stream_batches = std::max(2, stream_batches);
+            const std::vector<float> one_dist = bench.result_dist;
+            const std::vector<uint32_t> one_ids = bench.result_ids;
+            gpann_comm* comm_route = nullptr;
+            const char* addr = std::getenv("MASTER_ADDR");
+            if (gpann_comm_init(rank, comm_size, addr ? addr : "127.0.0.1", EnvInt("GPANN_COMM_PORT", EnvInt("MASTER_PORT", 29500) + 1) + 1, backend, device, EnvInt("GPANN_COMM_TIMEOUT", 120), &comm_route) != GPANN_OK)
+                throw std::runtime_error(std::string("second communicator: ") + gpann_comm_last_error());
+            bench.ProcessQueryStream(my_query_ids, queries, 2, comm_route);   // (untimed: streams and buffers)
+            DistributedQueryBenchmark::CheckComm(gpann_comm_barrier(comm), "barrier");
+            Timer timer;
+            timer.Start();
+            bench.ProcessQueryStream(my_query_ids, queries, stream_batches, comm_route);
+            double elapsed = timer.Stop();
+            DistributedQueryBenchmark::CheckComm(gpann_comm_barrier(comm), "barrier");
+            DistributedQueryBenchmark::CheckComm(gpann_comm_max_double(comm, &elapsed), "max");
+            stream_per_batch = elapsed / stream_batches;
+            stream_identical = one_ids == bench.result_ids && one_dist.size() == bench.result_dist.size() &&
+                               std::memcmp(one_dist.data(), bench.result_dist.data(), one_dist.size() * 4) == 0;
+            gpann_comm_destroy(comm_route);
+            if (!stream_identical) throw std::runtime_error("the pipelined stream's neighbours differ from the single batch's");
+        }
+
         // recall of my slice against the ground-truth file (recall.h:74-150), summed over the ranks
         uint64_t hits = 0;
         {
@@ -126,6 +157,9 @@ int main(int argc, const char* argv[]) {
             std::cout << "backend " << gpann_comm_backend_name(comm) << ", ranks " << comm_size << ", probes " << bench.num_probes << ", recall "
                       << double(total) / double(queries.n) / bench.num_neighbors << ", QPS " << queries.n / max_elapsed << std::endl;
             std::cout << "End-to-end time " << max_elapsed << std::endl;
+            if (stream_batches > 0)
+                std::cout << "Pipelined stream: " << stream_batches << " batches, " << stream_per_batch << " s per batch, QPS " << queries.n / stream_per_batch
+                          << ", neighbours identical to the single batch's " << (stream_identical ? 1 : 0) << std::endl;
         }
     } catch (const std::exception& e) {
         std::cerr << "rank " << rank << ": " << e.what() << std::endl;

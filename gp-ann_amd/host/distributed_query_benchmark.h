@@ -17,6 +17,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <memory>
 #include <numeric>
@@ -61,8 +62,11 @@ public:
         if (router) gpann_router_destroy(router);
         if (store) gpann_shards_destroy(store);
         for (void* p : {(void*)d_queries_, (void*)d_probes_, (void*)d_all_probes_, (void*)d_ids_, (void*)d_dist_, (void*)d_out_ids_, (void*)d_out_dist_, (void*)d_scratch_,
-                        (void*)d_map_})
+                        (void*)d_map_, (void*)d_probes2_[0], (void*)d_probes2_[1], (void*)d_all_probes2_[0], (void*)d_all_probes2_[1], (void*)d_ids2_[0], (void*)d_ids2_[1],
+                        (void*)d_dist2_[0], (void*)d_dist2_[1]})
             if (p) (void)hipFree(p);
+        for (hipStream_t st : {s_route_, s_scan_, s_x_})
+            if (st) (void)hipStreamDestroy(st);
     }
 
     void LoadPartition(const std::string& partition_file) {   // :43-46, + the shard -> rank placement
@@ -254,8 +258,138 @@ public:
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + " failed: " + hipGetErrorString(e));
     }
 
+    // A STREAM of `batches` batches (each the broadcast query block once more) as a three-stage pipeline — bench.py's N > 1 loop in the driver's
+    // own language; ProcessQueries above is one batch at a time, as the reference times it (distributed_bench.cpp:41-54):
+    //   route thread   routing of batch i + 2 on its own stream + the all-gather of its probe lists + the wait, through `comm_route` — a SECOND
+    //                  communicator (collectives of one communicator must be issued by one thread in one order)
+    //   this thread    the scan of batch i + 1 planned and enqueued behind batch i as a DEFERRED call (GPANN_SCAN_DEFER) into the other set of
+    //                  device arrays; batch i completed (gpann_scan_finish: an overflowed call is redone BEFORE its lists are exchanged), its
+    //                  lists exchanged on a third stream beside the scan of batch i + 1
+    //   merge thread   DedupNeighbors of batch i - 1
+    // Leaves the last batch's merged neighbours in result_dist / result_ids.
+    void ProcessQueryStream(const std::vector<int>& query_ids, PointSet& queries, int batches, gpann_comm* comm_route) {
+        const size_t nq = nq_, k = (size_t)num_neighbors, P = (size_t)num_probes;
+        if (queries.n != nq) throw std::runtime_error("ProcessQueryStream: BroadcastQueries first");
+        if (batches <= 0) return;
+        slice_begin = query_ids.empty() ? 0 : (size_t)query_ids.front();
+        slice_end = query_ids.empty() ? 0 : (size_t)query_ids.back() + 1;
+        const size_t chunk = (nq + comm_size - 1) / comm_size, cnt = slice_end - slice_begin, n = nq * P * k;
+        EnsureBuffers(nq, chunk);
+        EnsureStreamBuffers(n, chunk * P);
+        auto route_job = [&, this](int j) -> std::vector<int32_t> {   // the probe matrix of batch j (all ranks' slices)
+            HipCheck(hipSetDevice(device), "hipSetDevice");
+            std::vector<int32_t> mine(chunk * P, -1), probes(cnt * num_shards), all(chunk * P * comm_size);
+            float ms = 0.f;
+            if (cnt)
+                Check(gpann_router_query_batch(router, d_queries_ + slice_begin * dim, (uint32_t)cnt, (int32_t)router_options.search_budget, probes.data(), nullptr,
+                                               GPANN_QUERIES_ON_DEVICE, s_route_, &ms),
+                      "gpann_router_query_batch");
+            for (size_t q = 0; q < cnt; ++q) std::memcpy(&mine[q * P], &probes[q * num_shards], P * 4);
+            if (backend_ == GPANN_COMM_RCCL) {
+                int32_t *dp = d_probes2_[j & 1], *da = d_all_probes2_[j & 1];
+                HipCheck(hipMemcpyAsync(dp, mine.data(), mine.size() * 4, hipMemcpyHostToDevice, s_route_), "hipMemcpyAsync");
+                CheckComm(gpann_comm_allgather(comm_route, dp, da, mine.size() * 4, s_route_), "gpann_comm_allgather");
+                CheckComm(gpann_comm_wait(comm_route, s_route_, wait_timeout_s), "gpann_comm_wait");
+                HipCheck(hipMemcpyAsync(all.data(), da, all.size() * 4, hipMemcpyDeviceToHost, s_route_), "hipMemcpyAsync");
+                HipCheck(hipStreamSynchronize(s_route_), "hipStreamSynchronize");
+            } else {
+                CheckComm(gpann_comm_allgather(comm_route, mine.data(), all.data(), mine.size() * 4, nullptr), "gpann_comm_allgather");
+            }
+            all.resize(nq * P);
+            return all;
+        };
+        auto scan_begin = [&, this](const std::vector<int32_t>& all, int set) {
+            std::vector<int32_t> masked(nq * P);
+            CheckComm(gpann_mask_probes(all.data(), (uint32_t)nq, (uint32_t)P, (uint32_t)P, owner.data(), (uint32_t)num_shards, rank, masked.data()), "gpann_mask_probes");
+            float ms = 0.f;
+            Check(gpann_scan_buckets(store, d_queries_, (uint32_t)nq, (uint32_t)k, masked.data(), (uint32_t)P, (uint32_t)P, d_ids2_[set], d_dist2_[set], nullptr,
+                                     GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE | GPANN_SCAN_FOR_MERGE | GPANN_SCAN_DEFER, s_scan_, &ms),
+                  "gpann_scan_buckets");
+        };
+        std::vector<float> h_dist[2];
+        std::vector<uint32_t> h_ids[2];
+        for (int b = 0; b < 2; ++b) {
+            h_dist[b].resize(n);
+            h_ids[b].resize(n);
+        }
+        auto finish_and_exchange = [&, this](int set) {   // -> h_dist[set], h_ids[set]: every slot's list from its owner
+            float ms = 0.f;
+            Check(gpann_scan_finish(store, &ms), "gpann_scan_finish");
+            last_scan_ms = ms;
+            if (backend_ == GPANN_COMM_RCCL) {
+                CheckComm(gpann_comm_gather_slots(comm, d_dist2_[set], d_ids2_[set], n, d_out_dist_, d_out_ids_, d_scratch_, d_map_, s_x_),
+                          "gpann_comm_gather_slots");
+                CheckComm(gpann_comm_wait(comm, s_x_, wait_timeout_s), "gpann_comm_wait");
+                HipCheck(hipMemcpyAsync(h_dist[set].data(), d_out_dist_, n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
+                HipCheck(hipMemcpyAsync(h_ids[set].data(), d_out_ids_, n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
+                HipCheck(hipStreamSynchronize(s_x_), "hipStreamSynchronize");
+            } else {
+                std::vector<float> my_dist(n);
+                std::vector<uint32_t> my_ids(n);
+                HipCheck(hipMemcpyAsync(my_dist.data(), d_dist2_[set], n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
+                HipCheck(hipMemcpyAsync(my_ids.data(), d_ids2_[set], n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
+                HipCheck(hipStreamSynchronize(s_x_), "hipStreamSynchronize");
+                host_scratch_.resize(gpann_comm_gather_slots_scratch(comm_size, n));
+                CheckComm(gpann_comm_gather_slots(comm, my_dist.data(), my_ids.data(), n, h_dist[set].data(), h_ids[set].data(), host_scratch_.data(), local_to_global.data(),
+                                                  nullptr),
+                          "gpann_comm_gather_slots");
+            }
+        };
+        std::vector<float> m_dist(cnt * k);
+        std::vector<uint32_t> m_ids(cnt * k);
+        auto merge_job = [&, this](int set) {
+            if (cnt)
+                Check(gpann_merge_dedup(h_dist[set].data() + slice_begin * P * k, h_ids[set].data() + slice_begin * P * k, (uint32_t)cnt, (uint32_t)P, (uint32_t)P, (uint32_t)k,
+                                        m_dist.data(), m_ids.data(), nullptr),
+                      "gpann_merge_dedup");
+        };
+
+        std::future<std::vector<int32_t>> route_next = std::async(std::launch::async, route_job, 0), route_after;
+        std::future<void> merging;
+        {
+            const std::vector<int32_t> all0 = route_next.get();
+            if (batches > 1) route_next = std::async(std::launch::async, route_job, 1);
+            scan_begin(all0, 0);
+        }
+        for (int it = 0; it < batches; ++it) {
+            if (it + 1 < batches) {
+                const std::vector<int32_t> all = route_next.get();
+                if (it + 2 < batches) route_next = std::async(std::launch::async, route_job, it + 2);
+                scan_begin(all, (it + 1) & 1);   // (queued behind batch `it`, which the GPU is still working on)
+            }
+            if (merging.valid()) merging.get();   // (batch it - 1: its host lists are the set batch it + 1 will fill)
+            finish_and_exchange(it & 1);
+            merging = std::async(std::launch::async, merge_job, it & 1);
+        }
+        merging.get();
+        result_dist = m_dist;
+        result_ids = m_ids;
+    }
+
 private:
     static int Metric() { return gpann_host::MetricIsMIPS() ? GPANN_METRIC_MIPS : GPANN_METRIC_L2; }
+
+    void EnsureStreamBuffers(size_t n, size_t pw) {
+        if (s_route_ && n == sbuf_n_ && pw == sbuf_pw_) return;
+        HipCheck(hipSetDevice(device), "hipSetDevice");
+        if (!s_route_) {
+            HipCheck(hipStreamCreateWithFlags(&s_route_, hipStreamNonBlocking), "hipStreamCreate");
+            HipCheck(hipStreamCreateWithFlags(&s_scan_, hipStreamNonBlocking), "hipStreamCreate");
+            HipCheck(hipStreamCreateWithFlags(&s_x_, hipStreamNonBlocking), "hipStreamCreate");
+        }
+        for (int b = 0; b < 2; ++b) {
+            for (void** p : {(void**)&d_probes2_[b], (void**)&d_all_probes2_[b], (void**)&d_ids2_[b], (void**)&d_dist2_[b]}) {
+                if (*p) (void)hipFree(*p);
+                *p = nullptr;
+            }
+            HipCheck(hipMalloc(&d_probes2_[b], std::max<size_t>(pw, 1) * 4), "hipMalloc");
+            HipCheck(hipMalloc(&d_all_probes2_[b], std::max<size_t>(pw * comm_size, 1) * 4), "hipMalloc");
+            HipCheck(hipMalloc(&d_ids2_[b], std::max<size_t>(n, 1) * 4), "hipMalloc");
+            HipCheck(hipMalloc(&d_dist2_[b], std::max<size_t>(n, 1) * 4), "hipMalloc");
+        }
+        sbuf_n_ = n;
+        sbuf_pw_ = pw;
+    }
 
     void EnsureBuffers(size_t nq, size_t chunk) {
         const size_t n = nq * num_probes * num_neighbors, pw = chunk * num_probes;
@@ -357,4 +491,10 @@ private:
     float *d_dist_ = nullptr, *d_out_dist_ = nullptr;
     char* d_scratch_ = nullptr;
     std::vector<char> host_scratch_;
+    // ProcessQueryStream: its three streams and the two sets of per-batch device arrays
+    hipStream_t s_route_ = nullptr, s_scan_ = nullptr, s_x_ = nullptr;
+    size_t sbuf_n_ = 0, sbuf_pw_ = 0;
+    int32_t *d_probes2_[2] = {nullptr, nullptr}, *d_all_probes2_[2] = {nullptr, nullptr};
+    uint32_t* d_ids2_[2] = {nullptr, nullptr};
+    float* d_dist2_[2] = {nullptr, nullptr};
 };

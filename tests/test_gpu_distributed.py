@@ -111,14 +111,14 @@ def _join_ranks(procs, tag, limit_s=240.0):
     pytest.fail(report)
 
 
-def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False):
+def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False, **extra):
     f = data["files"]
     out = str(data["tmp"] / f"out_{tag}.bin")
     router = str(data["tmp"] / router_name)
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank)
+        env = _rank_env(data, rank, world, backend, port, out, one_gpu_per_rank, **extra)
         procs.append(subprocess.Popen([DB, f["points"], f["queries"], f["gt"], str(data["k"]), f["part"], router], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = _join_ranks(procs, tag)
@@ -131,6 +131,9 @@ def _run(data, world, backend, tag, router_name, one_gpu_per_rank=False):
     line = [ln for ln in outs[0][0].split("\n") if ln.startswith("backend ")][0]
     assert f"ranks {world}" in line and abs(float(line.split("recall ")[1].split(",")[0]) - data["recall"]) < 1e-6
     assert "End-to-end time" in outs[0][0]
+    if "GPANN_DIST_PIPELINE" in extra:
+        stream = [ln for ln in outs[0][0].split("\n") if ln.startswith("Pipelined stream: ")]
+        assert stream and "identical to the single batch's 1" in stream[0], outs[0][0][-800:]
     return line
 
 
@@ -152,6 +155,15 @@ def test_ranks_sharing_one_gpu_over_tcp(data, world):
     single = str(data["tmp"] / "router_r1.tree")
     if os.path.exists(single):
         assert a == open(single, "rb").read()
+
+
+@pytest.mark.parametrize("world,backend", [(1, "rccl"), (2, "tcp"), (3, "tcp")])
+def test_pipelined_stream_of_batches(data, world, backend):
+    """GPANN_DIST_PIPELINE: after the reference's one-batch protocol the driver runs the block as a stream of batches through the three-stage
+    pipeline (route-ahead thread on a second communicator, deferred scans, exchange on a third stream): the last batch's neighbours must be
+    the single batch's, bit for bit (the driver checks and says so), and what rank 0 writes out must be the oracle's"""
+    line = _run(data, world, backend, f"p{world}{backend}", f"router_p{world}.tree", GPANN_DIST_PIPELINE="5")
+    assert line.startswith(f"backend {backend}")
 
 
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the 1-GPU boxes of rounds 1-4 skip this)")
