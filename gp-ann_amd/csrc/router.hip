@@ -2818,9 +2818,13 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         // the threshold replay on a table the matrix cores wrote, canonical evaluation of the cut-off band only (RouterBoundedReplayKernel)
         const char* tmode = std::getenv("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
         const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
-        const bool bounded = threshold_ok && !min_only && r->cent_planes != nullptr && (rec_dist == nullptr || rec_keep > 0) && (uint64_t)budget <= C && !(tmode && tmode[0] == '0') &&
-                             !r->canonical_once && r->cent_node8 != nullptr && r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
-                             ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
+        const bool bounded_able = r->cent_planes != nullptr && !(tmode && tmode[0] == '0') && !r->canonical_once && r->cent_node8 != nullptr &&
+                                  r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
+                                  ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
+        // FrequencyQuery with a budget above the tree: every centroid is visited, no tree logic at all — the votes are the pairs within the error
+        // of the V-th smallest table value (any tree shape: the sorted replay's trees too)
+        const bool all_rec = rec_dist != nullptr && rec_keep > 0 && all_roots_open && (uint64_t)budget > C && !force_heap;
+        const bool bounded = bounded_able && ((threshold_ok && !min_only && (rec_dist == nullptr || rec_keep > 0) && (uint64_t)budget <= C) || all_rec);
         if (rec_small && !bounded) {
             if (rec_truncated) *rec_truncated = true;
             return GPANN_OK;
@@ -2913,13 +2917,13 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             ra.root_total = r->root_total;
             ra.sort_n = sort_n;
             ra.n_nodes = r->n_nodes;
-            if (sorted_ok || threshold_ok) {
+            if (sorted_ok || threshold_ok || bounded) {
                 GPANN_TRY(r->ws_redo.Reserve((size_t)nb * 4 + 64));
                 ra.redo = r->ws_redo.as<uint32_t>();
                 ra.redo_count = ra.redo + nb;   // (+ 1..4: the bounded replay's counters)
                 GPANN_HIP_TRY(hipMemsetAsync(ra.redo_count, 0, 56, st));
             }
-            if (sorted_ok) {
+            if (sorted_ok && !bounded) {
                 const size_t table_words = ((size_t)(r->n_nodes + 1) + (r->n_nodes + 1) / 2 + 3) & ~(size_t)3;
                 const size_t s_lds = (table_words + ((((size_t)2 * ra.sort_n + S) + 3) & ~(size_t)3) * kRWaves) * sizeof(float);
                 const uint32_t s_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / s_lds));
@@ -2929,7 +2933,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                 hipLaunchKernelGGL(RouterSortedReplayKernel, dim3(s_grid), dim3(64 * kRWaves), s_lds, st, ra);
                 GPANN_HIP_TRY(hipGetLastError());
                 ra.only_redo = 1;
-            } else if (threshold_ok) {
+            } else if (threshold_ok || bounded) {
                 // a wavefront per query while the pi scratch (n_nodes words per wavefront) stays below 2 GiB: the kernel lives on wavefronts in flight
                 const uint32_t t_bpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / t_lds));
                 const uint64_t t_fit = std::max<uint64_t>(1, (2ull << 30) / ((uint64_t)kRWaves * r->n_nodes * 4));

@@ -402,7 +402,8 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
     if not expect_table:
         return
     # FrequencyQuery through the same path: only the pairs within the error of the num_voting-th smallest table value are evaluated
-    for budget, votes in ((C // 2, 500), (C // 3, 7), (C // 5, 2048)):   # (the last: fewer visited centroids than votes)
+    # (C // 5, 2048): fewer visited centroids than votes; C + 50: the budget covers the tree — every centroid is visited, no tree logic at all
+    for budget, votes in ((C // 2, 500), (C // 3, 7), (C // 5, 2048), (C + 50, 500), (C + 50, 3)):
         before = router.stats()
         md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, votes)
         st = router.stats()
@@ -460,6 +461,14 @@ def test_bounded_table_replay_with_duplicate_points(orc, gp):
         wp, wm = tree.query_batch(queries, budget, nthreads=4)
         assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp), budget
     assert router.stats()["table_blocks"] == 3
+    # FrequencyQuery on the same tree of equal keys: inside the tree and with a budget that covers it (votes among masses of equal distances)
+    for budget, votes in ((C // 2, 40), (C + 10, 40), (C + 10, 500)):
+        md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, votes)
+        for q in range(0, len(queries), 9):
+            wmd, wnd, wns = tree.frequency_query(queries[q], budget, votes)
+            assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32)), (budget, votes, q)
+            assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (budget, votes, q)
+    assert router.stats()["table_blocks"] == 6
 
 
 @pytest.mark.parametrize("metric", [0, 1])
