@@ -54,7 +54,7 @@ while time.time() < t_end:
     queries = np.ascontiguousarray(queries, np.float32)
     router = gp.Router(f, metric, 0)
     n_cfg += 1
-    for budget in sorted(set(int(x) for x in [lo_budget, lo_budget + 1, C - 1, C, *rng.integers(lo_budget, C + 1, 4)])):
+    for budget in sorted(set(int(x) for x in [lo_budget, lo_budget + 1, C - 1, C, C + 5, *rng.integers(lo_budget, C + 1, 4)])):
         before = router.stats()
         os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
         p1, m1, _ = router.query_batch(queries, budget)
@@ -68,7 +68,7 @@ while time.time() < t_end:
             bad += 1
             q = np.flatnonzero((m1.view(np.uint32) != m0.view(np.uint32)).any(axis=1))
             print(f"DIFF Query: d {d} S {S} n {n} metric {metric} nc {nc} min_cluster {min_cluster} scale {scale:.3g} C {C} budget {budget} nq {nq}: {len(q)} queries, first {q[:3]}", flush=True)
-        if used and rng.random() < 0.5:
+        if (used or budget > C) and rng.random() < 0.5:
             votes = int(rng.choice([1, 7, 50, 500, 2048]))
             os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
             a1 = router.frequency_query_batch(queries, budget, votes)
