@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — QPS at recall@10 >= 0.9 of the route + shard-scan hot path on synthetic 100M x 128 float vectors.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: one rank per GPU — started by torch.distributed.run, or, without a
+                                                                launcher, by bench.py itself: spawn_ranks)
 
 One "step" = one pass of the hot path over one batch of 10 000 queries that are already resident in HBM:
     KMeansTreeRouter::Query (GPU walk + host std::sort)  ->  per-(query, probe) exact shard scan + top-k (GPU)
@@ -78,7 +79,120 @@ def lloyd_gpu(torch, pygpann, sample, k, rounds, seed, stream):
     return cent, assign
 
 
+def _free_ports(span):
+    """`span` consecutive free TCP ports on 127.0.0.1 below the kernel's ephemeral range (a port from bind(0) can be handed to a connecting
+    rank as its SOURCE port: the socket then connects to itself — tests/conftest.py free_port has the story)"""
+    import random
+    import socket
+    lo_eph = 32768
+    try:
+        lo_eph = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError):
+        pass
+    hi = max(12000, min(lo_eph, 32768) - span - 1)
+    rng = random.Random(os.getpid() * 1000003 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(400):
+        p0 = rng.randrange(11000, hi)
+        socks = []
+        try:
+            for i in range(span):
+                sk = socket.socket()
+                socks.append(sk)
+                sk.bind(("127.0.0.1", p0 + i))
+            return p0
+        except OSError:
+            continue
+        finally:
+            for sk in socks:
+                sk.close()
+    raise SystemExit("bench.py: no free TCP ports for the ranks' bootstrap")
+
+
+def spawn_ranks(n_gpus):
+    """`python3 bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher — the shape of
+    the reference's distributed_bench.cpp:26-54, where every rank runs the same main() and rank 0 prints.  It starts N copies of itself as CHILD
+    processes, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's one JSON line and
+    returns the worst exit code.  Nothing here touches the GPU (no HIP call, no torch.cuda.is_available(): torch.cuda.device_count() does not
+    initialise the runtime on this image) and nothing is exec'ed: a process that has initialised the GPU must not be replaced by another."""
+    import signal
+    import subprocess
+    if "GPANN_BENCH_FORCE_DEVICE" not in os.environ:   # (debugging aid: every rank on the one named GPU, --backend tcp)
+        import torch
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            print(f"bench.py: --gpus {n_gpus} but this node has {have} GPU(s) visible; nothing was started "
+                  f"(GPANN_BENCH_FORCE_DEVICE=<id> with --backend tcp runs every rank on one GPU)", file=sys.stderr, flush=True)
+            return 2
+    port = _free_ports(4)   # MASTER_PORT, the exchange's bootstrap (+1) and the routing communicator's (+2), one spare
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(n_gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LOCAL_WORLD_SIZE": str(n_gpus),
+                 "GPANN_BENCH_SPAWNED": "1"})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0.pop("GPANN_COMM_PORT", None)
+    procs = []
+    for r in range(n_gpus):
+        env = dict(env0)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        # rank 0's stdout is this process's stdout (its one JSON line); the other ranks print nothing there, and if they do it goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else sys.stderr,
+                                      start_new_session=True))
+    log(f"launcher: started {n_gpus} ranks (pids {[p.pid for p in procs]}), MASTER_PORT {port}")
+    worst, failed_first = 0, None
+    try:
+        live = set(range(n_gpus))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and failed_first is None:
+                    failed_first = (r, rc)
+            if failed_first is not None and live:
+                # a rank has failed: the others come back through gpann_comm_wait on their own; give them a moment, then end exactly the processes started here
+                deadline = time.time() + float(os.environ.get("GPANN_BENCH_SPAWN_GRACE_S", "30"))
+                while live and time.time() < deadline:
+                    for r in sorted(live):
+                        if procs[r].poll() is not None:
+                            live.discard(r)
+                    time.sleep(0.2)
+                for r in sorted(live):
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGTERM)
+                    except OSError:
+                        pass
+                for r in sorted(live):
+                    try:
+                        procs[r].wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        try:
+                            os.killpg(procs[r].pid, signal.SIGKILL)
+                        except OSError:
+                            pass
+                live.clear()
+            time.sleep(0.1)
+    except KeyboardInterrupt:
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        worst = 130
+    if failed_first is not None:
+        print(f"bench.py: rank {failed_first[0]} ended with code {failed_first[1]}; the run has no result line", file=sys.stderr, flush=True)
+        worst = failed_first[1] if failed_first[1] > 0 else 1
+    return worst
+
+
 def main():
+    # `python3 bench.py --gpus N` without a launcher: start the N ranks as children (before anything touches the GPU) and relay rank 0's line
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        known, _ = pre.parse_known_args()
+        if known.gpus > 1:
+            sys.exit(spawn_ranks(known.gpus))
     # stdout carries exactly ONE line, the result: everything any library prints there meanwhile (gloo's connection notes, the
     # host trainer's progress lines, ...) goes to stderr
     sys.stdout.flush()

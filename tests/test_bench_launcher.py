@@ -1,0 +1,39 @@
+"""CPU: `python3 bench.py --gpus N` without a launcher must not need one (bench.py spawn_ranks) — and must say so plainly, starting nothing,
+when the node has fewer GPUs than ranks were asked for."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _env(**extra):
+    env = dict(os.environ, **extra)
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)
+    return env
+
+
+def test_more_ranks_than_gpus_is_refused_with_a_clear_message():
+    import torch
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 8)], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 2
+    assert f"--gpus {have + 8} but this node has {have} GPU(s)" in r.stderr and "nothing was started" in r.stderr
+    assert "torch.distributed.run" not in r.stderr      # (the old answer was a launcher hint)
+    assert r.stdout.strip() == ""
+
+
+def test_spawned_ranks_get_their_environment_and_the_worst_exit_code_comes_back(tmp_path):
+    """every child gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; without a GPU each rank ends with an error, which the launcher reports"""
+    import torch
+    if torch.cuda.device_count() > 0:
+        import pytest
+        pytest.skip("the no-GPU leg of the launcher (the GPU leg is tests/test_gpu_bench_line.py)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "tcp"], capture_output=True, text=True, timeout=300,
+                       env=_env(GPANN_BENCH_FORCE_DEVICE="0"), cwd=str(tmp_path))
+    assert r.returncode == 1
+    assert "launcher: started 2 ranks" in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") == 2
+    assert "rank 0 ended with code 1" in r.stderr or "rank 1 ended with code 1" in r.stderr
+    assert r.stdout.strip() == ""

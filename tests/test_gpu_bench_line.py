@@ -42,3 +42,21 @@ def test_bench_prints_a_line_that_meets_the_contract(tmp_path):
     assert c["sample_rows_per_query"] > 0 and c["batch_rows_per_query"] > 0 and c["value_scaled_to_batch"] > 0
     assert "hard_workload" not in j["detail"]          # (only the default workload carries that leg)
     assert "deferred" in j["config"]["pipeline"] or "enqueued behind" in j["config"]["pipeline"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment — how the driver starts it — must spawn the two ranks itself
+    (bench.py spawn_ranks) and print rank 0's ONE line; here both ranks share the one GPU over the TCP backend."""
+    env = dict(os.environ, GPANN_BENCH_FORCE_DEVICE="0", GPANN_COMM_WAIT_S="120")
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPANN_COMM_PORT", "GPANN_ROUTER_VERIFY", "GPANN_ROUTER_STRICT"):
+        env.pop(name, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "tcp", "--points", "400000", "--d", "64", "--shards", "6", "--nq", "1000",
+           "--steps", "3", "--warmup", "1", "--router-budget", "3000", "--no-cpu-baseline", "--no-exact-compare"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["detail"]["world_size_seen"] == 2
+    assert j["scaling"] == "strong" and j["value"] > 0
+    assert "launcher: started 2 ranks" in r.stderr
