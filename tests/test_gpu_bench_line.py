@@ -57,6 +57,6 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["detail"]["world_size_seen"] == 2
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["world_size_seen"] == 2
     assert j["scaling"] == "strong" and j["value"] > 0
     assert "launcher: started 2 ranks" in r.stderr
