@@ -839,6 +839,39 @@ def main():
         torch.cuda.synchronize()
         lat.append(1e3 * (time.perf_counter() - t1))
     latency_ms_one_batch = float(np.mean(lat))
+    cu_sweep = None
+    if os.environ.get("GPANN_BENCH_CU_SWEEP") and not multi:
+        # measurement aid (not part of any result): the scan of one batch on a stream that may use only the first N compute units
+        # (hipExtStreamCreateWithCUMask; the mask's bits interleave the XCDs) — how much of the chip the rest pass needs, what the passes before it lose
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        cu_sweep = []
+        lp = np.ascontiguousarray(probes[:, :nprobe])
+        oi = torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev)
+        od = torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)
+        for n_cu in [int(x) for x in os.environ["GPANN_BENCH_CU_SWEEP"].split(",") if x]:
+            words = (ctypes.c_uint32 * 8)(*[(((1 << max(0, min(32, n_cu - 32 * w))) - 1) & 0xFFFFFFFF) for w in range(8)])
+            st_m = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st_m), 8, words)
+            if rc != 0:
+                cu_sweep.append({"cus": n_cu, "error": f"hipExtStreamCreateWithCUMask -> {rc}"})
+                continue
+            rows = []
+            for it in range(6):
+                t1 = time.perf_counter()
+                shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), st_m.value, timed=True, for_merge=merge_bound)
+                hip.hipStreamSynchronize(st_m)
+                wall = 1e3 * (time.perf_counter() - t1)
+                stt = shards.stats()
+                _, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, st_m.value, on_device=True, nq=nq, out_probes=r_bufs[0] if route_ahead else None,
+                                                want_min_dist=False, n_top=None if nprobe == S else nprobe)
+                if it:
+                    rows.append((wall, stt["scan_ms"], stt["filter_ms"], stt["filter_rest_ms"], r_ms))
+            a = np.array(rows).mean(axis=0)
+            cu_sweep.append({"cus": n_cu, "scan_wall_ms": round(float(a[0]), 3), "scan_kernels_ms": round(float(a[1]), 3), "filter_ms": round(float(a[2]), 3),
+                             "rest_pass_ms": round(float(a[3]), 3), "router_kernels_ms": round(float(a[4]), 3)})
+            log(f"CU sweep: {cu_sweep[-1]}")
+            hip.hipStreamDestroy(st_m)
     merger.shutdown()
     if route_ahead:
         router_pool.shutdown()
@@ -929,6 +962,8 @@ def main():
                                    "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
     result["backend"] = comm.name if multi else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
     result["world_size_seen"] = comm.world if multi else 1
+    if cu_sweep is not None:
+        result["detail"]["cu_sweep"] = cu_sweep
     if multi:
         # the work every rank actually did in the last timed step: task rows (pairs) of its scan
         per_rank = comm.allgather_host(np.array([float(stats["pairs"])], np.float64)).reshape(-1)

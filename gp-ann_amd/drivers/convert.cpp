@@ -1,28 +1,41 @@
-// convert.cpp — this build's Convert driver: the live branch of the reference's convert.cpp (:62-89): load a .routes and a
-// .searches file, replay every route over every shard search and write the Pareto front of (recall, QPS) configurations
-// (PrintCombinationsOfRoutesAndSearches, route_search_combination.cpp:121-226).  Same argv, same output format.  The
-// reference's other branches are compiled out there (#if false) and are not reproduced.
+// Convert — routes + shard searches -> Pareto front.  Contract (the one live branch of the reference's convert.cpp:62-89):
+//   argv    routes-file  searches-file  output-file  part-method  query-file
+//   output  <output-file>: the CSV PrintCombinationsOfRoutesAndSearches writes (route_search_combination.cpp:121-226), evaluated for k = 10 neighbours
+//           and 40 requested hosts; the query file is read only for its point count
+// Everything is host arithmetic over two text files (host/routes_host.cpp); no GPU work happens here.
+#include <cstdlib>
 #include <iostream>
+#include <string>
 
 #include "points_io.h"
 #include "route_search_combination.h"
 #include "routes.h"
 #include "shard_searches.h"
 
+namespace {
+constexpr int kNeighbours = 10, kRequestedHosts = 40;
+struct Inputs {
+    std::string routes, searches, output, part_method, queries;
+};
+}   // namespace
+
 int main(int argc, const char* argv[]) {
     if (argc != 6) {
         std::cerr << "Usage ./Convert routes searches output part-method query-file" << std::endl;
         std::abort();
     }
-    const std::string routes_file = argv[1], searches_file = argv[2], output_file = argv[3], part_method = argv[4], query_file = argv[5];
-    auto searches = DeserializeShardSearches(searches_file);
-    std::cout << "Finished loading searches" << std::endl;
-    auto routes = DeserializeRoutes(routes_file);
-    std::cout << "num routes " << routes.size() << " num searches " << searches.size() << std::endl;
-    const int num_actual_shards = (int)searches.front().neighbors.size();
-    std::cout << "num actual shards = " << num_actual_shards << std::endl;
-    auto queries = ReadPoints(query_file);
-    const int num_queries = (int)queries.n;
-    PrintCombinationsOfRoutesAndSearches(routes, searches, output_file, 10, num_queries, num_actual_shards, 40, part_method);
+    const Inputs in{argv[1], argv[2], argv[3], argv[4], argv[5]};
+    std::vector<ShardSearch> shard_searches = DeserializeShardSearches(in.searches);
+    std::vector<RoutingConfig> routings = DeserializeRoutes(in.routes);
+    if (shard_searches.empty() || routings.empty()) {
+        std::cerr << "Convert: " << in.routes << " holds " << routings.size() << " routes, " << in.searches << " holds " << shard_searches.size()
+                  << " searches; nothing to combine" << std::endl;
+        return 1;
+    }
+    const int shards = (int)shard_searches.front().neighbors.size();
+    const int n_queries = (int)ReadPoints(in.queries).n;
+    std::cout << "Convert: " << routings.size() << " routes x " << shard_searches.size() << " searches, " << shards << " shards, " << n_queries
+              << " queries" << std::endl;
+    PrintCombinationsOfRoutesAndSearches(routings, shard_searches, in.output, kNeighbours, n_queries, shards, kRequestedHosts, in.part_method);
     return 0;
 }

@@ -1,11 +1,17 @@
-// small_scale_queries.cpp — MI355X build of the reference's SmallScaleQueries experiment (small_scale_queries.cpp:25-165):
-//   read points / queries / ground truth -> KMeansTreeRouter::Train{32, 200, 50000, 5000} -> route every query ->
-//   InvertedIndex -> for nprobe = 1..S: QueryBucket of the nprobe-th probe, DedupNeighbors, Recall -> CSV.
-// Same argv, same CSV columns and file formats.  Only the rows the hot path covers are produced: routing = KMTR,
-// shard query = BruteForce.  (The HNSW router / IVF-HNSW rows of the reference need hnswlib.)  Routing and the per-probe
-// scans are issued as one GPU batch each instead of one query at a time; the reported latencies are batch time / #queries.
+// SmallScaleQueries — route + scan + merge + recall on one data set, as a CSV of (probes, latency, recall) rows.
+// Contract (reference small_scale_queries.cpp:25-165; only what a consumer of the experiment can observe):
+//   argv   input-points  queries  ground-truth-file  num-neighbors  partition  part-method  out-file
+//   files  ground truth is read if the file exists, otherwise computed (on the GPU) and written in the big-ann layout; the partition is a clusters file
+//   CSV    header `partitioning,routing,shard query,probes,latency,routing latency, query latency,recall`; one row per number of probes 1..S, cumulative
+//          (probe p adds the p-th shard of every query's route to what the earlier probes found, then DedupNeighbors + Recall)
+//   router KMeansTreeRouterOptions{num_centroids 32, min_cluster_size 200, budget 50000, search_budget 5000} (small_scale_queries.cpp:98-103)
+// Rows produced: routing = KMTR, shard query = BruteForce — the hot path of this build.  The reference's HNSW-router / IVF-HNSW rows and its unpartitioned
+// branch need hnswlib and are not built.  Every stage is ONE device batch (QueryBatch, QueryBucketBatch); latencies are batch time / #queries.
+#include <cstdlib>
 #include <filesystem>
+#include <fstream>
 #include <iostream>
+#include <string>
 
 #include "inverted_index.h"
 #include "kmeans_tree_router.h"
@@ -13,81 +19,86 @@
 #include "points_io.h"
 #include "recall.h"
 
+namespace {
+
+struct Args {
+    std::string points, queries, ground_truth, partition, part_method, csv;
+    int k = 10;
+};
+
+double Seconds(Timer& t) { return t.Stop(); }
+
+// distance to the k-th true neighbour of every query: what Recall() compares against (recall.h:74-137)
+std::vector<float> RecallThresholds(const Args& a, PointSet& points, PointSet& queries) {
+    std::vector<NNVec> truth;
+    if (std::filesystem::exists(a.ground_truth)) {
+        truth = ReadGroundTruth(a.ground_truth);
+    } else {
+        std::cout << "no ground truth at " << a.ground_truth << ": computing it" << std::endl;
+        truth = ComputeGroundTruth(points, queries, a.k);
+        WriteGroundTruth(a.ground_truth, truth);
+    }
+    return ConvertGroundTruthToDistanceToKthNeighbor(truth, a.k, points, queries);
+}
+
+KMeansTreeRouterOptions SmallScaleRouter() {
+    KMeansTreeRouterOptions o;
+    o.num_centroids = 32;
+    o.min_cluster_size = 200;
+    o.budget = 50000;
+    o.search_budget = 5000;
+    return o;
+}
+
+}   // namespace
+
 int main(int argc, const char* argv[]) {
     if (argc != 8) {
         std::cerr << "Usage ./SmallScaleQueries input-points queries ground-truth-file num-neighbors partition part-method out-file" << std::endl;
         std::abort();
     }
-    const std::string point_file = argv[1], query_file = argv[2], ground_truth_file = argv[3];
-    const int num_neighbors = std::stoi(argv[4]);
-    const std::string partition_file = argv[5], part_method = argv[6], out_file = argv[7];
+    Args a{argv[1], argv[2], argv[3], argv[5], argv[6], argv[7], std::stoi(argv[4])};
     if (const char* m = std::getenv("GPANN_METRIC")) gpann_host::SetMetricMIPS(std::string(m) == "mips");
-
-    PointSet points = ReadPoints(point_file);
-    PointSet queries = ReadPoints(query_file);
-
-    std::vector<NNVec> ground_truth;
-    if (std::filesystem::exists(ground_truth_file)) {
-        ground_truth = ReadGroundTruth(ground_truth_file);
-    } else {
-        std::cout << "start computing ground truth" << std::endl;
-        ground_truth = ComputeGroundTruth(points, queries, num_neighbors);
-        std::cout << "computed ground truth" << std::endl;
-        WriteGroundTruth(ground_truth_file, ground_truth);
-        std::cout << "wrote ground truth to file " << ground_truth_file << std::endl;
-    }
-    std::vector<float> distance_to_kth_neighbor = ConvertGroundTruthToDistanceToKthNeighbor(ground_truth, num_neighbors, points, queries);
-    std::cout << "finished converting ground truth to distances" << std::endl;
-
-    if (!std::filesystem::exists(partition_file) || part_method == "None") {
-        std::cerr << "Not partitioned: the unpartitioned branch of the reference runs HNSW and is not part of this build." << std::endl;
+    if (a.part_method == "None" || !std::filesystem::exists(a.partition)) {
+        std::cerr << "SmallScaleQueries: no partition (" << a.partition << ", method " << a.part_method
+                  << "): the unpartitioned experiment of the reference is HNSW on the whole input and is not part of this build" << std::endl;
         return 1;
     }
-    Clusters clusters = ReadClusters(partition_file);
-    const int num_shards = (int)clusters.size();
+    PointSet points = ReadPoints(a.points), queries = ReadPoints(a.queries);
+    const std::vector<float> kth_distance = RecallThresholds(a, points, queries);
+    const Clusters shards = ReadClusters(a.partition);
+    const size_t nq = queries.n, S = shards.size();
 
-    Timer timer;
-    timer.Start();
-    KMeansTreeRouterOptions options;
-    options.num_centroids = 32;
-    options.min_cluster_size = 200;
-    options.budget = 50000;
-    options.search_budget = 5000;
+    Timer clock;
+    const KMeansTreeRouterOptions opt = SmallScaleRouter();
     KMeansTreeRouter router;
-    router.Train(points, clusters, options);
-    std::cout << "Training KMTR took " << timer.Stop() << " seconds." << std::endl;
+    clock.Start();
+    router.Train(points, shards, opt);
+    std::cout << "router trained in " << Seconds(clock) << " s" << std::endl;
+    clock.Start();
+    const std::vector<std::vector<int>> route = router.QueryBatch(queries, (int)opt.search_budget);   // a full permutation of the shards per query
+    const double t_route = Seconds(clock);
+    std::cout << "routed " << nq << " queries in " << t_route << " s (" << nq / t_route << " QPS)" << std::endl;
+    clock.Start();
+    InvertedIndex index(points, shards);
+    std::cout << "shard store built in " << Seconds(clock) << " s" << std::endl;
 
-    timer.Start();
-    std::vector<std::vector<int>> probes = router.QueryBatch(queries, (int)options.search_budget);
-    const double routing_time = timer.Stop();
-    std::cout << "KMTR routing took " << routing_time << " seconds. That's " << 1000.0 * routing_time / queries.n << "ms per query, or "
-              << queries.n / routing_time << " QPS" << std::endl;
-
-    timer.Start();
-    InvertedIndex ivf(points, clusters);
-    std::cout << "Building IVF took " << timer.Stop() << " seconds." << std::endl;
-
-    std::ofstream out(out_file);
-    out << "partitioning,routing,shard query,probes,latency,routing latency, query latency,recall" << std::endl;
-    std::cout << "Start queries" << std::endl;
-
-    std::vector<NNVec> neighbors(queries.n);
-    double time = 0;
-    for (int num_probes = 1; num_probes <= num_shards; ++num_probes) {
-        // QueryBucket(q, k, probes[q][num_probes - 1]) for every query, as one batch
-        std::vector<std::vector<int>> this_probe(queries.n);
-        for (size_t q = 0; q < queries.n; ++q) this_probe[q] = {probes[q][num_probes - 1]};
-        timer.Start();
-        auto found = ivf.QueryBucketBatch(queries, num_neighbors, this_probe, 1);
-        time += timer.Stop();
-        for (size_t q = 0; q < queries.n; ++q) neighbors[q].insert(neighbors[q].end(), found[q][0].begin(), found[q][0].end());
-        DedupNeighbors(neighbors, num_neighbors);
-        const double recall = Recall(neighbors, distance_to_kth_neighbor, num_neighbors);
-        const double latency = (routing_time + time) / queries.n;
-        std::cout << "router = KMTR query = IVF nprobes = " << num_probes << " recall = " << recall << " time = " << time
-                  << " avg latency = " << 1000.0 * latency << " ms" << std::endl;
-        out << part_method << ",KMTR,BruteForce," << num_probes << "," << latency << "," << routing_time / queries.n << "," << time / queries.n << ","
-            << recall << std::endl;
+    std::ofstream csv(a.csv);
+    csv << "partitioning,routing,shard query,probes,latency,routing latency, query latency,recall" << std::endl;
+    std::vector<NNVec> found(nq);
+    std::vector<std::vector<int>> one_probe(nq, std::vector<int>(1));
+    double t_scan = 0.0;
+    for (size_t p = 0; p < S; ++p) {
+        for (size_t q = 0; q < nq; ++q) one_probe[q][0] = route[q][p];
+        clock.Start();
+        const auto lists = index.QueryBucketBatch(queries, a.k, one_probe, 1);   // QueryBucket(q, k, route[q][p]) for every q
+        t_scan += Seconds(clock);
+        for (size_t q = 0; q < nq; ++q) found[q].insert(found[q].end(), lists[q][0].begin(), lists[q][0].end());
+        DedupNeighbors(found, a.k);
+        const double recall = Recall(found, kth_distance, a.k);
+        std::cout << "probes " << p + 1 << ": recall " << recall << ", scan time so far " << t_scan << " s" << std::endl;
+        csv << a.part_method << ",KMTR,BruteForce," << p + 1 << "," << (t_route + t_scan) / nq << "," << t_route / nq << "," << t_scan / nq << "," << recall
+            << std::endl;
     }
     return 0;
 }
