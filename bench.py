@@ -29,12 +29,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 # N > 1: how long a rank waits for a collective before it gives the run up (gpann_comm_wait also returns as soon as another rank has left)
 COMM_WAIT_S = int(os.environ.get("GPANN_COMM_WAIT_S", "600"))
 _live_comm = []   # the communicator of this process, for the exit path of a failed run
+_live_turns = []  # the timed loop's collective schedule (Turnstile), for the same exit path
+
+
+class Turnstile:
+    """ONE launch order, the same on every rank, for the collectives of the timed loop's TWO communicators (the route-ahead thread's probe
+    all-gathers, this thread's slot exchanges).  Each communicator alone is driven by one thread in one order — but two communicators on one GPU
+    whose collectives are launched in a different relative order on different ranks can wait for each other for ever when the GPU cannot
+    co-schedule both kernels (RCCL / NCCL: concurrent communicators need a consistent launch order).  `order` lists the collectives of one
+    run_steps call; slot(key) blocks until every earlier entry has been LAUNCHED (not completed), so the schedule costs no overlap."""
+
+    def __init__(self, order):
+        import threading
+        self.pos = {key: i for i, key in enumerate(order)}
+        self.turn = 0
+        self.dead = False
+        self.cv = threading.Condition()
+
+    @contextlib.contextmanager
+    def slot(self, key):
+        with self.cv:
+            self.cv.wait_for(lambda: self.dead or self.turn == self.pos[key])
+            if self.dead:
+                raise RuntimeError("the timed loop was given up (another thread of this rank failed)")
+        try:
+            yield
+        finally:
+            with self.cv:
+                self.turn += 1
+                self.cv.notify_all()
+
+    def abort(self):
+        with self.cv:
+            self.dead = True
+            self.cv.notify_all()
 for p in (ROOT, os.path.join(ROOT, "gp-ann_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_I8_PEAK_TOPS = 5000.0       # dense int8 MFMA peak: 32x32x32 in the cycles of bf16 32x32x16, twice the K (MI355X_MICROARCH.md, matrix cores table)
 VALU_F32_PEAK_TLANEOPS = 78.65   # 157.3 TFLOP/s fp32 vector counts an FMA as 2: unfused lane-ops (sub, mul, add) issue at half of it
 POINT_SEED, QUERY_SEED, CENTER_SEED = 555, 556, 7
 N_CENTERS, SIGMA = 1024, 0.35
@@ -476,7 +511,7 @@ def main():
     host_out = {}   # pinned result buffers per (nq, nprobe)
     dev_out = {}    # device result buffers per nprobe
 
-    def scan_slots(probes, nprobe, timed=False, aux=False, buf=0, for_merge=False):
+    def scan_slots(probes, nprobe, timed=False, aux=False, buf=0, for_merge=False, in_turn=None):
         """per-(query, slot) exact top-k on this rank's shards, gathered over ranks; returns (dist, global ids) on host.
         buf: which of the two pinned host buffer sets receives the results (the timed loop merges batch i on a worker thread while
         batch i + 1 is on the GPU)"""
@@ -501,8 +536,10 @@ def main():
                                  torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev),
                                  torch.empty(comm.gather_slots_scratch(n_slots), dtype=torch.uint8, device=dev if on_dev else "cpu"))
             hd, hi, gd, gi, scratch = host_out[key]
+            in_turn = contextlib.nullcontext() if in_turn is None else in_turn
             if on_dev:
-                comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(), stream=stream)
+                with in_turn:
+                    comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(), stream=stream)
                 hd.copy_(gd, non_blocking=True)
                 hi.copy_(gi, non_blocking=True)
                 comm.wait(stream, COMM_WAIT_S)   # (a synchronise that gives up when a rank has left: gpann_comm_wait)
@@ -511,7 +548,8 @@ def main():
                 hi.copy_(oi, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 sd_, si_ = hd.numpy().copy(), hi.numpy().view(np.uint32).copy()
-                comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
+                with in_turn:
+                    comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
             dist_h = hd.numpy()
             ids_h = hi.numpy().view(np.uint32)
         else:
@@ -531,11 +569,12 @@ def main():
 
     probes_top = {}   # pinned [nq][n_top] arrays
 
-    def route(n_top=None, j=0, st=None, cm=None):
+    def route(n_top=None, j=0, st=None, cm=None, turn=None, turn_key=None):
         """KMeansTreeRouter::Query for the whole batch.  n_top: only the first n_top shards of every order come back (the timed steps
         probe nprobe shards; the sweep before them needs the whole order).  N > 1: the router is replicated, every rank routes its slice
         of the queries and the probe lists ([nq][S] int32, 1.6 MB) are all-gathered — on stream `st` through communicator `cm` into buffer
-        set `j` (the timed loop's route-ahead thread passes its own of each)."""
+        set `j` (the timed loop's route-ahead thread passes its own of each; `turn`: the loop's collective schedule, Turnstile)."""
+        in_turn = turn.slot(turn_key) if turn is not None else contextlib.nullcontext()
         st = stream if st is None else st
         cm = comm if cm is None else cm
         if not multi:   # (one reusable host array for the probe lists; min_dist itself is not needed here)
@@ -559,11 +598,13 @@ def main():
         if on_dev:   # all-gather of the probe lists over RCCL on this stream
             with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)) if st != stream else contextlib.nullcontext():
                 dev_mine.copy_(mine_t, non_blocking=True)
-                cm.allgather(dev_mine.data_ptr(), dev_all.data_ptr(), mine.nbytes, st)
+                with in_turn:   # (the launch has its place in the loop's schedule; the wait below does not hold it)
+                    cm.allgather(dev_mine.data_ptr(), dev_all.data_ptr(), mine.nbytes, st)
                 all_t.copy_(dev_all, non_blocking=True)
             cm.wait(st, COMM_WAIT_S)
         else:
-            cm.allgather(mine, allp, mine.nbytes)
+            with in_turn:
+                cm.allgather(mine, allp, mine.nbytes)
         return allp.reshape(-1, S)[:nq], r_ms
 
     if multi:
@@ -694,10 +735,10 @@ def main():
         r_stream = torch.cuda.Stream(device=dev)
         r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
         router_pool = concurrent.futures.ThreadPoolExecutor(1)
-        def route_job(j):
+        def route_job(j, turn=None):
             if multi:   # my slice, the all-gather of the probe lists and its wait: all on the second stream, buffer sets 1 / 2 alternating
                 torch.cuda.set_device(local_rank)
-                pr, r_ms = route(j=1 + (j & 1), st=r_stream.cuda_stream, cm=comm_r)
+                pr, r_ms = route(j=1 + (j & 1), st=r_stream.cuda_stream, cm=comm_r, turn=turn, turn_key=("R", j))
                 return pr, r_ms, router.stats()
             pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j % 3],
                                              want_min_dist=False, n_top=None if nprobe == S else nprobe)
@@ -722,8 +763,9 @@ def main():
         shards.scan_buckets_device(queries.data_ptr(), nq, k, np.ascontiguousarray(pr[:, :nprobe]), nprobe, hi.data_ptr(), hd.data_ptr(), stream, for_merge=merge_bound,
                                    defer=True, host_out=True)
 
-    def scan_finish(buf):
+    def scan_finish(buf, in_turn=None):
         ms = shards.finish()
+        in_turn = contextlib.nullcontext() if in_turn is None else in_turn
         if multi:   # the batch's scan is complete (an overflowed filter call redone): its slot lists are exchanged on the third stream
             key = (nq, nprobe, buf)
             n_slots = nq * nprobe * k
@@ -735,8 +777,9 @@ def main():
             oi, od = dev_sets[buf]
             with torch.cuda.stream(x_stream):
                 if on_dev:
-                    comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(),
-                                      stream=x_stream.cuda_stream)
+                    with in_turn:
+                        comm.gather_slots(od.data_ptr(), oi.data_ptr(), n_slots, gd.data_ptr(), gi.data_ptr(), scratch.data_ptr(), id_map=my_ids_dev.data_ptr(),
+                                          stream=x_stream.cuda_stream)
                     hd.copy_(gd, non_blocking=True)
                     hi.copy_(gi, non_blocking=True)
                 else:
@@ -747,7 +790,8 @@ def main():
             else:
                 x_stream.synchronize()
                 sd_, si_ = hd.numpy().copy(), hi.numpy().view(np.uint32).copy()
-                comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
+                with in_turn:
+                    comm.gather_slots(sd_, si_, n_slots, hd.numpy(), hi.numpy().view(np.uint32), scratch.numpy(), id_map=my_ids_host)
             return hd.numpy(), hi.numpy().view(np.uint32), ms
         hd, hi = host_out[(nq, nprobe, buf)]
         return hd.numpy(), hi.numpy().view(np.uint32), ms
@@ -769,11 +813,24 @@ def main():
             algo_bytes.append(nonlocal_stats["algorithmic_bytes"])
             record["stats"] = nonlocal_stats
             record["router_bound_flops"] = rst["last_bound_flops"]
+        # several ranks: the loop's collectives — R j: the probe all-gather of batch j (route-ahead thread, second communicator), X i: the slot
+        # exchange of batch i (this thread) — are LAUNCHED in one order on every rank (Turnstile)
+        turn = None
+        if multi and route_ahead and count:
+            ahead = 2 if scan_ahead else 1
+            order = [("R", j) for j in range(min(ahead, count))]
+            for it in range(count):
+                if it + ahead < count:
+                    order.append(("R", it + ahead))
+                order.append(("X", it))
+            turn = Turnstile(order)
+            _live_turns.append(turn)
+        x_turn = (lambda it: turn.slot(("X", it))) if turn is not None else (lambda it: None)
         if scan_ahead and count:
             # routes run two batches ahead of the batch being completed, scans one
-            routes = {0: router_pool.submit(route_job, 0)}
+            routes = {0: router_pool.submit(route_job, 0, turn)}
             if count > 1:
-                routes[1] = router_pool.submit(route_job, 1)
+                routes[1] = router_pool.submit(route_job, 1, turn)
             info = {}
             pr, r_ms, rst = routes.pop(0).result()
             info[0] = (r_ms, rst)
@@ -787,22 +844,22 @@ def main():
                     pr, r_ms, rst = routes.pop(it + 1).result()
                     info[it + 1] = (r_ms, rst)
                     if it + 2 < count:
-                        routes[it + 2] = router_pool.submit(route_job, it + 2)
+                        routes[it + 2] = router_pool.submit(route_job, it + 2, turn)
                     scan_begin(pr, (it + 1) & 1)     # (batch it + 1 queued behind batch it, which the GPU is still working on)
-                sd, si, s_ms = scan_finish(it & 1)
+                sd, si, s_ms = scan_finish(it & 1, x_turn(it))
                 pending = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
                 note(t_step, info[it][0], s_ms, info.pop(it)[1])
                 t_step = time.perf_counter()
             if pending is not None:
                 md, mi, _ = pending.result()
             return md, mi
-        nxt = router_pool.submit(route_job, 0) if route_ahead and count else None
+        nxt = router_pool.submit(route_job, 0, turn) if route_ahead and count else None
         for it in range(count):
             t_step = time.perf_counter()
             if route_ahead:
                 pr, r_ms, rst = nxt.result()
-                nxt = router_pool.submit(route_job, it + 1) if it + 1 < count else None
-                sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=it & 1, for_merge=merge_bound)
+                nxt = router_pool.submit(route_job, it + 1, turn) if it + 1 < count else None
+                sd, si, s_ms = scan_slots(pr, nprobe, timed=True, buf=it & 1, for_merge=merge_bound, in_turn=x_turn(it))
                 fut = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
             else:
                 fut, _, r_ms, s_ms = step(buf=it & 1, merge_later=merger)
@@ -909,8 +966,14 @@ def main():
     if filtered:
         f_s = float(np.mean(filter_ms)) / 1000.0
         r_s = float(np.mean(rest_ms)) / 1000.0
-        flops = stats["filter_pairs"] * d * 6.0   # (upper bound: the hi-plane-only passes run 2 of the 3 products)
-        tflops = flops / f_s / 1e12 if f_s > 0 else 0.0
+        # matrix-core work: the wave-instructions the filter kernels ISSUED, counted by the kernels themselves (gpann_scan_stats.filter_mfma_*: KS per
+        # plane product of a (row tile, query tile) pair; the 8-bit passes' second half only where the H.P' test did not rule the product out), each
+        # dtype against its own dense peak.  The two dtypes share the filter launches' time (f_s: the head pass and the sample..rest interval, HIP
+        # events), so each fraction is a lower bound of that dtype's own utilisation and their sum is at most 1; the rest pass alone — int8 only when
+        # it runs on the 8-bit plane — is divided by its own launch time
+        bf16_tflops = stats["filter_mfma_bf16"] * 32768.0 / f_s / 1e12 if f_s > 0 else 0.0     # v_mfma_f32_32x32x16_bf16: 32 x 32 x 16 x 2 flop
+        i8_tops = stats["filter_mfma_i8"] * 65536.0 / f_s / 1e12 if f_s > 0 else 0.0           # v_mfma_i32_32x32x32_i8: 32 x 32 x 32 x 2 integer ops
+        rest_i8_tops = stats["filter_rest_mfma_i8"] * 65536.0 / r_s / 1e12 if r_s > 0 else 0.0
         # bytes the rest pass has to read: its row tiles x (bf16 hi plane [+ lo plane] + the row's norm word)
         ks_read = stats["filter_plane_ksteps"]   # 16-dim k-steps a plane row is stored with and the kernel loads (32 B each; ceil(d / 16) rounded up to a kernel instance)
         # (bf16 hi plane: 32 B per k-step of 16 dimensions; 8-bit plane: 32 B per k-step of 32 dimensions — the library reports which)
@@ -941,7 +1004,15 @@ def main():
                                       "exceeds the HBM peak because the exact answer is produced without that work (cell pruning, bf16 matrix-core bound, "
                                       "canonical re-scoring of the candidates only) and is not a roofline fraction",
                               "algorithmic_GBps": hbm_alg, "algorithmic_bytes_per_step": float(np.mean(algo_bytes)),
-                              "filter_kernels_ms": 1000.0 * f_s, "filter_mfma_TFLOPs": tflops, "filter_mfma_frac": tflops / MFMA_BF16_PEAK_TFLOPS,
+                              "filter_kernels_ms": 1000.0 * f_s,
+                              "filter_mfma_bf16_TFLOPs": bf16_tflops, "filter_mfma_frac_bf16": bf16_tflops / MFMA_BF16_PEAK_TFLOPS,
+                              "filter_mfma_i8_TOPs": i8_tops, "filter_mfma_frac_i8": i8_tops / MFMA_I8_PEAK_TOPS,
+                              "rest_pass_mfma_i8_TOPs": rest_i8_tops, "rest_pass_mfma_frac_i8": rest_i8_tops / MFMA_I8_PEAK_TOPS,
+                              "filter_mfma_issued": {"bf16_32x32x16": stats["filter_mfma_bf16"], "i8_32x32x32": stats["filter_mfma_i8"],
+                                                     "i8_32x32x32_rest_pass": stats["filter_rest_mfma_i8"]},
+                              "filter_mfma_note": "issued matrix instructions counted by the kernels (not pairs x d): bf16 against 2.5 PFLOP/s, int8 against 5 POP/s "
+                                                  "(MI355X_MICROARCH.md: 2x the bf16 rate per clock); filter_* over the filter launches' HIP-event time, rest_pass_* over "
+                                                  "the rest pass's own",
                               "filter_pairs": stats["filter_pairs"], "filter_candidates": stats["filter_candidates"], "filter_dirty_tasks": stats["filter_dirty_tasks"],
                               "filter_rows": stats["filter_rows"], "filter_rest_rows": stats["filter_rest_rows"]}
     else:
@@ -992,6 +1063,12 @@ def main():
                         "router_configs": [{kk: c[kk] for kk in ("index_budget", "nprobe", "trial_ms", "train_s", "recall_curve", "frequency_query") if kk in c} | {"centroids": int(c["tree"]["centroids"].shape[0]), "nodes": int(len(c["tree"]["node_shard"]))} for c in candidates],
                         "router_nodes": int(len(tree["node_shard"])),
                         "router_centroids": int(tree["centroids"].shape[0]), "setup_s": time.time() - t_setup}
+    # the router's always-on self-checks over the whole run (gpann_router_get_stats): events where the matrix-core bound path left a minimum unset and the
+    # block was re-evaluated canonically (bound_selfcheck), blocks GPANN_ROUTER_VERIFY compared and found different (verify_failures) — both must be 0
+    rs_all = router.stats()
+    result["detail"]["router_selfcheck_events"] = int(rs_all["bound_selfcheck"])
+    result["detail"]["router_verify_failures"] = int(rs_all["verify_failures"])
+    result["detail"]["router_bound_calls"] = int(rs_all["bound_calls"])
 
     # tuning aid (off by default): GPANN_BENCH_SWEEP="GPANN_FILTER_SEED_ROWS=64,128;GPANN_FILTER_HEAD_ROWS=512,0" times a few steps for every
     # combination of the listed library knobs (they are read per call) and checks that the results do not change
@@ -1431,10 +1508,14 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
     dt, _, _ = run(orc, sub, cores)
     # the same sub-sample with the flags upstream ships (-O3 -march=native -ffast-math, CMakeLists.txt:15): not the parity oracle
     # (results may differ in the last bits), reported so the strict flags do not flatter the GPU
-    fast = None
+    fast = fast32 = None
     try:
-        dtf, _, _ = run(pyoracle.Oracle("refflags"), sub, cores)
+        o_fast = pyoracle.Oracle("refflags")
+        dtf, _, _ = run(o_fast, sub, cores)
         fast = len(sub) / dtf
+        # ... and on the reference's 32 workers over the WHOLE sample: the cell next to value_32_threads (same queries, same threads, upstream's flags)
+        dtf32, _, _ = run(o_fast, everything, t32)
+        fast32 = len(qidx) / dtf32
     except Exception:
         pass
     # `value` = the better of the two thread counts (on a 256-thread host the reference's own cap of 32 workers is the faster setting: the
@@ -1442,7 +1523,7 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
     v_all, v_32 = len(sub) / dt, len(qidx) / dt32
     return {"value": max(v_all, v_32), "unit": "queries/s", "cores": cores if v_all >= v_32 else t32, "kind": "port", "cpu_model": cpu_model(),
             "value_all_threads": v_all, "threads_all": cores,
-            "value_reference_flags": fast, "value_32_threads": v_32, "threads_32": t32, "results_match_gpu": match,
+            "value_reference_flags": fast, "value_32_threads": v_32, "threads_32": t32, "value_reference_flags_32_threads": fast32, "results_match_gpu": match,
             "sample_queries": int(len(qidx)), "sample_pairs": pairs, "sample_GBps": pairs * d * 4 / dt32 / 1e9,
             "sample_rows_per_query": sample_rows_per_query, "batch_rows_per_query": batch_rows_per_query,
             "value_scaled_to_batch": max(v_all, v_32) * sample_rows_per_query / max(batch_rows_per_query, 1.0),
@@ -1451,7 +1532,8 @@ def cpu_baseline(args, shards, tree, queries, probes, nprobe, kth, counts, gpu_d
             "sample": f"{len(qidx)} of {len(first)} queries (those routed entirely into shards {chosen}), same nprobe={nprobe}; "
                       f"{pairs:.3g} (query,row) pairs = {pairs * d * 4 / 1e9:.0f} GB streamed in {dt32:.1f}s on {t32} threads — the reference's own cap — (rows "
                       f"first-touched by {touchers} threads in interleaved 2 MiB blocks); strict build (-O2, no fast-math/FMA/AVX); value_all_threads: {len(sub)} of "
-                      f"them on {cores} threads in {dt:.1f}s; value_reference_flags: those {len(sub)} with -O3 -march=native -ffast-math on {cores} threads",
+                      f"them on {cores} threads in {dt:.1f}s; value_reference_flags: those {len(sub)} with -O3 -march=native -ffast-math on {cores} threads; "
+                      f"value_reference_flags_32_threads: all {len(qidx)} with those flags on {t32} threads (cell for cell beside value_32_threads)",
             "seconds": dt32}
 
 
@@ -1461,6 +1543,8 @@ if __name__ == "__main__":
     except BaseException:
         # a rank that fails leaves without waiting for collectives the others may be in (ncclCommDestroy could block on them); closing the
         # bootstrap connections is what makes their gpann_comm_wait return
+        for t in _live_turns:   # (a route-ahead job waiting for its place in the schedule leaves instead of waiting for ever)
+            t.abort()
         for c in _live_comm:
             c.abort()
         raise

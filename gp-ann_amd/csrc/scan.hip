@@ -710,7 +710,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     group_first[G] = (uint32_t)items_cap;
     const size_t gtab_words = ((size_t)3 * G + 1 + 3) / 4 * 4;   // group_first [G+1] | group_count [G] | group_cursor [G], 16-byte multiple
     const size_t ticket_words = 0;
-    GPANN_TRY(s->ws_need.Reserve((4 * need_words + ticket_words) * 4 + (size_t)G * sizeof(CellGroup) + 64 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
+    GPANN_TRY(s->ws_need.Reserve((4 * need_words + ticket_words) * 4 + (size_t)G * sizeof(CellGroup) + 96 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
     need_pass[0] = s->ws_need.as<uint32_t>();
     need_pass[1] = need_pass[0] + need_words;
@@ -719,7 +719,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     uint32_t* d_tickets = done_head + need_words;      // (zeroed with the masks)
     CellGroup* d_groups_own = reinterpret_cast<CellGroup*>(d_tickets + ticket_words);
     unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_groups_own + G);   // [0..2] work counters (scan_cells.h), [3] = [1] before the rest pass
-    uint32_t* d_group_first_own = reinterpret_cast<uint32_t*>(d_work + 4);
+    uint32_t* d_group_first_own = reinterpret_cast<uint32_t*>(d_work + 8);   // (8 counters: [4] / [5] = bf16 / int8 matrix instructions issued, [6] = [5] before the rest pass, [7] spare)
     uint32_t* d_group_count = d_group_first_own + G + 1;   // (+ the claim cursors: zeroed together by NeedKernel)
     CellItem* d_items = reinterpret_cast<CellItem*>(d_group_first_own + gtab_words);
     // the call's tables join the task arrays in the upload batch (one copy for all of them, flushed below)
@@ -855,8 +855,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         ia.zero_words[1] = T;
         ia.zero[2] = need_pass[0];             // the passes' need / done masks
         ia.zero_words[2] = 4 * (uint64_t)need_words + ticket_words;
-        ia.zero[4] = reinterpret_cast<uint32_t*>(d_work);   // work counters (4 x u64)
-        ia.zero_words[4] = 8;
+        ia.zero[4] = reinterpret_cast<uint32_t*>(d_work);   // work counters (8 x u64)
+        ia.zero_words[4] = 16;
         ia.zero[3] = cand_cnt;                 // [T]
         ia.zero_words[3] = T;
         ia.query_tau = d_query_tau;
@@ -1253,7 +1253,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // after this function in a plain call, in gpann_scan_finish for a deferred one) — nothing here waits for the device
         uint32_t* pin = CS(s).pin_words;
         GPANN_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 16, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(pin + 4, d_work, 32, hipMemcpyDeviceToHost, st));
+        GPANN_HIP_TRY(hipMemcpyAsync(pin + 4, d_work, 56, hipMemcpyDeviceToHost, st));
         GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));
         const size_t n = (size_t)T * k;
         hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k,
@@ -1268,14 +1268,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
 // than the pipeline redoes itself: the data defeats the filter, the call has to be redone with the plain exact scan.
 static void CollectFilterCounters(gpann_shards::CallState& c, bool* overflow) {
     const uint32_t* h_words = c.pin_words;
-    unsigned long long h_work[4];
-    std::memcpy(h_work, c.pin_words + 4, 32);
+    unsigned long long h_work[7];
+    std::memcpy(h_work, c.pin_words + 4, 56);
     ScanPlan& plan = c.plan;
     plan.filter_rest_rows = (uint64_t)(h_work[1] - h_work[3]) * kGTileRows;
     plan.filter_candidates = (uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32);
     plan.filter_pairs = (uint64_t)h_work[0] * 1024ull;
     plan.filter_rows = (uint64_t)(h_work[1] + h_work[2]) * kGTileRows;
     plan.filter_two_plane_rows = (uint64_t)h_work[2] * kGTileRows;
+    plan.filter_mfma_bf16 = h_work[4];
+    plan.filter_mfma_i8 = h_work[5];
+    plan.filter_rest_mfma_i8 = h_work[5] - h_work[6];
     plan.filter_dirty_tasks = h_words[1];
     *overflow = h_words[1] > c.dirty_cap;
     if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] buckets overflowed (task x pass) %u, dirty tasks redone exactly %u (cap %u)\n", h_words[0], h_words[1], c.dirty_cap);
@@ -1416,6 +1419,9 @@ static void FillStats(gpann_shards* s, const gpann_shards::CallState& c, bool fi
     s->stats.filter_candidates = plan.filter_candidates;
     s->stats.filter_plane_ksteps = filtered ? s->cells.plane_ks : 0u;
     s->stats.filter_two_plane_rows = plan.filter_two_plane_rows;
+    s->stats.filter_mfma_bf16 = plan.filter_mfma_bf16;
+    s->stats.filter_mfma_i8 = plan.filter_mfma_i8;
+    s->stats.filter_rest_mfma_i8 = plan.filter_rest_mfma_i8;
     s->stats.filter_dirty_tasks = plan.filter_dirty_tasks;
     s->stats.filter_rest_row_bytes = filtered ? plan.filter_rest_row_bytes : 0u;
     s->stats.filter_seed_rows = filtered ? plan.padded_pairs : 0;

@@ -375,7 +375,8 @@ struct CellFilterArgs {
     const uint32_t* done0b;      // (optional) OR-ed into done0
     const uint32_t* done1;
     uint32_t kmax, head_tiles, sample_div, pass;
-    unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] / [2] += row tiles streamed by hi-plane / two-plane launches
+    unsigned long long* work;    // [0] += (query tile, row tile) products run, [1] / [2] += row tiles streamed by hi-plane / two-plane launches,
+                                 // [3] = [1] before the rest pass, [4] / [5] += bf16 / int8 matrix instructions issued, [6] = [5] before the rest pass
     uint32_t n_groups;
     // the pass's work items, written by FilterItemsKernel: a (task group, cell) block's tile range cut into pieces of <= seg_tiles.
     // The items of task group g are items[group_first[g] .. + group_count[g]) (group_first: capacities, computed by the host);
@@ -673,7 +674,10 @@ static __global__ void __launch_bounds__(kItemsThreads) PassItemsKernel(PassSetu
     if (tid == 0) {
         f.group_count[g] = s_misc[0];
         f.group_cursor[g] = 0u;
-        if (g == 0 && f.pass == 2 && f.work) f.work[3] = f.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
+        if (g == 0 && f.pass == 2 && f.work) {
+            f.work[3] = f.work[1];   // hi-plane row tiles streamed before the rest pass (its own rows = the difference)
+            f.work[6] = f.work[5];   // ... and the int8 matrix instructions issued before it
+        }
     }
 }
 
@@ -818,6 +822,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     // pass: 4.21 against 4.08 ms.)
     __shared__ uint32_t s_claim[4];
     uint32_t my_products = 0, my_tiles = 0;
+    uint32_t my_second = 0;   // (MODE 2) products whose second half — L.P', KS more matrix instructions — was multiplied too
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t ld = a.ld;
@@ -925,7 +930,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_init[r] = BIAS ? kBiasBits : 0;
     if constexpr (BIAS) asm volatile("" : "+v"(acc_init));
-    uint32_t q8_seen = 0, q8_hits = 0;   // (MODE 2) products this wavefront has run / that had a candidate
+    uint32_t q8_hits = 0;   // (MODE 2) products of this wavefront that had a candidate (of my_products: counted per unit of work, so it runs up to a unit ahead)
     uint32_t iter = 0;
     uint32_t r_t_begin, r_t_end, r_t_a, r_t_b, r_task_begin, r_lo_shift, r_acts, r_group, r_block = 0, r_scale_bits = 0, r_hi_shift = 0;
     {
@@ -1039,8 +1044,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     // word, so nmax is as good as a row's own; lb costs about 0.13 standard deviations of V.)  No lane >= 0: no row of the tile can pass,
     // the 4 KS matrix instructions of L.P' and the 16 row tests are skipped.
     auto quick8 = [&](const i32x16& h0, float2 bound, int q0) __attribute__((always_inline)) {
-        ++q8_seen;
-        if (!(q8_seen >= 16u && q8_hits * 4u < q8_seen)) return true;
+        if (!(my_products >= 16u && q8_hits * 4u < my_products)) return true;
         int hm = h0[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) hm = max(hm, h0[r]);
@@ -1079,6 +1083,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
             }
             const bool run0 = quick8(h0, bound0, q0), run1 = quick8(h1, bound1, q0);
             if (!(run0 || run1)) continue;
+            my_second += 2u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v4i32 a0 = __builtin_bit_cast(v4i32, A0[ks].q), a1 = __builtin_bit_cast(v4i32, A1[ks].q);
@@ -1165,6 +1170,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
                 h0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bh0, h0, 0, 0, 0);
             }
             if (!quick8(h0, nmax, q0)) return;
+            my_second += 1u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v4i32 av = __builtin_bit_cast(v4i32, Ah[ks].q);
@@ -1304,6 +1310,10 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
         atomicAdd(&a.work[HI_ONLY ? 1 : 2], (unsigned long long)my_tiles);   // (row tiles of hi-plane launches / of two-plane launches)
+        // matrix instructions this wavefront ISSUED: v_mfma_f32_32x32x16_bf16 — KS per plane product, two or three products — into [4],
+        // v_mfma_i32_32x32x32_i8 — KS for H.P' of every product, KS more where L.P' was multiplied — into [5]
+        if (Q8) atomicAdd(&a.work[5], (unsigned long long)(my_products + my_second) * (unsigned long long)KS);
+        else atomicAdd(&a.work[4], (unsigned long long)my_products * (unsigned long long)(KS * (HI_ONLY ? 2 : 3)));
     }
 }
 

@@ -26,6 +26,7 @@ struct ScanPlan {
     std::vector<uint32_t> task_query, task_out, task_part, task_nseg, task_shard, shard_task_begin;
     std::vector<ScanUnit> units;
     uint64_t n_lists = 0, pairs = 0, padded_pairs = 0, filter_pairs = 0, filter_candidates = 0, filter_rows = 0, filter_rest_rows = 0, filter_two_plane_rows = 0;
+    uint64_t filter_mfma_bf16 = 0, filter_mfma_i8 = 0, filter_rest_mfma_i8 = 0;
     bool filter_rest_hi_only = false;
     uint32_t filter_launches = 0, filter_dirty_tasks = 0, filter_rest_row_bytes = 0;
     void Clear() {
@@ -37,6 +38,7 @@ struct ScanPlan {
         shard_task_begin.clear();
         units.clear();
         n_lists = pairs = padded_pairs = filter_pairs = filter_candidates = filter_rows = filter_rest_rows = filter_two_plane_rows = 0;
+        filter_mfma_bf16 = filter_mfma_i8 = filter_rest_mfma_i8 = 0;
         filter_launches = filter_dirty_tasks = filter_rest_row_bytes = 0;
     }
 };
@@ -165,7 +167,7 @@ struct gpann_shards {
         int filter_passes_timed = 0;
         gpann::ScanPlan plan;
         gpann::PinnedStage stage;
-        uint32_t* pin_words = nullptr;   // pinned [16]: the filtered pipeline's counters land here (overflow / dirty words [0..3], work counters [4..11])
+        uint32_t* pin_words = nullptr;   // pinned [24]: the filtered pipeline's counters land here (overflow / dirty words [0..3], work counters [4..17])
         // what the completion of the call (CompleteCall: at once, or in gpann_scan_finish) needs to know
         bool pending = false;            // enqueued, not completed yet
         bool filtered = false;           // the filtered pipeline ran (its counters are on their way to pin_words)

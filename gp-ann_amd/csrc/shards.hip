@@ -133,7 +133,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     for (auto& c : s->cs) {
         for (auto& e : c.ev) TRY_OR_FAIL(hipEventCreate(&e));
         for (auto& e : c.ev_filter) TRY_OR_FAIL(hipEventCreate(&e));
-        TRY_OR_FAIL(hipHostMalloc(reinterpret_cast<void**>(&c.pin_words), 64, hipHostMallocDefault));
+        TRY_OR_FAIL(hipHostMalloc(reinterpret_cast<void**>(&c.pin_words), 96, hipHostMallocDefault));
     }
 
     if (rows) {

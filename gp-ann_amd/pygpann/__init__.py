@@ -45,7 +45,8 @@ class ScanStats(C.Structure):
                 ("scan_ms", C.c_float), ("merge_ms", C.c_float), ("filter_ms", C.c_float), ("filter_dirty_tasks", C.c_uint32),
                 ("filter_rows", C.c_uint64), ("filter_rest_rows", C.c_uint64), ("filter_rest_ms", C.c_float), ("filter_rest_hi_only", C.c_uint32),
                 ("filter_two_plane_rows", C.c_uint64), ("filter_seed_rows", C.c_uint64),
-                ("filter_rest_row_bytes", C.c_uint32), ("reserved3", C.c_uint32)]
+                ("filter_rest_row_bytes", C.c_uint32), ("reserved3", C.c_uint32),
+                ("filter_mfma_bf16", C.c_uint64), ("filter_mfma_i8", C.c_uint64), ("filter_rest_mfma_i8", C.c_uint64)]
 
 
 class RouterStats(C.Structure):

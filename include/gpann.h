@@ -177,6 +177,9 @@ typedef struct gpann_scan_stats {
     uint64_t filter_seed_rows;   /* rows evaluated exactly for the first lists (filter mode: tasks x seed rows) */
     uint32_t filter_rest_row_bytes; /* bytes the rest pass reads per row: 32 x k-steps (bf16 hi plane) or 32 x ceil(d / 32) (8-bit plane) + the norm word */
     uint32_t reserved3;
+    uint64_t filter_mfma_bf16;   /* v_mfma_f32_32x32x16_bf16 wave-instructions the filter kernels ISSUED (32 x 32 x 16 x 2 flop each), counted by the kernels */
+    uint64_t filter_mfma_i8;     /* v_mfma_i32_32x32x32_i8 wave-instructions issued (32 x 32 x 32 x 2 integer ops each): H.P' of every product + L.P' where it was not skipped */
+    uint64_t filter_rest_mfma_i8;/* of filter_mfma_i8: the rest pass alone (0 when it ran on the bf16 plane) */
 } gpann_scan_stats;
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
 

@@ -60,3 +60,25 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["world_size_seen"] == 2
     assert j["scaling"] == "strong" and j["value"] > 0
     assert "launcher: started 2 ranks" in r.stderr
+
+
+def test_matrix_core_figures_are_counted_not_modelled(tmp_path):
+    """roofline.filter_mfma_*: issued matrix instructions from the kernels' own counters, each dtype against its own peak — a cloud without cluster
+    structure (every query tile on every row tile: where the old pairs x d x 6 / bf16-peak figure read 2.3) must give fractions in (0, 1]"""
+    env = dict(os.environ)
+    env.pop("GPANN_ROUTER_VERIFY", None)
+    env.pop("GPANN_ROUTER_STRICT", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--points", "600000", "--d", "128", "--shards", "6", "--nq", "1000", "--steps", "3", "--warmup", "1",
+           "--router-budget", "3000", "--dist", "uniform", "--nprobe", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.split("\n") if ln.strip()][-1])
+    ro = j["roofline"]
+    assert "filter_mfma_frac" not in ro and "filter_mfma_TFLOPs" not in ro
+    issued = ro["filter_mfma_issued"]
+    assert issued["i8_32x32x32"] > 0 and issued["bf16_32x32x16"] > 0 and 0 < issued["i8_32x32x32_rest_pass"] <= issued["i8_32x32x32"]
+    assert 0.0 < ro["filter_mfma_frac_i8"] <= 1.0 and 0.0 < ro["filter_mfma_frac_bf16"] <= 1.0 and 0.0 < ro["rest_pass_mfma_frac_i8"] <= 1.0
+    assert ro["filter_mfma_frac_i8"] + ro["filter_mfma_frac_bf16"] <= 1.0
+    # every (row tile, query tile) product of an 8-bit pass issues KS = d / 32 instructions for H.P' and at most as many again for L.P'
+    assert j["detail"]["router_selfcheck_events"] == 0 and j["detail"]["router_verify_failures"] == 0
+    assert j["detail"]["exact_mode"]["results_identical_to_filter_mode"] is True
