@@ -731,6 +731,10 @@ def main():
     # (several ranks: the scan is deferred the same way — into device arrays, two sets — and the exchange of batch i's slot lists (gather_slots,
     # the copies to the host) runs on a THIRD stream once its scan has been completed, next to the scan of batch i + 1)
     scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
+    # (round 5) ... on the handle's own two streams (GPANN_SCAN_OVERLAP): the passes before the rest pass of batch i + 1 — short launches that leave
+    # most of the chip idle — run BESIDE the rest pass of batch i, which is bound by HBM and gives up compute units every few work items.
+    # GPANN_BENCH_OVERLAP=0: both calls on one stream, batch i + 1 strictly behind batch i.
+    scan_overlap = scan_ahead and os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0"
     if route_ahead:
         r_stream = torch.cuda.Stream(device=dev)
         r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
@@ -755,13 +759,13 @@ def main():
             if buf not in dev_sets:
                 dev_sets[buf] = (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev))
             oi, od = dev_sets[buf]
-            shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, for_merge=merge_bound, defer=True)
+            shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, for_merge=merge_bound, defer=True, overlap=scan_overlap)
             return
         if key not in host_out:
             host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory())
         hd, hi = host_out[key]
         shards.scan_buckets_device(queries.data_ptr(), nq, k, np.ascontiguousarray(pr[:, :nprobe]), nprobe, hi.data_ptr(), hd.data_ptr(), stream, for_merge=merge_bound,
-                                   defer=True, host_out=True)
+                                   defer=True, host_out=True, overlap=scan_overlap)
 
     def scan_finish(buf, in_turn=None):
         ms = shards.finish()
@@ -1033,8 +1037,6 @@ def main():
                                    "router_mfma_note": "RouterBoundKernel passes 1 + 2 (HIP events on the router's stream): 2 passes x 3 bf16 products x 2 nq C d flops"})
     result["backend"] = comm.name if multi else "none (1 rank)"      # what libgpann_comm.so reports: "rccl <version>" / "tcp"
     result["world_size_seen"] = comm.world if multi else 1
-    if cu_sweep is not None:
-        result["detail"]["cu_sweep"] = cu_sweep
     if multi:
         # the work every rank actually did in the last timed step: task rows (pairs) of its scan
         per_rank = comm.allgather_host(np.array([float(stats["pairs"])], np.float64)).reshape(-1)
@@ -1045,7 +1047,8 @@ def main():
     result["config"]["slot_lists"] = ("cut at the query's merge bound (GPANN_SCAN_FOR_MERGE): the merged neighbours are bit-identical to the merge of the "
                                       "complete QueryBucket lists" if merge_bound else "complete QueryBucket lists")
     result["config"]["pipeline"] = (("batches overlap: batch i+2 is routed (second stream), the scan of batch i+1 is planned and enqueued behind batch i (deferred "
-                                     "scan call) and batch i-1 is merged on the host while batch i is scanned" if scan_ahead else
+                                     "scan call" + (" on the store's own two streams: its passes before the rest pass run BESIDE the rest pass of batch i, GPANN_SCAN_OVERLAP"
+                                                    if scan_overlap else "") + ") and batch i-1 is merged on the host while batch i is scanned" if scan_ahead else
                                      "batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned")
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
     if multi and route_ahead:
@@ -1069,6 +1072,8 @@ def main():
     result["detail"]["router_selfcheck_events"] = int(rs_all["bound_selfcheck"])
     result["detail"]["router_verify_failures"] = int(rs_all["verify_failures"])
     result["detail"]["router_bound_calls"] = int(rs_all["bound_calls"])
+    if cu_sweep is not None:
+        result["detail"]["cu_sweep"] = cu_sweep
 
     # tuning aid (off by default): GPANN_BENCH_SWEEP="GPANN_FILTER_SEED_ROWS=64,128;GPANN_FILTER_HEAD_ROWS=512,0" times a few steps for every
     # combination of the listed library knobs (they are read per call) and checks that the results do not change
@@ -1286,7 +1291,8 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
                 t_c = time.perf_counter()
                 di, dd = dsets[i & 1]
-                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), stream, for_merge=merge_bound, defer=True)
+                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), stream, for_merge=merge_bound, defer=True,
+                                       overlap=os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0")
                 host_t[:3] += (t_b - t_a, t_c - t_b, time.perf_counter() - t_c)
                 return nxt
 

@@ -365,8 +365,8 @@ struct UploadBatch {
     template <typename T>
     T* Add(T* own_dst, const void* src, size_t bytes) {
         if (bytes == 0) return own_dst;
-        void* p = s->ws_stage_dev.ptr ? CS(s).stage.Take(bytes) : nullptr;
-        if (!p || (size_t)(static_cast<char*>(p) - CS(s).stage.base) + bytes > s->ws_stage_dev.bytes) {
+        void* p = CS(s).ws_stage_dev.ptr ? CS(s).stage.Take(bytes) : nullptr;
+        if (!p || (size_t)(static_cast<char*>(p) - CS(s).stage.base) + bytes > CS(s).ws_stage_dev.bytes) {
             const hipError_t e = UploadAsync(s, own_dst, src, bytes, st);
             if (err == hipSuccess) err = e;
             return own_dst;
@@ -375,12 +375,12 @@ struct UploadBatch {
         const size_t off = (size_t)(static_cast<char*>(p) - CS(s).stage.base);
         first = std::min(first, off);
         last = std::max(last, off + bytes);
-        return reinterpret_cast<T*>(s->ws_stage_dev.as<char>() + off);
+        return reinterpret_cast<T*>(CS(s).ws_stage_dev.as<char>() + off);
     }
     hipError_t Flush() {
         hipError_t e = err;
         if (first < last) {
-            const hipError_t c = hipMemcpyAsync(s->ws_stage_dev.as<char>() + first, CS(s).stage.base + first, last - first, hipMemcpyHostToDevice, st);
+            const hipError_t c = hipMemcpyAsync(CS(s).ws_stage_dev.as<char>() + first, CS(s).stage.base + first, last - first, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = c;
         }
         first = SIZE_MAX;
@@ -493,8 +493,8 @@ static gpann_status StageQueries(gpann_shards* s, const float* queries, uint32_t
         return GPANN_OK;
     }
     const size_t bytes = (size_t)nq * s->ld * sizeof(float);
-    GPANN_TRY(s->ws_queries.Reserve(std::max<size_t>(bytes, 256)));
-    float* dst = s->ws_queries.as<float>();
+    GPANN_TRY(CS(s).ws_queries.Reserve(std::max<size_t>(bytes, 256)));
+    float* dst = CS(s).ws_queries.as<float>();
     if (s->ld != s->d) GPANN_HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
     GPANN_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(float), queries, (size_t)s->d * sizeof(float), (size_t)s->d * sizeof(float), nq,
                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -516,20 +516,20 @@ struct TaskArrays {   // device copies of the shard-sorted task arrays
 static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta, const float* d_queries, uint32_t k, int flags, hipStream_t st,
                                   MergeArgs m) {
     const uint32_t T = (uint32_t)plan.task_query.size();
-    GPANN_TRY(s->ws_units.Reserve(std::max<size_t>(plan.units.size() * sizeof(ScanUnit), 256)));
-    GPANN_TRY(s->ws_partials.Reserve(std::max<size_t>(plan.n_lists * k * 8, 256)));
-    float* d_part_dist = s->ws_partials.as<float>();
+    GPANN_TRY(CS(s).ws_units.Reserve(std::max<size_t>(plan.units.size() * sizeof(ScanUnit), 256)));
+    GPANN_TRY(CS(s).ws_partials.Reserve(std::max<size_t>(plan.n_lists * k * 8, 256)));
+    float* d_part_dist = CS(s).ws_partials.as<float>();
     uint32_t* d_part_row = reinterpret_cast<uint32_t*>(d_part_dist + plan.n_lists * k);
     if (T) {
         GPANN_HIP_TRY(UploadAsync(s, ta.part, plan.task_part.data(), T * 4, st));
         GPANN_HIP_TRY(UploadAsync(s, ta.nseg, plan.task_nseg.data(), T * 4, st));
     }
     if (!plan.units.empty()) {
-        GPANN_HIP_TRY(UploadAsync(s, s->ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), st));
+        GPANN_HIP_TRY(UploadAsync(s, CS(s).ws_units.ptr, plan.units.data(), plan.units.size() * sizeof(ScanUnit), st));
         ScanArgs a;
         a.points = s->points;
         a.queries = d_queries;
-        a.units = s->ws_units.as<ScanUnit>();
+        a.units = CS(s).ws_units.as<ScanUnit>();
         a.task_query = ta.query;
         a.task_part = ta.part;
         a.part_dist = d_part_dist;
@@ -587,8 +587,13 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
+// `st`: the stream of the call's FRONT — everything before the rest pass; `st_rest`: the stream of the rest pass and what follows it.  The same
+// stream for a plain call; GPANN_SCAN_OVERLAP: the handle's two streams (the rest stream waits for the end of the front: CallState::ev_x[1]).
+// *st_end = the stream the call's last launch went to.
 static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, UploadBatch& up, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call,
-                                        uint32_t k, int flags, hipStream_t st, DeviceLists out) {
+                                        uint32_t k, int flags, hipStream_t st, hipStream_t st_rest, hipStream_t* st_end, DeviceLists out) {
+    *st_end = st;
+    const bool overlap = st_rest != st;
     TaskArrays ta = ta_in;   // (query / out point to the re-ordered copies once the tasks are grouped by nearest cell; the caller's arrays keep the host's order)
     CS(s).filter_passes_timed = 0;
     const uint32_t S = s->S, T = (uint32_t)plan.task_query.size();
@@ -650,9 +655,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         const uint64_t fit = (256ull << 20) / ((uint64_t)dirty_cap * k * 8);   // partial lists: at most 256 MiB
         range_segs = (uint32_t)std::max<uint64_t>(512, std::min<uint64_t>(std::min<uint64_t>(8192, fit), (uint64_t)largest / 512));
     }
-    GPANN_TRY(s->ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 8 + (size_t)dirty_cap * 8 + 64));
-    GPANN_TRY(s->ws_partials.Reserve((size_t)dirty_cap * range_segs * k * 8 + 256));
-    float* list_dist = s->ws_lists.as<float>();
+    GPANN_TRY(CS(s).ws_lists.Reserve((size_t)T * k * 8 + (size_t)T * 4 + 256 + 64 + (size_t)nq * 4 + (size_t)T * 8 + (size_t)dirty_cap * 8 + 64));
+    GPANN_TRY(CS(s).ws_partials.Reserve((size_t)dirty_cap * range_segs * k * 8 + 256));
+    float* list_dist = CS(s).ws_lists.as<float>();
     uint32_t* list_row = reinterpret_cast<uint32_t*>(list_dist + (size_t)T * k);
     float* task_U = reinterpret_cast<float*>(list_row + (size_t)T * k);
     uint32_t* d_overflow = reinterpret_cast<uint32_t*>(task_U + T + ((T & 1) ? 1 : 0));   // [0] overflow count, [2..3] candidate total (u64)
@@ -662,8 +667,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     uint32_t* d_query_tau = for_merge ? d_overflow + 16 : nullptr;
     uint32_t* d_dirty_flag = d_overflow + 16 + nq;   // [T] | dirty_list [dirty_cap] uint2 (8-byte aligned below)
     uint2* d_dirty_list = reinterpret_cast<uint2*>(d_dirty_flag + (size_t)T + ((reinterpret_cast<uintptr_t>(d_dirty_flag + (size_t)T) & 4) ? 1 : 0));
-    GPANN_TRY(s->ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
-    uint32_t* cand_cnt = s->ws_cand.as<uint32_t>();
+    GPANN_TRY(CS(s).ws_cand.Reserve((size_t)T * 4 + (size_t)T * cap * 4));
+    uint32_t* cand_cnt = CS(s).ws_cand.as<uint32_t>();
     uint32_t* cand_row = cand_cnt + T;
 
     // groups of <= 256 tasks per shard; distance-table tiles of <= 64 tasks
@@ -684,8 +689,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // (the 8-bit passes of a squared-L2 store whose plane has its own norm words bound the quantisation error in the frame of the cell: |q - c|_1 per (task, cell))
     // (GPANN_FILTER_Q8_L1=0: no table — |q - c|_1 <= sqrt(d) |q - c|_2 from the table of squared distances instead, ~25 % looser)
     const bool cell_l1 = use_q8 && C.q8_norm != nullptr && EnvU32("GPANN_FILTER_Q8_L1", 1) != 0;
-    GPANN_TRY(s->ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 * (cell_l1 ? 2 : 1) + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
-    double* d_task_nq = s->ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
+    GPANN_TRY(CS(s).ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 * (cell_l1 ? 2 : 1) + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
+    double* d_task_nq = CS(s).ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
     double* d_task_q1 = d_task_nq + T;              // |q~|_1 (old order) ...
     float* d_task_tscale = reinterpret_cast<float*>(d_task_q1 + T);   // ... the 8-bit query step (old order) ...
     float* d_task_qscale = d_task_tscale + T;                          // ... and step / 254 in the NEW order (QueryImageQ8Kernel)
@@ -710,9 +715,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     group_first[G] = (uint32_t)items_cap;
     const size_t gtab_words = ((size_t)3 * G + 1 + 3) / 4 * 4;   // group_first [G+1] | group_count [G] | group_cursor [G], 16-byte multiple
     const size_t ticket_words = 0;
-    GPANN_TRY(s->ws_need.Reserve((4 * need_words + ticket_words) * 4 + (size_t)G * sizeof(CellGroup) + 96 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
+    GPANN_TRY(CS(s).ws_need.Reserve((4 * need_words + ticket_words) * 4 + (size_t)G * sizeof(CellGroup) + 96 + gtab_words * 4 + (size_t)items_cap * sizeof(CellItem)));
     uint32_t* need_pass[3];
-    need_pass[0] = s->ws_need.as<uint32_t>();
+    need_pass[0] = CS(s).ws_need.as<uint32_t>();
     need_pass[1] = need_pass[0] + need_words;
     need_pass[2] = need_pass[1] + need_words;
     uint32_t* done_head = need_pass[2] + need_words;   // need_pass[0] | need_pass[1]
@@ -758,9 +763,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         }
         if (!sitems.empty()) {
             const size_t stab_words = ((size_t)3 * G + 3) / 4 * 4;
-            GPANN_TRY(s->ws_misc.Reserve(sitems.size() * sizeof(CellItem) + stab_words * 4 + 64));
-            d_stab = up.Add(s->ws_misc.as<uint32_t>(), stab.data(), (size_t)3 * G * 4);
-            d_sitems = up.Add(reinterpret_cast<CellItem*>(s->ws_misc.as<uint32_t>() + stab_words), sitems.data(), sitems.size() * sizeof(CellItem));
+            GPANN_TRY(CS(s).ws_misc.Reserve(sitems.size() * sizeof(CellItem) + stab_words * 4 + 64));
+            d_stab = up.Add(CS(s).ws_misc.as<uint32_t>(), stab.data(), (size_t)3 * G * 4);
+            d_sitems = up.Add(reinterpret_cast<CellItem*>(CS(s).ws_misc.as<uint32_t>() + stab_words), sitems.data(), sitems.size() * sizeof(CellItem));
         }
     }
 
@@ -807,9 +812,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
 
     // ---- the groups' query images (bf16 fragments in MFMA B-operand order), once per call
-    GPANN_TRY(s->ws_image.Reserve((size_t)G * QT * KS * 2048 + 256));
+    GPANN_TRY(CS(s).ws_image.Reserve((size_t)G * QT * KS * 2048 + 256));
     {
-        char* img = s->ws_image.as<char>();
+        char* img = CS(s).ws_image.as<char>();
         switch (KS) {
 #define GPANN_IMAGE(KS_)                                                                                                                              \
     case KS_:                                                                                                                                         \
@@ -830,8 +835,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // (one threshold table PER 8-bit pass, both set to +inf — "this task does not need this cell" — by FilterInitKernel below: a pass's set-up
         // launch then writes the few needed (task, cell) slots only.  With one table every slot had to be rewritten in every pass: 20 000 scattered
         // 4-byte stores per task group)
-        GPANN_TRY(s->ws_q8.Reserve(img8 + 2 * b_words * 4 + 256));
-        q8_image = s->ws_q8.as<char>();
+        GPANN_TRY(CS(s).ws_q8.Reserve(img8 + 2 * b_words * 4 + 256));
+        q8_image = CS(s).ws_q8.as<char>();
         q8_B = reinterpret_cast<float*>(q8_image + img8);
         q8_B_words = b_words;
         switch (KS8) {
@@ -971,7 +976,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     fa.group_first = d_group_first;
     fa.group_count = d_group_count;
     fa.group_cursor = d_group_count + G;
-    fa.image = s->ws_image.as<char>();
+    fa.image = CS(s).ws_image.as<char>();
     fa.seg_tiles = seg_tiles;
     fa.q8_planes = C.q8_planes;
     fa.q8_norm = C.q8_norm ? C.q8_norm : C.plane_norm;
@@ -1003,7 +1008,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.dirty_cap = dirty_cap;
     ra.range_segs = 0;
     ra.parts = 1;
-    ra.part_dist = s->ws_partials.as<float>();
+    ra.part_dist = CS(s).ws_partials.as<float>();
     ra.part_row = reinterpret_cast<uint32_t*>(ra.part_dist + (size_t)dirty_cap * range_segs * k);
     ra.seed_rows = 0;
     ra.nearest = d_nearest;
@@ -1073,11 +1078,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // at 40 000 tasks (C3) 8 parts cost more in workgroups started than the split saves (2, 4, 8 parts: 2.28, 2.33, 2.38 ms of scan kernels; NS with
     // 10 000 tasks: 4.44, 4.19, 4.15)
     const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", std::max<uint32_t>(2, std::min<uint32_t>(8, 131072u / std::max<uint32_t>(T, 1u))))));
-    GPANN_TRY(s->ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
+    GPANN_TRY(CS(s).ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
     ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 128));
     ra.stat_overflowed = d_overflow;
     ra.stat_candidates = d_cand_total;
-    ra.split_dist = s->ws_split.as<float>();
+    ra.split_dist = CS(s).ws_split.as<float>();
     ra.split_row = reinterpret_cast<uint32_t*>(ra.split_dist + (size_t)T * split_parts * k);
     auto launch_rescore = [&](uint32_t parts) {
         ra.parts = parts;
@@ -1090,6 +1095,16 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     bool buckets_pending = false;   // a bucket re-scoring has run and the pieces of its split buckets are not merged yet
     int n_cus = 256;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
+    // GPANN_SCAN_OVERLAP: the front of this call shares the chip with the rest pass of the call before it (and its own rest pass with the front of
+    // the next).  A filter launch takes whole CUs (one 512-thread workgroup with ~all of a CU's registers and most of its LDS), so the two sides are
+    // kept apart by their GRID sizes: the front's filter launches start at most front_cus workgroups; the rest pass either rest_cus persistent ones
+    // (GPANN_OVERLAP_REST_ITEMS=0) or — the default — as many workgroups as its items need, each leaving after rest_items items: the rest stream has
+    // the lower priority, so a CU it gives up goes to the front when the front has a workgroup waiting and back to the rest pass when it has not.
+    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, EnvU32("GPANN_OVERLAP_FRONT_CUS", 96))) : (uint32_t)n_cus;
+    const uint32_t rest_items_env = overlap ? EnvU32("GPANN_OVERLAP_REST_ITEMS", 4) : 0u;
+    const uint32_t rest_items = rest_items_env == 0 ? 0u : std::max<uint32_t>(2, rest_items_env);   // (a workgroup's first two claims are made before anything is counted)
+    const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, EnvU32("GPANN_OVERLAP_REST_CUS", 160))) : (uint32_t)n_cus;
+    fa.wg_item_budget = 0;
 
     bool seed_wrote_U = false;
     if (seed_rows != 0) {
@@ -1148,7 +1163,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             fs.need = nullptr;
             fs.done0 = fs.done0b = fs.done1 = nullptr;
             void* sargs[] = {&fs};
-            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)n_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
+            GPANN_HIP_TRY(hipLaunchKernel(fn, dim3((uint32_t)std::min<size_t>((size_t)front_cus, sitems.size())), dim3(64 * kFWaves), sargs, glds, st));
             launch_rescore(split_parts);
             buckets_pending = true;
             GPANN_HIP_TRY(hipGetLastError());
@@ -1157,6 +1172,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         GPANN_REQUIRE(PassSetupLdsBytes(kmax) <= (64u << 10), "too many cells in one shard for the pass set-up kernel");
+        if (pass == 2 && overlap) {   // the front ends here: the rest pass (its set-up included) and everything behind it go to the rest stream
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[1], st));
+            GPANN_HIP_TRY(hipStreamWaitEvent(st_rest, CS(s).ev_x[1], 0));
+            st = st_rest;
+            *st_end = st_rest;
+        }
+        const uint32_t pass_cus = pass == 2 ? rest_cus : front_cus;
         if (CS(s).filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
         // NeedKernel also sets the pass up: thresholds from the current lists, candidate counters and the item cursor back to zero
@@ -1177,7 +1199,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
         fa.done1 = pass == 2 ? need_pass[1] : nullptr;
-        void* kargs[] = {&fa};
         {   // one launch sets the pass up: split buckets of the previous pass merged, thresholds, cell tests, work items (PassSetupKernel)
             PassSetupArgs ps;
             ps.need = na;
@@ -1202,11 +1223,24 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pass_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
+            // (the rest pass beside another call's front: workgroups that leave after rest_items items, as many as the item capacity can need)
+            uint64_t grid8 = std::min<uint64_t>((uint64_t)pass_cus, items_cap);
+            if (pass == 2 && rest_items != 0) {
+                f8.wg_item_budget = rest_items;
+                grid8 = std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus);
+            }
             void* kargs8[] = {&f8};
-            GPANN_HIP_TRY(hipLaunchKernel((pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * q8_waves), kargs8, glds8, st));
+            GPANN_HIP_TRY(hipLaunchKernel((pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)grid8), dim3(64 * q8_waves), kargs8, glds8, st));
             if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
-            GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)std::min<uint64_t>((uint64_t)n_cus, items_cap)), dim3(64 * kFWaves), kargs, glds, st));
+            CellFilterArgs fb = fa;
+            uint64_t gridb = std::min<uint64_t>((uint64_t)pass_cus, items_cap);
+            if (pass == 2 && rest_items != 0 && hi_pass) {   // (the two-plane kernel has no item budget: persistent workgroups, all CUs — a store without hi-only passes)
+                fb.wg_item_budget = rest_items;
+                gridb = std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus);
+            }
+            void* kargsb[] = {&fb};
+            GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)gridb), dim3(64 * kFWaves), kargsb, glds, st));
             if (pass == 2) plan.filter_rest_row_bytes = (hi_pass ? 32u : 64u) * KS + 4u;
         }
         GPANN_HIP_TRY(hipGetLastError());
@@ -1319,19 +1353,44 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms);
 // Plans the call and ENQUEUES its device work (tasks + scan + merge; results land in the device arrays `out`): nothing here waits for the
 // device.  The call is completed — counters read, an overflowed filter call redone exactly, statistics, timing — by CompleteCall, which the
 // entry points run before they return unless the caller asked for GPANN_SCAN_DEFER.
+// A new call takes the slot of the call before last (completing it first if it still waits for its gpann_scan_finish) and makes it the call in
+// progress: from here on CS(s) — host state AND device workspaces — is this call's.  Every entry point does this before it touches a workspace.
+static gpann_status AcquireSlot(gpann_shards* s, hipStream_t st) {
+    const int n = s->cur ^ 1;
+    if (s->cs[n].pending) GPANN_TRY(CompleteCall(s, n, nullptr));
+    // (rounds 1-4: the two slots shared the device workspaces, and a call on another stream than the most recent one had to wait for it here.
+    // The workspaces are per slot now; what is left to order is this slot's OWN previous call — ScanToDevice waits for its ev[3] — and, for
+    // callers that pass device buffers of their own to both calls, their own streams.)
+    (void)st;
+    s->cur = n;
+    return GPANN_OK;
+}
+
+// GPANN_SCAN_OVERLAP: the handle's two streams (created at the first such call).  Priorities: the front high — short launches on a chain of
+// dependencies —, the rest pass low: it takes the compute units the fronts leave.
+static gpann_status OverlapStreams(gpann_shards* s) {
+    if (s->st_front && s->st_rest) return GPANN_OK;
+    int least = 0, greatest = 0;
+    GPANN_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (!s->st_front) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_front, hipStreamNonBlocking, greatest));
+    if (!s->st_rest) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_rest, hipStreamNonBlocking, least));
+    return GPANN_OK;
+}
+
 static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
-                                 uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st, DeviceLists out) {
-    // the slot of the call before last: if that call is still waiting for its gpann_scan_finish it is completed now
-    {
-        const int n = s->cur ^ 1;
-        if (s->cs[n].pending) GPANN_TRY(CompleteCall(s, n, nullptr));
-        // the most recent call's device work shares the handle's device workspaces with this one: on the same stream the stream orders them,
-        // on another stream this call waits for it (concurrent callers of one handle take turns)
-        gpann_shards::CallState& last = s->cs[s->cur];
-        if (last.stage_in_flight && last.stream != static_cast<void*>(st)) GPANN_HIP_TRY(hipEventSynchronize(last.ev[3]));
-        s->cur = n;
-    }
+                                 uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st_caller, DeviceLists out) {
     ScanPlan& plan = CS(s).plan;
+    // GPANN_SCAN_OVERLAP (a deferred call in filter mode whose queries the kernels read in place — the conditions under which the call stays
+    // deferred): the call's work goes to the handle's own streams; the caller's stream only orders its start
+    hipStream_t st = st_caller, st_rest = st_caller;
+    if ((flags & GPANN_SCAN_OVERLAP) && (flags & GPANN_SCAN_DEFER) && (flags & GPANN_QUERIES_ON_DEVICE) && FilterWanted(s, k) && s->ld == s->d &&
+        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
+        GPANN_TRY(OverlapStreams(s));
+        GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[0], st_caller));
+        GPANN_HIP_TRY(hipStreamWaitEvent(s->st_front, CS(s).ev_x[0], 0));
+        st = s->st_front;
+        st_rest = s->st_rest;
+    }
     // The pinned staging area and the plan's host arrays of this slot are the sources of an earlier call's asynchronous uploads: that call may
     // have returned with them still queued (device output, no timing — nothing made it synchronise), so wait for the end of its work first.
     if (CS(s).stage_in_flight) {
@@ -1343,7 +1402,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
     // (task arrays, group / tile tables, unit lists: ~32 bytes per task + per-shard tables; exact-mode unit lists fall back to pageable copies if larger)
     CS(s).stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
-    if (s->ws_stage_dev.Reserve(std::max<size_t>(CS(s).stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
+    if (CS(s).ws_stage_dev.Reserve(std::max<size_t>(CS(s).stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
     UploadBatch up{s, st};
     const size_t n_out = (size_t)nq * nprobe;
 
@@ -1351,9 +1410,9 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     GPANN_TRY(StageQueries(s, queries, nq, (flags & GPANN_QUERIES_ON_DEVICE) != 0, st, &d_queries));
 
     // task arrays: query | out | part | nseg | shard
-    GPANN_TRY(s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256)));
+    GPANN_TRY(CS(s).ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256)));
     TaskArrays ta;
-    ta.query = s->ws_tasks.as<uint32_t>();
+    ta.query = CS(s).ws_tasks.as<uint32_t>();
     ta.out = ta.query + T;
     ta.part = ta.out + T;
     ta.nseg = ta.part + T;
@@ -1391,8 +1450,11 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     c.host_dist = nullptr;
     c.host_ids = c.host_rows = nullptr;
     if (want_filter) {
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, out));
+        hipStream_t st_end = st;
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, st_rest, &st_end, out));
         c.filtered = T != 0;
+        st = st_end;
+        c.stream = st_end;   // (what follows the call — the copies to the host, a redo, the caller's own merge — is queued behind its LAST launch)
     } else {
         GPANN_TRY(RunExactPath(s, ta, up, d_queries, nq, nprobe, k, flags, st, out));
     }
@@ -1480,10 +1542,10 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms) {
         const uint32_t T = c.T;
         c.stage.used = 0;
         UploadBatch up{s, st};
-        gpann_status rc = s->ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256));
+        gpann_status rc = CS(s).ws_tasks.Reserve(std::max<size_t>((size_t)T * 5 * sizeof(uint32_t), 256));
         if (rc == GPANN_OK) {
             TaskArrays ta;
-            ta.query = s->ws_tasks.as<uint32_t>();
+            ta.query = CS(s).ws_tasks.as<uint32_t>();
             ta.out = ta.query + T;
             ta.part = ta.out + T;
             ta.nseg = ta.part + T;
@@ -1493,7 +1555,7 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms) {
             ta.shard = up.Add(ta.shard, plan.task_shard.data(), (size_t)T * 4);
             if (c.host_ids) {   // a call with host outputs: its device lists live in ws_out, which a later call may have re-grown (same layout)
                 const size_t n = (size_t)c.nq * c.nprobe * c.k;
-                c.out_dist = s->ws_out.as<float>();
+                c.out_dist = CS(s).ws_out.as<float>();
                 c.out_ids = reinterpret_cast<uint32_t*>(c.out_dist + n);
                 c.out_rows = c.out_ids + n;
             }
@@ -1547,6 +1609,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
         if (elapsed_ms) *elapsed_ms = 0.f;
         return GPANN_OK;
     }
+    GPANN_TRY(AcquireSlot(s, st));
     DeviceLists dl;
     const bool dev_out = (flags & GPANN_OUTPUT_ON_DEVICE) != 0;
     if (dev_out) {
@@ -1554,8 +1617,8 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
         dl.dist = out_dist;
         dl.rows = out_rows;
     } else {
-        GPANN_TRY(s->ws_out.Reserve(n * 12));
-        dl.dist = s->ws_out.as<float>();
+        GPANN_TRY(CS(s).ws_out.Reserve(n * 12));
+        dl.dist = CS(s).ws_out.as<float>();
         dl.ids = reinterpret_cast<uint32_t*>(dl.dist + n);
         dl.rows = dl.ids + n;
     }
@@ -1600,9 +1663,14 @@ gpann_status gpann_scan_merged(gpann_shards* s, const float* queries, uint32_t n
         return GPANN_OK;
     }
     // per-slot lists (dist,rows) in workspace, then one more merge across the slots of a query
-    GPANN_TRY(s->ws_out.Reserve(n_slot * 8 + n * 8 + 256));
+    GPANN_TRY(AcquireSlot(s, st));
+    if (CS(s).stage_in_flight) {   // (this slot's previous call may still read ws_out: an untimed device-output merge)
+        GPANN_HIP_TRY(hipEventSynchronize(CS(s).ev[3]));
+        CS(s).stage_in_flight = false;
+    }
+    GPANN_TRY(CS(s).ws_out.Reserve(n_slot * 8 + n * 8 + 256));
     DeviceLists slot;
-    slot.dist = s->ws_out.as<float>();
+    slot.dist = CS(s).ws_out.as<float>();
     slot.rows = reinterpret_cast<uint32_t*>(slot.dist + n_slot);
     slot.ids = nullptr;
     float* d_out_dist = reinterpret_cast<float*>(slot.rows + n_slot);
@@ -1659,9 +1727,14 @@ gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint
     const size_t n = (size_t)nq * S * k;
     if (n == 0) return GPANN_OK;
     // workspace: slot dist | slot ids | hits ids | hits count | kth
-    GPANN_TRY(s->ws_out.Reserve(n * 12 + (size_t)nq * S * 4 + (size_t)nq * 4 + 256));
+    GPANN_TRY(AcquireSlot(s, st));
+    if (CS(s).stage_in_flight) {
+        GPANN_HIP_TRY(hipEventSynchronize(CS(s).ev[3]));
+        CS(s).stage_in_flight = false;
+    }
+    GPANN_TRY(CS(s).ws_out.Reserve(n * 12 + (size_t)nq * S * 4 + (size_t)nq * 4 + 256));
     DeviceLists slot;
-    slot.dist = s->ws_out.as<float>();
+    slot.dist = CS(s).ws_out.as<float>();
     slot.ids = reinterpret_cast<uint32_t*>(slot.dist + n);
     slot.rows = nullptr;
     uint32_t* d_hits = slot.ids + n;

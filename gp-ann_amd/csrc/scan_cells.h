@@ -396,6 +396,11 @@ struct CellFilterArgs {
     const float* task_qscale;    // [tasks] t_q / 254, in the CURRENT task order
     const float* q8_scale;       // [cells]
     uint32_t round_tiles;        // wavefronts x FilterUnitTiles of the kernel that runs this pass's items (FilterItemsKernel cuts pieces in whole rounds of the workgroup)
+    // 0: persistent workgroups (one per CU, each claims items until the lists are empty).  n > 0: a workgroup claims at most n items and leaves —
+    // the launch then has more workgroups than CUs (scan.hip sizes the grid from the item capacity) and a CU changes hands every few items: a
+    // launch of ANOTHER stream gets compute units within one item's time instead of at the end of this one (GPANN_SCAN_OVERLAP: the rest pass
+    // of call i beside the front of call i + 1).  Price: the claim -> record -> image -> first tile chain once per workgroup instead of once per CU.
+    uint32_t wg_item_budget;
 };
 
 // wavefronts per workgroup of FilterKernelCells (one workgroup per CU): all of them stream row tiles round robin
@@ -955,7 +960,12 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     const uint32_t task_begin = r_task_begin, task_count = (acts >> 24) + 1u;
     const uint32_t act_head = acts & 0xFFu, act_sample = acts >> 8 & 0xFFu, mask = acts >> 16 & 0xFFu;
     uint32_t next_idx = 0;
-    if (tid == 0 && !drained) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
+    // (wg_item_budget >= 2: this workgroup leaves after that many items.  `iter` items are done, two more are claimed: the budget is met when
+    // iter + 2 reaches it — decided BEFORE the cursor is advanced: an index taken from it is an item that has to be run.  Uniform over the
+    // workgroup, and once true it stays true.)
+    // (Compiled into the hi-plane and 8-bit kernels only — the ones a rest pass runs on; the two-plane kernel, already at its register limit, keeps its code.)
+    const bool budget_met = MODE >= 1 && a.wg_item_budget != 0u && iter + 2u >= a.wg_item_budget;
+    if (tid == 0 && !drained && !budget_met) next_idx = atomicAdd(&a.group_cursor[c_g], 1u);
     const CellItem* rn = a.items + (nxt != kNoItem ? nxt : item);
     const uint4 n_lo = reinterpret_cast<const uint4*>(rn)[0], n_hi = reinterpret_cast<const uint4*>(rn)[1];
     const uint4 n_x = reinterpret_cast<const uint4*>(rn)[2];
@@ -1229,7 +1239,7 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     loaded_group = r_group;
     DmaWaitAll();      // this wavefront's part of the image is in LDS (so are its first tile, the next record and the claim)
     if (wave == 0) {
-        const uint32_t got = claim_for(uniform(next_idx));
+        const uint32_t got = budget_met ? kNoItem : claim_for(uniform(next_idx));
         if (lane == 0) s_claim[2 + (iter & 1u)] = got;
     }
     __syncthreads();

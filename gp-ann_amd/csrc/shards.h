@@ -154,8 +154,6 @@ struct gpann_shards {
     gpann_status filter_fail_status = GPANN_OK;   // why BuildCells gave up (cells.hip): GPANN_ERR_OOM (an allocation), GPANN_ERR_HIP (a device / kernel error), GPANN_ERR_INTERNAL (no cells)
     int scan_mode = 0;               // 0 = exact scan, 1 = MFMA-filtered exact scan (gpann_shards_set_scan_mode)
 
-    // per-call workspace, grown on demand and reused
-    gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8, ws_split;
     // Per-call host state, TWO sets (round 4): a call issued with GPANN_SCAN_DEFER returns once its work is enqueued, and the NEXT call may be
     // planned, staged and enqueued behind it before gpann_scan_finish completes the first — the host-side planning of batch i + 1 then runs under
     // the kernels of batch i.  `cur` is the slot of the most recent call.
@@ -164,6 +162,8 @@ struct gpann_shards {
         bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
         hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
                                                                                               // and of the rest pass's filter launch alone
+        hipEvent_t ev_x[2] = {nullptr, nullptr};   // GPANN_SCAN_OVERLAP: [0] what the caller's stream held when the call was issued (the front stream
+                                                   // waits for it), [1] the end of the call's front (the rest stream waits for it)
         int filter_passes_timed = 0;
         gpann::ScanPlan plan;
         gpann::PinnedStage stage;
@@ -182,10 +182,23 @@ struct gpann_shards {
         float* host_dist = nullptr;      // host destinations of a call without GPANN_OUTPUT_ON_DEVICE (null: none)
         uint32_t* host_ids = nullptr;
         uint32_t* host_rows = nullptr;
+        // The call's DEVICE workspaces, grown on demand and reused by the next call on this slot.  One set per slot (round 5; rounds 1-4: one set
+        // per handle, shared by both slots and kept apart only by stream order): two calls of a handle can be on the device AT ONCE — the passes
+        // before the rest pass of call i + 1 run beside the rest pass of call i on streams of their own (GPANN_SCAN_OVERLAP) — and a workspace
+        // that grows (hipFree synchronises the whole device) can no longer stall or clobber the other call.  ws_stage_dev: the device mirror of
+        // this slot's pinned `stage` (the call's small arrays arrive in it with one copy: scan.hip UploadBatch).
+        gpann::DeviceBuffer ws_queries, ws_tasks, ws_units, ws_partials, ws_out, ws_misc, ws_lists, ws_cand, ws_celld, ws_need, ws_image, ws_q8, ws_split, ws_stage_dev;
+        void ReleaseWorkspaces() {
+            for (gpann::DeviceBuffer* b : {&ws_queries, &ws_tasks, &ws_units, &ws_partials, &ws_out, &ws_misc, &ws_lists, &ws_cand, &ws_celld, &ws_need, &ws_image, &ws_q8,
+                                           &ws_split, &ws_stage_dev})
+                b->Release();
+        }
     } cs[2];
     int cur = 0;
     gpann_scan_stats stats{};
-    gpann::DeviceBuffer ws_stage_dev;   // device mirror of the calls' pinned `stage`s (uploads are stream-ordered: one mirror serves both slots): the call's small arrays arrive in it with one copy (scan.hip UploadBatch)
+    // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): the calls' fronts in order on one (high priority: short,
+    // latency-bound launches), their rest passes in order on the other (low priority: it takes what the fronts leave)
+    hipStream_t st_front = nullptr, st_rest = nullptr;
 };
 
 namespace gpann {

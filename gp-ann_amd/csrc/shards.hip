@@ -133,6 +133,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     for (auto& c : s->cs) {
         for (auto& e : c.ev) TRY_OR_FAIL(hipEventCreate(&e));
         for (auto& e : c.ev_filter) TRY_OR_FAIL(hipEventCreate(&e));
+        for (auto& e : c.ev_x) TRY_OR_FAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         TRY_OR_FAIL(hipHostMalloc(reinterpret_cast<void**>(&c.pin_words), 96, hipHostMallocDefault));
     }
 
@@ -254,28 +255,19 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     if (s->d_shard_rmax) (void)hipFree(s->d_shard_rmax);
     if (s->frag_planes) (void)hipFree(s->frag_planes);
     ReleaseCells(s);
-    s->ws_lists.Release();
-    s->ws_cand.Release();
-    s->ws_celld.Release();
-    s->ws_need.Release();
-    s->ws_image.Release();
-    s->ws_q8.Release();
-    s->ws_split.Release();
-    s->ws_stage_dev.Release();
-    s->ws_queries.Release();
-    s->ws_tasks.Release();
-    s->ws_units.Release();
-    s->ws_partials.Release();
-    s->ws_out.Release();
-    s->ws_misc.Release();
     for (auto& c : s->cs) {
+        c.ReleaseWorkspaces();
         c.stage.Release();
         if (c.pin_words) (void)hipHostFree(c.pin_words);
         for (auto& e : c.ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c.ev_filter)
             if (e) (void)hipEventDestroy(e);
+        for (auto& e : c.ev_x)
+            if (e) (void)hipEventDestroy(e);
     }
+    if (s->st_front) (void)hipStreamDestroy(s->st_front);
+    if (s->st_rest) (void)hipStreamDestroy(s->st_rest);
     delete s;
     return GPANN_OK;
 }

@@ -16,8 +16,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <future>
+#include <mutex>
 #include <iostream>
 #include <memory>
 #include <numeric>
@@ -267,8 +269,49 @@ public:
     //                  lists exchanged on a third stream beside the scan of batch i + 1
     //   merge thread   DedupNeighbors of batch i - 1
     // Leaves the last batch's merged neighbours in result_dist / result_ids.
+    //
+    // Two communicators on one GPU: each is driven by one thread in one order, but their collectives must also be LAUNCHED in the same relative
+    // order on every rank — kernels of two communicators that the GPU cannot co-schedule would otherwise wait for each other across ranks for
+    // ever (RCCL / NCCL: concurrent communicators need a consistent launch order).  `LaunchOrder` is that order: R j = the probe all-gather of
+    // batch j (route thread), X i = the slot exchange of batch i (this thread); sequence R0, R1, then per batch i: R i+2, X i.  A collective
+    // takes its place when every earlier one has been launched (not completed: the schedule costs no overlap).  If any stage throws, the
+    // schedule and the routing communicator are given up (`Abort`, gpann_comm_abort) BEFORE the futures are destroyed, so a route job parked in
+    // the schedule or in an unmatched collective fails at once instead of keeping this rank alive until the communicator's timeout.
+    struct LaunchOrder {
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t turn = 0;
+        bool dead = false;
+        int batches = 0;
+        size_t PosR(int j) const { return j < 2 ? (size_t)j : (size_t)(2 * j - 2); }                     // R0 R1 | R2 X0 | R3 X1 | ...
+        size_t PosX(int i) const {
+            const int routed = std::min(batches, i + 3);   // route collectives launched before X i: R0 .. R(i + 2), as far as they exist
+            return (size_t)(routed + i);
+        }
+        void Enter(size_t pos) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return dead || turn == pos; });
+            if (dead) throw std::runtime_error("ProcessQueryStream was given up: another stage of this rank failed");
+        }
+        void Leave() {
+            { std::lock_guard<std::mutex> lk(mu); ++turn; }
+            cv.notify_all();
+        }
+        void Abort() {
+            { std::lock_guard<std::mutex> lk(mu); dead = true; }
+            cv.notify_all();
+        }
+    };
+    struct InTurn {   // a collective's place in the schedule: taken in the constructor, handed on in the destructor (also when the launch throws)
+        LaunchOrder& o;
+        InTurn(LaunchOrder& order, size_t pos) : o(order) { o.Enter(pos); }
+        ~InTurn() { o.Leave(); }
+    };
+
     void ProcessQueryStream(const std::vector<int>& query_ids, PointSet& queries, int batches, gpann_comm* comm_route) {
         const size_t nq = nq_, k = (size_t)num_neighbors, P = (size_t)num_probes;
+        LaunchOrder order;
+        order.batches = batches;
         if (queries.n != nq) throw std::runtime_error("ProcessQueryStream: BroadcastQueries first");
         if (batches <= 0) return;
         slice_begin = query_ids.empty() ? 0 : (size_t)query_ids.front();
@@ -288,11 +331,15 @@ public:
             if (backend_ == GPANN_COMM_RCCL) {
                 int32_t *dp = d_probes2_[j & 1], *da = d_all_probes2_[j & 1];
                 HipCheck(hipMemcpyAsync(dp, mine.data(), mine.size() * 4, hipMemcpyHostToDevice, s_route_), "hipMemcpyAsync");
-                CheckComm(gpann_comm_allgather(comm_route, dp, da, mine.size() * 4, s_route_), "gpann_comm_allgather");
+                {
+                    InTurn turn(order, order.PosR(j));
+                    CheckComm(gpann_comm_allgather(comm_route, dp, da, mine.size() * 4, s_route_), "gpann_comm_allgather");
+                }
                 CheckComm(gpann_comm_wait(comm_route, s_route_, wait_timeout_s), "gpann_comm_wait");
                 HipCheck(hipMemcpyAsync(all.data(), da, all.size() * 4, hipMemcpyDeviceToHost, s_route_), "hipMemcpyAsync");
                 HipCheck(hipStreamSynchronize(s_route_), "hipStreamSynchronize");
             } else {
+                InTurn turn(order, order.PosR(j));
                 CheckComm(gpann_comm_allgather(comm_route, mine.data(), all.data(), mine.size() * 4, nullptr), "gpann_comm_allgather");
             }
             all.resize(nq * P);
@@ -312,13 +359,17 @@ public:
             h_dist[b].resize(n);
             h_ids[b].resize(n);
         }
-        auto finish_and_exchange = [&, this](int set) {   // -> h_dist[set], h_ids[set]: every slot's list from its owner
+        auto finish_and_exchange = [&, this](int it) {   // batch `it` -> h_dist[it & 1], h_ids[it & 1]: every slot's list from its owner
+            const int set = it & 1;
             float ms = 0.f;
             Check(gpann_scan_finish(store, &ms), "gpann_scan_finish");
             last_scan_ms = ms;
             if (backend_ == GPANN_COMM_RCCL) {
-                CheckComm(gpann_comm_gather_slots(comm, d_dist2_[set], d_ids2_[set], n, d_out_dist_, d_out_ids_, d_scratch_, d_map_, s_x_),
-                          "gpann_comm_gather_slots");
+                {
+                    InTurn turn(order, order.PosX(it));
+                    CheckComm(gpann_comm_gather_slots(comm, d_dist2_[set], d_ids2_[set], n, d_out_dist_, d_out_ids_, d_scratch_, d_map_, s_x_),
+                              "gpann_comm_gather_slots");
+                }
                 CheckComm(gpann_comm_wait(comm, s_x_, wait_timeout_s), "gpann_comm_wait");
                 HipCheck(hipMemcpyAsync(h_dist[set].data(), d_out_dist_, n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
                 HipCheck(hipMemcpyAsync(h_ids[set].data(), d_out_ids_, n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
@@ -330,6 +381,7 @@ public:
                 HipCheck(hipMemcpyAsync(my_ids.data(), d_ids2_[set], n * 4, hipMemcpyDeviceToHost, s_x_), "hipMemcpyAsync");
                 HipCheck(hipStreamSynchronize(s_x_), "hipStreamSynchronize");
                 host_scratch_.resize(gpann_comm_gather_slots_scratch(comm_size, n));
+                InTurn turn(order, order.PosX(it));
                 CheckComm(gpann_comm_gather_slots(comm, my_dist.data(), my_ids.data(), n, h_dist[set].data(), h_ids[set].data(), host_scratch_.data(), local_to_global.data(),
                                                   nullptr),
                           "gpann_comm_gather_slots");
@@ -344,24 +396,31 @@ public:
                       "gpann_merge_dedup");
         };
 
-        std::future<std::vector<int32_t>> route_next = std::async(std::launch::async, route_job, 0), route_after;
+        // (declared before the try block: when a stage throws, the catch gives the schedule and the routing communicator up FIRST and only then
+        // are these futures destroyed — an std::async future joins its thread in the destructor)
+        std::future<std::vector<int32_t>> route_next, route_cur;
         std::future<void> merging;
-        {
-            const std::vector<int32_t> all0 = route_next.get();
-            if (batches > 1) route_next = std::async(std::launch::async, route_job, 1);
+        try {
+            route_cur = std::async(std::launch::async, route_job, 0);
+            const std::vector<int32_t> all0 = route_cur.get();
+            if (batches > 1) route_next = std::async(std::launch::async, route_job, 1);   // (one route job at a time: they share the router handle and its stream)
             scan_begin(all0, 0);
-        }
-        for (int it = 0; it < batches; ++it) {
-            if (it + 1 < batches) {
-                const std::vector<int32_t> all = route_next.get();
-                if (it + 2 < batches) route_next = std::async(std::launch::async, route_job, it + 2);
-                scan_begin(all, (it + 1) & 1);   // (queued behind batch `it`, which the GPU is still working on)
+            for (int it = 0; it < batches; ++it) {
+                if (it + 1 < batches) {
+                    const std::vector<int32_t> all = route_next.get();
+                    if (it + 2 < batches) route_next = std::async(std::launch::async, route_job, it + 2);
+                    scan_begin(all, (it + 1) & 1);   // (queued behind batch `it`, which the GPU is still working on)
+                }
+                if (merging.valid()) merging.get();   // (batch it - 1: its host lists are the set batch it + 1 will fill)
+                finish_and_exchange(it);
+                merging = std::async(std::launch::async, merge_job, it & 1);
             }
-            if (merging.valid()) merging.get();   // (batch it - 1: its host lists are the set batch it + 1 will fill)
-            finish_and_exchange(it & 1);
-            merging = std::async(std::launch::async, merge_job, it & 1);
+            merging.get();
+        } catch (...) {
+            order.Abort();
+            if (comm_route) (void)gpann_comm_abort(comm_route);
+            throw;
         }
-        merging.get();
         result_dist = m_dist;
         result_ids = m_ids;
     }

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1
-QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN, SCAN_FOR_MERGE, SCAN_DEFER = 1, 2, 4, 8, 16, 32, 64
+QUERIES_ON_DEVICE, OUTPUT_ON_DEVICE, POINTS_ON_DEVICE, AUX_PASS, STORE_PLAIN, SCAN_FOR_MERGE, SCAN_DEFER, SCAN_OVERLAP = 1, 2, 4, 8, 16, 32, 64, 128
 MAX_K = 64
 NO_ID = np.uint32(0xFFFFFFFF)
 
@@ -235,14 +235,16 @@ class Shards:
         return ids, dist, ms.value
 
     def scan_buckets_device(self, queries_ptr, nq, k, probes, nprobe, out_ids_ptr, out_dist_ptr, stream=None, timed=False, aux=False, for_merge=False,
-                            defer=False, host_out=False):
+                            defer=False, host_out=False, overlap=False):
         """Same with queries resident on the device (raw pointer) and the outputs on the device (raw pointers) or — host_out — in host
         arrays given by address (pinned ones for an asynchronous copy); asynchronous unless timed.  defer: GPANN_SCAN_DEFER — the call only
-        enqueues its work and finish() completes it; one more call may be issued before that."""
+        enqueues its work and finish() completes it; one more call may be issued before that.  overlap (with defer): GPANN_SCAN_OVERLAP — the
+        call runs on the handle's own two streams, its front beside the previous call's rest pass; results are in place after finish()."""
         probes = _np(probes, np.int32)
         stride = probes.shape[1]
         ms = C.c_float(0)
-        flags = QUERIES_ON_DEVICE | (0 if host_out else OUTPUT_ON_DEVICE) | (AUX_PASS if aux else 0) | (SCAN_FOR_MERGE if for_merge else 0) | (SCAN_DEFER if defer else 0)
+        flags = QUERIES_ON_DEVICE | (0 if host_out else OUTPUT_ON_DEVICE) | (AUX_PASS if aux else 0) | (SCAN_FOR_MERGE if for_merge else 0) | (SCAN_DEFER if defer else 0) | \
+            (SCAN_OVERLAP if overlap and defer else 0)
         _check(lib().gpann_scan_buckets(self.h, C.c_void_p(int(queries_ptr)), nq, k, probes.ctypes.data_as(_i32p), stride, nprobe,
                                         C.c_void_p(int(out_ids_ptr)), C.c_void_p(int(out_dist_ptr)) if out_dist_ptr else None, None,
                                         flags, C.c_void_p(stream or 0), C.byref(ms) if (timed and not defer) else None))

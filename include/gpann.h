@@ -69,6 +69,14 @@ enum {
                                           among the first k of the merge: the merged result is bit-identical to the one over the full lists.
                                           In filter mode tau_q bounds every shard of the query, not only the one that produced it — rows and
                                           cells beyond it are never evaluated. */
+    GPANN_SCAN_OVERLAP = 1 << 7,       /* gpann_scan_buckets, filter mode, with GPANN_SCAN_DEFER (ignored without it, and in exact mode): the call's device
+                                          work runs on two streams of the HANDLE instead of `stream` — the passes before the rest pass (tables,
+                                          seed, shard-sample, head, sample and their re-scoring: short launches that leave most of the chip idle)
+                                          on one, the rest pass and everything after it (the launch that streams the store once, HBM-bound) on the
+                                          other — so that the front of call i + 1 runs BESIDE the rest pass of call i (the two calls own separate
+                                          device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
+                                          is issued); its results are in place when gpann_scan_finish returns, NOT when `stream` has drained.
+                                          Results are the same bits as without the flag. */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
                                           with the plain exact scan should the data have defeated the filter, statistics, timing).  ONE further

@@ -175,12 +175,22 @@ def _hip():
     return C, hip, ok
 
 
+@pytest.mark.parametrize("overlap", [False, True, "persistent"])
 @pytest.mark.parametrize("mode", ["filter", "exact", "overflow", "filter_ip_2probes"])
-def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
+def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode, overlap, monkeypatch):
     """GPANN_SCAN_DEFER (include/gpann.h): a call only enqueues its work, the NEXT call is planned and enqueued behind it, gpann_scan_finish
     completes them oldest first.  Results (pinned host arrays) and statistics of every call equal the plain call's and the oracle's —
     `overflow`: the first batch floods its buckets with tied rows, so its filtered attempt is redone with the exact scan AT ITS FINISH, after the
-    second batch has already been enqueued behind it."""
+    second batch has already been enqueued behind it.
+    overlap: GPANN_SCAN_OVERLAP — the calls run on the store's own two streams, the front of call i + 1 beside the rest pass of call i (per-slot
+    device workspaces; rest-pass workgroups that leave after a few items, or — "persistent" — a rest pass on fewer persistent workgroups): same bits."""
+    if overlap == "persistent":
+        monkeypatch.setenv("GPANN_OVERLAP_REST_ITEMS", "0")
+        monkeypatch.setenv("GPANN_OVERLAP_REST_CUS", "100")
+        monkeypatch.setenv("GPANN_OVERLAP_FRONT_CUS", "60")
+    elif overlap:
+        monkeypatch.setenv("GPANN_OVERLAP_REST_ITEMS", "2")
+    overlap = bool(overlap)
     C, hip, ok = _hip()
     rng = np.random.default_rng(77)
     two = mode == "filter_ip_2probes"          # inner product, three shards, two probes per query, lists cut at the merge bound
@@ -216,12 +226,12 @@ def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
         return np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_uint32)), shape=(nq * nprobe * k,)).view(dtype).reshape(nq, nprobe, k)
 
     # batch 0 and 1 enqueued back to back, then: finish(0), enqueue 2, finish(1), finish(2)
-    shards.scan_buckets_device(q_dev[0].value, nq, k, probes, nprobe, h_ids[0].value, h_dist[0].value, st.value, defer=True, host_out=True, for_merge=two)
-    shards.scan_buckets_device(q_dev[1].value, nq, k, probes, nprobe, h_ids[1].value, h_dist[1].value, st.value, defer=True, host_out=True, for_merge=two)
+    shards.scan_buckets_device(q_dev[0].value, nq, k, probes, nprobe, h_ids[0].value, h_dist[0].value, st.value, defer=True, host_out=True, for_merge=two, overlap=overlap)
+    shards.scan_buckets_device(q_dev[1].value, nq, k, probes, nprobe, h_ids[1].value, h_dist[1].value, st.value, defer=True, host_out=True, for_merge=two, overlap=overlap)
     stats = []
     shards.finish()
     stats.append(shards.stats())
-    shards.scan_buckets_device(q_dev[2].value, nq, k, probes, nprobe, h_ids[2].value, h_dist[2].value, st.value, defer=True, host_out=True, for_merge=two)
+    shards.scan_buckets_device(q_dev[2].value, nq, k, probes, nprobe, h_ids[2].value, h_dist[2].value, st.value, defer=True, host_out=True, for_merge=two, overlap=overlap)
     shards.finish()
     stats.append(shards.stats())
     shards.finish()
@@ -253,3 +263,71 @@ def test_deferred_calls_overlap_and_finish_in_order(orc, gp, mode):
         ok(hip.hipHostFree(h))
     ok(hip.hipStreamDestroy(st))
     shards.close()
+
+
+@pytest.mark.parametrize("rest_items,metric,d", [("2", 0, 64), ("3", 1, 100), ("5", 0, 128), ("0", 0, 96)])
+def test_overlapped_stream_of_batches_many_cells(orc, gp, monkeypatch, rest_items, metric, d):
+    """GPANN_SCAN_OVERLAP on a store with many cells and several task groups per shard: six batches in a pipeline of depth two — the front of batch
+    i + 1 on the store's front stream beside the rest pass of batch i on its rest stream, the rest pass's workgroups leaving after `rest_items`
+    work items (0: persistent workgroups on part of the chip).  Every batch's lists must be the oracle's and the bits of the same call without
+    the flag; the statistics must say the filtered pipeline ran."""
+    monkeypatch.setenv("GPANN_CELL_ROWS", "1500")
+    monkeypatch.setenv("GPANN_FILTER_SEG_TILES", "8")      # many short work items
+    monkeypatch.setenv("GPANN_OVERLAP_REST_ITEMS", rest_items)
+    monkeypatch.setenv("GPANN_OVERLAP_FRONT_CUS", "64")
+    monkeypatch.setenv("GPANN_OVERLAP_REST_CUS", "128")
+    C, hip, ok = _hip()
+    rng = np.random.default_rng(101 + d)
+    n, S, nq, k, nprobe = 150000, 3, 700, 10, 2
+    pts = make_mixture(orc, n, d, n_centers=48)
+    clusters = random_clusters(rng, n, S, overlap=0.1)
+    batches = [make_mixture(orc, nq, d, seed=600 + i, n_centers=48) for i in range(6)]
+    probes = np.stack([rng.permutation(S)[:nprobe] for _ in range(nq)]).astype(np.int32)
+    shards = gp.Shards(pts, clusters, metric, 0)
+    shards.set_scan_mode(1)
+    ivf = orc.ivf_build(pts, clusters)
+    st = C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(st)))
+    nb = nq * nprobe * k * 4
+    q_dev, h_ids, h_dist = [], [], []
+    for q in batches:
+        p = C.c_void_p()
+        ok(hip.hipMalloc(C.byref(p), C.c_size_t(q.nbytes)))
+        ok(hip.hipMemcpy(p, q.ctypes.data_as(C.c_void_p), C.c_size_t(q.nbytes), 1))
+        q_dev.append(p)
+        for lst in (h_ids, h_dist):
+            h = C.c_void_p()
+            ok(hip.hipHostMalloc(C.byref(h), C.c_size_t(nb), 0))
+            lst.append(h)
+    ok(hip.hipDeviceSynchronize())
+
+    def host_view(h, dtype):
+        return np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_uint32)), shape=(nq * nprobe * k,)).view(dtype).reshape(nq, nprobe, k).copy()
+
+    def begin(i):
+        shards.scan_buckets_device(q_dev[i].value, nq, k, probes, nprobe, h_ids[i].value, h_dist[i].value, st.value, defer=True, host_out=True, for_merge=True, overlap=True)
+
+    stats = []
+    begin(0)
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            begin(i + 1)
+        shards.finish()
+        stats.append(shards.stats())
+    for i, q in enumerate(batches):
+        got_i, got_d = host_view(h_ids[i], np.uint32), host_view(h_dist[i], np.uint32)
+        ids, dist, _ = shards.scan_buckets(q, k, probes, nprobe, for_merge=True)     # the same call, one stream, nothing beside it
+        assert np.array_equal(got_i, ids) and np.array_equal(got_d, dist.view(np.uint32)), (rest_items, i)
+        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, q, k, probes, nprobe, metric, nthreads=4)
+        tau = wd[:, :, -1].min(axis=1)
+        cut = ~(wd <= tau[:, None, None])
+        wd, wi = wd.copy(), wi.copy()
+        wd[cut] = np.inf
+        wi[cut] = 0xFFFFFFFF
+        assert np.array_equal(got_i, wi) and np.array_equal(got_d, wd.view(np.uint32)), (rest_items, i)
+        assert stats[i]["filtered"] == 1 and stats[i]["tasks"] == nq * nprobe and stats[i]["filter_rest_rows"] > 0, stats[i]
+    for p in q_dev:
+        ok(hip.hipFree(p))
+    for h in h_ids + h_dist:
+        ok(hip.hipHostFree(h))
+    ok(hip.hipStreamDestroy(st))
