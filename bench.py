@@ -692,16 +692,13 @@ def main():
             fq = {}
             outs = {}
             for name, env in (("bounded", None), ("canonical_table", "0")):
-                if env is None:
-                    os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
-                else:
-                    os.environ["GPANN_ROUTER_BOUND_TABLE"] = env
+                router.set_option("GPANN_ROUTER_BOUND_TABLE", env)
                 outs[name] = router.frequency_query_batch(hq, args.search_budget, 500)
                 t0 = time.perf_counter()
                 for _ in range(2):
                     router.frequency_query_batch(hq, args.search_budget, 500)
                 fq[name + "_ms"] = 1000.0 * (time.perf_counter() - t0) / 2
-            os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+            router.set_option("GPANN_ROUTER_BOUND_TABLE", None)
             a_, b_ = outs["bounded"], outs["canonical_table"]
             fq["identical"] = bool(all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a_[:4], b_[:4])))
             candidates[-1]["frequency_query"] = fq
@@ -820,37 +817,41 @@ def main():
         # several ranks: the loop's collectives — R j: the probe all-gather of batch j (route-ahead thread, second communicator), X i: the slot
         # exchange of batch i (this thread) — are LAUNCHED in one order on every rank (Turnstile)
         turn = None
+        # scans in flight while one is being completed: 1 (the deferred call of round 4), 2 with GPANN_SCAN_OVERLAP — the front stream then always
+        # holds the next front, so the rest passes follow each other without a gap; the routes run one batch further ahead than the scans
+        scans_ahead = (2 if scan_overlap else 1) if scan_ahead else 0
         if multi and route_ahead and count:
-            ahead = 2 if scan_ahead else 1
-            order = [("R", j) for j in range(min(ahead, count))]
+            r_ahead = scans_ahead + 1
+            order = [("R", j) for j in range(min(r_ahead, count))]
             for it in range(count):
-                if it + ahead < count:
-                    order.append(("R", it + ahead))
+                if it + r_ahead < count:
+                    order.append(("R", it + r_ahead))
                 order.append(("X", it))
             turn = Turnstile(order)
             _live_turns.append(turn)
         x_turn = (lambda it: turn.slot(("X", it))) if turn is not None else (lambda it: None)
         if scan_ahead and count:
-            # routes run two batches ahead of the batch being completed, scans one
+            depth = scans_ahead + 1     # host / device buffer sets: one per scan in flight
             routes = {0: router_pool.submit(route_job, 0, turn)}
-            if count > 1:
-                routes[1] = router_pool.submit(route_job, 1, turn)
             info = {}
-            pr, r_ms, rst = routes.pop(0).result()
-            info[0] = (r_ms, rst)
-            scan_begin(pr, 0)
+
+            def begin(j):
+                """the routing of batch j has arrived: the next one goes to the router thread, the scan of batch j is planned and enqueued"""
+                pr, r_ms, rst = routes.pop(j).result()
+                info[j] = (r_ms, rst)
+                if j + 1 < count:
+                    routes[j + 1] = router_pool.submit(route_job, j + 1, turn)
+                scan_begin(pr, j % depth)
+            for j in range(min(scans_ahead, count)):
+                begin(j)
             t_step = time.perf_counter()
             for it in range(count):
-                if pending is not None:   # the merge of batch it - 1 (submitted a whole batch ago): its host buffers are handed to batch it + 1 next
+                if pending is not None:   # the merge of batch it - 1 (submitted a whole batch ago): its host buffers are handed to the batch begun next
                     md, mi, _ = pending.result()
                     pending = None
-                if it + 1 < count:
-                    pr, r_ms, rst = routes.pop(it + 1).result()
-                    info[it + 1] = (r_ms, rst)
-                    if it + 2 < count:
-                        routes[it + 2] = router_pool.submit(route_job, it + 2, turn)
-                    scan_begin(pr, (it + 1) & 1)     # (batch it + 1 queued behind batch it, which the GPU is still working on)
-                sd, si, s_ms = scan_finish(it & 1, x_turn(it))
+                if it + scans_ahead < count:
+                    begin(it + scans_ahead)     # (queued behind the batches the GPU is still working on)
+                sd, si, s_ms = scan_finish(it % depth, x_turn(it))
                 pending = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
                 note(t_step, info[it][0], s_ms, info.pop(it)[1])
                 t_step = time.perf_counter()
@@ -942,7 +943,7 @@ def main():
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
     qps = nq * args.steps / elapsed
     # what the merge of the last step had to drop: ids that came back from more than one probed shard (overlapping shards only)
-    last_ids = np.sort(host_out[(nq, nprobe, (args.steps - 1) & 1)][1].numpy().view(np.uint32).reshape(nq, -1), axis=1)
+    last_ids = np.sort(host_out[(nq, nprobe, (args.steps - 1) % (3 if scan_overlap else 2))][1].numpy().view(np.uint32).reshape(nq, -1), axis=1)
     dup_ids = int(np.count_nonzero((last_ids[:, 1:] == last_ids[:, :-1]) & (last_ids[:, 1:] != 0xFFFFFFFF)))
     slot_entries = int(np.count_nonzero(last_ids != 0xFFFFFFFF))
 
@@ -1076,14 +1077,14 @@ def main():
         result["detail"]["cu_sweep"] = cu_sweep
 
     # tuning aid (off by default): GPANN_BENCH_SWEEP="GPANN_FILTER_SEED_ROWS=64,128;GPANN_FILTER_HEAD_ROWS=512,0" times a few steps for every
-    # combination of the listed library knobs (they are read per call) and checks that the results do not change
+    # combination of the listed options of the store (gpann_shards_set_option: read by every call) and checks that the results do not change
     if os.environ.get("GPANN_BENCH_SWEEP") and world == 1:
         import itertools
         knobs = [(kv.split("=")[0], kv.split("=")[1].split(",")) for kv in os.environ["GPANN_BENCH_SWEEP"].split(";") if kv]
         sweep = []
         for combo in itertools.product(*[v for _, v in knobs]):
             for (name, _), val in zip(knobs, combo):
-                os.environ[name] = val
+                shards.set_option(name, val)
             step()
             barrier()
             t0 = time.perf_counter()
@@ -1098,7 +1099,7 @@ def main():
                           "identical": same})
             log(f"sweep {sweep[-1]}")
         for name, _ in knobs:
-            os.environ.pop(name, None)
+            shards.set_option(name, None)
         result["detail"]["sweep"] = sweep
 
     # the same steps with the plain exact (VALU) scan, for reference: identical results, no matrix cores

@@ -471,7 +471,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     // the shard sample: the first rows of every shard (store order = the order of Clusters[b] = a random sample), appended as tiles of their own
     std::vector<uint32_t> sample_perm_host;
     {
-        const char* sr = std::getenv("GPANN_FILTER_EXACT_ROWS");   // (historic name: the rows of the first, shard-wide sample)
+        const char* sr = s->opt.Get("GPANN_FILTER_EXACT_ROWS");   // (historic name: the rows of the first, shard-wide sample)
         const uint64_t want = sr ? (uint64_t)std::max(64L, std::atol(sr)) : 4096;
         C.sample_tile_begin.assign(S + 1, 0);
         for (uint32_t b = 0; b < S; ++b) {
@@ -488,14 +488,14 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     // The 8-bit plane comes first: when the store has one, the rest pass never reads the bf16 planes, and only the tiles the earlier
     // passes can reach keep a bf16 hi tile (below).
     {
-        const char* q8_env = std::getenv("GPANN_FILTER_Q8");
+        const char* q8_env = s->opt.Get("GPANN_FILTER_Q8");
         if (!(q8_env && q8_env[0] == '0')) {
             C.q8_ks = (s->d + 31) / 32;
             const bool qok = hipMalloc(&C.q8_planes, (C.n_tiles + 2) * (size_t)C.q8_ks * 1024) == hipSuccess && hipMalloc(&C.d_q8_scale, (size_t)C.n_cells * 4) == hipSuccess &&
                              hipMalloc(&C.d_q8_cnorm, (size_t)C.n_cells * 8) == hipSuccess && hipMalloc(&C.d_tile_bound, (C.n_tiles + 2) * 8) == hipSuccess &&
                              hipMemset(C.q8_planes + C.n_tiles * (size_t)C.q8_ks * 1024, 0, 2 * (size_t)C.q8_ks * 1024) == hipSuccess &&
                              // (GPANN_FILTER_Q8_CELL_FRAME=0 at store build: the plain norm words and the looser (s/2) |q~|_1 error term of round 3)
-                             (s->metric != GPANN_METRIC_L2 || (std::getenv("GPANN_FILTER_Q8_CELL_FRAME") && std::getenv("GPANN_FILTER_Q8_CELL_FRAME")[0] == '0') ||
+                             (s->metric != GPANN_METRIC_L2 || (s->opt.Get("GPANN_FILTER_Q8_CELL_FRAME") && s->opt.Get("GPANN_FILTER_Q8_CELL_FRAME")[0] == '0') ||
                               hipMalloc(&C.q8_norm, ((C.n_tiles + 2) * kGTileRows + 64) * 4) == hipSuccess);
             if (!qok) {   // the store works without it
                 (void)hipGetLastError();
@@ -518,8 +518,8 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     constexpr uint32_t kHiKeepDiv = kFilterFrontDiv;
     std::vector<uint32_t> cell_lo_begin(C.n_cells + 1, 0), cell_hi_begin(C.n_cells + 1, 0), tile_lo_index, tile_hi_index;
     {
-        const char* lr = std::getenv("GPANN_FILTER_LO_ROWS");
-        const char* hr = std::getenv("GPANN_FILTER_HI_ROWS");
+        const char* lr = s->opt.Get("GPANN_FILTER_LO_ROWS");
+        const char* hr = s->opt.Get("GPANN_FILTER_HI_ROWS");
         C.lo_full = lr && std::string(lr) == "all";
         C.hi_compact = C.q8_planes != nullptr && !C.lo_full && !(hr && std::string(hr) == "all");
         const uint64_t lo_rows = C.plane_ks > 8 ? 0 : (lr && !C.lo_full ? (uint64_t)std::max(0L, std::atol(lr)) : 512);
@@ -594,7 +594,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     // squared L2: everything the matrix-core bound touches is taken around the store's mean row (translation leaves the distances alone
     // and makes |p|, |q| — which the bound's error terms scale with — as small as the data allows; a cloud that sits at +100 in every
     // coordinate would otherwise have error terms larger than its k-th distances).  GPANN_FILTER_CENTER=0 switches it off.
-    const char* centre_env = std::getenv("GPANN_FILTER_CENTER");
+    const char* centre_env = s->opt.Get("GPANN_FILTER_CENTER");
     if (ok && s->metric == GPANN_METRIC_L2 && !(centre_env && centre_env[0] == '0')) {
         double* d_sums = nullptr;
         unsigned long long* d_max_bits = reinterpret_cast<unsigned long long*>(s->d_shard_rmax);
@@ -624,7 +624,7 @@ gpann_status BuildCells(gpann_shards* s, uint32_t target_rows) {
     }
     if (ok) {
         // (GPANN_FILTER_SORT_ROWS=0: the cells' rows stay in slab order throughout — the layout of the earlier rounds, for comparison)
-        const char* sort_env = std::getenv("GPANN_FILTER_SORT_ROWS");
+        const char* sort_env = s->opt.Get("GPANN_FILTER_SORT_ROWS");
         uint32_t* by_norm = sort_env && sort_env[0] == '0' ? nullptr : RowsByNorm(session.rows(), s->rows, member_begin, cell_size, C.cell_tile_begin, s->neg_half_norm);
         hipLaunchKernelGGL(CellLayoutKernel, dim3(C.n_cells), dim3(256), 0, 0, by_norm ? by_norm : session.rows(), d_member_begin, d_cell_size, C.d_cell_tile_begin,
                            s->neg_half_norm, C.plane_perm, C.plane_norm);

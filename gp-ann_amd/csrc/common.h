@@ -3,6 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <map>
+#include <string>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -49,7 +53,40 @@ void SetLastError(const char* fmt, ...);
 
 gpann_status EnsureDevice(int device);
 
-// Growable device buffer owned by a handle.
+// The knobs of a handle (include/gpann.h: gpann_shards_set_option / gpann_router_set_option).  A handle takes a SNAPSHOT of the process
+// environment's GPANN_* variables when it is created — the defaults of a deployment still come from the environment — and never looks at the
+// environment again: what a call does afterwards depends on the handle alone (set_option), is visible to a C-ABI caller (get_option) and cannot
+// race with another thread's setenv.  Only debug output (GPANN_CELLS_DEBUG, GPANN_ROUTER_DEBUG, the path GPANN_VERIFY_REPORT) is still read
+// from the environment where it is used.  Not synchronised: set an option while no call is in flight on the handle.
+struct Options {
+    std::map<std::string, std::string> kv;
+    void SnapshotEnvironment();                       // (common.h users link shards.hip, which defines these)
+    static std::string Canonical(const char* name);   // "FILTER_HEAD_ROWS" and "GPANN_FILTER_HEAD_ROWS" name the same knob
+    static bool Known(const std::string& canonical);
+    const char* Get(const char* name) const {         // the interface of getenv: nullptr = not set
+        auto it = kv.find(name);
+        return it == kv.end() ? nullptr : it->second.c_str();
+    }
+    bool IsSet(const char* name) const { return Get(name) != nullptr; }
+    bool IsZero(const char* name) const {             // set and begins with '0'
+        const char* v = Get(name);
+        return v && v[0] == '0';
+    }
+    uint32_t U32(const char* name, uint32_t dflt) const {
+        const char* v = Get(name);
+        if (!v || !*v) return dflt;
+        char* end = nullptr;
+        long x = std::strtol(v, &end, 10);
+        return (end != v && x >= 0) ? (uint32_t)x : dflt;
+    }
+};
+gpann_status SetOption(Options& o, const char* name, const char* value);
+gpann_status GetOption(const Options& o, const char* name, char* out, size_t cap);
+
+// Growable device buffer owned by a handle.  (Growth goes through hipFree, which synchronises the whole DEVICE: a buffer never shrinks, every
+// scan call slot and every router block owns its own buffers, and nothing that is still read by an enqueued kernel is ever re-grown — the callers
+// wait for the slot's previous call first (scan.hip ScanToDevice, stage_in_flight).  Do not switch this to hipFreeAsync / a pool without
+// revisiting those waits.)
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;

@@ -38,6 +38,7 @@ struct gpann_router {
     // The reference's callers invoke Query / FrequencyQuery concurrently, one query per call (routes.cpp:194-200); a handle owns ONE set of
     // device workspaces, so concurrent calls on it take turns (recursive: entry points call each other).
     std::recursive_mutex call_mutex;
+    gpann::Options opt;   // the handle's knobs: the environment's GPANN_* at creation, then gpann_router_set_option (common.h)
     int device = 0;
     int metric = 0;
     uint32_t d = 0, ld = 0, S = 0, n_nodes = 0;
@@ -1826,6 +1827,7 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
     GPANN_TRY(EnsureDevice(device));
 
     auto* r = new gpann_router();
+    r->opt.SnapshotEnvironment();   // (the one look at the environment: gpann_router_set_option from here on)
     r->device = device;
     r->metric = metric;
     r->d = d;
@@ -1944,7 +1946,7 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         // leaves the distances alone; the bound's error terms scale with the norms).
         bool finite = true;
         std::vector<float> mu(r->ld, 0.f);
-        const char* centre_env = std::getenv("GPANN_FILTER_CENTER");
+        const char* centre_env = r->opt.Get("GPANN_FILTER_CENTER");
         const bool centred = metric == GPANN_METRIC_L2 && nc > 0 && !(centre_env && centre_env[0] == '0');
         if (centred) {
             std::vector<double> sum(d, 0.0);
@@ -2058,6 +2060,16 @@ gpann_status gpann_router_export(const gpann_router* r, int32_t* node_shard, uin
     if (centroids && r->n_centroids)
         GPANN_HIP_TRY(hipMemcpy2D(centroids, (size_t)r->d * 4, r->centroids, (size_t)r->ld * 4, (size_t)r->d * 4, r->n_centroids, hipMemcpyDeviceToHost));
     return GPANN_OK;
+}
+
+gpann_status gpann_router_set_option(gpann_router* r, const char* name, const char* value) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    std::lock_guard<std::recursive_mutex> turn(r->call_mutex);
+    return SetOption(r->opt, name, value);
+}
+gpann_status gpann_router_get_option(const gpann_router* r, const char* name, char* out, size_t cap) {
+    GPANN_REQUIRE(r != nullptr, "router handle is null");
+    return GetOption(r->opt, name, out, cap);
 }
 
 gpann_status gpann_router_destroy(gpann_router* r) {
@@ -2304,8 +2316,18 @@ gpann_status EnqueueBound(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     // segments = 320 workgroups on 256 CUs ran as 256 + 64, i.e. at the pace of 160
     ba.n_seg = std::max(1u, std::min(std::min(80u, (n_tiles + 7) / 8), std::max(1u, (uint32_t)r->num_cus / groups)));
     // counters: [0] candidate slots, [1] unset minima after pass 2, [2..3] (verify mode), [4] pairs pass 1 left without a maximum / a finite threshold
-    hipLaunchKernelGGL(BoundInitKernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)cand_cap + 255) / 256)), dim3(256), 0, st, ba.max_bits, nb_s, ba.cand, (size_t)cand_cap,
-                       ba.cand_count, da.out_min_bits);
+    if (r->opt.IsSet("GPANN_ROUTER_LEGACY_MEMSET")) {
+        // debug: the set-up of rounds 1-3 — three runtime memsets and a fill launch.  The intermittent "minima unset" event of those rounds has
+        // not been seen since BoundInitKernel replaced them; tools/stress_suite_context.sh runs this variant under the determinism probe to
+        // find out whether the event lives in the runtime's memsets
+        GPANN_HIP_TRY(hipMemsetAsync(ba.max_bits, 0, nb_s * 4, st));
+        GPANN_HIP_TRY(hipMemsetAsync(ba.cand_count, 0, 32, st));
+        GPANN_HIP_TRY(hipMemsetAsync(ba.cand, 0xFF, (size_t)cand_cap * 8, st));
+        hipLaunchKernelGGL(FillMinBitsKernel, dim3((uint32_t)((nb_s + 255) / 256)), dim3(256), 0, st, da.out_min_bits, nb_s);
+    } else {
+        hipLaunchKernelGGL(BoundInitKernel, dim3((uint32_t)std::min<uint64_t>(1024, ((uint64_t)cand_cap + 255) / 256)), dim3(256), 0, st, ba.max_bits, nb_s, ba.cand, (size_t)cand_cap,
+                           ba.cand_count, da.out_min_bits);
+    }
     GPANN_HIP_TRY(hipGetLastError());
     const bool l2 = r->metric == GPANN_METRIC_L2, ks4 = r->d <= 64;
     const size_t blds = (size_t)(ks16 ? 4 * 16 : 8 * (ks4 ? 4 : 8)) * 2048 + 8 * kGTileRows * sizeof(float);
@@ -2621,8 +2643,8 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     const size_t nb_s = (size_t)nb * r->S;
     BoundArgs ba;
     float* thr = nullptr;
-    const bool defer = may_defer && !std::getenv("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK") &&
-                       !std::getenv("GPANN_ROUTER_PROBE") && !std::getenv("GPANN_ROUTER_FORCE_EVIDENCE");
+    const bool defer = may_defer && !r->opt.Get("GPANN_ROUTER_VERIFY") && !std::getenv("GPANN_ROUTER_DEBUG") && !r->opt.Get("GPANN_ROUTER_FORCE_RECHECK") &&
+                       !r->opt.Get("GPANN_ROUTER_PROBE") && !r->opt.Get("GPANN_ROUTER_FORCE_EVIDENCE");
     GPANN_TRY(EnqueueBound(r, da, nb, st, ba, thr, /*convert_minima=*/defer));
     if (defer) {
         // no round trip in the middle of the call: the counters go to the host with the results (ResolvePendingBound)
@@ -2645,15 +2667,15 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
     }
     const uint32_t n_cand = counters[0];
     if (std::getenv("GPANN_ROUTER_DEBUG")) fprintf(stderr, "[gpann router] bound: %u candidate slots for %u x %u (query, shard) pairs\n", n_cand, nb, r->S);
-    if (std::getenv("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
+    if (r->opt.Get("GPANN_ROUTER_FORCE_RECHECK")) counters[1] = 1;   // test hook: take the canonical re-evaluation
     if (counters[1] != 0 || counters[4] != 0) {
         ++r->stat_bound_selfcheck;
         fprintf(stderr,
                 "[gpann router] bound path self-check: pass 1 left %u of %zu (query, shard) pairs without a maximum or with a non-finite threshold, %u minima are unset "
                 "after pass 2 (%u candidate slots, cap %u); evaluating every pair canonically instead\n",
                 counters[4], nb_s, counters[1], n_cand, ba.cand_cap);
-        const bool strict = std::getenv("GPANN_ROUTER_STRICT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK");
-        if (strict || (std::getenv("GPANN_VERIFY_REPORT") && !std::getenv("GPANN_ROUTER_FORCE_RECHECK"))) {
+        const bool strict = r->opt.Get("GPANN_ROUTER_STRICT") && !r->opt.Get("GPANN_ROUTER_FORCE_RECHECK");
+        if (strict || (std::getenv("GPANN_VERIFY_REPORT") && !r->opt.Get("GPANN_ROUTER_FORCE_RECHECK"))) {
             // the record of a rare event (3 in ~50 test suites of rounds 1-3, none in 7 200 stand-alone runs): the block's arrays, the same block once
             // more on the same inputs, the canonical minima — as text and as a binary dump (BoundEvidence)
             size_t bad = 0;
@@ -2672,9 +2694,9 @@ gpann_status RunBoundPath(gpann_router* r, const DenseArgs& da, uint32_t nb, hip
         ++r->stat_bound_overflow;
         return GPANN_OK;
     }
-    if (std::getenv("GPANN_ROUTER_VERIFY")) GPANN_TRY(VerifyBound(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
-    if (std::getenv("GPANN_ROUTER_PROBE")) GPANN_TRY(ProbeBoundDeterminism(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
-    if (std::getenv("GPANN_ROUTER_FORCE_EVIDENCE")) {   // test hook: the evidence machinery on a healthy block (its report then says: nothing differs)
+    if (r->opt.Get("GPANN_ROUTER_VERIFY")) GPANN_TRY(VerifyBound(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
+    if (r->opt.Get("GPANN_ROUTER_PROBE")) GPANN_TRY(ProbeBoundDeterminism(r, da, nb, st, ba, thr, caller_queries, caller_on_device));
+    if (r->opt.Get("GPANN_ROUTER_FORCE_EVIDENCE")) {   // test hook: the evidence machinery on a healthy block (its report then says: nothing differs)
         size_t bad = 0;
         GPANN_TRY(BoundEvidence(r, da, nb, st, ba, thr, caller_queries, caller_on_device, "forced (GPANN_ROUTER_FORCE_EVIDENCE, a test hook)", &bad));
     }
@@ -2700,7 +2722,7 @@ gpann_status ResolvePendingBound(gpann_router* r, bool* repeat) {
                 "[gpann router] bound path self-check: pass 1 left %u of %zu (query, shard) pairs without a maximum or with a non-finite threshold, %u minima are unset "
                 "after pass 2 (%u candidate slots); evaluating every pair canonically instead\n",
                 bad1, (size_t)r->pending_bound.nb * r->S, unset, n_cand);
-        if (std::getenv("GPANN_ROUTER_STRICT")) {
+        if (r->opt.Get("GPANN_ROUTER_STRICT")) {
             SetLastError("router bound path self-check fired: pass 1 %u, pass 2 %u (query, shard) pairs (GPANN_ROUTER_STRICT)", bad1, unset);
             return GPANN_ERR_INTERNAL;
         }
@@ -2723,7 +2745,7 @@ const void* BoundedReplayFn(int metric, bool rec) {
 gpann_status EnqueueBoundTable(gpann_router* r, const float* d_queries, uint32_t nb, hipStream_t st, float* table, uint64_t table_ld, float* base, float* eps) {
     float *h_lo = eps + nb, *h_scale = eps + 2 * (size_t)nb;   // (the frame: four arrays of nb floats, base first)
     double eps_scale = 1.0;
-    if (const char* e = std::getenv("GPANN_ROUTER_EPS_SCALE")) eps_scale = std::max(1.0, std::atof(e));   // test knob: a wider band, the same bits
+    if (const char* e = r->opt.Get("GPANN_ROUTER_EPS_SCALE")) eps_scale = std::max(1.0, std::atof(e));   // test knob: a wider band, the same bits
     BoundArgs ba{};
     ba.queries = d_queries;
     ba.cent_planes = r->cent_planes;
@@ -2784,14 +2806,14 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     cap = std::max<uint64_t>(cap, S);
     struct { int multiProcessorCount; } prop{r->num_cus};
     GPANN_TRY(r->ws_out.Reserve((size_t)nq * S * 4));
-    const char* force = std::getenv("GPANN_ROUTER_MODE");   // "walk" | "dense" (default: by size)
+    const char* force = r->opt.Get("GPANN_ROUTER_MODE");   // "walk" | "dense" (default: by size)
     const uint64_t C = r->n_centroids;
     // dense + replay: all distances of a block of queries at once (exact, tiled), then the queue logic on the table
     const uint64_t dense_cap = 6ull << 30;   // bytes of distance table per block of queries
     // (which is cheaper: measured on the NS trees, search budget 50 000 — the walk costs ~1.2 us per (query, evaluated centroid) in its queue and
     // its L2 traffic (252k-centroid tree: 602 ms per 10k queries), the table 0.02 us per (query, centroid) (139k centroids: 26 ms): the table
     // wins until the tree is ~60x the budget.  Rounds 1-2 switched at 4x and sent the 200k and 1M indices of the reference's grid to the walk.)
-    const uint64_t dense_factor = (uint64_t)std::max(1, std::atoi(std::getenv("GPANN_ROUTER_DENSE_FACTOR") ? std::getenv("GPANN_ROUTER_DENSE_FACTOR") : "32"));
+    const uint64_t dense_factor = (uint64_t)std::max(1, std::atoi(r->opt.Get("GPANN_ROUTER_DENSE_FACTOR") ? r->opt.Get("GPANN_ROUTER_DENSE_FACTOR") : "32"));
     bool dense = budget > 0 && C <= dense_factor * (uint64_t)budget && C < 0xFFFFFFFFull && C * 4 * 64 <= dense_cap;
     if (force && std::string(force) == "walk") dense = false;
     if (force && std::string(force) == "dense" && C * 4 * 64 <= dense_cap) dense = budget > 0;
@@ -2801,7 +2823,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
     }
     GPANN_HIP_TRY(hipEventRecord(r->ev[0], st));
     if (dense) {
-        const char* rmode = std::getenv("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
+        const char* rmode = r->opt.Get("GPANN_ROUTER_REPLAY");   // "heap" = always the real queue; "threshold" = skip the sorted replay
         const bool force_heap = rmode && std::string(rmode) == "heap";
         const bool all_roots_open = (int64_t)budget > (int64_t)r->root_total - (int64_t)r->root_min;
         uint32_t sort_n = 1;
@@ -2816,7 +2838,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         // every node is visited iff the budget left after the roots exceeds all non-root sizes together, i.e. budget > C
         const bool min_only = all_roots_open && (uint64_t)budget > C && rec_dist == nullptr && !force_heap;
         // the threshold replay on a table the matrix cores wrote, canonical evaluation of the cut-off band only (RouterBoundedReplayKernel)
-        const char* tmode = std::getenv("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
+        const char* tmode = r->opt.Get("GPANN_ROUTER_BOUND_TABLE");   // "0": the canonical table (DenseDistKernel) for every tree
         const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
         const bool bounded_able = r->cent_planes != nullptr && !(tmode && tmode[0] == '0') && !r->canonical_once && r->cent_node8 != nullptr &&
                                   r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
@@ -2833,7 +2855,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const uint32_t q_block = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(64, dense_cap / (row_floats * 4) / 64 * 64));
         GPANN_TRY(r->ws_dense.Reserve(std::max<size_t>((size_t)q_block * row_floats * 4, 256)));
         uint32_t band_cap = 512;
-        if (const char* e = std::getenv("GPANN_ROUTER_BAND_CAP")) band_cap = (uint32_t)std::min(4096, std::max(96, std::atoi(e)));
+        if (const char* e = r->opt.Get("GPANN_ROUTER_BAND_CAP")) band_cap = (uint32_t)std::min(4096, std::max(96, std::atoi(e)));
         for (uint32_t q0 = 0; q0 < nq; q0 += q_block) {
             const uint32_t nb = std::min(q_block, nq - q0);
             DenseArgs da;
@@ -2852,7 +2874,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
             if (min_only) {
                 // the budget exceeds the tree and nobody asked for the evaluated distances: the per-shard minima are the whole answer
                 const size_t nb_s = (size_t)nb * S;
-                const char* bmode = std::getenv("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
+                const char* bmode = r->opt.Get("GPANN_ROUTER_BOUND");   // "0": canonical evaluation of every pair (DenseDistKernel)
                 if (r->cent_planes && !(bmode && bmode[0] == '0') && !r->canonical_once) {
                     // matrix-core bound, canonical evaluation of the few pairs that can be the minimum (router_bound.h; its init launch sets the minima to FLT_MAX)
                     bool settled = false;
@@ -3023,7 +3045,7 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
                     fprintf(stderr, "[gpann router] %s replay: %u of %u queries need the real priority queue\n", sorted_ok ? "sorted" : "threshold", marked, nb);
                 hgrid = std::min<uint32_t>(grid, std::max<uint32_t>(1, (marked + kRWaves - 1) / kRWaves * 4));
             }
-            if (need_heap && ra.only_redo && !(std::getenv("GPANN_ROUTER_HOST_REDO") && std::getenv("GPANN_ROUTER_HOST_REDO")[0] == '0')) {
+            if (need_heap && ra.only_redo && !(r->opt.Get("GPANN_ROUTER_HOST_REDO") && r->opt.Get("GPANN_ROUTER_HOST_REDO")[0] == '0')) {
                 // the marked queries go to host threads and the real std::priority_queue (HostReplayMarked); the device heap kernel
                 // stays for batches whose marked rows would not fit the staging budget
                 bool done = false;
@@ -3304,7 +3326,7 @@ gpann_status gpann_router_frequency_query_batch(gpann_router* r, const float* qu
     // on the NS trees: 8 blocks of 1310 queries).  A query whose records do not fit, or a tree / budget the bounded replay does not take,
     // repeats the call the old way.
     uint64_t small_cap = std::max<uint64_t>(4ull * num_voting, (uint64_t)num_voting + 4096);
-    const char* small_env = std::getenv("GPANN_ROUTER_FREQ_SMALL");   // "0": never; n > 1 (tests): n records per query (at least num_voting)
+    const char* small_env = r->opt.Get("GPANN_ROUTER_FREQ_SMALL");   // "0": never; n > 1 (tests): n records per query (at least num_voting)
     if (small_env && std::atoll(small_env) > 1) small_cap = std::max<uint64_t>((uint64_t)std::atoll(small_env), num_voting);
     if (num_voting >= 1 && num_voting <= 2048 && small_cap < rec_cap && !(small_env && small_env[0] == '0')) {
         bool truncated = false;

@@ -390,13 +390,6 @@ struct UploadBatch {
     }
 };
 
-static uint32_t EnvU32(const char* name, uint32_t dflt) {
-    const char* v = std::getenv(name);
-    if (!v || !*v) return dflt;
-    char* end = nullptr;
-    long x = std::strtol(v, &end, 10);
-    return (end != v && x >= 0) ? (uint32_t)x : dflt;
-}
 
 // Group the caller's (query, slot) pairs by shard (counting sort): the TASKS of this call.
 static gpann_status BuildTasks(const gpann_shards* s, uint32_t nq, const int32_t* probes, uint32_t probe_stride, uint32_t nprobe, ScanPlan& plan) {
@@ -433,7 +426,7 @@ static gpann_status BuildTasks(const gpann_shards* s, uint32_t nq, const int32_t
 // Units of the exact kernel for the row range [lo[b], hi[b]) of every shard: (<= 64 tasks) x (one row segment).  Segments
 // are sized so that the launch has enough workgroups to fill 256 CUs several times over while each unit still amortises
 // the warm-up of its top-k lists.
-static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vector<int64_t>& lo, const std::vector<int64_t>& hi) {
+static gpann_status BuildExactUnits(const gpann_shards* s, ScanPlan& plan, uint32_t S, const std::vector<int64_t>& lo, const std::vector<int64_t>& hi) {
     const std::vector<uint32_t>& count = plan.shard_task_begin;
     const uint32_t T = count[S];
     plan.task_part.assign(T, 0);
@@ -441,8 +434,8 @@ static gpann_status BuildExactUnits(ScanPlan& plan, uint32_t S, const std::vecto
     plan.units.clear();
     uint64_t tile_rows = 0;
     for (uint32_t b = 0; b < S; ++b) tile_rows += (uint64_t)((count[b + 1] - count[b] + kQT - 1) / kQT) * (uint64_t)std::max<int64_t>(0, hi[b] - lo[b]);
-    const uint32_t target_units = std::max<uint32_t>(1, EnvU32("GPANN_SCAN_TARGET_UNITS", 8192));
-    const uint32_t min_seg_rows = std::max<uint32_t>(64, EnvU32("GPANN_SCAN_MIN_SEG_ROWS", 1024));
+    const uint32_t target_units = std::max<uint32_t>(1, s->opt.U32("GPANN_SCAN_TARGET_UNITS", 8192));
+    const uint32_t min_seg_rows = std::max<uint32_t>(64, s->opt.U32("GPANN_SCAN_MIN_SEG_ROWS", 1024));
     uint64_t seg_rows = std::max<uint64_t>(min_seg_rows, (tile_rows + target_units - 1) / std::max<uint32_t>(1, target_units));
     // short scans (stage 0 of the filtered pipeline with few tasks): rather 256-row segments than fewer than ~500 workgroups
     if (tile_rows / seg_rows < 512) seg_rows = std::max<uint64_t>(256, std::min<uint64_t>(seg_rows, tile_rows / 1024));
@@ -587,11 +580,11 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
 //   by the exact re-scoring of its candidates.  `ta.query` / `ta.out` are re-uploaded in the new task order.
-// `st`: the stream of the call's FRONT — everything before the rest pass; `st_rest`: the stream of the rest pass and what follows it.  The same
-// stream for a plain call; GPANN_SCAN_OVERLAP: the handle's two streams (the rest stream waits for the end of the front: CallState::ev_x[1]).
+// `st`: the stream of the call's FRONT — everything before the rest pass's filter launch; `st_rest`: the stream of that launch; `st_tail`: what follows
+// it.  The same stream for a plain call; GPANN_SCAN_OVERLAP: the handle's three streams (each waits for the stage before it: CallState::ev_x).
 // *st_end = the stream the call's last launch went to.
 static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const TaskArrays& ta_in, UploadBatch& up, const float* d_queries, uint32_t nq, uint32_t nprobe_of_call,
-                                        uint32_t k, int flags, hipStream_t st, hipStream_t st_rest, hipStream_t* st_end, DeviceLists out) {
+                                        uint32_t k, int flags, hipStream_t st, hipStream_t st_rest, hipStream_t st_tail, hipStream_t* st_end, DeviceLists out) {
     *st_end = st;
     const bool overlap = st_rest != st;
     TaskArrays ta = ta_in;   // (query / out point to the re-ordered copies once the tasks are grouped by nearest cell; the caller's arrays keep the host's order)
@@ -605,10 +598,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     const auto& C = s->cells;
     const uint32_t kmax = C.kmax;
-    const int64_t m0 = (int64_t)EnvU32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
+    const int64_t m0 = (int64_t)s->opt.U32("GPANN_FILTER_EXACT_ROWS", 4096) / kPT * kPT;
     // candidate bucket per task: what its rows cost is the candidates actually written, so the size is only bounded by memory (6 GiB);
     // the pass structure below is laid out for a fill of about a quarter of min(cap, 4096)
-    const uint32_t cap = EnvU32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1024, (6144ull << 20) / (4ull * T))));
+    const uint32_t cap = s->opt.U32("GPANN_FILTER_CAND_CAP", (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1024, (6144ull << 20) / (4ull * T))));
     const uint32_t cap_plan = std::min<uint32_t>(cap, 4096);
     // Three filter passes keep the candidate buckets small whatever the geometry: rows inside a cell are in store order, i.e.
     // a random sample of the cell, so after a pass over a fraction 1/f of the needed rows only about f * k rows of the rest can
@@ -616,7 +609,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
     // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
     // (the head pass multiplies both planes: it cannot reach past the rows that have a lo tile)
-    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(EnvU32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows,
+    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(s->opt.U32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows,
                                                                       C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles),
                                                    C.hi_compact ? 16u : 0xFFFFFFFFu);   // (compact hi planes keep 16 tiles of every cell at least)
     int64_t max_rows = 1;
@@ -625,7 +618,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const uint64_t div_auto = ((uint64_t)max_rows * k * 4 + (uint64_t)m0 * cap_plan - 1) / ((uint64_t)std::max<int64_t>(m0, 1) * cap_plan);
     // (compact hi planes: the sample segment has to stay inside the tiles that kept a bf16 hi tile)
     // (round 3, buckets of up to 16k candidates: half of that share is enough — NS 10 -> 8: 0.1 ms of 4.3, C5 18 -> 9; profiles/r03/sweep_sample_div.md)
-    const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), EnvU32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto / 2))));
+    const uint32_t sample_div = std::max<uint32_t>(std::max<uint32_t>(2, C.hi_keep_div), s->opt.U32("GPANN_FILTER_SAMPLE_DIV", (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, div_auto / 2))));
     if (std::getenv("GPANN_CELLS_DEBUG")) fprintf(stderr, "[gpann cells] sample_div %u (auto %llu)\n", sample_div, (unsigned long long)div_auto);
     const bool l2 = s->metric == GPANN_METRIC_L2;
     (void)flags;
@@ -633,12 +626,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const bool wide = KS > 8;   // beyond 128 dimensions: hi-plane passes only, 4 query tiles per group
     // the rest pass on the 8-bit plane (scan_cells.h MODE 2) when the store has one: a quarter of the fp32 bytes per row instead of half
     // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
-    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || EnvU32("GPANN_FILTER_Q8", 1) != 0);
+    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || s->opt.U32("GPANN_FILTER_Q8", 1) != 0);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
     // (never the head pass: an 8-bit pass gives a task candidates only from the cells NeedKernel marked for it — its per-(task, cell) thresholds —
     // while the later passes skip a segment for a whole query tile once the tile has run on it; the head pass marks one cell per task, the bf16
     // kernel's per-task threshold tests every task of the tile against it all the same.  Measured with the clamp lifted: wrong lists.)
-    const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, EnvU32("GPANN_FILTER_Q8_FROM_PASS", 1)));
+    const int q8_from_pass = (int)std::max<uint32_t>(1, std::min<uint32_t>(2, s->opt.U32("GPANN_FILTER_Q8_FROM_PASS", 1)));
     const uint32_t group_tasks = 32u * QT;   // the query image of a group has to fit LDS
 
     // ---- workspace
@@ -688,7 +681,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t need_words = (size_t)G * kmax;
     // (the 8-bit passes of a squared-L2 store whose plane has its own norm words bound the quantisation error in the frame of the cell: |q - c|_1 per (task, cell))
     // (GPANN_FILTER_Q8_L1=0: no table — |q - c|_1 <= sqrt(d) |q - c|_2 from the table of squared distances instead, ~25 % looser)
-    const bool cell_l1 = use_q8 && C.q8_norm != nullptr && EnvU32("GPANN_FILTER_Q8_L1", 1) != 0;
+    const bool cell_l1 = use_q8 && C.q8_norm != nullptr && s->opt.U32("GPANN_FILTER_Q8_L1", 1) != 0;
     GPANN_TRY(CS(s).ws_celld.Reserve((size_t)T * 16 + (size_t)T * 8 + (size_t)T * kmax * 4 * (cell_l1 ? 2 : 1) + (size_t)T * 20 + dtiles.size() * sizeof(CellTileRef) + (size_t)(S + 1) * 4 + 256));
     double* d_task_nq = CS(s).ws_celld.as<double>();   // |q|^2 of every task (old task order, like the table and the nearest cells)
     double* d_task_q1 = d_task_nq + T;              // |q~|_1 (old order) ...
@@ -700,7 +693,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     uint32_t* d_task_group_own = d_nearest + T;
     CellTileRef* d_dtiles_own = reinterpret_cast<CellTileRef*>(d_task_group_own + T + (T & 1));
     // work items of a pass: pieces of at most seg_tiles row tiles (small stores: small pieces, so that every CU gets some)
-    const uint32_t seg_tiles = std::max<uint32_t>(8, EnvU32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
+    const uint32_t seg_tiles = std::max<uint32_t>(8, s->opt.U32("GPANN_FILTER_SEG_TILES", (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, C.n_tiles / 2048))));
     GPANN_REQUIRE(((uint64_t)C.sample_tile_base + C.n_sample_tiles + 2) * kGTileRows < 0xFFFFFFFFull, "plane rows beyond 32 bits");
     // one item list per task group: group_first[g] = where it starts (capacity: every cell of the group's shard cut into pieces)
     uint64_t items_cap = 0;
@@ -737,7 +730,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of that pass's lists
     uint32_t* d_stab = nullptr;
     CellItem* d_sitems = nullptr;
-    const bool shard_sample_pass = C.n_sample_tiles != 0 && EnvU32("GPANN_FILTER_SEED_ROWS", 128) != 0 && EnvU32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0;
+    const bool shard_sample_pass = C.n_sample_tiles != 0 && s->opt.U32("GPANN_FILTER_SEED_ROWS", 128) != 0 && s->opt.U32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0;
     if (shard_sample_pass) {
         const uint32_t piece = 32;   // row tiles per work item
         for (uint32_t g = 0; g < G; ++g) {
@@ -882,7 +875,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     //      threshold as the k-th of 4096 random rows of the whole shard, for 1/64 of the evaluations (0.77 -> 0.1 ms per 10k tasks on
     //      the NS workload).  GPANN_FILTER_SEED_ROWS=0: the earlier exact scan of the first m0 rows of the shard (ScanTileKernel).
     // (at least 6 k rows: the k-th of the seed rows has to be a quantile of them, not their maximum)
-    const uint32_t seed_rows_env = EnvU32("GPANN_FILTER_SEED_ROWS", 128);   // (NS: 128 rows 1 % faster end to end than 64, 10 % fewer candidates)
+    const uint32_t seed_rows_env = s->opt.U32("GPANN_FILTER_SEED_ROWS", 128);   // (NS: 128 rows 1 % faster end to end than 64, 10 % fewer candidates)
     const uint32_t seed_rows = seed_rows_env == 0 ? 0u : std::max<uint32_t>(seed_rows_env, (6 * k + 15) / 16 * 16);
     plan.padded_pairs = 0;
     if (seed_rows == 0) {
@@ -891,7 +884,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             lo[b] = s->offsets[b];
             hi[b] = std::min<int64_t>(s->offsets[b + 1], s->offsets[b] + m0);
         }
-        GPANN_TRY(BuildExactUnits(plan, S, lo, hi));
+        GPANN_TRY(BuildExactUnits(s, plan, S, lo, hi));
         MergeArgs m{};
         m.out_index = nullptr;   // identity: list t
         m.permutation = s->permutation;
@@ -1041,8 +1034,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates).  A store
     // built with GPANN_FILTER_LO_ROWS=all has a lo tile for every tile: GPANN_FILTER_HI_ONLY=0 then keeps all three products everywhere,
     // GPANN_FILTER_HI_FROM_PASS chooses the first hi-plane pass.  Beyond 128 dimensions every pass is a hi-plane pass.
-    const bool hi_last = wide || !C.lo_full || (EnvU32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
-    const int hi_from_pass = wide ? 0 : (C.lo_full ? (int)EnvU32("GPANN_FILTER_HI_FROM_PASS", 1) : (int)std::min<uint32_t>(1, EnvU32("GPANN_FILTER_HI_FROM_PASS", 1)));
+    const bool hi_last = wide || !C.lo_full || (s->opt.U32("GPANN_FILTER_HI_ONLY", 1) != 0 && cap >= 2048);   // (small buckets of huge task counts cannot take the extra candidates)
+    const int hi_from_pass = wide ? 0 : (C.lo_full ? (int)s->opt.U32("GPANN_FILTER_HI_FROM_PASS", 1) : (int)std::min<uint32_t>(1, s->opt.U32("GPANN_FILTER_HI_FROM_PASS", 1)));
     const size_t glds = FilterLdsBytes((size_t)QT * KS * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
@@ -1077,9 +1070,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // — as many as keep the launch near 128k wavefronts: every (task, part) is a workgroup, most of which find nothing to do and return, and
     // at 40 000 tasks (C3) 8 parts cost more in workgroups started than the split saves (2, 4, 8 parts: 2.28, 2.33, 2.38 ms of scan kernels; NS with
     // 10 000 tasks: 4.44, 4.19, 4.15)
-    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, EnvU32("GPANN_RESCORE_PARTS", std::max<uint32_t>(2, std::min<uint32_t>(8, 131072u / std::max<uint32_t>(T, 1u))))));
+    const uint32_t split_parts = std::max<uint32_t>(1, std::min<uint32_t>(8, s->opt.U32("GPANN_RESCORE_PARTS", std::max<uint32_t>(2, std::min<uint32_t>(8, 131072u / std::max<uint32_t>(T, 1u))))));
     GPANN_TRY(CS(s).ws_split.Reserve((size_t)T * split_parts * k * 8 + 256));
-    ra.split_min = std::max<uint32_t>(64, EnvU32("GPANN_RESCORE_SPLIT_MIN", 128));
+    ra.split_min = std::max<uint32_t>(64, s->opt.U32("GPANN_RESCORE_SPLIT_MIN", 128));
     ra.stat_overflowed = d_overflow;
     ra.stat_candidates = d_cand_total;
     ra.split_dist = CS(s).ws_split.as<float>();
@@ -1100,17 +1093,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // kept apart by their GRID sizes: the front's filter launches start at most front_cus workgroups; the rest pass either rest_cus persistent ones
     // (GPANN_OVERLAP_REST_ITEMS=0) or — the default — as many workgroups as its items need, each leaving after rest_items items: the rest stream has
     // the lower priority, so a CU it gives up goes to the front when the front has a workgroup waiting and back to the rest pass when it has not.
-    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, EnvU32("GPANN_OVERLAP_FRONT_CUS", 96))) : (uint32_t)n_cus;
-    const uint32_t rest_items_env = overlap ? EnvU32("GPANN_OVERLAP_REST_ITEMS", 4) : 0u;
+    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_FRONT_CUS", 96))) : (uint32_t)n_cus;
+    const uint32_t rest_items_env = overlap ? s->opt.U32("GPANN_OVERLAP_REST_ITEMS", 4) : 0u;
     const uint32_t rest_items = rest_items_env == 0 ? 0u : std::max<uint32_t>(2, rest_items_env);   // (a workgroup's first two claims are made before anything is counted)
-    const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, EnvU32("GPANN_OVERLAP_REST_CUS", 160))) : (uint32_t)n_cus;
+    const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_REST_CUS", 160))) : (uint32_t)n_cus;
     fa.wg_item_budget = 0;
 
     bool seed_wrote_U = false;
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
         // (under the merge bound only the first slot of a query is seeded: RescoreArgs::seed_first_slot_of)
-        ra.seed_first_slot_of = for_merge && nprobe_of_call > 1 && EnvU32("GPANN_FILTER_SEED_ALL", 0) == 0 ? nprobe_of_call : 0u;
+        ra.seed_first_slot_of = for_merge && nprobe_of_call > 1 && s->opt.U32("GPANN_FILTER_SEED_ALL", 0) == 0 ? nprobe_of_call : 0u;
         ra.seed_catch_up = 0;
         // every task seeded: the seed launch also writes the shard-sample pass's thresholds (one launch less); under the merge bound with several
         // probes only the first slots are seeded and the thresholds need the queries' bounds: ThresholdKernel, below
@@ -1172,12 +1165,6 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         GPANN_REQUIRE(PassSetupLdsBytes(kmax) <= (64u << 10), "too many cells in one shard for the pass set-up kernel");
-        if (pass == 2 && overlap) {   // the front ends here: the rest pass (its set-up included) and everything behind it go to the rest stream
-            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[1], st));
-            GPANN_HIP_TRY(hipStreamWaitEvent(st_rest, CS(s).ev_x[1], 0));
-            st = st_rest;
-            *st_end = st_rest;
-        }
         const uint32_t pass_cus = pass == 2 ? rest_cus : front_cus;
         if (CS(s).filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
@@ -1194,7 +1181,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         fa.need = na.need;
         fa.pass = (uint32_t)pass;
         // (the 8-bit sample pass: one row tile per unit of work by default — GPANN_FILTER_SAMPLE_UNIT=2: the rest pass's kernel, two tiles per unit)
-        const bool sample_wide = q8_pass && pass == 1 && EnvU32("GPANN_FILTER_SAMPLE_UNIT", 1) >= 2 && q8_unit_tiles >= 2;
+        const bool sample_wide = q8_pass && pass == 1 && s->opt.U32("GPANN_FILTER_SAMPLE_UNIT", 1) >= 2 && q8_unit_tiles >= 2;
         fa.round_tiles = q8_pass ? q8_waves * ((pass == 2 || sample_wide) ? q8_unit_tiles : 1u) : (uint32_t)kFWaves;
         fa.done0 = pass == 0 ? nullptr : need_pass[0];
         fa.done0b = pass == 2 ? need_pass[1] : nullptr;
@@ -1212,6 +1199,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             hipLaunchKernelGGL(PassItemsKernel, dim3(G), dim3(kItemsThreads), 0, st, ps);
             buckets_pending = false;
         }
+        if (pass == 2 && overlap) {   // the front ends here (the rest pass's set-up was its last launch): the rest stream carries nothing but the calls'
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[1], st));   // rest-pass launches, back to back
+            GPANN_HIP_TRY(hipStreamWaitEvent(st_rest, CS(s).ev_x[1], 0));
+            st = st_rest;
+        }
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it (FilterItemsKernel keeps the count, work[3]), and its begin / end
             GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
@@ -1219,7 +1211,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         if (q8_pass) {
             // (measurement aid, WRONG RESULTS: GPANN_DEBUG_Q8_NO_CAND=1 raises every threshold to +inf after the items are built — the launch streams
             // and multiplies the same tiles but finds no candidate: what the candidate hand-off costs)
-            if (EnvU32("GPANN_DEBUG_Q8_NO_CAND", 0) != 0)
+            if (s->opt.U32("GPANN_DEBUG_Q8_NO_CAND", 0) != 0)
                 GPANN_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pass_B), 0x7F800000, (size_t)G * kmax * 32u * QT8, st));
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
@@ -1245,6 +1237,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         }
         GPANN_HIP_TRY(hipGetLastError());
         if (pass == 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[5], st));
+        if (pass == 2 && overlap) {   // ... and what follows the launch — re-scoring, final merge, the lists' way out — goes to the tail stream: the NEXT call's rest pass starts at once
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[2], st));
+            GPANN_HIP_TRY(hipStreamWaitEvent(st_tail, CS(s).ev_x[2], 0));
+            st = st_tail;
+            *st_end = st_tail;
+        }
         // (the handle times two filter launches: the head pass and, as one interval, the sample and rest passes)
         if (pass == 0 || pass == 2) {
             GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed + 1], st));
@@ -1320,7 +1318,7 @@ static void CollectFilterCounters(gpann_shards::CallState& c, bool* overflow) {
 
 static bool FilterWanted(const gpann_shards* s, uint32_t k) {
     if (!s->filter_ok || s->cells.n_cells == 0 || s->frag_planes == nullptr || s->d > 256u || k > GPANN_MAX_K) return false;
-    const char* mode = std::getenv("GPANN_SCAN_MODE");
+    const char* mode = s->opt.Get("GPANN_SCAN_MODE");
     if (mode && *mode) return std::string(mode) == "filter";
     return s->scan_mode == 1;
 }
@@ -1333,7 +1331,7 @@ static gpann_status RunExactPath(gpann_shards* s, const TaskArrays& ta, UploadBa
     GPANN_HIP_TRY(up.Flush());
     std::vector<int64_t> lo(s->offsets.begin(), s->offsets.end() - 1), hi(s->offsets.begin() + 1, s->offsets.end());
     plan.padded_pairs = 0;
-    GPANN_TRY(BuildExactUnits(plan, s->S, lo, hi));
+    GPANN_TRY(BuildExactUnits(s, plan, s->S, lo, hi));
     MergeArgs m{};
     m.out_index = ta.out;
     m.permutation = s->permutation;
@@ -1356,7 +1354,7 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms);
 // A new call takes the slot of the call before last (completing it first if it still waits for its gpann_scan_finish) and makes it the call in
 // progress: from here on CS(s) — host state AND device workspaces — is this call's.  Every entry point does this before it touches a workspace.
 static gpann_status AcquireSlot(gpann_shards* s, hipStream_t st) {
-    const int n = s->cur ^ 1;
+    const int n = (s->cur + 1) % gpann_shards::kCallSlots;   // the oldest slot
     if (s->cs[n].pending) GPANN_TRY(CompleteCall(s, n, nullptr));
     // (rounds 1-4: the two slots shared the device workspaces, and a call on another stream than the most recent one had to wait for it here.
     // The workspaces are per slot now; what is left to order is this slot's OWN previous call — ScanToDevice waits for its ev[3] — and, for
@@ -1369,11 +1367,12 @@ static gpann_status AcquireSlot(gpann_shards* s, hipStream_t st) {
 // GPANN_SCAN_OVERLAP: the handle's two streams (created at the first such call).  Priorities: the front high — short launches on a chain of
 // dependencies —, the rest pass low: it takes the compute units the fronts leave.
 static gpann_status OverlapStreams(gpann_shards* s) {
-    if (s->st_front && s->st_rest) return GPANN_OK;
+    if (s->st_front && s->st_rest && s->st_tail) return GPANN_OK;
     int least = 0, greatest = 0;
     GPANN_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     if (!s->st_front) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_front, hipStreamNonBlocking, greatest));
     if (!s->st_rest) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_rest, hipStreamNonBlocking, least));
+    if (!s->st_tail) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_tail, hipStreamNonBlocking, greatest));
     return GPANN_OK;
 }
 
@@ -1382,7 +1381,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     ScanPlan& plan = CS(s).plan;
     // GPANN_SCAN_OVERLAP (a deferred call in filter mode whose queries the kernels read in place — the conditions under which the call stays
     // deferred): the call's work goes to the handle's own streams; the caller's stream only orders its start
-    hipStream_t st = st_caller, st_rest = st_caller;
+    hipStream_t st = st_caller, st_rest = st_caller, st_tail = st_caller;
     if ((flags & GPANN_SCAN_OVERLAP) && (flags & GPANN_SCAN_DEFER) && (flags & GPANN_QUERIES_ON_DEVICE) && FilterWanted(s, k) && s->ld == s->d &&
         (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
         GPANN_TRY(OverlapStreams(s));
@@ -1390,6 +1389,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         GPANN_HIP_TRY(hipStreamWaitEvent(s->st_front, CS(s).ev_x[0], 0));
         st = s->st_front;
         st_rest = s->st_rest;
+        st_tail = s->st_tail;
     }
     // The pinned staging area and the plan's host arrays of this slot are the sources of an earlier call's asynchronous uploads: that call may
     // have returned with them still queued (device output, no timing — nothing made it synchronise), so wait for the end of its work first.
@@ -1451,7 +1451,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     c.host_ids = c.host_rows = nullptr;
     if (want_filter) {
         hipStream_t st_end = st;
-        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, st_rest, &st_end, out));
+        GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, st_rest, st_tail, &st_end, out));
         c.filtered = T != 0;
         st = st_end;
         c.stream = st_end;   // (what follows the call — the copies to the host, a redo, the caller's own merge — is queued behind its LAST launch)
@@ -1646,8 +1646,10 @@ gpann_status gpann_scan_finish(gpann_shards* s, float* elapsed_ms) {
     std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
     GPANN_TRY(EnsureDevice(s->device));
     if (elapsed_ms) *elapsed_ms = 0.f;
-    const int older = s->cur ^ 1;
-    if (s->cs[older].pending) return CompleteCall(s, older, elapsed_ms);   // the oldest deferred call first
+    for (int age = gpann_shards::kCallSlots - 1; age > 0; --age) {   // the oldest deferred call first
+        const int slot = (s->cur + gpann_shards::kCallSlots - age) % gpann_shards::kCallSlots;
+        if (s->cs[slot].pending) return CompleteCall(s, slot, elapsed_ms);
+    }
     return CompleteCall(s, s->cur, elapsed_ms);
 }
 

@@ -78,6 +78,7 @@ struct gpann_shards {
     // The reference's callers invoke Query / QueryBucket concurrently, one query per call (shard_searches.cpp:48); a handle owns ONE set of
     // device workspaces and one pinned staging area, so concurrent calls on it take turns (recursive: entry points call each other).
     std::recursive_mutex call_mutex;
+    gpann::Options opt;  // the handle's knobs: the environment's GPANN_* at creation, then gpann_shards_set_option (common.h)
     int device = 0;
     int metric = 0;
     uint32_t d = 0;      // true dimension
@@ -157,13 +158,15 @@ struct gpann_shards {
     // Per-call host state, TWO sets (round 4): a call issued with GPANN_SCAN_DEFER returns once its work is enqueued, and the NEXT call may be
     // planned, staged and enqueued behind it before gpann_scan_finish completes the first — the host-side planning of batch i + 1 then runs under
     // the kernels of batch i.  `cur` is the slot of the most recent call.
+    static constexpr int kCallSlots = 3;   // a call in progress + two deferred ones behind it (GPANN_SCAN_DEFER, include/gpann.h)
     struct CallState {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2] begin / scan end / merge end of the call, [3] the end of its enqueued device work
         bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
         hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
                                                                                               // and of the rest pass's filter launch alone
-        hipEvent_t ev_x[2] = {nullptr, nullptr};   // GPANN_SCAN_OVERLAP: [0] what the caller's stream held when the call was issued (the front stream
-                                                   // waits for it), [1] the end of the call's front (the rest stream waits for it)
+        hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};   // GPANN_SCAN_OVERLAP: [0] what the caller's stream held when the call was issued (the front
+                                                            // stream waits for it), [1] the end of the call's front (the rest stream waits for it),
+                                                            // [2] the end of its rest-pass launch (the tail stream waits for it)
         int filter_passes_timed = 0;
         gpann::ScanPlan plan;
         gpann::PinnedStage stage;
@@ -193,12 +196,13 @@ struct gpann_shards {
                                            &ws_split, &ws_stage_dev})
                 b->Release();
         }
-    } cs[2];
+    } cs[kCallSlots];
     int cur = 0;
     gpann_scan_stats stats{};
     // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): the calls' fronts in order on one (high priority: short,
-    // latency-bound launches), their rest passes in order on the other (low priority: it takes what the fronts leave)
-    hipStream_t st_front = nullptr, st_rest = nullptr;
+    // latency-bound launches), their rest-pass launches back to back on the second (low priority: it takes what the others leave), what follows a
+    // rest pass — the re-scoring of its candidates, the final merge, the lists' way out — on the third
+    hipStream_t st_front = nullptr, st_rest = nullptr, st_tail = nullptr;
 };
 
 namespace gpann {

@@ -59,6 +59,103 @@ __global__ void __launch_bounds__(256) GatherRowsKernel(const float* __restrict_
     }
 }
 
+// ---- the handles' knobs (common.h Options) -------------------------------------------------------------------------------
+// Every name a handle understands.  `when`: B = read while the store / router is BUILT (gpann_shards_create, gpann_shards_build_filter,
+// gpann_router_create / _train): set it in the environment before the handle is created, or — stores built in two steps — between
+// gpann_shards_create(GPANN_STORE_PLAIN) and gpann_shards_build_filter; C = read by every call.
+struct Knob {
+    const char* name;
+    char when;
+    const char* what;
+};
+static const Knob kKnobs[] = {
+    // store build
+    {"GPANN_CELL_ROWS", 'B', "target rows per cell (default: rows per shard / 128, between 2048 and 32768)"},
+    {"GPANN_FILTER_PLANES", 'B', "0: no planes / cells — the store offers the plain exact scan only"},
+    {"GPANN_FILTER_LO_ROWS", 'B', "rows per cell that keep a bf16 lo tile (default 512; all: every row — allows GPANN_FILTER_HI_ONLY=0)"},
+    {"GPANN_FILTER_HI_ROWS", 'B', "all: every tile keeps its bf16 hi tile although the store has the 8-bit plane"},
+    {"GPANN_FILTER_Q8", 'B', "0: no 8-bit plane (store build); per call: 0 = the sample / rest passes on the bf16 hi plane where the store has one"},
+    {"GPANN_FILTER_Q8_CELL_FRAME", 'B', "0: plain norm words for the 8-bit passes (round 3's error term)"},
+    {"GPANN_FILTER_SORT_ROWS", 'B', "0: a cell's rows stay in slab order behind its front"},
+    {"GPANN_FILTER_CENTER", 'B', "0: planes / router images in the original frame, not around the mean row"},
+    {"GPANN_FILTER_EXACT_ROWS", 'B', "rows of the shard sample (default 4096)"},
+    // scan calls
+    {"GPANN_SCAN_MODE", 'C', "exact | filter: overrides gpann_shards_set_scan_mode"},
+    {"GPANN_FILTER_CAND_CAP", 'C', "candidate bucket size per task (default: 1024 .. 16384 from the 6 GiB budget)"},
+    {"GPANN_FILTER_HEAD_ROWS", 'C', "rows of the head pass (default 512; 0: no head pass)"},
+    {"GPANN_FILTER_SAMPLE_DIV", 'C', "the sample pass covers 1 / n of a needed cell (default: 8 .. 64 from the bucket size)"},
+    {"GPANN_FILTER_Q8_FROM_PASS", 'C', "first pass on the 8-bit plane: 1 sample (default), 2 rest"},
+    {"GPANN_FILTER_Q8_L1", 'C', "0: no |q - c|_1 table — Cauchy-Schwarz on the squared distances"},
+    {"GPANN_FILTER_SEG_TILES", 'C', "row tiles per work item (default: 16 .. 256 from the store size)"},
+    {"GPANN_FILTER_SEED_ROWS", 'C', "rows of the nearest cell evaluated exactly for the first lists (default 128; 0: exact scan of the shard sample)"},
+    {"GPANN_FILTER_SHARD_SAMPLE", 'C', "0: no shard-sample pass"},
+    {"GPANN_FILTER_SEED_ALL", 'C', "1: seed every task under the merge bound, not only a query's first slot"},
+    {"GPANN_FILTER_SAMPLE_UNIT", 'C', "2: the sample pass on the rest pass's kernel (two row tiles per unit)"},
+    {"GPANN_FILTER_HI_ONLY", 'C', "0: all three bf16 products in every pass (needs GPANN_FILTER_LO_ROWS=all)"},
+    {"GPANN_FILTER_HI_FROM_PASS", 'C', "first hi-plane-only pass (default 1)"},
+    {"GPANN_RESCORE_PARTS", 'C', "wavefronts a heavy candidate bucket is split over (default: 2 .. 8 from the task count)"},
+    {"GPANN_RESCORE_SPLIT_MIN", 'C', "candidates per piece of a split bucket (default 128)"},
+    {"GPANN_SCAN_TARGET_UNITS", 'C', "exact mode: workgroups a launch is cut into (default 8192)"},
+    {"GPANN_SCAN_MIN_SEG_ROWS", 'C', "exact mode: smallest row segment of a unit"},
+    {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of the front's filter launches (default 96)"},
+    {"GPANN_OVERLAP_REST_ITEMS", 'C', "GPANN_SCAN_OVERLAP: work items after which a rest-pass workgroup leaves (default 4; 0: persistent workgroups)"},
+    {"GPANN_OVERLAP_REST_CUS", 'C', "GPANN_SCAN_OVERLAP with persistent rest-pass workgroups: how many (default 160)"},
+    {"GPANN_DEBUG_Q8_NO_CAND", 'C', "measurement aid, WRONG RESULTS: the 8-bit passes find no candidate"},
+    // router
+    {"GPANN_ROUTER_MODE", 'C', "walk | dense: force the tree walk / the distance table + replay (default: by tree size and budget)"},
+    {"GPANN_ROUTER_DENSE_FACTOR", 'C', "table + replay up to trees this many times the budget (default 32)"},
+    {"GPANN_ROUTER_REPLAY", 'C', "heap | threshold: force a replay kernel"},
+    {"GPANN_ROUTER_BOUND", 'C', "0: canonical evaluation of every (query, centroid) pair instead of the matrix-core bound"},
+    {"GPANN_ROUTER_BOUND_TABLE", 'C', "0: the canonical distance table instead of the matrix-core table + bounded replay"},
+    {"GPANN_ROUTER_BAND_CAP", 'C', "band list capacity of the bounded replay (96 .. 4096, default 512)"},
+    {"GPANN_ROUTER_EPS_SCALE", 'C', "test knob: widens the bounded replay's band (same bits)"},
+    {"GPANN_ROUTER_HOST_REDO", 'C', "0: marked queries are replayed by the device heap kernel, not on host threads"},
+    {"GPANN_ROUTER_FREQ_SMALL", 'C', "FrequencyQuery: 0 never records only the smallest pairs; n: that many records per query"},
+    {"GPANN_ROUTER_VERIFY", 'C', "set: every block of the bound path is compared with the canonical evaluation"},
+    {"GPANN_ROUTER_STRICT", 'C', "set: a fired self-check is GPANN_ERR_INTERNAL instead of a canonical re-evaluation"},
+    {"GPANN_ROUTER_PROBE", 'C', "set: every bound block runs twice and every bit is compared"},
+    {"GPANN_ROUTER_FORCE_RECHECK", 'C', "test hook: take the canonical re-evaluation"},
+    {"GPANN_ROUTER_FORCE_EVIDENCE", 'C', "test hook: write the evidence report for a healthy block"},
+    {"GPANN_ROUTER_LEGACY_MEMSET", 'C', "debug: set the bound block up with three runtime memsets + a fill launch (the pre-66a007d path) instead of BoundInitKernel"},
+};
+
+std::string Options::Canonical(const char* name) {
+    std::string n = name ? name : "";
+    if (n.rfind("GPANN_", 0) != 0) n = "GPANN_" + n;
+    return n;
+}
+bool Options::Known(const std::string& canonical) {
+    for (const Knob& k : kKnobs)
+        if (canonical == k.name) return true;
+    return false;
+}
+void Options::SnapshotEnvironment() {
+    for (const Knob& k : kKnobs)
+        if (const char* v = std::getenv(k.name)) kv[k.name] = v;
+}
+gpann_status SetOption(Options& o, const char* name, const char* value) {
+    GPANN_REQUIRE(name != nullptr && *name, "option name is null");
+    const std::string n = Options::Canonical(name);
+    if (!Options::Known(n)) {
+        SetLastError("unknown option %s (gpann_option_name lists them)", n.c_str());
+        return GPANN_ERR_INVALID;
+    }
+    if (value) o.kv[n] = value;
+    else o.kv.erase(n);
+    return GPANN_OK;
+}
+gpann_status GetOption(const Options& o, const char* name, char* out, size_t cap) {
+    GPANN_REQUIRE(name != nullptr && out != nullptr && cap > 0, "null argument");
+    const std::string n = Options::Canonical(name);
+    if (!Options::Known(n)) {
+        SetLastError("unknown option %s", n.c_str());
+        return GPANN_ERR_INVALID;
+    }
+    const char* v = o.Get(n.c_str());
+    std::snprintf(out, cap, "%s", v ? v : "");
+    return GPANN_OK;
+}
+
 }  // namespace gpann
 
 using namespace gpann;
@@ -68,7 +165,7 @@ using namespace gpann;
 // them, smaller ones add work items); 10M x 96 in 16 shards and 1M x 128 in 8 shards want 4k / 2k rows (their mixture components are that
 // small: larger cells mix components and their balls prune nothing).
 static uint32_t DefaultCellRows(const gpann_shards* s) {
-    if (const char* cr = std::getenv("GPANN_CELL_ROWS")) return (uint32_t)std::max(64L, std::atol(cr));
+    if (const char* cr = s->opt.Get("GPANN_CELL_ROWS")) return (uint32_t)std::max(64L, std::atol(cr));
     const uint64_t per_shard = s->rows / std::max<uint32_t>(1, s->S);
     return (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(2048, per_shard / 128));
 }
@@ -78,6 +175,21 @@ extern "C" {
 const char* gpann_last_error(void) { return g_last_error.c_str(); }
 
 const char* gpann_version(void) { return "gpann-hip 0.1 (gfx950)"; }
+
+uint32_t gpann_option_count(void) { return (uint32_t)(sizeof(kKnobs) / sizeof(kKnobs[0])); }
+const char* gpann_option_name(uint32_t i) { return i < gpann_option_count() ? kKnobs[i].name : nullptr; }
+const char* gpann_option_help(uint32_t i) { return i < gpann_option_count() ? kKnobs[i].what : nullptr; }
+int gpann_option_read_at_build(uint32_t i) { return i < gpann_option_count() && kKnobs[i].when == 'B' ? 1 : 0; }
+
+gpann_status gpann_shards_set_option(gpann_shards* s, const char* name, const char* value) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    std::lock_guard<std::recursive_mutex> turn(s->call_mutex);
+    return SetOption(s->opt, name, value);
+}
+gpann_status gpann_shards_get_option(const gpann_shards* s, const char* name, char* out, size_t cap) {
+    GPANN_REQUIRE(s != nullptr, "shards handle is null");
+    return GetOption(s->opt, name, out, cap);
+}
 
 gpann_status gpann_device_count(int* count) {
     GPANN_REQUIRE(count != nullptr, "count is null");
@@ -104,6 +216,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     GPANN_TRY(EnsureDevice(device));
 
     auto* s = new gpann_shards();
+    s->opt.SnapshotEnvironment();   // (the one look at the environment: gpann_shards_set_option from here on)
     s->device = device;
     s->metric = metric;
     s->d = d;
@@ -208,7 +321,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
         // filter support (scan mode 1): the rows once more as bf16 hi/lo planes grouped by cell (cells.hip).  Optional: without it
         // (allocation failure, GPANN_FILTER_PLANES=0, d > 256, non-finite data) the store only offers the plain exact scan.
         // GPANN_CELL_ROWS sets the target cell size.
-        const char* want = std::getenv("GPANN_FILTER_PLANES");
+        const char* want = s->opt.Get("GPANN_FILTER_PLANES");
         const uint32_t cell_rows = DefaultCellRows(s);
         if (s->filter_ok && d <= 256 && !(want && want[0] == '0') && !(flags & GPANN_STORE_PLAIN)) {
             gpann_status cst = BuildCells(s, cell_rows);
@@ -268,6 +381,7 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
     }
     if (s->st_front) (void)hipStreamDestroy(s->st_front);
     if (s->st_rest) (void)hipStreamDestroy(s->st_rest);
+    if (s->st_tail) (void)hipStreamDestroy(s->st_tail);
     delete s;
     return GPANN_OK;
 }

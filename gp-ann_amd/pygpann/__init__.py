@@ -30,6 +30,8 @@ EXPORTS = [
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
     "gpann_scan_last_stats", "gpann_scan_finish", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_query_batch_top", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
+    "gpann_option_count", "gpann_option_name", "gpann_option_help", "gpann_option_read_at_build",
+    "gpann_shards_set_option", "gpann_shards_get_option", "gpann_router_set_option", "gpann_router_get_option",
 ]
 
 
@@ -77,6 +79,16 @@ def lib():
     L.gpann_last_error.restype = C.c_char_p
     L.gpann_version.restype = C.c_char_p
     L.gpann_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.gpann_option_count.restype = C.c_uint32
+    L.gpann_option_name.restype = C.c_char_p
+    L.gpann_option_name.argtypes = [C.c_uint32]
+    L.gpann_option_help.restype = C.c_char_p
+    L.gpann_option_help.argtypes = [C.c_uint32]
+    L.gpann_option_read_at_build.argtypes = [C.c_uint32]
+    for fn in (L.gpann_shards_set_option, L.gpann_router_set_option):
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    for fn in (L.gpann_shards_get_option, L.gpann_router_get_option):
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.gpann_shards_create.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, _u32p, _u64p, C.c_uint32, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
     L.gpann_shards_destroy.argtypes = [C.c_void_p]
@@ -117,6 +129,12 @@ def lib():
 def _check(status):
     if status != OK:
         raise GpannError(status, lib().gpann_last_error().decode())
+
+
+def options():
+    """[(name, read_at_build, help)]: the table of handle options (gpann_option_*)"""
+    L = lib()
+    return [(L.gpann_option_name(i).decode(), bool(L.gpann_option_read_at_build(i)), L.gpann_option_help(i).decode()) for i in range(L.gpann_option_count())]
 
 
 def device_count():
@@ -191,6 +209,16 @@ class Shards:
         kk = C.c_uint32(0)
         _check(lib().gpann_kmeans(self.h, C.c_uint32(int(k)), C.c_int(int(seed)), part.ctypes.data_as(_i32p), cent.ctypes.data_as(_f32p), C.byref(kk)))
         return part, cent[:kk.value].copy()
+
+    def set_option(self, name, value):
+        """a knob of this handle (gpann_shards_set_option; include/gpann.h "Options"): value None = back to the default.  The handle took the
+        environment's GPANN_* variables when it was created and does not look at the environment again."""
+        _check(lib().gpann_shards_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(256)
+        _check(lib().gpann_shards_get_option(self.h, name.encode(), buf, 256))
+        return buf.value.decode()
 
     def set_scan_mode(self, mode):
         """0 = exact VALU scan, 1 = exact scan with the MFMA pre-filter (same results)"""
@@ -341,6 +369,15 @@ class Router:
                                          flat["node_child_first"].ctypes.data_as(_u32p), flat["node_child_count"].ctypes.data_as(_u32p),
                                          flat["shard_root"].ctypes.data_as(_u32p), flat["centroids"].ctypes.data_as(_f32p)))
         return flat
+
+    def set_option(self, name, value):
+        """a knob of this handle (gpann_router_set_option): value None = back to the default"""
+        _check(lib().gpann_router_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(256)
+        _check(lib().gpann_router_get_option(self.h, name.encode(), buf, 256))
+        return buf.value.decode()
 
     def stats(self):
         """Counters of this handle (gpann_router_get_stats); bound_selfcheck and verify_failures must stay 0."""

@@ -70,18 +70,18 @@ enum {
                                           In filter mode tau_q bounds every shard of the query, not only the one that produced it — rows and
                                           cells beyond it are never evaluated. */
     GPANN_SCAN_OVERLAP = 1 << 7,       /* gpann_scan_buckets, filter mode, with GPANN_SCAN_DEFER (ignored without it, and in exact mode): the call's device
-                                          work runs on two streams of the HANDLE instead of `stream` — the passes before the rest pass (tables,
+                                          work runs on three streams of the HANDLE instead of `stream` — the passes before the rest pass (tables,
                                           seed, shard-sample, head, sample and their re-scoring: short launches that leave most of the chip idle)
-                                          on one, the rest pass and everything after it (the launch that streams the store once, HBM-bound) on the
-                                          other — so that the front of call i + 1 runs BESIDE the rest pass of call i (the two calls own separate
-                                          device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
+                                          on one, the rest pass's launch (it streams the store once: HBM-bound) on the second, what follows it on
+                                          the third — so that the fronts of calls i + 1, i + 2 run BESIDE the rest pass of call i and the rest
+                                          passes follow each other without a gap (every call in flight owns its device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
                                           is issued); its results are in place when gpann_scan_finish returns, NOT when `stream` has drained.
                                           Results are the same bits as without the flag. */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
-                                          with the plain exact scan should the data have defeated the filter, statistics, timing).  ONE further
-                                          call may be issued on the handle before the finish: its host-side planning and uploads then run while
-                                          the device works on the first (a call issued with two unfinished calls outstanding completes the older
+                                          with the plain exact scan should the data have defeated the filter, statistics, timing).  TWO further
+                                          calls may be issued on the handle before the finish: their host-side planning and uploads then run while
+                                          the device works on the first (a call issued with three unfinished calls outstanding completes the oldest
                                           one itself).  Contract until the finish: the same `stream` for the calls, device queries in the layout the
                                           kernels read in place (GPANN_QUERIES_ON_DEVICE, d % 4 == 0, 16-byte aligned — otherwise the call simply
                                           completes before it returns), queries and output arrays left alone (device outputs: not reused by the
@@ -102,6 +102,19 @@ typedef struct gpann_router gpann_router;   /* device-resident flattened k-means
 /* thread-local, human-readable description of the last failure in the calling thread */
 const char* gpann_last_error(void);
 const char* gpann_version(void);
+
+/* Options.  Every knob that changes what a call does is a named option of the HANDLE (string values; names with or without the GPANN_
+ * prefix).  A handle takes a snapshot of the process environment's GPANN_* variables when it is created — so a deployment's defaults can
+ * still be given in the environment — and never reads the environment again: gpann_*_set_option is how a caller changes a knob afterwards
+ * (value NULL: back to the built-in default), gpann_*_get_option reads it back ("" = not set).  Unknown names are GPANN_ERR_INVALID.  Options
+ * marked "read at build" (gpann_option_read_at_build) shape the store / router while it is built: set them in the environment before the
+ * handle is created (or, for a store built in two steps, before gpann_shards_build_filter).  Set options while no call is in flight on the
+ * handle.  gpann_option_count / _name / _help enumerate the table (INTEGRATION.md lists it).  Only debug OUTPUT is still switched by the
+ * environment where it is produced: GPANN_CELLS_DEBUG, GPANN_ROUTER_DEBUG, and the path GPANN_VERIFY_REPORT. */
+uint32_t gpann_option_count(void);
+const char* gpann_option_name(uint32_t i);
+const char* gpann_option_help(uint32_t i);
+int gpann_option_read_at_build(uint32_t i);
 gpann_status gpann_device_count(int* count);
 
 /* ------------------------------------------------------------------------------------------------ shard store */
@@ -114,6 +127,8 @@ gpann_status gpann_device_count(int* count);
 gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, int metric, const uint32_t* ids_concat,
                                  const uint64_t* shard_offsets, uint32_t S, int device, int flags, gpann_shards** out);
 gpann_status gpann_shards_destroy(gpann_shards* s);
+gpann_status gpann_shards_set_option(gpann_shards* s, const char* name, const char* value);
+gpann_status gpann_shards_get_option(const gpann_shards* s, const char* name, char* out, size_t cap);
 /* Builds the filter support data (bf16 planes grouped by cell, radii) of a store created with GPANN_STORE_PLAIN — i.e. in a second step,
  * after the caller has released its own copy of the points: at 100M x 200 the rows are 80 GB and the planes 102 GB, and three copies
  * do not fit one GPU.  No-op if the data is already there; GPANN_ERR_UNSUPPORTED if the store's data is unfit (non-finite, d > 256).
@@ -206,6 +221,8 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
                                  const uint32_t* node_cent_first, const uint32_t* node_child_first, const uint32_t* node_child_count,
                                  const uint32_t* shard_root, const float* centroids, int device, gpann_router** out);
 gpann_status gpann_router_destroy(gpann_router* r);
+gpann_status gpann_router_set_option(gpann_router* r, const char* name, const char* value);
+gpann_status gpann_router_get_option(const gpann_router* r, const char* name, char* out, size_t cap);
 
 /* KMeansTreeRouter::Train (src/kmeans_tree_router.cpp:9-91) on the GPU, over the rows of a shard store: shard b of the
  * store is Clusters[b] in the reference's call, in the same order.  All k-means problems of one tree level run as one

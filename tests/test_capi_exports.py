@@ -83,3 +83,33 @@ def test_merge_dedup_is_host_side(orc):
             offs.append(len(flat_d))
         od, oi, oc = orc.dedup_neighbors(np.asarray(flat_d, np.float32), np.asarray(flat_i, np.uint32), np.asarray(offs, np.uint64), k)
         assert np.array_equal(mi, oi) and np.array_equal(md, od) and np.array_equal(mc, oc)
+
+
+def test_options_table_and_no_getenv_on_the_call_paths():
+    """every knob is a named option of the handle (include/gpann.h "Options"): the table enumerates, and the kernel translation units read the
+    environment in ONE place — the snapshot a handle takes when it is created — plus the debug-output switches"""
+    import pygpann
+    pygpann.build()
+    opts = pygpann.options()
+    names = [n for n, _, _ in opts]
+    assert len(names) == len(set(names)) >= 40 and all(n.startswith("GPANN_") for n in names) and all(h for _, _, h in opts)
+    for must in ("GPANN_FILTER_HEAD_ROWS", "GPANN_ROUTER_BOUND_TABLE", "GPANN_ROUTER_HOST_REDO", "GPANN_FILTER_Q8_FROM_PASS", "GPANN_OVERLAP_REST_ITEMS", "GPANN_CELL_ROWS"):
+        assert must in names
+    assert dict((n, b) for n, b, _ in opts)["GPANN_CELL_ROWS"] is True and dict((n, b) for n, b, _ in opts)["GPANN_FILTER_HEAD_ROWS"] is False
+    csrc = os.path.join(ROOT, "gp-ann_amd", "csrc")
+    allowed = {"GPANN_CELLS_DEBUG", "GPANN_ROUTER_DEBUG", "GPANN_VERIFY_REPORT"}     # debug output only
+    for fn in sorted(os.listdir(csrc)):
+        if fn == "comm.hip":        # (the communicator reads MASTER_ADDR / ports when it is CREATED: its own, creation-time, contract)
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        for m in re.finditer(r"getenv\(([^)]*)\)", text):
+            arg = m.group(1).strip()
+            if arg.startswith('"'):
+                assert arg.strip('"') in allowed, f"{fn}: getenv({arg}) — make it an option of the handle (shards.hip kKnobs)"
+            else:
+                assert fn == "shards.hip", f"{fn}: getenv({arg})"    # Options::SnapshotEnvironment
+    # every option name a translation unit asks its handle for is in the table (a typo would silently read the default)
+    for fn in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, fn)).read()
+        for m in re.finditer(r"opt\.(?:Get|U32|IsSet|IsZero)\(\"(GPANN_[A-Z0-9_]+)\"", text):
+            assert m.group(1) in names, f"{fn}: option {m.group(1)} is not in the table"

@@ -309,9 +309,10 @@ def test_overlapped_stream_of_batches_many_cells(orc, gp, monkeypatch, rest_item
 
     stats = []
     begin(0)
+    begin(1)                                 # two calls behind the one being completed: the handle has three call slots
     for i in range(len(batches)):
-        if i + 1 < len(batches):
-            begin(i + 1)
+        if i + 2 < len(batches):
+            begin(i + 2)
         shards.finish()
         stats.append(shards.stats())
     for i, q in enumerate(batches):

@@ -118,13 +118,13 @@ def test_router_deep_tree_threshold_replay(orc, gp, metric, monkeypatch):
     queries = make_mixture(orc, 300, 16, seed=556, n_centers=24)
     router = gp.Router(f, metric, 0)
     for mode in ("", "heap"):                          # default (threshold replay) and the real queue on the same table
-        monkeypatch.setenv("GPANN_ROUTER_REPLAY", mode)
+        router.set_option("GPANN_ROUTER_REPLAY", mode)
         for budget in (C // 4 + 1, C // 3, C // 2, (3 * C) // 4, C - 1, C, C + 50):
             probes, md, _ = router.query_batch(queries, budget)
             wp, wm = tree.query_batch(queries, budget, nthreads=8)
             assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), (mode, budget)
             assert np.array_equal(probes, wp), (mode, budget)
-    monkeypatch.delenv("GPANN_ROUTER_REPLAY")
+    router.set_option("GPANN_ROUTER_REPLAY", None)
     # FrequencyQuery over the same walk
     budget = C // 2
     md, nd, ns, nc, _ = router.frequency_query_batch(queries, budget, 50)
@@ -181,7 +181,7 @@ def test_router_bound_self_check_falls_back_to_canonical_evaluation(orc, gp, mon
     tree = orc.kmtr_train(pts, clusters, 64, 350, 20000, 0, nthreads=4)
     want_p, want_md = tree.query_batch(queries, 50000, nthreads=4)
     router = gp.Router(tree.flat(), 0)
-    monkeypatch.setenv("GPANN_ROUTER_FORCE_RECHECK", "1")
+    router.set_option("GPANN_ROUTER_FORCE_RECHECK", "1")
     p, md, _ = router.query_batch(queries, 50000)
     assert np.array_equal(p, want_p) and np.array_equal(md.view(np.uint32), want_md.view(np.uint32))
     assert "bound path self-check" in capfd.readouterr().err
@@ -394,10 +394,10 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
             assert st["table_exact"] > before["table_exact"]
         assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)), budget
         assert np.array_equal(probes, wp), budget
-        monkeypatch.setenv("GPANN_ROUTER_BOUND_TABLE", "0")
+        router.set_option("GPANN_ROUTER_BOUND_TABLE", "0")
         p0, m0, _ = router.query_batch(queries, budget)
         assert router.stats()["table_blocks"] == st["table_blocks"]
-        monkeypatch.delenv("GPANN_ROUTER_BOUND_TABLE")
+        router.set_option("GPANN_ROUTER_BOUND_TABLE", None)
         assert np.array_equal(m0.view(np.uint32), md.view(np.uint32)) and np.array_equal(p0, probes), budget
     if not expect_table:
         return
@@ -414,32 +414,32 @@ def test_bounded_table_replay_matches_the_canonical_table(orc, gp, metric, d, S,
             assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (budget, votes, q)
     # ... with room for few records per query (what the full-size trees get: the batch in one block): enough room, and too little (the call is repeated)
     for cap, votes in (("600", 500), ("56", 50), ("8", 7)):
-        monkeypatch.setenv("GPANN_ROUTER_FREQ_SMALL", cap)
+        router.set_option("GPANN_ROUTER_FREQ_SMALL", cap)
         md, nd, ns, nc, _ = router.frequency_query_batch(queries, C // 2, votes)
         for q in range(0, len(queries), 7):
             wmd, wnd, wns = tree.frequency_query(queries[q], C // 2, votes)
             assert np.array_equal(md[q].view(np.uint32), wmd.view(np.uint32)), (cap, votes, q)
             assert nc[q] == len(wnd) and np.array_equal(nd[q, :nc[q]].view(np.uint32), wnd.view(np.uint32)) and np.array_equal(ns[q, :nc[q]], wns), (cap, votes, q)
-    monkeypatch.delenv("GPANN_ROUTER_FREQ_SMALL")
+    router.set_option("GPANN_ROUTER_FREQ_SMALL", None)
     # a 30 times wider band (the error bound inflated): many more canonical evaluations, the same bits
     budget = C // 2
     wp, wm = tree.query_batch(queries, budget, nthreads=8)
-    monkeypatch.setenv("GPANN_ROUTER_EPS_SCALE", "30")
+    router.set_option("GPANN_ROUTER_EPS_SCALE", "30")
     before = router.stats()
     probes, md, _ = router.query_batch(queries, budget)
     st = router.stats()
     assert st["table_band_nodes"] - before["table_band_nodes"] > 3 * before["table_band_nodes"] / 5 / 2, (before, st)
     assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
     # ... and with a tiny band list on top: overflowing queries are marked and replayed on canonical rows — same bits
-    monkeypatch.setenv("GPANN_ROUTER_EPS_SCALE", "300")
-    monkeypatch.setenv("GPANN_ROUTER_BAND_CAP", "96")
+    router.set_option("GPANN_ROUTER_EPS_SCALE", "300")
+    router.set_option("GPANN_ROUTER_BAND_CAP", "96")
     before = router.stats()
     probes, md, _ = router.query_batch(queries, budget)
     st = router.stats()
     assert st["table_band_overflow"] > before["table_band_overflow"], st
     assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
     # ... and with the device queue instead of the host's
-    monkeypatch.setenv("GPANN_ROUTER_HOST_REDO", "0")
+    router.set_option("GPANN_ROUTER_HOST_REDO", "0")
     probes, md, _ = router.query_batch(queries, budget)
     assert np.array_equal(md.view(np.uint32), wm.view(np.uint32)) and np.array_equal(probes, wp)
 

@@ -56,11 +56,11 @@ while time.time() < t_end:
     n_cfg += 1
     for budget in sorted(set(int(x) for x in [lo_budget, lo_budget + 1, C - 1, C, C + 5, *rng.integers(lo_budget, C + 1, 4)])):
         before = router.stats()
-        os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+        router.set_option("GPANN_ROUTER_BOUND_TABLE", None)
         p1, m1, _ = router.query_batch(queries, budget)
         st = router.stats()
         used = st["table_blocks"] > before["table_blocks"]
-        os.environ["GPANN_ROUTER_BOUND_TABLE"] = "0"
+        router.set_option("GPANN_ROUTER_BOUND_TABLE", "0")
         p0, m0, _ = router.query_batch(queries, budget)
         n_calls += 1
         n_table += int(used)
@@ -70,15 +70,15 @@ while time.time() < t_end:
             print(f"DIFF Query: d {d} S {S} n {n} metric {metric} nc {nc} min_cluster {min_cluster} scale {scale:.3g} C {C} budget {budget} nq {nq}: {len(q)} queries, first {q[:3]}", flush=True)
         if (used or budget > C) and rng.random() < 0.5:
             votes = int(rng.choice([1, 7, 50, 500, 2048]))
-            os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+            router.set_option("GPANN_ROUTER_BOUND_TABLE", None)
             a1 = router.frequency_query_batch(queries, budget, votes)
-            os.environ["GPANN_ROUTER_BOUND_TABLE"] = "0"
+            router.set_option("GPANN_ROUTER_BOUND_TABLE", "0")
             a0 = router.frequency_query_batch(queries, budget, votes)
             n_calls += 1
             if not all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a1[:4], a0[:4])):
                 bad += 1
                 print(f"DIFF FrequencyQuery: d {d} S {S} n {n} metric {metric} nc {nc} scale {scale:.3g} C {C} budget {budget} nq {nq} votes {votes}", flush=True)
-    os.environ.pop("GPANN_ROUTER_BOUND_TABLE", None)
+    router.set_option("GPANN_ROUTER_BOUND_TABLE", None)
     st = router.stats()
     for k_ in tot:
         tot[k_] += st[k_]
