@@ -251,7 +251,8 @@ int gpann_host_router_query_threads(uint32_t d, int mips, uint32_t S, uint32_t n
 // InvertedIndex::QueryBucket(Q, k, probes[q]) from `threads` host threads, one call per query: out_ids / out_dist [nq][k]
 int gpann_host_index_query_bucket_threads(const float* points, uint64_t n, uint32_t d, int mips, const uint32_t* ids, const uint64_t* offsets, uint32_t S,
                                           const float* queries, uint32_t nq, uint32_t k, const int32_t* bucket, int threads, int coalesce, uint32_t* out_ids,
-                                          float* out_dist, double* seconds, uint64_t* batches) {
+                                          float* out_dist, double* seconds, uint64_t* batches, uint8_t* failed) {
+    // `failed` (may be null): [nq], 1 where THAT query's call threw — the call of another thread must not fail with it; null: any failure fails the run
     try {
         gpann_host::SetMetricMIPS(mips != 0);
         PointSet ps;
@@ -276,9 +277,14 @@ int gpann_host_index_query_bucket_threads(const float* points, uint64_t n, uint3
                     out_dist[i * k + x] = x < r.size() ? r[x].first : std::numeric_limits<float>::infinity();
                     out_ids[i * k + x] = x < r.size() ? r[x].second : 0xFFFFFFFFu;
                 }
+                if (failed) failed[i] = 0;
             } catch (const std::exception& e) {
-                std::lock_guard<std::mutex> lk(err_mutex);
-                err = e.what();
+                if (failed) {
+                    failed[i] = 1;
+                } else {
+                    std::lock_guard<std::mutex> lk(err_mutex);
+                    err = e.what();
+                }
             }
         });
         *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -132,16 +132,11 @@ gpann_host::Coalescer<ScanReq>& ScanQueue() {
     static gpann_host::Coalescer<ScanReq>* q = new gpann_host::Coalescer<ScanReq>();
     return *q;
 }
-void RunScanBatch(std::vector<ScanReq*>& batch) {
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i]) continue;
-        std::vector<ScanReq*> group;
-        for (size_t j = i; j < batch.size(); ++j)
-            if (!taken[j] && batch[j]->handle == batch[i]->handle && batch[j]->merged == batch[i]->merged && batch[j]->k == batch[i]->k) {
-                taken[j] = 1;
-                group.push_back(batch[j]);
-            }
+// One device call for a group of requests that share (handle, kind, k).  If the call fails and the group has several members, every member is run
+// again AS A BATCH OF ONE: a caller's bad argument (a bucket out of range, k beyond GPANN_MAX_K) then fails that caller alone — what the reference's
+// one-query-per-call interface promises — instead of every thread that happened to share its device batch.
+void RunScanGroup(std::vector<ScanReq*>& group) {
+    {
         const uint32_t n = (uint32_t)group.size(), d = group[0]->d, k = group[0]->k;
         uint32_t np = 0;
         for (ScanReq* r : group) np = std::max<uint32_t>(np, (uint32_t)r->probes.size());
@@ -163,8 +158,28 @@ void RunScanBatch(std::vector<ScanReq*>& batch) {
                 group[x]->dist.assign(dist.begin() + (size_t)x * k, dist.begin() + (size_t)(x + 1) * k);
             }
         } catch (...) {
-            for (ScanReq* r : group) r->error = std::current_exception();
+            if (group.size() == 1) {
+                group[0]->error = std::current_exception();
+            } else {
+                for (ScanReq* r : group) {
+                    std::vector<ScanReq*> one{r};
+                    RunScanGroup(one);
+                }
+            }
         }
+    }
+}
+void RunScanBatch(std::vector<ScanReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<ScanReq*> group;
+        for (size_t j = i; j < batch.size(); ++j)
+            if (!taken[j] && batch[j]->handle == batch[i]->handle && batch[j]->merged == batch[i]->merged && batch[j]->k == batch[i]->k) {
+                taken[j] = 1;
+                group.push_back(batch[j]);
+            }
+        RunScanGroup(group);
     }
 }
 }   // namespace

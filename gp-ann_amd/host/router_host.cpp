@@ -395,6 +395,27 @@ gpann_host::Coalescer<RouterQueryReq>& RouterQueue() {
     static gpann_host::Coalescer<RouterQueryReq>* q = new gpann_host::Coalescer<RouterQueryReq>();   // (never destroyed: callers may outlive static destruction order)
     return *q;
 }
+// one device batch for requests that share (handle, budget); a failed batch of several is retried request by request, so that an error reaches only
+// the caller whose request causes it (index_host.cpp RunScanGroup)
+void RunRouterGroup(std::vector<RouterQueryReq*>& group) {
+    const uint32_t n = (uint32_t)group.size(), d = group[0]->d, S = group[0]->S;
+    std::vector<float> q((size_t)n * d);
+    for (uint32_t x = 0; x < n; ++x) std::memcpy(&q[(size_t)x * d], group[x]->Q, (size_t)d * sizeof(float));
+    std::vector<int32_t> probes((size_t)n * S);
+    try {
+        gpann_host::Check(gpann_router_query_batch(group[0]->handle, q.data(), n, group[0]->budget, probes.data(), nullptr, 0, nullptr, nullptr), "gpann_router_query_batch");
+        for (uint32_t x = 0; x < n; ++x) group[x]->probes.assign(probes.begin() + (size_t)x * S, probes.begin() + (size_t)(x + 1) * S);
+    } catch (...) {
+        if (n == 1) {
+            group[0]->error = std::current_exception();
+        } else {
+            for (RouterQueryReq* r : group) {
+                std::vector<RouterQueryReq*> one{r};
+                RunRouterGroup(one);
+            }
+        }
+    }
+}
 void RunRouterBatch(std::vector<RouterQueryReq*>& batch) {
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
@@ -405,16 +426,7 @@ void RunRouterBatch(std::vector<RouterQueryReq*>& batch) {
                 taken[j] = 1;
                 group.push_back(batch[j]);
             }
-        const uint32_t n = (uint32_t)group.size(), d = group[0]->d, S = group[0]->S;
-        std::vector<float> q((size_t)n * d);
-        for (uint32_t x = 0; x < n; ++x) std::memcpy(&q[(size_t)x * d], group[x]->Q, (size_t)d * sizeof(float));
-        std::vector<int32_t> probes((size_t)n * S);
-        try {
-            gpann_host::Check(gpann_router_query_batch(group[0]->handle, q.data(), n, group[0]->budget, probes.data(), nullptr, 0, nullptr, nullptr), "gpann_router_query_batch");
-            for (uint32_t x = 0; x < n; ++x) group[x]->probes.assign(probes.begin() + (size_t)x * S, probes.begin() + (size_t)(x + 1) * S);
-        } catch (...) {
-            for (RouterQueryReq* r : group) r->error = std::current_exception();
-        }
+        RunRouterGroup(group);
     }
 }
 }   // namespace

@@ -37,7 +37,7 @@ def lib():
         L.gpann_host_router_query_threads.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, _f32p, C.c_uint32, C.c_int,
                                                       C.c_int, C.c_int, _i32p, C.POINTER(C.c_double), _u64p]
         L.gpann_host_index_query_bucket_threads.argtypes = [_f32p, C.c_uint64, C.c_uint32, C.c_int, _u32p, _u64p, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, _i32p,
-                                                            C.c_int, C.c_int, _u32p, _f32p, C.POINTER(C.c_double), _u64p]
+                                                            C.c_int, C.c_int, _u32p, _f32p, C.POINTER(C.c_double), _u64p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -92,9 +92,10 @@ def router_query_threads(tree, queries, budget, threads, coalesce, mips=False):
     return probes, sec.value, batches.value
 
 
-def index_query_bucket_threads(points, clusters, queries, k, buckets, threads, coalesce, mips=False):
+def index_query_bucket_threads(points, clusters, queries, k, buckets, threads, coalesce, mips=False, tolerate_failures=False):
     """InvertedIndex::QueryBucket(Q, k, buckets[q]) from `threads` host threads, one call per query (shard_searches.cpp:48) — coalescing queue on or
-    off.  Returns (ids [nq][k], dist [nq][k], seconds, device batches)."""
+    off.  Returns (ids [nq][k], dist [nq][k], seconds, device batches) — tolerate_failures: + failed [nq] (1 where that query's call threw; the others'
+    results stand)."""
     points = np.ascontiguousarray(points, np.float32)
     queries = np.ascontiguousarray(queries, np.float32)
     buckets = np.ascontiguousarray(buckets, np.int32)
@@ -103,11 +104,15 @@ def index_query_bucket_threads(points, clusters, queries, k, buckets, threads, c
     ids = np.empty((nq, k), np.uint32)
     dist = np.empty((nq, k), np.float32)
     sec, batches = C.c_double(0), C.c_uint64(0)
+    failed = np.zeros(nq, np.uint8) if tolerate_failures else None
     rc = lib().gpann_host_index_query_bucket_threads(points.ctypes.data_as(_f32p), points.shape[0], d, int(mips), ids_csr.ctypes.data_as(_u32p), offs.ctypes.data_as(_u64p),
                                                      len(clusters), queries.ctypes.data_as(_f32p), nq, int(k), buckets.ctypes.data_as(_i32p), int(threads),
-                                                     int(bool(coalesce)), ids.ctypes.data_as(_u32p), dist.ctypes.data_as(_f32p), C.byref(sec), C.byref(batches))
+                                                     int(bool(coalesce)), ids.ctypes.data_as(_u32p), dist.ctypes.data_as(_f32p), C.byref(sec), C.byref(batches),
+                                                     failed.ctypes.data_as(C.c_void_p) if tolerate_failures else None)
     if rc != 0:
         raise RuntimeError(lib().gpann_host_last_error().decode())
+    if tolerate_failures:
+        return ids, dist, sec.value, batches.value, failed
     return ids, dist, sec.value, batches.value
 
 

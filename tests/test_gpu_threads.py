@@ -85,3 +85,26 @@ def test_one_query_calls_from_many_threads_are_coalesced(orc, gp):
     rate_on, rate_off = nq / s_on, 300 / s_off
     print(f"QueryBucket: {rate_on:.0f} calls/s coalesced ({nq / b_on:.1f} per batch) vs {rate_off:.0f} one by one: {rate_on / rate_off:.1f}x")
     assert rate_on > 2.0 * rate_off
+
+
+def test_a_bad_request_fails_its_caller_alone(orc, gp):
+    """with the coalescing queue on, one caller's bad argument (a bucket that does not exist) used to fail every thread that shared its
+    device batch.  A failed group is now retried request by request (index_host.cpp RunScanGroup): the offender gets the exception, everybody
+    else the reference's answer."""
+    from pygpann import host
+    rng = np.random.default_rng(43)
+    n, d, S, nq, k = 20000, 24, 3, 400, 10
+    pts = make_mixture(orc, n, d, n_centers=12)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556, n_centers=12)
+    buckets = rng.integers(0, S, nq).astype(np.int32)
+    bad = np.array([7, 8, 150, 399])
+    buckets_bad = buckets.copy()
+    buckets_bad[bad] = S + 5                      # no such shard
+    ivf = orc.ivf_build(pts, clusters)
+    wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, buckets.reshape(-1, 1), 1, 0, nthreads=4)
+    ids, dist, _, batches, failed = host.index_query_bucket_threads(pts, clusters, queries, k, buckets_bad, 32, True, tolerate_failures=True)
+    assert batches < nq                            # the queue did coalesce
+    assert np.array_equal(np.flatnonzero(failed), bad)
+    ok = failed == 0
+    assert np.array_equal(ids[ok], wi[ok, 0]) and np.array_equal(dist[ok].view(np.uint32), wd[ok, 0].view(np.uint32))
