@@ -26,6 +26,10 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# The timed loop keeps three scan calls, the router and the lists' way out in flight on streams of their own; the HIP runtime multiplexes a
+# process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and a stream that shares a queue with the rest pass waits for it.
+# Read when the runtime is initialised: set before anything touches HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # N > 1: how long a rank waits for a collective before it gives the run up (gpann_comm_wait also returns as soon as another rank has left)
 COMM_WAIT_S = int(os.environ.get("GPANN_COMM_WAIT_S", "600"))
 _live_comm = []   # the communicator of this process, for the exit path of a failed run
@@ -711,6 +715,7 @@ def main():
     log(f"timed configuration: index budget {best['index_budget']}, nprobe {nprobe}")
 
     scan_ms, router_ms, algo_bytes, filter_ms, rest_ms, step_wall_ms, stats = [], [], [], [], [], [], None
+    host_trace = []   # GPANN_BENCH_TRACE=1: (event, batch, ms since the timed loop began) of the main thread
     router_bound_ms, router_bound_flops = [], 0.0
     import concurrent.futures
     # The timed loop is a software pipeline over the batches, one step = route + scan + merge of one batch, K of each inside the clock:
@@ -819,7 +824,7 @@ def main():
         turn = None
         # scans in flight while one is being completed: 1 (the deferred call of round 4), 2 with GPANN_SCAN_OVERLAP — the front stream then always
         # holds the next front, so the rest passes follow each other without a gap; the routes run one batch further ahead than the scans
-        scans_ahead = (2 if scan_overlap else 1) if scan_ahead else 0
+        scans_ahead = (max(1, min(2, int(os.environ.get("GPANN_BENCH_SCANS_AHEAD", "2")))) if scan_overlap else 1) if scan_ahead else 0
         if multi and route_ahead and count:
             r_ahead = scans_ahead + 1
             order = [("R", j) for j in range(min(r_ahead, count))]
@@ -835,13 +840,19 @@ def main():
             routes = {0: router_pool.submit(route_job, 0, turn)}
             info = {}
 
+            t_origin = time.perf_counter()
+            stamp = (lambda what, j: host_trace.append((what, j, round(1e3 * (time.perf_counter() - t_origin), 3)))) if (trace and record is not None) else (lambda what, j: None)
+
             def begin(j):
                 """the routing of batch j has arrived: the next one goes to the router thread, the scan of batch j is planned and enqueued"""
+                stamp("route_wait", j)
                 pr, r_ms, rst = routes.pop(j).result()
                 info[j] = (r_ms, rst)
                 if j + 1 < count:
                     routes[j + 1] = router_pool.submit(route_job, j + 1, turn)
+                stamp("begin", j)
                 scan_begin(pr, j % depth)
+                stamp("begun", j)
             for j in range(min(scans_ahead, count)):
                 begin(j)
             t_step = time.perf_counter()
@@ -851,7 +862,9 @@ def main():
                     pending = None
                 if it + scans_ahead < count:
                     begin(it + scans_ahead)     # (queued behind the batches the GPU is still working on)
+                stamp("finish", it)
                 sd, si, s_ms = scan_finish(it % depth, x_turn(it))
+                stamp("finished", it)
                 pending = merger.submit(pygpann.merge_dedup, sd, si, nprobe, k)
                 note(t_step, info[it][0], s_ms, info.pop(it)[1])
                 t_step = time.perf_counter()
@@ -891,7 +904,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # the same step strictly one batch at a time (route -> scan -> D2H -> merge, nothing of another batch in flight): the per-batch wall
     # time the metric's "10k batched queries" literally describes; `value` above is the pipelined throughput
-    lat = []
+    lat, rest_alone_ms, scan_alone_ms = [], [], []
     for _ in range(2):
         step()
     barrier()
@@ -900,6 +913,9 @@ def main():
         step()
         torch.cuda.synchronize()
         lat.append(1e3 * (time.perf_counter() - t1))
+        st_alone = shards.stats()     # (the launches of a step with the chip to themselves: what the rest pass takes when nothing runs beside it)
+        rest_alone_ms.append(st_alone["filter_rest_ms"])
+        scan_alone_ms.append(st_alone["scan_ms"])
     latency_ms_one_batch = float(np.mean(lat))
     cu_sweep = None
     if os.environ.get("GPANN_BENCH_CU_SWEEP") and not multi:
@@ -993,8 +1009,16 @@ def main():
                       + (stats["filter_candidates"] + stats["filter_seed_rows"]) * d * 4.0
                       + 2.0 * tree["centroids"].shape[0] * 64.0 * ks_read)
         step_s = elapsed / args.steps
+        ra_s = float(np.mean(rest_alone_ms)) / 1000.0 if rest_alone_ms else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": rest_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rest_gbps / HBM_PEAK_GBPS,
                               "traffic": traffic, "traffic_source": traffic_src,
+                              "kernel_ms_alone": 1000.0 * ra_s, "achieved_alone": rest_bytes / ra_s / 1e9 if ra_s > 0 else None,
+                              "frac_alone": rest_bytes / ra_s / 1e9 / HBM_PEAK_GBPS if ra_s > 0 else None,
+                              "overlap_note": ("kernel_ms / achieved / frac are the rest pass's launches INSIDE the timed loop, where (GPANN_SCAN_OVERLAP) the fronts of "
+                                               "the next two batches and the router run beside it on the same chip and the same HBM — by design its time there "
+                                               "is longer than alone; kernel_ms_alone / frac_alone = the same launch of the same batch in the one-batch loop of this "
+                                               "run (nothing beside it); frac_step = what all launches of a step together make of the HBM peak"
+                                               if scan_overlap else "nothing runs beside the rest pass in this run's timed loop"),
                               "frac_step": step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, "step_bytes": step_bytes,
                               "frac_step_note": "bytes ALL launches of a step have to read (plane rows of every filter pass, exactly re-scored rows, the router's "
                                                 "centroid planes) / ms_per_step / 8 TB/s: what the step as a whole makes of the memory system",
@@ -1075,6 +1099,9 @@ def main():
     result["detail"]["router_bound_calls"] = int(rs_all["bound_calls"])
     if cu_sweep is not None:
         result["detail"]["cu_sweep"] = cu_sweep
+    if host_trace:
+        result["detail"]["host_trace"] = host_trace[:160]
+        result["detail"]["per_step"] = {"router_ms": [round(x, 3) for x in router_ms], "scan_call_ms": [round(x, 3) for x in scan_ms], "rest_ms": [round(x, 3) for x in rest_ms]}
 
     # tuning aid (off by default): GPANN_BENCH_SWEEP="GPANN_FILTER_SEED_ROWS=64,128;GPANN_FILTER_HEAD_ROWS=512,0" times a few steps for every
     # combination of the listed options of the store (gpann_shards_set_option: read by every call) and checks that the results do not change

@@ -293,9 +293,21 @@ gpann_status gpann_comm_init(int rank, int world, const char* master_addr, int p
         // the communicator is bound to `device`, which STAYS the calling thread's current device (include/gpann_comm.h): a rank process that
         // has not touched HIP yet relies on this call to select its GPU — restoring "the previous device" would silently put its buffers on
         // device 0 while the communicator lives on LOCAL_RANK.  A caller that works on another device calls hipSetDevice itself afterwards.
+        int before = -1;
+        if (hipGetDevice(&before) != hipSuccess) (void)hipGetLastError();
         if (hipSetDevice(device) != hipSuccess) {
             SetErr("hipSetDevice(%d) failed", device);
             return fail(GPANN_ERR_HIP);
+        }
+        // (a caller that had chosen ANOTHER device before — its buffers may live there — is told once that its current device has changed: a
+        // later allocation would otherwise land on the communicator's device without a word; n_dev > 1: on a one-GPU box there is nothing to mix up)
+        if (before >= 0 && before != device && n_dev > 1) {
+            static bool warned = false;
+            if (!warned) {
+                warned = true;
+                fprintf(stderr, "[gpann comm] gpann_comm_init: the calling thread's HIP device was %d; it is now %d, the communicator's (include/gpann_comm.h) — "
+                                "call hipSetDevice again if your buffers live elsewhere\n", before, device);
+            }
         }
         ncclUniqueId id;
         std::memset(&id, 0, sizeof id);

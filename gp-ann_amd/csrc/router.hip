@@ -46,6 +46,7 @@ struct gpann_router {
     uint32_t max_children = 0;
     uint32_t max_node = 1;   // largest node (centroids)
     int num_cus = 256;       // cached hipDeviceProp_t::multiProcessorCount
+    size_t lds_per_wg = 160u << 10;   // cached hipDeviceProp_t::sharedMemPerBlock: what one workgroup may allocate (gfx950: 160 KiB)
     float* centroids = nullptr;          // [n_centroids][ld]
     int32_t* node_shard = nullptr;
     uint32_t* node_cent_first = nullptr; // [n_nodes+1]
@@ -1873,6 +1874,7 @@ gpann_status gpann_router_create(uint32_t d, int metric, uint32_t S, uint32_t n_
         hipDeviceProp_t prop;
         TRY_OR_FAIL(hipGetDeviceProperties(&prop, device));
         r->num_cus = prop.multiProcessorCount;
+        if (prop.sharedMemPerBlock > 0) r->lds_per_wg = prop.sharedMemPerBlock;
         for (uint32_t u = 0; u < n_nodes; ++u) r->max_node = std::max(r->max_node, node_cent_first[u + 1] - node_cent_first[u]);
         std::vector<uint8_t> is_root(n_nodes, 0);
         r->root_min = 0xFFFFFFFFu;
@@ -2842,7 +2844,8 @@ gpann_status LaunchWalk(gpann_router* r, const float* queries, uint32_t nq, int3
         const uint64_t table_ld = (C + kGTileRows - 1) / kGTileRows * kGTileRows;
         const bool bounded_able = r->cent_planes != nullptr && !(tmode && tmode[0] == '0') && !r->canonical_once && r->cent_node8 != nullptr &&
                                   r->n_nodes < (1u << kBandNodeBits) && r->max_node < (1u << (32 - kBandNodeBits)) &&
-                                  ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 <= 150 * 1024;   // (the visited bitmap lives in LDS)
+                                  ((size_t)1024 + S + 3 * 4096 + r->n_nodes / 32 + 64) * 4 + (10u << 10) <= r->lds_per_wg;   // (the visited bitmap lives in LDS;
+                                                                                       // against the DEVICE's limit, not a constant: a part with less LDS takes the canonical table)
         // FrequencyQuery with a budget above the tree: every centroid is visited, no tree logic at all — the votes are the pairs within the error
         // of the V-th smallest table value (any tree shape: the sorted replay's trees too)
         const bool all_rec = rec_dist != nullptr && rec_keep > 0 && all_roots_open && (uint64_t)budget > C && !force_heap;

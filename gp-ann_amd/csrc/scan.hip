@@ -1367,12 +1367,13 @@ static gpann_status AcquireSlot(gpann_shards* s, hipStream_t st) {
 // GPANN_SCAN_OVERLAP: the handle's two streams (created at the first such call).  Priorities: the front high — short launches on a chain of
 // dependencies —, the rest pass low: it takes the compute units the fronts leave.
 static gpann_status OverlapStreams(gpann_shards* s) {
-    if (s->st_front && s->st_rest && s->st_tail) return GPANN_OK;
+    if (s->st_rest) return GPANN_OK;
     int least = 0, greatest = 0;
     GPANN_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (!s->st_front) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_front, hipStreamNonBlocking, greatest));
-    if (!s->st_rest) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_rest, hipStreamNonBlocking, least));
+    for (hipStream_t& st : s->st_front)
+        if (!st) GPANN_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     if (!s->st_tail) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_tail, hipStreamNonBlocking, greatest));
+    if (!s->st_rest) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_rest, hipStreamNonBlocking, least));
     return GPANN_OK;
 }
 
@@ -1386,8 +1387,10 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
         GPANN_TRY(OverlapStreams(s));
         GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[0], st_caller));
-        GPANN_HIP_TRY(hipStreamWaitEvent(s->st_front, CS(s).ev_x[0], 0));
-        st = s->st_front;
+        // (a front stream per slot: the fronts of the calls in flight run side by side; 1: one after the other)
+        const uint32_t n_front = std::max<uint32_t>(1, std::min<uint32_t>(gpann_shards::kCallSlots, s->opt.U32("GPANN_OVERLAP_FRONT_STREAMS", 3)));
+        st = s->st_front[(uint32_t)s->cur % n_front];
+        GPANN_HIP_TRY(hipStreamWaitEvent(st, CS(s).ev_x[0], 0));
         st_rest = s->st_rest;
         st_tail = s->st_tail;
     }

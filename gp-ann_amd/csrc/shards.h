@@ -199,10 +199,14 @@ struct gpann_shards {
     } cs[kCallSlots];
     int cur = 0;
     gpann_scan_stats stats{};
-    // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): the calls' fronts in order on one (high priority: short,
-    // latency-bound launches), their rest-pass launches back to back on the second (low priority: it takes what the others leave), what follows a
-    // rest pass — the re-scoring of its candidates, the final merge, the lists' way out — on the third
-    hipStream_t st_front = nullptr, st_rest = nullptr, st_tail = nullptr;
+    // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): a front stream per call slot (high priority: short,
+    // latency-bound launches; GPANN_OVERLAP_FRONT_STREAMS = 1: the fronts one after the other, 3: the fronts of all calls in flight side by side —
+    // chains of dependent launches fill each other's gaps), the rest-pass launches of all calls back to back on ONE stream (low priority: it takes
+    // what the others leave), what follows a rest pass — the re-scoring of its candidates, the final merge, the lists' way out — on ONE tail stream (the tails are
+    // short and ordered like the rest passes anyway; every stream more is one more candidate for sharing a hardware queue with the rest pass:
+    // the runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and a front that lands in the rest
+    // pass's queue waits for it — INTEGRATION.md)
+    hipStream_t st_front[kCallSlots] = {nullptr, nullptr, nullptr}, st_rest = nullptr, st_tail = nullptr;
 };
 
 namespace gpann {

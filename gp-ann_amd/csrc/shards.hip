@@ -100,6 +100,7 @@ static const Knob kKnobs[] = {
     {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of the front's filter launches (default 96)"},
     {"GPANN_OVERLAP_REST_ITEMS", 'C', "GPANN_SCAN_OVERLAP: work items after which a rest-pass workgroup leaves (default 4; 0: persistent workgroups)"},
     {"GPANN_OVERLAP_REST_CUS", 'C', "GPANN_SCAN_OVERLAP with persistent rest-pass workgroups: how many (default 160)"},
+    {"GPANN_OVERLAP_FRONT_STREAMS", 'C', "GPANN_SCAN_OVERLAP: 1 = the fronts of the calls in flight one after the other, 3 (default) = side by side, a stream per call slot"},
     {"GPANN_DEBUG_Q8_NO_CAND", 'C', "measurement aid, WRONG RESULTS: the 8-bit passes find no candidate"},
     // router
     {"GPANN_ROUTER_MODE", 'C', "walk | dense: force the tree walk / the distance table + replay (default: by tree size and budget)"},
@@ -379,9 +380,11 @@ gpann_status gpann_shards_destroy(gpann_shards* s) {
         for (auto& e : c.ev_x)
             if (e) (void)hipEventDestroy(e);
     }
-    if (s->st_front) (void)hipStreamDestroy(s->st_front);
-    if (s->st_rest) (void)hipStreamDestroy(s->st_rest);
+    for (hipStream_t st : s->st_front)
+        if (st) (void)hipStreamDestroy(st);
     if (s->st_tail) (void)hipStreamDestroy(s->st_tail);
+    if (s->st_rest) (void)hipStreamDestroy(s->st_rest);
+
     delete s;
     return GPANN_OK;
 }

@@ -3,7 +3,10 @@
 # suite (a parent pytest process holding a GPU context, DistributedBench children with 2-3 ranks sharing the GPU and RCCL set-up / tear-down
 # right before the reference's QueryAttribution driver) — instead of the stand-alone harness, which never showed it.  Every router call runs
 # with GPANN_ROUTER_VERIFY + STRICT (conftest) and GPANN_ROUTER_PROBE=1: each bound block is run twice and every bit of the two runs compared.
-#   tools/stress_suite_context.sh OUT_DIR PAIR_LOOPS CONCURRENT_PROCS CONCURRENT_RUNS [FULL_SUITES]
+#   tools/stress_suite_context.sh OUT_DIR PAIR_LOOPS CONCURRENT_PROCS CONCURRENT_RUNS [FULL_SUITES] [LEGACY_MEMSET]
+# LEGACY_MEMSET=1 (round 5): every router handle sets its bound blocks up the way rounds 1-3 did — three runtime memsets + a fill launch
+# (GPANN_ROUTER_LEGACY_MEMSET, csrc/router.hip EnqueueBound) instead of one BoundInitKernel.  All three historical events predate the kernel; if
+# the event lives in the runtime's memsets it shows in this variant under the probe and nowhere else.
 # Evidence of an event: OUT_DIR/router_verify_report.txt (+ .bin dumps), and the failing pytest log.
 set -u
 OUT=${1:-gpurun_out/r4_stress}
@@ -11,7 +14,9 @@ PAIRS=${2:-40}
 PROCS=${3:-4}
 RUNS=${4:-20}
 FULL=${5:-1}
+LEGACY=${6:-0}
 mkdir -p "$OUT"
+if [ "$LEGACY" = 1 ]; then export GPANN_ROUTER_LEGACY_MEMSET=1; echo "(legacy memset set-up of the bound blocks)" > "$OUT/variant.txt"; fi
 export GPANN_ROUTER_PROBE=1
 export GPANN_VERIFY_REPORT="$PWD/$OUT/router_verify_report.txt"
 events=0
