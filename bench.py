@@ -618,7 +618,7 @@ def main():
             dm = torch.empty((chunk_q, S), dtype=torch.int32, device=dev) if on_dev else None
             da = torch.empty((world, chunk_q, S), dtype=torch.int32, device=dev) if on_dev else None
             return mine_t, all_t, dm, da
-        route_sets = [_route_set() for _ in range(3)]   # [0]: the calls outside the timed loop; [1], [2]: the route-ahead thread, alternating
+        route_sets = [_route_set() for _ in range(4)]   # [0]: the calls outside the timed loop; [1] .. [3]: the route-ahead thread, in turn
 
     # ---------------------------------------------------------------- ground truth (same kernel, every shard) + nprobe sweep
     t0 = time.time()
@@ -738,19 +738,23 @@ def main():
     # GPANN_BENCH_OVERLAP=0: both calls on one stream, batch i + 1 strictly behind batch i.
     scan_overlap = scan_ahead and os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0"
     if route_ahead:
-        r_stream = torch.cuda.Stream(device=dev)
+        r_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("GPANN_BENCH_ROUTER_PRIORITY", "0")))
         r_bufs = [torch.empty((nq, nprobe), dtype=torch.int32).pin_memory().numpy() for _ in range(3)]
         router_pool = concurrent.futures.ThreadPoolExecutor(1)
         def route_job(j, turn=None):
             if multi:   # my slice, the all-gather of the probe lists and its wait: all on the second stream, buffer sets 1 / 2 alternating
                 torch.cuda.set_device(local_rank)
-                pr, r_ms = route(j=1 + (j & 1), st=r_stream.cuda_stream, cm=comm_r, turn=turn, turn_key=("R", j))
+                pr, r_ms = route(j=1 + j % 3, st=r_stream.cuda_stream, cm=comm_r, turn=turn, turn_key=("R", j))
                 return pr, r_ms, router.stats()
             pr, _, r_ms = router.query_batch(queries.data_ptr(), args.search_budget, r_stream.cuda_stream, on_device=True, nq=nq, out_probes=r_bufs[j % 3],
                                              want_min_dist=False, n_top=None if nprobe == S else nprobe)
             return pr, r_ms, router.stats()
 
     x_stream = torch.cuda.Stream(device=dev) if multi else None
+    # the deferred scan calls are issued on a stream of their own, not on the legacy default stream: under GPANN_SCAN_OVERLAP the caller's stream
+    # only orders a call's START (an event recorded on it), and an event on the default stream waits for every blocking stream of the process —
+    # the router's among them: the front of batch i + 2 would wait for the routing of batch i + 3
+    s_stream = torch.cuda.Stream(device=dev)
     dev_sets = {}
 
     def scan_begin(pr, buf):
@@ -761,13 +765,14 @@ def main():
             if buf not in dev_sets:
                 dev_sets[buf] = (torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev), torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev))
             oi, od = dev_sets[buf]
-            shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), stream, for_merge=merge_bound, defer=True, overlap=scan_overlap)
+            shards.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, oi.data_ptr(), od.data_ptr(), s_stream.cuda_stream if scan_overlap else stream,
+                                       for_merge=merge_bound, defer=True, overlap=scan_overlap)
             return
         if key not in host_out:
             host_out[key] = (torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory())
         hd, hi = host_out[key]
-        shards.scan_buckets_device(queries.data_ptr(), nq, k, np.ascontiguousarray(pr[:, :nprobe]), nprobe, hi.data_ptr(), hd.data_ptr(), stream, for_merge=merge_bound,
-                                   defer=True, host_out=True, overlap=scan_overlap)
+        shards.scan_buckets_device(queries.data_ptr(), nq, k, np.ascontiguousarray(pr[:, :nprobe]), nprobe, hi.data_ptr(), hd.data_ptr(),
+                                   s_stream.cuda_stream if scan_overlap else stream, for_merge=merge_bound, defer=True, host_out=True, overlap=scan_overlap)
 
     def scan_finish(buf, in_turn=None):
         ms = shards.finish()
@@ -825,8 +830,11 @@ def main():
         # scans in flight while one is being completed: 1 (the deferred call of round 4), 2 with GPANN_SCAN_OVERLAP — the front stream then always
         # holds the next front, so the rest passes follow each other without a gap; the routes run one batch further ahead than the scans
         scans_ahead = (max(1, min(2, int(os.environ.get("GPANN_BENCH_SCANS_AHEAD", "2")))) if scan_overlap else 1) if scan_ahead else 0
+        # the routes run routes_ahead batches ahead of the scan being begun: beside three scans the router's launches take up to ten times their
+        # time alone, and a route that is not there when its scan is to begin stalls the whole pipeline
+        routes_ahead = max(1, min(2, int(os.environ.get("GPANN_BENCH_ROUTES_AHEAD", "2")))) if scan_overlap else 1
         if multi and route_ahead and count:
-            r_ahead = scans_ahead + 1
+            r_ahead = scans_ahead + routes_ahead
             order = [("R", j) for j in range(min(r_ahead, count))]
             for it in range(count):
                 if it + r_ahead < count:
@@ -837,7 +845,7 @@ def main():
         x_turn = (lambda it: turn.slot(("X", it))) if turn is not None else (lambda it: None)
         if scan_ahead and count:
             depth = scans_ahead + 1     # host / device buffer sets: one per scan in flight
-            routes = {0: router_pool.submit(route_job, 0, turn)}
+            routes = {j: router_pool.submit(route_job, j, turn) for j in range(min(routes_ahead, count))}
             info = {}
 
             t_origin = time.perf_counter()
@@ -848,8 +856,8 @@ def main():
                 stamp("route_wait", j)
                 pr, r_ms, rst = routes.pop(j).result()
                 info[j] = (r_ms, rst)
-                if j + 1 < count:
-                    routes[j + 1] = router_pool.submit(route_job, j + 1, turn)
+                if j + routes_ahead < count:
+                    routes[j + routes_ahead] = router_pool.submit(route_job, j + routes_ahead, turn)
                 stamp("begin", j)
                 scan_begin(pr, j % depth)
                 stamp("begun", j)

@@ -25,9 +25,42 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 
 #define CS(s) ((s)->cs[(s)->cur])   // the per-call host state of the call in progress (shards.h)
+
+// GPANN_SCAN_DEBUG_HOST=1: where the HOST time of a scan call goes (stderr, calls that take more than a millisecond to enqueue)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    char buf[512];
+    size_t len = 0;
+    HostTrace() {
+        const char* v = std::getenv("GPANN_SCAN_DEBUG_HOST");
+        on = v && v[0] == '1';
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void Mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        if (ms > 0.05 && len + 48 < sizeof buf) len += (size_t)std::snprintf(buf + len, sizeof buf - len, " %s %.2f", what, ms);
+    }
+    ~HostTrace();
+};
+static thread_local HostTrace* g_host_trace = nullptr;
+#define HT_MARK(what)                                   \
+    do {                                                \
+        if (g_host_trace) g_host_trace->Mark(what);     \
+    } while (0)
+HostTrace::~HostTrace() {
+        if (g_host_trace == this) g_host_trace = nullptr;
+        if (!on) return;
+        const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (total > 1.0) fprintf(stderr, "[gpann scan host] %.2f ms:%.*s\n", total, (int)len, buf);
+}
 
 namespace gpann {
 
@@ -790,7 +823,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         uint32_t* stb_own = reinterpret_cast<uint32_t*>(d_dtiles_own + dtiles.size()) + 3 * (size_t)T;   // (behind tmp_q | tmp_o | task_src, below)
         d_stb = up.Add(stb_own, plan.shard_task_begin.data(), (size_t)(S + 1) * 4);
     }
+    HT_MARK("plan+reserve");
     GPANN_HIP_TRY(up.Flush());   // task arrays, tables, the shard-sample items: one copy
+    HT_MARK("flush");
     GPANN_TRY(cell_table(true));
     uint32_t* d_task_src = nullptr;
     {
@@ -1093,12 +1128,17 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // kept apart by their GRID sizes: the front's filter launches start at most front_cus workgroups; the rest pass either rest_cus persistent ones
     // (GPANN_OVERLAP_REST_ITEMS=0) or — the default — as many workgroups as its items need, each leaving after rest_items items: the rest stream has
     // the lower priority, so a CU it gives up goes to the front when the front has a workgroup waiting and back to the rest pass when it has not.
-    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_FRONT_CUS", 96))) : (uint32_t)n_cus;
-    const uint32_t rest_items_env = overlap ? s->opt.U32("GPANN_OVERLAP_REST_ITEMS", 4) : 0u;
+    // Defaults (NS sweeps, profiles/r05/NOTES.md): a store whose rest pass streams gigabytes — 160 persistent rest workgroups, 96 for a front's filter
+    // launches (the rest pass is HBM-bound: on 160 of 256 CUs it loses a fifth of its speed and the fronts get what they need); a small store (its
+    // planes below 4 GB: the step is its launches, not its bytes) — no partition at all, every launch may take the whole chip.
+    const bool big_store = (uint64_t)C.n_tiles * kGTileRows * (use_q8 ? 32u * KS8 + 4u : 32u * KS + 4u) >= (4ull << 30);
+    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_FRONT_CUS", big_store ? 96 : (uint32_t)n_cus))) : (uint32_t)n_cus;
+    const uint32_t rest_items_env = overlap ? s->opt.U32("GPANN_OVERLAP_REST_ITEMS", 0) : 0u;
     const uint32_t rest_items = rest_items_env == 0 ? 0u : std::max<uint32_t>(2, rest_items_env);   // (a workgroup's first two claims are made before anything is counted)
-    const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_REST_CUS", 160))) : (uint32_t)n_cus;
+    const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_REST_CUS", big_store ? 160 : (uint32_t)n_cus))) : (uint32_t)n_cus;
     fa.wg_item_budget = 0;
 
+    HT_MARK("tables+images");
     bool seed_wrote_U = false;
     if (seed_rows != 0) {
         ra.seed_rows = seed_rows;
@@ -1165,6 +1205,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     }
     for (int pass = head_tiles ? 0 : 1; pass < 3; ++pass) {
         GPANN_REQUIRE(PassSetupLdsBytes(kmax) <= (64u << 10), "too many cells in one shard for the pass set-up kernel");
+        HT_MARK(pass == 0 ? "seed+sample" : pass == 1 ? "head" : "sample");
         const uint32_t pass_cus = pass == 2 ? rest_cus : front_cus;
         if (CS(s).filter_passes_timed < 2) GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[2 * CS(s).filter_passes_timed], st));
         const bool hi_pass = hi_last && pass >= hi_from_pass;
@@ -1267,6 +1308,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                     (unsigned long long)((uint64_t)h_words[2] | ((uint64_t)h_words[3] << 32)), h_words[0]);
         }
     }
+    HT_MARK("rest");
     {   // the dirty tasks: their whole shards exactly, range_segs segments each on a wavefront of its own, merged into their lists
         // (launched whatever the count — no host round trip: without dirty tasks both launches end at once)
         RescoreArgs rr = ra;
@@ -1374,11 +1416,37 @@ static gpann_status OverlapStreams(gpann_shards* s) {
         if (!st) GPANN_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
     if (!s->st_tail) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_tail, hipStreamNonBlocking, greatest));
     if (!s->st_rest) GPANN_HIP_TRY(hipStreamCreateWithPriority(&s->st_rest, hipStreamNonBlocking, least));
+    // The runtime sets a stream's queues and copy paths up when they are FIRST used — 5 to 30 ms each, on the host, in the middle of whichever call
+    // comes first (measured: an 11 ms D2H enqueue on the tail stream, 5 ms H2D flushes on the front streams, scattered over the first calls of a
+    // timed loop).  Touch every stream once here: a copy to the device, a launch, a copy back.
+    {
+        uint32_t *pin = nullptr, *d_tmp = nullptr;
+        GPANN_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), 64, hipHostMallocDefault));
+        std::memset(pin, 0, 64);
+        GPANN_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tmp), 256));
+        hipStream_t all[gpann_shards::kCallSlots + 2];
+        int n = 0;
+        for (hipStream_t st : s->st_front) all[n++] = st;
+        all[n++] = s->st_rest;
+        all[n++] = s->st_tail;
+        for (int i = 0; i < n; ++i) {
+            (void)hipMemcpyAsync(d_tmp, pin, 64, hipMemcpyHostToDevice, all[i]);
+            hipLaunchKernelGGL(FillKernel, dim3(1), dim3(64), 0, all[i], reinterpret_cast<float*>(d_tmp), d_tmp + 16, d_tmp + 32, (size_t)8);
+            (void)hipMemcpyAsync(pin, d_tmp, 64, hipMemcpyDeviceToHost, all[i]);
+            (void)hipStreamSynchronize(all[i]);
+        }
+        (void)hipFree(d_tmp);
+        (void)hipHostFree(pin);
+        (void)hipGetLastError();
+    }
     return GPANN_OK;
 }
 
 static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes,
                                  uint32_t probe_stride, uint32_t nprobe, int flags, hipStream_t st_caller, DeviceLists out) {
+    HostTrace local_trace;
+    if (!g_host_trace) g_host_trace = &local_trace;   // (gpann_scan_buckets traces the whole entry point; the other entry points from here)
+    HostTrace& ht = *g_host_trace;
     ScanPlan& plan = CS(s).plan;
     // GPANN_SCAN_OVERLAP (a deferred call in filter mode whose queries the kernels read in place — the conditions under which the call stays
     // deferred): the call's work goes to the handle's own streams; the caller's stream only orders its start
@@ -1394,14 +1462,17 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         st_rest = s->st_rest;
         st_tail = s->st_tail;
     }
+    ht.Mark("streams");
     // The pinned staging area and the plan's host arrays of this slot are the sources of an earlier call's asynchronous uploads: that call may
     // have returned with them still queued (device output, no timing — nothing made it synchronise), so wait for the end of its work first.
     if (CS(s).stage_in_flight) {
         GPANN_HIP_TRY(hipEventSynchronize(CS(s).ev[3]));
         CS(s).stage_in_flight = false;
     }
+    ht.Mark("stage_wait");
     plan.Clear();
     GPANN_TRY(BuildTasks(s, nq, probes, probe_stride, nprobe, plan));
+    ht.Mark("tasks");
     const uint32_t T = (uint32_t)plan.task_query.size(), S = s->S;
     // (task arrays, group / tile tables, unit lists: ~32 bytes per task + per-shard tables; exact-mode unit lists fall back to pageable copies if larger)
     CS(s).stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
@@ -1409,6 +1480,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     UploadBatch up{s, st};
     const size_t n_out = (size_t)nq * nprobe;
 
+    ht.Mark("stage_reserve");
     const float* d_queries = nullptr;
     GPANN_TRY(StageQueries(s, queries, nq, (flags & GPANN_QUERIES_ON_DEVICE) != 0, st, &d_queries));
 
@@ -1452,6 +1524,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     c.out_rows = out.rows;
     c.host_dist = nullptr;
     c.host_ids = c.host_rows = nullptr;
+    ht.Mark("pre");
     if (want_filter) {
         hipStream_t st_end = st;
         GPANN_TRY(RunCellFilteredScan(s, plan, ta, up, d_queries, nq, nprobe, k, flags, st, st_rest, st_tail, &st_end, out));
@@ -1461,8 +1534,10 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     } else {
         GPANN_TRY(RunExactPath(s, ta, up, d_queries, nq, nprobe, k, flags, st, out));
     }
+    ht.Mark("pipeline");
     GPANN_HIP_TRY(hipEventRecord(c.ev[2], st));
     GPANN_HIP_TRY(hipEventRecord(c.ev[3], st));   // the end of the device work of this call so far (uploads AND kernels: a later call on this slot waits for it; an entry point that enqueues more records it again)
+    ht.Mark("end_events");
     c.stage_in_flight = true;
     c.pending = true;
     return GPANN_OK;
@@ -1602,8 +1677,12 @@ extern "C" {
 gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t nq, uint32_t k, const int32_t* probes, uint32_t probe_stride,
                                 uint32_t nprobe, uint32_t* out_ids, float* out_dist, uint32_t* out_rows, int flags, void* stream,
                                 float* elapsed_ms) {
+    HostTrace entry_trace;
+    g_host_trace = &entry_trace;
     GPANN_TRY(CheckScanArgs(s, queries, nq, k, probes, nprobe, probe_stride));
+    HT_MARK("args+device");
     std::lock_guard<std::recursive_mutex> turn(s->call_mutex);   // (concurrent calls on one handle take turns: shards.h)
+    HT_MARK("lock");
     GPANN_REQUIRE(out_ids != nullptr, "out_ids is null");
     GPANN_REQUIRE(!(flags & GPANN_SCAN_FOR_MERGE) || !(flags & GPANN_OUTPUT_ON_DEVICE) || out_dist != nullptr, "GPANN_SCAN_FOR_MERGE with device output needs out_dist");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1613,6 +1692,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
         return GPANN_OK;
     }
     GPANN_TRY(AcquireSlot(s, st));
+    HT_MARK("slot");
     DeviceLists dl;
     const bool dev_out = (flags & GPANN_OUTPUT_ON_DEVICE) != 0;
     if (dev_out) {
@@ -1632,6 +1712,7 @@ gpann_status gpann_scan_buckets(gpann_shards* s, const float* queries, uint32_t 
         c.host_dist = out_dist;
         c.host_rows = out_rows;
         GPANN_TRY(EnqueueHostCopies(s, c));
+        HT_MARK("host_copies");
     }
     // GPANN_SCAN_DEFER: the call is completed by gpann_scan_finish — provided a redo could still find its inputs: device queries read in place
     if ((flags & GPANN_SCAN_DEFER) && c.d_queries == queries) return GPANN_OK;

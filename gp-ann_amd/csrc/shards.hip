@@ -97,9 +97,9 @@ static const Knob kKnobs[] = {
     {"GPANN_RESCORE_SPLIT_MIN", 'C', "candidates per piece of a split bucket (default 128)"},
     {"GPANN_SCAN_TARGET_UNITS", 'C', "exact mode: workgroups a launch is cut into (default 8192)"},
     {"GPANN_SCAN_MIN_SEG_ROWS", 'C', "exact mode: smallest row segment of a unit"},
-    {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of the front's filter launches (default 96)"},
-    {"GPANN_OVERLAP_REST_ITEMS", 'C', "GPANN_SCAN_OVERLAP: work items after which a rest-pass workgroup leaves (default 4; 0: persistent workgroups)"},
-    {"GPANN_OVERLAP_REST_CUS", 'C', "GPANN_SCAN_OVERLAP with persistent rest-pass workgroups: how many (default 160)"},
+    {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of a front's filter launches (default 96; stores whose planes are below 4 GB: all CUs)"},
+    {"GPANN_OVERLAP_REST_ITEMS", 'C', "GPANN_SCAN_OVERLAP: work items after which a rest-pass workgroup leaves (default 0: persistent workgroups, GPANN_OVERLAP_REST_CUS of them)"},
+    {"GPANN_OVERLAP_REST_CUS", 'C', "GPANN_SCAN_OVERLAP with persistent rest-pass workgroups: how many (default 160; stores whose planes are below 4 GB: all CUs)"},
     {"GPANN_OVERLAP_FRONT_STREAMS", 'C', "GPANN_SCAN_OVERLAP: 1 = the fronts of the calls in flight one after the other, 3 (default) = side by side, a stream per call slot"},
     {"GPANN_DEBUG_Q8_NO_CAND", 'C', "measurement aid, WRONG RESULTS: the 8-bit passes find no candidate"},
     // router

@@ -97,7 +97,7 @@ def test_options_table_and_no_getenv_on_the_call_paths():
         assert must in names
     assert dict((n, b) for n, b, _ in opts)["GPANN_CELL_ROWS"] is True and dict((n, b) for n, b, _ in opts)["GPANN_FILTER_HEAD_ROWS"] is False
     csrc = os.path.join(ROOT, "gp-ann_amd", "csrc")
-    allowed = {"GPANN_CELLS_DEBUG", "GPANN_ROUTER_DEBUG", "GPANN_VERIFY_REPORT"}     # debug output only
+    allowed = {"GPANN_CELLS_DEBUG", "GPANN_ROUTER_DEBUG", "GPANN_VERIFY_REPORT", "GPANN_SCAN_DEBUG_HOST"}     # debug output only
     for fn in sorted(os.listdir(csrc)):
         if fn == "comm.hip":        # (the communicator reads MASTER_ADDR / ports when it is CREATED: its own, creation-time, contract)
             continue
