@@ -390,9 +390,41 @@ static hipError_t UploadAsync(gpann_shards* s, void* dst, const void* src, size_
 // hipMemcpyAsync into a device mirror of that area (Flush); Add returns the address an array has there.  (One copy per array was a dozen
 // launches per call, each with its own few microseconds of stream time and host work between them.)  Without room in the stage an array goes to
 // its own destination at once, as before.
+// Copies by a KERNEL between device memory and PINNED host memory (through the host allocation's device address).  GPANN_SCAN_OVERLAP uses them
+// instead of hipMemcpyAsync: a runtime copy enqueued on a stream that is waiting for another stream's event was seen to block the HOST until that
+// event had fired (5 - 8 ms inside the upload of a call whose front stream waited for an earlier rest pass, and inside the copies of the lists to the
+// host on the tail stream) — the hand-over between the streams is the whole point of that mode.  16-byte words; n16 words.
+__global__ void CopyWords16Kernel(uint4* dst, const uint4* src, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void CopyWords4Kernel(uint32_t* dst, const uint32_t* src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the device address of a pinned host allocation (nullptr: not device-accessible — the caller falls back to the runtime's copy)
+static void* DeviceAddressOfPinned(const void* host) {
+    void* dp = nullptr;
+    if (host == nullptr || hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dp;
+}
+static hipError_t KernelCopy(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15u) == 0) {
+        const size_t n16 = bytes / 16;
+        hipLaunchKernelGGL(CopyWords16Kernel, dim3((uint32_t)std::min<size_t>(256, (n16 + 255) / 256)), dim3(256), 0, st, static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16);
+    } else {
+        const size_t n = bytes / 4;   // (every array that travels this way is made of 4-byte words)
+        hipLaunchKernelGGL(CopyWords4Kernel, dim3((uint32_t)std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n);
+    }
+    return hipGetLastError();
+}
+
 struct UploadBatch {
     gpann_shards* s;
     hipStream_t st;
+    bool by_kernel = false;   // GPANN_SCAN_OVERLAP: the staged arrays reach the device mirror through CopyWords16Kernel (above)
     size_t first = SIZE_MAX, last = 0;
     hipError_t err = hipSuccess;
     template <typename T>
@@ -413,7 +445,14 @@ struct UploadBatch {
     hipError_t Flush() {
         hipError_t e = err;
         if (first < last) {
-            const hipError_t c = hipMemcpyAsync(CS(s).ws_stage_dev.as<char>() + first, CS(s).stage.base + first, last - first, hipMemcpyHostToDevice, st);
+            hipError_t c;
+            char* src_dev = by_kernel ? static_cast<char*>(DeviceAddressOfPinned(CS(s).stage.base)) : nullptr;
+            if (src_dev) {   // (stage offsets are 64-byte aligned: PinnedStage::Take)
+                const size_t a = first & ~(size_t)15, b = (last + 15) & ~(size_t)15;
+                c = KernelCopy(CS(s).ws_stage_dev.as<char>() + a, src_dev + a, std::min(b, CS(s).ws_stage_dev.bytes) - a, st);
+            } else {
+                c = hipMemcpyAsync(CS(s).ws_stage_dev.as<char>() + first, CS(s).stage.base + first, last - first, hipMemcpyHostToDevice, st);
+            }
             if (e == hipSuccess) e = c;
         }
         first = SIZE_MAX;
@@ -1131,8 +1170,16 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // Defaults (NS sweeps, profiles/r05/NOTES.md): a store whose rest pass streams gigabytes — 160 persistent rest workgroups, 96 for a front's filter
     // launches (the rest pass is HBM-bound: on 160 of 256 CUs it loses a fifth of its speed and the fronts get what they need); a small store (its
     // planes below 4 GB: the step is its launches, not its bytes) — no partition at all, every launch may take the whole chip.
-    const bool big_store = (uint64_t)C.n_tiles * kGTileRows * (use_q8 ? 32u * KS8 + 4u : 32u * KS + 4u) >= (4ull << 30);
-    const uint32_t front_cus = overlap ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_FRONT_CUS", big_store ? 96 : (uint32_t)n_cus))) : (uint32_t)n_cus;
+    // ... and no partition either where the rest pass is bound by its PRODUCTS, not by HBM (overlapping clusters, data without structure: every row
+    // tile meets many query tiles) — there it needs every CU it can get, and a split costs exactly what it takes away.  Known from the previous
+    // completed call's counters: (query tile, row tile) products per row tile of the rest pass (NS 1.7, sigma 0.8 ~8, one blob ~9); unknown: no split.
+    const double ppt_max = (double)s->opt.U32("GPANN_OVERLAP_SPLIT_MAX_PRODUCTS", 3);
+    const bool big_store = (uint64_t)C.n_tiles * kGTileRows * (use_q8 ? 32u * KS8 + 4u : 32u * KS + 4u) >= (4ull << 30) && s->rest_products_per_tile > 0.0 &&
+                           s->rest_products_per_tile <= ppt_max;
+    // (a call with nothing else in flight — the first of a stream of batches — has the chip to itself until its own rest pass: no cap on its front)
+    bool others_in_flight = false;
+    for (int i = 1; i < gpann_shards::kCallSlots; ++i) others_in_flight = others_in_flight || s->cs[(s->cur + i) % gpann_shards::kCallSlots].pending;
+    const uint32_t front_cus = overlap && others_in_flight ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_FRONT_CUS", big_store ? 96 : (uint32_t)n_cus))) : (uint32_t)n_cus;
     const uint32_t rest_items_env = overlap ? s->opt.U32("GPANN_OVERLAP_REST_ITEMS", 0) : 0u;
     const uint32_t rest_items = rest_items_env == 0 ? 0u : std::max<uint32_t>(2, rest_items_env);   // (a workgroup's first two claims are made before anything is counted)
     const uint32_t rest_cus = overlap && rest_items == 0 ? std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)n_cus, s->opt.U32("GPANN_OVERLAP_REST_CUS", big_store ? 160 : (uint32_t)n_cus))) : (uint32_t)n_cus;
@@ -1245,6 +1292,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             GPANN_HIP_TRY(hipStreamWaitEvent(st_rest, CS(s).ev_x[1], 0));
             st = st_rest;
         }
+        if (pass == 2 && overlap) {   // (fires when the previous call's rest pass has ended and this call's front is done: this rest pass starts)
+            GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[3], st));
+            CS(s).rest_begin_recorded = true;
+        }
         if (pass == 2) {   // the big launch on its own: row tiles streamed before it (FilterItemsKernel keeps the count, work[3]), and its begin / end
             GPANN_HIP_TRY(hipEventRecord(CS(s).ev_filter[4], st));
             plan.filter_rest_hi_only = hi_pass;
@@ -1326,8 +1377,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // the pipeline's counters travel to the call's pinned words; they are looked at when the call is completed (CollectFilterCounters: right
         // after this function in a plain call, in gpann_scan_finish for a deferred one) — nothing here waits for the device
         uint32_t* pin = CS(s).pin_words;
-        GPANN_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 16, hipMemcpyDeviceToHost, st));
-        GPANN_HIP_TRY(hipMemcpyAsync(pin + 4, d_work, 56, hipMemcpyDeviceToHost, st));
+        uint32_t* pin_dev = overlap ? static_cast<uint32_t*>(DeviceAddressOfPinned(pin)) : nullptr;
+        if (pin_dev) {   // (GPANN_SCAN_OVERLAP: no runtime copies on the call's streams — KernelCopy)
+            GPANN_HIP_TRY(KernelCopy(pin_dev, d_overflow, 16, st));
+            GPANN_HIP_TRY(KernelCopy(pin_dev + 4, d_work, 56, st));
+        } else {
+            GPANN_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 16, hipMemcpyDeviceToHost, st));
+            GPANN_HIP_TRY(hipMemcpyAsync(pin + 4, d_work, 56, hipMemcpyDeviceToHost, st));
+        }
         GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));
         const size_t n = (size_t)T * k;
         hipLaunchKernelGGL(ListOutputKernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, list_dist, list_row, ta.out, s->permutation, T, k,
@@ -1459,6 +1516,12 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
         const uint32_t n_front = std::max<uint32_t>(1, std::min<uint32_t>(gpann_shards::kCallSlots, s->opt.U32("GPANN_OVERLAP_FRONT_STREAMS", 3)));
         st = s->st_front[(uint32_t)s->cur % n_front];
         GPANN_HIP_TRY(hipStreamWaitEvent(st, CS(s).ev_x[0], 0));
+        // Pacing: this front does not start before the rest pass of the call TWO before it has started (= the call before that has left the rest
+        // stream).  Without it three fronts start together after a cold start, finish together and leave the rest stream idle in between — a convoy
+        // that takes ten steps to dissolve; with it the fronts are one rest pass apart from the first step on.
+        gpann_shards::CallState& two_before = s->cs[(s->cur + 1) % gpann_shards::kCallSlots];
+        if (two_before.pending && two_before.rest_begin_recorded && s->opt.U32("GPANN_OVERLAP_PACE", 1) != 0)
+            GPANN_HIP_TRY(hipStreamWaitEvent(st, two_before.ev_x[3], 0));
         st_rest = s->st_rest;
         st_tail = s->st_tail;
     }
@@ -1478,6 +1541,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     CS(s).stage.Reserve(std::min<size_t>((size_t)T * 40 + (size_t)S * 64 + (256u << 10), 256u << 20));
     if (CS(s).ws_stage_dev.Reserve(std::max<size_t>(CS(s).stage.cap, 256)) != GPANN_OK) (void)hipGetLastError();   // (no mirror: every array on its own)
     UploadBatch up{s, st};
+    up.by_kernel = st != st_caller;   // (the call runs on the store's own streams)
     const size_t n_out = (size_t)nq * nprobe;
 
     ht.Mark("stage_reserve");
@@ -1510,6 +1574,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     GPANN_HIP_TRY(hipEventRecord(CS(s).ev[1], st));   // (re-recorded where the scan kernels end; a call without tasks ends here)
     gpann_shards::CallState& c = CS(s);
     c.filter_passes_timed = 0;
+    c.rest_begin_recorded = false;
     c.filtered = false;
     c.dirty_cap = 0;
     c.d_queries = d_queries;
@@ -1592,9 +1657,17 @@ static gpann_status FinishTiming(gpann_shards* s, gpann_shards::CallState& c, fl
 static gpann_status EnqueueHostCopies(gpann_shards* s, gpann_shards::CallState& c) {
     hipStream_t st = static_cast<hipStream_t>(c.stream);
     const size_t n = (size_t)c.nq * c.nprobe * c.k;
-    if (c.host_ids) GPANN_HIP_TRY(hipMemcpyAsync(c.host_ids, c.out_ids, n * 4, hipMemcpyDeviceToHost, st));
-    if (c.host_dist) GPANN_HIP_TRY(hipMemcpyAsync(c.host_dist, c.out_dist, n * 4, hipMemcpyDeviceToHost, st));
-    if (c.host_rows) GPANN_HIP_TRY(hipMemcpyAsync(c.host_rows, c.out_rows, n * 4, hipMemcpyDeviceToHost, st));
+    // (GPANN_SCAN_OVERLAP and pinned, device-accessible destinations: by kernel — see KernelCopy; anything else through the runtime)
+    auto to_host = [&](void* host, const void* dev) -> gpann_status {
+        if (!host) return GPANN_OK;
+        void* host_dev = (c.flags & GPANN_SCAN_OVERLAP) && st != nullptr && (st == s->st_tail) ? DeviceAddressOfPinned(host) : nullptr;
+        if (host_dev) GPANN_HIP_TRY(KernelCopy(host_dev, dev, n * 4, st));
+        else GPANN_HIP_TRY(hipMemcpyAsync(host, dev, n * 4, hipMemcpyDeviceToHost, st));
+        return GPANN_OK;
+    };
+    GPANN_TRY(to_host(c.host_ids, c.out_ids));
+    GPANN_TRY(to_host(c.host_dist, c.out_dist));
+    GPANN_TRY(to_host(c.host_rows, c.out_rows));
     GPANN_HIP_TRY(hipEventRecord(c.ev[3], st));
     return GPANN_OK;
 }
@@ -1610,6 +1683,8 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms) {
     c.stage_in_flight = false;
     bool overflow = false;
     if (c.filtered) CollectFilterCounters(c, &overflow);
+    if (c.filtered && !overflow && c.plan.filter_rest_rows != 0)   // (what the next overlapped call's CU split goes by: RunCellFilteredScan)
+        s->rest_products_per_tile = ((double)c.plan.filter_pairs / 1024.0) / ((double)c.plan.filter_rest_rows / (double)kGTileRows);
     if (overflow) {
         // the redo runs as "the call in progress" of its own slot (its plan's host arrays are intact, its pinned stage is free again); a later
         // call that is already queued on the stream simply runs before it

@@ -164,9 +164,11 @@ struct gpann_shards {
         bool stage_in_flight = false;    // ev[3] is recorded and not yet waited for: the pinned stage / plan arrays may still be read by the device
         hipEvent_t ev_filter[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end of the head pass, of the sample + rest passes,
                                                                                               // and of the rest pass's filter launch alone
-        hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};   // GPANN_SCAN_OVERLAP: [0] what the caller's stream held when the call was issued (the front
+        hipEvent_t ev_x[4] = {nullptr, nullptr, nullptr, nullptr};   // GPANN_SCAN_OVERLAP: [0] what the caller's stream held when the call was issued (the front
                                                             // stream waits for it), [1] the end of the call's front (the rest stream waits for it),
-                                                            // [2] the end of its rest-pass launch (the tail stream waits for it)
+                                                            // [2] the end of its rest-pass launch (the tail stream waits for it),
+                                                            // [3] the START of its rest-pass launch (the front of the call two after it waits for it)
+        bool rest_begin_recorded = false;                   // ev_x[3] was recorded for the call this slot holds
         int filter_passes_timed = 0;
         gpann::ScanPlan plan;
         gpann::PinnedStage stage;
@@ -198,6 +200,7 @@ struct gpann_shards {
         }
     } cs[kCallSlots];
     int cur = 0;
+    double rest_products_per_tile = 0.0;   // (query tile, row tile) products per row tile of the last completed filtered call (0: none yet) — all passes' products over the rest pass's tiles
     gpann_scan_stats stats{};
     // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): a front stream per call slot (high priority: short,
     // latency-bound launches; GPANN_OVERLAP_FRONT_STREAMS = 1: the fronts one after the other, 3: the fronts of all calls in flight side by side —

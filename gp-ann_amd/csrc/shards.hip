@@ -100,6 +100,8 @@ static const Knob kKnobs[] = {
     {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of a front's filter launches (default 96; stores whose planes are below 4 GB: all CUs)"},
     {"GPANN_OVERLAP_REST_ITEMS", 'C', "GPANN_SCAN_OVERLAP: work items after which a rest-pass workgroup leaves (default 0: persistent workgroups, GPANN_OVERLAP_REST_CUS of them)"},
     {"GPANN_OVERLAP_REST_CUS", 'C', "GPANN_SCAN_OVERLAP with persistent rest-pass workgroups: how many (default 160; stores whose planes are below 4 GB: all CUs)"},
+    {"GPANN_OVERLAP_SPLIT_MAX_PRODUCTS", 'C', "GPANN_SCAN_OVERLAP: the CU split applies while the previous call ran at most this many (query tile, row tile) products per rest-pass row tile (default 3: an HBM-bound rest pass)"},
+    {"GPANN_OVERLAP_PACE", 'C', "GPANN_SCAN_OVERLAP: 0 = a call's front may start at once (default 1: not before the rest pass of the call two before it has started)"},
     {"GPANN_OVERLAP_FRONT_STREAMS", 'C', "GPANN_SCAN_OVERLAP: 1 = the fronts of the calls in flight one after the other, 3 (default) = side by side, a stream per call slot"},
     {"GPANN_DEBUG_Q8_NO_CAND", 'C', "measurement aid, WRONG RESULTS: the 8-bit passes find no candidate"},
     // router

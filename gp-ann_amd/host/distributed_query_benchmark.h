@@ -17,6 +17,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <mutex>
@@ -350,7 +351,7 @@ public:
             CheckComm(gpann_mask_probes(all.data(), (uint32_t)nq, (uint32_t)P, (uint32_t)P, owner.data(), (uint32_t)num_shards, rank, masked.data()), "gpann_mask_probes");
             float ms = 0.f;
             Check(gpann_scan_buckets(store, d_queries_, (uint32_t)nq, (uint32_t)k, masked.data(), (uint32_t)P, (uint32_t)P, d_ids2_[set], d_dist2_[set], nullptr,
-                                     GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE | GPANN_SCAN_FOR_MERGE | GPANN_SCAN_DEFER, s_scan_, &ms),
+                                     GPANN_QUERIES_ON_DEVICE | GPANN_OUTPUT_ON_DEVICE | GPANN_SCAN_FOR_MERGE | GPANN_SCAN_DEFER | overlap_flag_, s_scan_, &ms),
                   "gpann_scan_buckets");
         };
         std::vector<float> h_dist[2];
@@ -426,6 +427,9 @@ public:
     }
 
 private:
+    // GPANN_DIST_OVERLAP=0: the deferred scans on ONE stream (round 4); default: GPANN_SCAN_OVERLAP — the front of batch i + 1 beside the rest pass of
+    // batch i on the store's own streams (results are in place when gpann_scan_finish returns: the exchange below only starts after it)
+    int overlap_flag_ = (std::getenv("GPANN_DIST_OVERLAP") && std::getenv("GPANN_DIST_OVERLAP")[0] == '0') ? 0 : GPANN_SCAN_OVERLAP;
     static int Metric() { return gpann_host::MetricIsMIPS() ? GPANN_METRIC_MIPS : GPANN_METRIC_L2; }
 
     void EnsureStreamBuffers(size_t n, size_t pw) {

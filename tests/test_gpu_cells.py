@@ -313,7 +313,8 @@ def test_cells_all_hi_tiles_kept_allows_switching_the_rest_pass(orc, gp, monkeyp
     ivf = orc.ivf_build(pts, clusters)
     wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, S, 0, nthreads=4)
     for q8, row_bytes in (("1", 132), ("0", 260)):
-        monkeypatch.setenv("GPANN_FILTER_Q8", q8)
+        shards.set_option("GPANN_FILTER_Q8", q8)          # (an option of the handle, read by every call)
+        assert shards.get_option("FILTER_Q8") == q8       # (names with or without the prefix)
         ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
         st = shards.stats()
         assert st["filtered"] == 1 and st["filter_rest_row_bytes"] == row_bytes, st
