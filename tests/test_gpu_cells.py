@@ -319,6 +319,16 @@ def test_cells_all_hi_tiles_kept_allows_switching_the_rest_pass(orc, gp, monkeyp
         st = shards.stats()
         assert st["filtered"] == 1 and st["filter_rest_row_bytes"] == row_bytes, st
         assert np.array_equal(ids, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32))
+    # the option table: a name the library does not know is an error, not a silently ignored default; NULL puts the default back; the handle no
+    # longer looks at the environment (a variable set AFTER it was created changes nothing)
+    with pytest.raises(gp.GpannError):
+        shards.set_option("GPANN_FILTER_NOT_A_KNOB", "1")
+    shards.set_option("GPANN_FILTER_Q8", None)
+    assert shards.get_option("GPANN_FILTER_Q8") == ""
+    monkeypatch.setenv("GPANN_FILTER_Q8", "0")
+    ids, dist, _ = shards.scan_buckets(queries, k, probes, S)
+    assert shards.stats()["filter_rest_row_bytes"] == 132 and np.array_equal(ids, wi)
+    assert shards.get_option("GPANN_FILTER_HI_ROWS") == "all"      # (the snapshot taken when the store was created)
     shards.close()
 
 
