@@ -1282,7 +1282,7 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             build_s = time.time() - t_b
             oi = torch.empty((nq, nprobe, k), dtype=torch.int32, device=dev)
             od = torch.empty((nq, nprobe, k), dtype=torch.float32, device=dev)
-            hbuf = [(torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory()) for _ in range(2)]
+            hbuf = [(torch.empty((nq, nprobe, k), dtype=torch.float32).pin_memory(), torch.empty((nq, nprobe, k), dtype=torch.int32).pin_memory()) for _ in range(3)]
             lo, hi = min(nq, r * chunk_q), min(nq, (r + 1) * chunk_q)
             route_bufs = [torch.empty((max(hi - lo, 1), S), dtype=torch.int32).pin_memory().numpy() for _ in range(2)]
             merger = concurrent.futures.ThreadPoolExecutor(1)
@@ -1298,7 +1298,10 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
 
             scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
             x_stream = torch.cuda.Stream(device=dev)
-            dsets = [(oi, od), (torch.empty_like(oi), torch.empty_like(od))]
+            dsets = [(oi, od), (torch.empty_like(oi), torch.empty_like(od)), (torch.empty_like(oi), torch.empty_like(od))]
+            emu_overlap = scan_ahead and os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0"
+            emu_depth = 3 if emu_overlap else 2     # scans in flight (the real loop: run_steps)
+            s_stream = torch.cuda.Stream(device=dev)
 
             def one(i, routed):
                 """like the real loop of a rank with GPANN_BENCH_SCAN_AHEAD=0: batch i + 1 is routed on a second stream by a second thread while batch i is scanned"""
@@ -1326,9 +1329,9 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 t_b = time.perf_counter()
                 lp = (gcomm.mask_probes_replicated(probes, nprobe, rep_begin, rep_rank, r) if args.replica_capacity > 0 else gcomm.mask_probes(probes, nprobe, owner, r))
                 t_c = time.perf_counter()
-                di, dd = dsets[i & 1]
-                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), stream, for_merge=merge_bound, defer=True,
-                                       overlap=os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0")
+                di, dd = dsets[i % emu_depth]
+                sh.scan_buckets_device(queries.data_ptr(), nq, k, lp, nprobe, di.data_ptr(), dd.data_ptr(), s_stream.cuda_stream if emu_overlap else stream,
+                                       for_merge=merge_bound, defer=True, overlap=emu_overlap)
                 host_t[:3] += (t_b - t_a, t_c - t_b, time.perf_counter() - t_c)
                 return nxt
 
@@ -1337,8 +1340,8 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 t_a = time.perf_counter()
                 sh.finish()
                 t_b = time.perf_counter()
-                di, dd = dsets[i & 1]
-                hd, hi_ = hbuf[i & 1]
+                di, dd = dsets[i % emu_depth]
+                hd, hi_ = hbuf[i % emu_depth]
                 with torch.cuda.stream(x_stream):
                     hd.copy_(dd, non_blocking=True)
                     hi_.copy_(di, non_blocking=True)
@@ -1350,14 +1353,17 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
             def loop(count):
                 if scan_ahead:
                     pending = None
-                    nxt = begin(0, router_pool.submit(route_share, 0, r_stream.cuda_stream))
+                    ahead = emu_depth - 1
+                    nxt = router_pool.submit(route_share, 0, r_stream.cuda_stream)
+                    for j in range(min(ahead, count)):
+                        nxt = begin(j, nxt)
                     for i in range(count):
                         if pending is not None:
                             t_a = time.perf_counter()
                             pending.result()
                             host_t[5] += time.perf_counter() - t_a
-                        if i + 1 < count:
-                            nxt = begin(i + 1, nxt)
+                        if i + ahead < count:
+                            nxt = begin(i + ahead, nxt)
                         pending = finish(i)
                     pending.result()
                     nxt.result()
@@ -1375,7 +1381,7 @@ def emulate_worlds_on_one_gpu(args, worlds, torch, pygpann, gcomm, dev, device_i
                 torch.cuda.synchronize()
 
             loop(max(2, args.warmup))
-            steps = max(5, args.steps // 2)
+            steps = max(10, args.steps)
             t0 = time.perf_counter()
             loop(steps)
             ms = 1000.0 * (time.perf_counter() - t0) / steps
