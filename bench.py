@@ -1011,7 +1011,10 @@ def main():
         traffic, traffic_src = lookup_traffic(n, d, S, nprobe, "FilterKernelCells<", {"": 1}, largest_launch=True, kernel_bytes=rest_bytes)
         # step level: the bytes every launch of the step has to read — plane rows of all filter launches (two-plane launches twice the plane
         # bytes), the rows re-scored exactly (candidates + seed rows, d x 4 each), the router's centroid planes (both passes, both planes)
-        row_hi = 32.0 * ks_read + 4.0
+        # (the sample pass — the hi-plane rows outside the rest pass — streams the int8 plane too unless the store has none or GPANN_FILTER_Q8_FROM_PASS=2:
+        # until round 5 it was charged the bf16 hi plane's 260 B per row, 1.3 GB too many at NS)
+        sample_on_q8 = stats["filter_rest_row_bytes"] < 32 * ks_read + 4 and shards.get_option("GPANN_FILTER_Q8_FROM_PASS") != "2"
+        row_hi = float(stats["filter_rest_row_bytes"]) if sample_on_q8 else 32.0 * ks_read + 4.0
         hi_rows = stats["filter_rows"] - stats["filter_two_plane_rows"] - stats["filter_rest_rows"]
         step_bytes = (rest_bytes + hi_rows * row_hi + stats["filter_two_plane_rows"] * (64.0 * ks_read + 4.0)
                       + (stats["filter_candidates"] + stats["filter_seed_rows"]) * d * 4.0

@@ -1115,7 +1115,9 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     // the sample pass under a symbol of its own (TAG 1: the rest pass keeps rocprofv3's per-kernel statistics to itself) and with one row tile per
     // unit of work: its items are the 20-odd tiles of a cell's front — three rounds of 8 tiles instead of two of 16, the second a fifth full
-    const void *fn_q8 = nullptr, *fn_q8_sample = nullptr;
+    // (TAG 2: the rest pass of a call that runs BESIDE other calls, GPANN_SCAN_OVERLAP — the same code under a symbol of its own, so that rocprofv3's
+    // per-kernel statistics keep the launches that share the chip apart from the ones that have it to themselves)
+    const void *fn_q8 = nullptr, *fn_q8_sample = nullptr, *fn_q8_beside = nullptr;
     uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8), q8_waves = (uint32_t)FilterWaves(2, (int)KS8);
     size_t glds8 = 0;
     if (use_q8) {
@@ -1124,6 +1126,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     case KS_:                                                                                                                                  \
         fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 2, 8>; \
         fn_q8_sample = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 1, KS_, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 1, KS_, 2, 8, 1>; \
+        fn_q8_beside = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 2, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 2, KS_, 2, 8>; \
         break;
             GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
 #undef GPANN_PICK8
@@ -1134,6 +1137,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8_beside, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }
     const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
     if (rlds > (48u << 10)) {
@@ -1314,7 +1318,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
                 grid8 = std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus);
             }
             void* kargs8[] = {&f8};
-            GPANN_HIP_TRY(hipLaunchKernel((pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)grid8), dim3(64 * q8_waves), kargs8, glds8, st));
+            GPANN_HIP_TRY(hipLaunchKernel(pass == 2 && overlap ? fn_q8_beside : (pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)grid8), dim3(64 * q8_waves),
+                                          kargs8, glds8, st));
             if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             CellFilterArgs fb = fa;

@@ -37,3 +37,50 @@ def test_spawned_ranks_get_their_environment_and_the_worst_exit_code_comes_back(
     assert r.stderr.count("bench.py needs a GPU") == 2
     assert "rank 0 ended with code 1" in r.stderr or "rank 1 ended with code 1" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_turnstile_launches_the_two_communicators_collectives_in_one_order():
+    """bench.Turnstile: the route-ahead thread's all-gathers (R j) and the main thread's slot exchanges (X i) take their places in ONE schedule —
+    whatever the threads' timing, the order of the launches is the order of the list; a failure elsewhere releases a waiting thread with an error"""
+    import importlib.util
+    import random
+    import threading
+    import time
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    count, r_ahead = 12, 3
+    order = [("R", j) for j in range(min(r_ahead, count))]
+    for it in range(count):
+        if it + r_ahead < count:
+            order.append(("R", it + r_ahead))
+        order.append(("X", it))
+    turn = bench.Turnstile(order)
+    seen, lock = [], threading.Lock()
+    rng = random.Random(5)
+
+    def worker(kind, n):
+        for j in range(n):
+            time.sleep(rng.random() * 0.002)
+            with turn.slot((kind, j)):
+                with lock:
+                    seen.append((kind, j))
+    a, b = threading.Thread(target=worker, args=("R", count)), threading.Thread(target=worker, args=("X", count))
+    a.start(); b.start(); a.join(10); b.join(10)
+    assert seen == order
+    # abort: a thread parked in the schedule leaves with an error instead of waiting for ever
+    turn2 = bench.Turnstile([("R", 0), ("X", 0)])
+    err = []
+
+    def parked():
+        try:
+            with turn2.slot(("X", 0)):
+                pass
+        except RuntimeError as e:
+            err.append(str(e))
+    t = threading.Thread(target=parked)
+    t.start()
+    time.sleep(0.05)
+    turn2.abort()
+    t.join(5)
+    assert err and "given up" in err[0]
