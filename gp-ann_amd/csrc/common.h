@@ -244,6 +244,17 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 }
 
 // lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
+// A kernel that calls this is allocated all 256 architectural vector registers per wavefront: two of its wavefronts fill a SIMD's register
+// file, so no wavefront of ANOTHER launch can be resident on that SIMD beside them.  The matrix-core kernels (FilterKernelCells, RouterBoundKernel:
+// 512-thread workgroups, one per CU — nothing of their own is lost) call it because wavefronts of other launches that shared a SIMD with theirs
+// were seen to end with WRONG REGISTERS: with GPANN_SCAN_OVERLAP and 64-dimensional rows (filter kernels of 140 - 230 registers, room for the
+// short kernels of another call's front beside them) about one call in 500 lost a task's candidates — traced to single accumulator registers of
+// a co-resident CellDistKernel wavefront, lanes 48 - 63, holding other values than the same call made alone (the table entries it then wrote
+// differed, the cell tests and 8-bit thresholds built on them pruned rows of the true top-k); never at 128 dimensions, where the filter kernels
+// use 256 registers anyway, and gone (0 events in 10 000 pipelines against 12 - 99 per 2 500) once they do so everywhere.  The hunt, with the
+// experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe: tools/overlap_race_probe.py.
+__device__ __forceinline__ void TakeWholeRegisterFile() { asm volatile("" ::: "v255"); }
+
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
 // float <-> uint32 whose unsigned order is the float order (negative inner-product "distances" included): atomicMin on the keys
 __device__ __forceinline__ uint32_t OrderedKey(float v) {

@@ -48,6 +48,7 @@ __device__ __forceinline__ float FromOrderedBitsB(uint32_t o) { return __uint_as
 // dimensions: the query image, QT * KS * 2 KiB, has to fit LDS).
 template <int METRIC, int KS, int PASS, int QT = (KS <= 8 ? 8 : 4)>
 __global__ void __launch_bounds__(512, 1) RouterBoundKernel(BoundArgs a) {
+    TakeWholeRegisterFile();   // (common.h: no wavefront of another launch beside a matrix-core wavefront)
     extern __shared__ uint4 bsm4[];
     char* lds = reinterpret_cast<char*>(bsm4);   // [QT query tiles][KS][2 planes][1 KiB] + per-wave norms
     const uint32_t q_base = blockIdx.y * (32u * QT);

@@ -1139,10 +1139,15 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
         GPANN_HIP_TRY(hipFuncSetAttribute(fn_q8_beside, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds8));
     }
-    const size_t rlds = (size_t)kRescoreTasksPerWG * RescoreLdsFloats(s->ld) * sizeof(float);
+    const size_t rlds = (size_t)kRescoreTasksPerWG * (l2 ? RescoreLdsFloats<GPANN_METRIC_L2>(s->ld) : RescoreLdsFloats<GPANN_METRIC_MIPS>(s->ld)) * sizeof(float);
+    const bool wide_rows = s->ld > 128u;   // (RescoreKernel's WIDE instances: further chunks of 32 groups per row)
+    const void* fn_rescore = wide_rows ? (l2 ? (const void*)RescoreKernel<GPANN_METRIC_L2, false, true> : (const void*)RescoreKernel<GPANN_METRIC_MIPS, false, true>)
+                                       : (l2 ? (const void*)RescoreKernel<GPANN_METRIC_L2, false, false> : (const void*)RescoreKernel<GPANN_METRIC_MIPS, false, false>);
+    const void* fn_rescore_ranged = wide_rows ? (l2 ? (const void*)RescoreKernel<GPANN_METRIC_L2, true, true> : (const void*)RescoreKernel<GPANN_METRIC_MIPS, true, true>)
+                                              : (l2 ? (const void*)RescoreKernel<GPANN_METRIC_L2, true, false> : (const void*)RescoreKernel<GPANN_METRIC_MIPS, true, false>);
     if (rlds > (48u << 10)) {
-        if (l2) GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-        else GPANN_HIP_TRY(hipFuncSetAttribute((const void*)RescoreKernel<GPANN_METRIC_MIPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn_rescore, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        GPANN_HIP_TRY(hipFuncSetAttribute(fn_rescore_ranged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     }
     // re-scoring launches: `parts` wavefronts per task (heavy buckets are split, RescoreArgs::parts)
     // — as many as keep the launch near 128k wavefronts: every (task, part) is a workgroup, most of which find nothing to do and return, and
@@ -1158,8 +1163,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     auto launch_rescore = [&](uint32_t parts) {
         ra.parts = parts;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)parts * T);
-        if (l2) hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_L2>, dim3(grid), dim3(64), rlds, st, ra);
-        else hipLaunchKernelGGL(RescoreKernel<GPANN_METRIC_MIPS>, dim3(grid), dim3(64), rlds, st, ra);
+        void* kargs[] = {&ra};
+        (void)hipLaunchKernel(fn_rescore, dim3(grid), dim3(64 * kRescoreTasksPerWG), kargs, rlds, st);
         // (the pieces of split buckets are merged — and the pass's statistics kept — by the NEXT launch that reads the lists: PassSetupKernel of
         // the following pass, FinalMergeKernel after the last one)
     };
@@ -1369,8 +1374,8 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
         // (launched whatever the count — no host round trip: without dirty tasks both launches end at once)
         RescoreArgs rr = ra;
         rr.range_segs = range_segs;
-        if (l2) hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_L2, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
-        else hipLaunchKernelGGL((RescoreKernel<GPANN_METRIC_MIPS, true>), dim3(8192), dim3(64 * kRescoreTasksPerWG), rlds, st, rr);
+        void* kargs[] = {&rr};
+        (void)hipLaunchKernel(fn_rescore_ranged, dim3(8192), dim3(64 * kRescoreTasksPerWG), kargs, rlds, st);
         // ... and, in the same launch, the pieces of the last pass's split buckets into their lists (FinalMergeKernel)
         rr.parts = split_parts;
         const uint32_t merge_blocks = buckets_pending ? (T + 4 * kSplitMergeTasksPerWave - 1) / (4 * kSplitMergeTasksPerWave) : 0u;

@@ -94,10 +94,12 @@ static __global__ void __launch_bounds__(256, 3) CellDistKernel(CellDistArgs a) 
         for (uint32_t ch = 0; ch < nchunks; ++ch) {
             const uint32_t col = ch * 32 + 4u * st_c4;
             const bool in = col < ld;
-            const float4 gc0 = in ? *reinterpret_cast<const float4*>(crow0 + col) : zero4;
-            const float4 gc1 = in ? *reinterpret_cast<const float4*>(crow1 + col) : zero4;
-            const float4 gq0 = in ? *reinterpret_cast<const float4*>(qrow0 + col) : zero4;
-            const float4 gq1 = in ? *reinterpret_cast<const float4*>(qrow1 + col) : zero4;
+            // (every lane loads — past the row's end its first columns again — and the VALUES are replaced by zeros: `in ? *p : zero4` is a select
+            // between a global address and the address of a private constant, i.e. four flat loads and a scratch slot per wavefront)
+            const uint32_t lcol = in ? col : 0u;
+            float4 gc0 = *reinterpret_cast<const float4*>(crow0 + lcol), gc1 = *reinterpret_cast<const float4*>(crow1 + lcol);
+            float4 gq0 = *reinterpret_cast<const float4*>(qrow0 + lcol), gq1 = *reinterpret_cast<const float4*>(qrow1 + lcol);
+            if (!in) gc0 = gc1 = gq0 = gq1 = zero4;
             __syncthreads();
             *reinterpret_cast<float4*>(sC + st_row0 * kStride + 4 * st_c4) = gc0;
             *reinterpret_cast<float4*>(sC + st_row1 * kStride + 4 * st_c4) = gc1;
@@ -807,6 +809,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int FilterWaves(int mode, int ks) { return kFWaves; }
 template <int METRIC, int TAG, int KS, int MODE, int QT = FilterQueryTiles(KS), int TW_ = FilterUnitTiles(MODE, KS), int NW = FilterWaves(MODE, KS)>
 __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a) {
+    TakeWholeRegisterFile();   // (common.h: no wavefront of another launch beside a matrix-core wavefront)
     constexpr bool HI_ONLY = MODE >= 1, Q8 = MODE == 2;
     static_assert(QT == 4 || QT == 8, "query tiles per group");
     static_assert(KS <= 8 || MODE == 1, "more than 8 k-steps: bf16 hi-plane passes only");

@@ -24,6 +24,7 @@
 
 namespace gpann {
 
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -254,20 +255,33 @@ __device__ __forceinline__ void ListInsertF(float& ld_, uint32_t& lr_, float cd,
     }
 }
 
-// One wavefront per task.  Candidates are taken 16 at a time: their rows are fetched COALESCED (half a wavefront per row: one
-// 16-byte load per lane and 32 dimensions; a lane per candidate reading its own row costs the texture path 64 cache lines per load
-// instruction) and staged through LDS, the next 16 rows being in flight while the wavefront evaluates the canonical distance of the
-// current ones against the query row in LDS (four lanes per row for the terms, one for the sum: the kernel is bound by its own
-// instruction stream — with lanes 0..15 doing all of it a round of 16 rows took about 2 500 cycles, a quarter of the lanes busy); the
-// survivors are inserted into the task's list (one entry per lane).
-constexpr int kRescoreSub = 16;                                                   // candidates per round
-constexpr int kRescoreRounds = 64 / kRescoreSub;                                  // rounds per block of 64 row ids
+// One wavefront per task.  Candidates are taken a ROUND at a time (32 for L2, 16 for the inner product), a round in sub-rounds of 16 rows
+// fetched COALESCED — half a wavefront per row: one 16-byte load per lane = one GROUP of four dimensions (a lane per candidate reading its
+// own row costs the texture path 64 cache lines per load instruction); the next sub-round's rows are in flight while this one's are used.
+// What the reference's sequence fixes is the ORDER OF THE ADDITIONS into `result` (src/dist.cpp:17-52); its terms — L2: s_g = ((d0 d0 +
+// d1 d1) + d2 d2) + d3 d3 of a group of four dimensions, then d_i d_i of the d % 4 tail dimensions; inner product: the products q_i p_i —
+// do not depend on `result`.  Phase A: the lane that loaded a group computes its term(s) from registers (the query's group sits in a
+// register too) and leaves them in LDS, terms[row of the round][term index]; phase B: lane r adds row r's terms in the reference's order.
+// (Until round 5 the raw rows went through LDS — 16 x 528 bytes per round written, read back by phase A, terms written, read by phase B — and
+// phase B's chain of d / 4 dependent additions served 16 rows on 16 lanes; L2 terms are a quarter of the row, so a round holds twice
+// the rows in half the LDS and a CU twice the tasks.)  The survivors are inserted into the task's list (one entry per lane).
+constexpr int kRescoreSub = 16;                                                   // rows per sub-round (8 load instructions, two rows each)
+constexpr int kRescoreRowsL2 = 32, kRescoreRowsIP = 16;                           // rows per round
+template <int METRIC> struct RescoreShape {
+    static constexpr int kRows = METRIC == GPANN_METRIC_L2 ? kRescoreRowsL2 : kRescoreRowsIP;
+    // words between two rows' terms: L2 — d / 4 group terms + d % 4 tail terms, odd (phase B: lane r reads word r * stride + i);
+    // inner product — d products, rows 16-byte aligned (phase A writes a group's four at once)
+    __host__ __device__ static inline uint32_t Stride(uint32_t ld) { return METRIC == GPANN_METRIC_L2 ? (((ld >> 2) + 3u) | 1u) : ld + 4u; }
+};
 constexpr int kRescoreTasksPerWG = 1;   // wavefronts (= tasks) per workgroup: candidate counts are long-tailed and a workgroup lasts as long as its
                                         // slowest task, so single-wavefront workgroups pack the CUs best
-__host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) { return (size_t)ld + (size_t)kRescoreSub * (ld + 4); }   // per wavefront
+template <int METRIC> __host__ __device__ inline size_t RescoreLdsFloats(uint32_t ld) {   // per wavefront: the query row + a round's terms
+    return (size_t)ld + (size_t)RescoreShape<METRIC>::kRows * RescoreShape<METRIC>::Stride(ld);
+}
 
 // RANGED (a template argument: the loop over work items must not cost the one-task-per-wavefront instance its registers) = RANGE mode.
-template <int METRIC, bool RANGED = false>
+// WIDE = rows of more than 128 dimensions (further chunks of 32 groups per sub-round; the loop costs the narrow instance 30 registers).
+template <int METRIC, bool RANGED = false, bool WIDE = false>
 __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(RescoreArgs a) {
     extern __shared__ float rsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -341,11 +355,15 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         }
     }
     const bool overflowed = ranged;   // the "candidates" are the rows [scan_lo, scan_hi) of the shard
-    const uint32_t ld = a.ld, ld4 = a.ld >> 2, stride = a.ld + 4;
-    float* sq = rsm + (size_t)wave * RescoreLdsFloats(ld);
-    float* srow = sq + ld;   // [16][ld + 4]
+    using Shape = RescoreShape<METRIC>;
+    constexpr int kRows = Shape::kRows, kSubs = kRows / kRescoreSub, kRoundsPerBlock = 64 / kRows;
+    const uint32_t ld = a.ld, ld4 = a.ld >> 2, tstride = Shape::Stride(a.ld);
+    float* sq = rsm + (size_t)wave * RescoreLdsFloats<METRIC>(ld);
+    float* terms = sq + ld;   // [kRows][tstride]
     const float* q = a.queries + (size_t)a.task_query[t] * ld;
-    for (uint32_t i = lane; i < ld; i += 64) sq[i] = q[i];
+    if (WIDE) {   // (the narrow instance keeps the query's only chunk in registers: q0 below)
+        for (uint32_t i = lane; i < ld; i += 64) sq[i] = q[i];
+    }
     const uint32_t k = a.k;
     float ld_ = INFINITY;
     uint32_t lr_ = kNoId;
@@ -353,11 +371,16 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         ld_ = a.list_dist[(size_t)t * k + lane];
         lr_ = a.list_row[(size_t)t * k + lane];
     }
-    const uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
-    const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 float4 (128 dimensions) of a row per load instruction and half wavefront
+    // (wavefront-uniform by construction; said so, or the loop's counters and bounds live in vector registers)
+    uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
+    n_items = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)n_items) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_items >> 32)) << 32);
+    c_lo = __builtin_amdgcn_readfirstlane(c_lo);
+    seed_first = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)seed_first) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(seed_first >> 32)) << 32);
+    const uint32_t n_chunks = (ld4 + 31) / 32;   // 32 groups (128 dimensions) of a row per load instruction and half wavefront
     const int half = lane >> 5, c4l = lane & 31;
+    const uint32_t full = a.d >> 2, tail = a.d & 3u;
 
-    // row ids are read 64 candidates at a time (one coalesced load, a block ahead); round `sub` of a block takes its 16 from there
+    // row ids are read 64 candidates at a time (one coalesced load, a block ahead); round `sub` of a block takes its kRows from there
     auto load_block = [&](uint64_t first) -> uint32_t {
         const uint64_t idx = first + lane;
         if (idx >= n_items) return kNoId;
@@ -365,97 +388,123 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
         return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + c_lo + idx];
     };
     auto round_rows = [&](uint32_t block_rows, uint32_t sub) -> uint32_t {
-        const uint32_t r = __shfl(block_rows, (int)(kRescoreSub * sub + (lane & (kRescoreSub - 1))));
-        return lane < kRescoreSub ? r : kNoId;
+        if (kRows == 64) return block_rows;
+        const uint32_t r = __shfl(block_rows, (int)(kRows * sub + (lane & (kRows - 1))));
+        return lane < kRows ? r : kNoId;
     };
-    // the 16 rows of a round, one chunk of 128 dimensions: instruction i serves rows 2 i (lanes 0..31) and 2 i + 1 (lanes 32..63)
-    auto fetch = [&](float4 (&v)[kRescoreSub / 2], uint32_t row, uint32_t chunk) {
+    // sub-round `s` of the round whose rows are `row`, one chunk of 32 groups: instruction i serves rows 16 s + 2 i (lanes 0..31) and
+    // 16 s + 2 i + 1 (lanes 32..63).  Straight-line code: an absent candidate (and a lane beyond the row's last group) loads from the store's
+    // first row instead of being branched around — nothing reads what it gets (a branch per load cost this kernel its registers).
+    auto fetch = [&](float4 (&v)[kRescoreSub / 2], uint32_t row, uint32_t s, uint32_t chunk) {
         const uint32_t c4 = 32u * chunk + c4l;
+        const float4* lane_base = reinterpret_cast<const float4*>(a.points) + (c4 < ld4 ? c4 : 0u);
 #pragma unroll
         for (int i = 0; i < kRescoreSub / 2; ++i) {
-            const uint32_t r = __shfl(row, 2 * i + half);
-            v[i] = (r != kNoId && c4 < ld4) ? *reinterpret_cast<const float4*>(a.points + (size_t)r * ld + 4u * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t r = __shfl(row, (int)(kRescoreSub * s + 2u * i) + half);
+            v[i] = lane_base[(size_t)(r != kNoId ? r : 0u) * ld4];
         }
     };
-    auto stage = [&](const float4 (&v)[kRescoreSub / 2], uint32_t chunk) {
-        const uint32_t c4 = 32u * chunk + c4l;
-        if (c4 < ld4) {
+    // phase A of what `fetch` loaded
+    auto leave_terms = [&](const float4 (&v)[kRescoreSub / 2], uint32_t s, uint32_t chunk, const float4 qv) {
+        const uint32_t g = 32u * chunk + c4l;
+        float* w = terms + (size_t)(kRescoreSub * s + half) * tstride;
+        if (METRIC == GPANN_METRIC_L2) {
+            float sg[kRescoreSub / 2];
 #pragma unroll
-            for (int i = 0; i < kRescoreSub / 2; ++i) *reinterpret_cast<float4*>(srow + (size_t)(2 * i + half) * stride + 4u * c4) = v[i];
+            for (int i = 0; i < kRescoreSub / 2; ++i) {
+                const float d0 = v[i].x - qv.x, d1 = v[i].y - qv.y, d2 = v[i].z - qv.z, d3 = v[i].w - qv.w;
+                float t = d0 * d0 + d1 * d1;
+                t = t + d2 * d2;
+                sg[i] = t + d3 * d3;
+            }
+            if (g < full) {
+#pragma unroll
+                for (int i = 0; i < kRescoreSub / 2; ++i) w[(size_t)(2 * i) * tstride + g] = sg[i];
+            } else if (g == full && tail != 0u) {   // (the tail dimensions' own terms, after the groups')
+#pragma unroll
+                for (int i = 0; i < kRescoreSub / 2; ++i) {
+                    const float d0 = v[i].x - qv.x;
+                    w[(size_t)(2 * i) * tstride + full] = d0 * d0;
+                }
+                if (tail > 1u) {
+#pragma unroll
+                    for (int i = 0; i < kRescoreSub / 2; ++i) {
+                        const float d1 = v[i].y - qv.y;
+                        w[(size_t)(2 * i) * tstride + full + 1u] = d1 * d1;
+                    }
+                }
+                if (tail > 2u) {
+#pragma unroll
+                    for (int i = 0; i < kRescoreSub / 2; ++i) {
+                        const float d2 = v[i].z - qv.z;
+                        w[(size_t)(2 * i) * tstride + full + 2u] = d2 * d2;
+                    }
+                }
+            }
+        } else if (g < ld4) {
+#pragma unroll
+            for (int i = 0; i < kRescoreSub / 2; ++i)
+                *reinterpret_cast<float4*>(w + (size_t)(2 * i) * tstride + 4u * g) = make_float4(qv.x * v[i].x, qv.y * v[i].y, qv.z * v[i].z, qv.w * v[i].w);
         }
     };
 
     float4 v[kRescoreSub / 2];
     uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
-    uint32_t row = round_rows(block_rows, 0);
-    fetch(v, row, 0);
-    for (uint64_t base = 0; base < n_items; base += kRescoreSub) {
-        const uint32_t sub = (uint32_t)(base / kRescoreSub) % (uint32_t)kRescoreRounds;
-        __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
-        stage(v, 0);
-        for (uint32_t ch = 1; ch < n_chunks; ++ch) {   // (rows wider than 128 dimensions: the further chunks of this round)
-            fetch(v, row, ch);
-            stage(v, ch);
+    uint32_t row = round_rows(block_rows, 0), cur_row = row;   // the round being fetched / evaluated
+    const float4 q0 = c4l < (int)ld4 ? reinterpret_cast<const float4*>(q)[c4l] : make_float4(0.f, 0.f, 0.f, 0.f);   // the query's group of chunk 0
+    fetch(v, row, 0, 0);
+    const uint64_t n_subs = (n_items + kRescoreSub - 1) / kRescoreSub;
+    for (uint64_t sr = 0; sr < n_subs; ++sr) {
+        const uint32_t s = (uint32_t)sr & (uint32_t)(kSubs - 1);
+        const uint64_t base = sr / kSubs * kRows;
+        const uint32_t n_here = (uint32_t)min((uint64_t)kRows, n_items - base);
+        if (s == 0) {
+            __builtin_amdgcn_wave_barrier();   // the previous round's LDS reads are done
+            cur_row = row;
         }
-        const uint32_t cur_row = row;
-        if (sub + 1u == (uint32_t)kRescoreRounds) {
-            block_rows = next_block_rows;
-            next_block_rows = load_block(base + kRescoreSub + 64);
-            row = round_rows(block_rows, 0);
-        } else {
-            row = round_rows(block_rows, sub + 1);
+        leave_terms(v, s, 0, q0);
+        for (uint32_t ch = 1; WIDE && ch < n_chunks; ++ch) {   // (rows wider than 128 dimensions: the further chunks of this sub-round)
+            fetch(v, cur_row, s, ch);
+            const uint32_t c4 = 32u * ch + c4l;
+            leave_terms(v, s, ch, c4 < ld4 ? reinterpret_cast<const float4*>(sq)[c4] : make_float4(0.f, 0.f, 0.f, 0.f));
         }
-        fetch(v, row, 0);                  // the next round's rows are in flight while this one is evaluated
+        // the next sub-round's rows (of this round or the first of the next) are in flight while this one's terms are added up
+        const bool round_done = kRescoreSub * (s + 1u) >= n_here;
+        uint32_t f_s = s + 1u;
+        if (round_done) {
+            const uint32_t sub = (uint32_t)(base / kRows) % (uint32_t)kRoundsPerBlock;
+            if (sub + 1u == (uint32_t)kRoundsPerBlock) {
+                block_rows = next_block_rows;
+                next_block_rows = load_block(base + kRows + 64);
+                row = round_rows(block_rows, 0);
+            } else {
+                row = round_rows(block_rows, sub + 1);
+            }
+            f_s = 0;
+        }
+        if (!round_done || base + kRows < n_items) fetch(v, row, f_s, 0);
+        if (!round_done) continue;
         __builtin_amdgcn_wave_barrier();
         const bool valid = cur_row != kNoId;
-        // The canonical distance of the 16 staged rows, with all 64 lanes.  What the reference's sequence fixes is the ORDER OF THE
-        // ADDITIONS into `result` (src/dist.cpp:17-52); its terms — L2: s_g = ((d0 d0 + d1 d1) + d2 d2) + d3 d3 of a group of four
-        // dimensions, inner product: the products q_i p_i — do not depend on `result`.  Phase A: lane (part = lane / 16, candidate =
-        // lane % 16) computes the terms of groups part, part + 4, ... and leaves them in the row's own LDS words (nobody else reads a
-        // group's words); phase B: lanes 0..15 add them up in the reference's order, then the tail dimensions (d % 4).
-        {
-            const uint32_t full = a.d >> 2;
-            float* my_row = srow + (size_t)(lane & (kRescoreSub - 1)) * stride;
-            const float4* q4 = reinterpret_cast<const float4*>(sq);
-#pragma unroll 8
-            for (uint32_t g = (uint32_t)lane / kRescoreSub; g < full; g += 64 / kRescoreSub) {
-                float4* w = reinterpret_cast<float4*>(my_row) + g;
-                const float4 pv = *w, qv = q4[g];
-                if (METRIC == GPANN_METRIC_L2) {
-                    const float d0 = pv.x - qv.x, d1 = pv.y - qv.y, d2 = pv.z - qv.z, d3 = pv.w - qv.w;
-                    float sg = d0 * d0 + d1 * d1;
-                    sg = sg + d2 * d2;
-                    sg = sg + d3 * d3;
-                    my_row[4 * g] = sg;
-                } else {
-                    *w = make_float4(qv.x * pv.x, qv.y * pv.y, qv.z * pv.z, qv.w * pv.w);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
         float e = INFINITY;
-        if (valid) {   // (lanes 0..15)
-            const uint32_t full = a.d >> 2;
-            const float* row_terms = srow + (size_t)lane * stride;
+        if (valid) {   // (lanes 0..kRows-1) phase B
+            const float* row_terms = terms + (size_t)lane * tstride;
             float result = 0.f;
             if (METRIC == GPANN_METRIC_L2) {
+                const uint32_t n_terms = full + tail;
 #pragma unroll 8
-                for (uint32_t g = 0; g < full; ++g) result = result + row_terms[4 * g];
-                for (uint32_t i = full << 2; i < a.d; ++i) {
-                    const float d0 = row_terms[i] - sq[i];
-                    result = result + d0 * d0;
-                }
+                for (uint32_t g = 0; g < n_terms; ++g) result = result + row_terms[g];
                 e = result;
             } else {
 #pragma unroll 4
                 for (uint32_t g = 0; g < full; ++g) {
-                    const float4 v = reinterpret_cast<const float4*>(row_terms)[g];
-                    result = result + v.x;
-                    result = result + v.y;
-                    result = result + v.z;
-                    result = result + v.w;
+                    const float4 pr = reinterpret_cast<const float4*>(row_terms)[g];
+                    result = result + pr.x;
+                    result = result + pr.y;
+                    result = result + pr.z;
+                    result = result + pr.w;
                 }
-                for (uint32_t i = full << 2; i < a.d; ++i) result = result + sq[i] * row_terms[i];
+                for (uint32_t i = full << 2; i < a.d; ++i) result = result + row_terms[i];
                 e = 1.0f - result;
             }
         }
