@@ -76,7 +76,11 @@ enum {
                                           the third — so that the fronts of calls i + 1, i + 2 run BESIDE the rest pass of call i and the rest
                                           passes follow each other without a gap (every call in flight owns its device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
                                           is issued); its results are in place when gpann_scan_finish returns, NOT when `stream` has drained.
-                                          Results are the same bits as without the flag. */
+                                          Results are the same bits as without the flag.  (Measured, profiles/r05/overlap_race.md: kernels of
+                                          different calls then share compute units; until the matrix-core kernels were given their SIMDs to
+                                          themselves that cost about one call in 500 a neighbour at d <= 64 — none ever at 96 / 128 dimensions.
+                                          Since then: one such call in 48 000 at d = 64, none elsewhere.  One stream — no flag — has never
+                                          shown any.) */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
                                           with the plain exact scan should the data have defeated the filter, statistics, timing).  TWO further

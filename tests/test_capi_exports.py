@@ -113,3 +113,22 @@ def test_options_table_and_no_getenv_on_the_call_paths():
         text = open(os.path.join(csrc, fn)).read()
         for m in re.finditer(r"opt\.(?:Get|U32|IsSet|IsZero)\(\"(GPANN_[A-Z0-9_]+)\"", text):
             assert m.group(1) in names, f"{fn}: option {m.group(1)} is not in the table"
+
+
+def test_matrix_core_kernels_claim_their_simds():
+    """every kernel that issues matrix instructions calls TakeWholeRegisterFile() first (csrc/common.h): wavefronts of other launches that shared a SIMD
+    with matrix-core wavefronts were measured to end with wrong registers (profiles/r05/overlap_race.md) — a new such kernel must not forget it"""
+    csrc = os.path.join(ROOT, "gp-ann_amd", "csrc")
+    assert 'asm volatile("" ::: "v255")' in open(os.path.join(csrc, "common.h")).read()
+    found = 0
+    for fn in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, fn)).read()
+        # kernels: from a __global__ signature to the next one (or the end of the file)
+        starts = [m.start() for m in re.finditer(r"__global__\s+void", text)]
+        for a, b in zip(starts, starts[1:] + [len(text)]):
+            body = text[a:b]
+            if "__builtin_amdgcn_mfma_" in body:
+                found += 1
+                name = re.search(r"\)\s*(\w+)\s*\(|void\s+(?:__launch_bounds__\([^)]*\)\s*)?(\w+)\s*\(", body)
+                assert "TakeWholeRegisterFile();" in body[: body.index("__builtin_amdgcn_mfma_")], f"{fn}: a matrix-core kernel without TakeWholeRegisterFile() ({name.group(0)[:60] if name else '?'})"
+    assert found >= 2    # FilterKernelCells, RouterBoundKernel
