@@ -311,6 +311,21 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     const bool seed = a.seed_rows != 0;
     uint64_t seed_first = 0;   // first plane row of the task's nearest cell
     uint32_t cnt;
+    // Bucket mode: what does not depend on the bucket's size — the task's list, the first 64 row ids of its bucket — is loaded BEFORE the size is
+    // known (the size, the ids and the rows were three dependent round trips on every task's chain; the ids of a small bucket's slots beyond its
+    // size are whatever an earlier pass left there: masked below).
+    const float* q = a.queries + (size_t)a.task_query[t] * a.ld;
+    const float4 q0 = (uint32_t)(lane & 31) < (a.ld >> 2) ? reinterpret_cast<const float4*>(q)[lane & 31] : make_float4(0.f, 0.f, 0.f, 0.f);   // the query's group of chunk 0
+    const bool bucket = !seed && !ranged;
+    uint32_t early_ids = kNoId, early_lr = kNoId;
+    float early_ld = INFINITY;
+    if (bucket) {
+        if (part == 0 && (uint32_t)lane < a.cand_cap) early_ids = a.cand_row[(size_t)t * a.cand_cap + lane];
+        if (lane < (int)a.k) {
+            early_ld = a.list_dist[(size_t)t * a.k + lane];
+            early_lr = a.list_row[(size_t)t * a.k + lane];
+        }
+    }
     if (seed && a.seed_first_slot_of != 0) {
         const bool first_slot = a.task_out[t] % a.seed_first_slot_of == 0;
         if (!a.seed_catch_up) {
@@ -360,17 +375,12 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     const uint32_t ld = a.ld, ld4 = a.ld >> 2, tstride = Shape::Stride(a.ld);
     float* sq = rsm + (size_t)wave * RescoreLdsFloats<METRIC>(ld);
     float* terms = sq + ld;   // [kRows][tstride]
-    const float* q = a.queries + (size_t)a.task_query[t] * ld;
     if (WIDE) {   // (the narrow instance keeps the query's only chunk in registers: q0 below)
         for (uint32_t i = lane; i < ld; i += 64) sq[i] = q[i];
     }
     const uint32_t k = a.k;
-    float ld_ = INFINITY;
-    uint32_t lr_ = kNoId;
-    if (lane < (int)k && !seed && !ranged) {
-        ld_ = a.list_dist[(size_t)t * k + lane];
-        lr_ = a.list_row[(size_t)t * k + lane];
-    }
+    float ld_ = early_ld;      // (bucket mode: the task's list; seed / range mode: empty)
+    uint32_t lr_ = early_lr;
     // (wavefront-uniform by construction; said so, or the loop's counters and bounds live in vector registers)
     uint64_t n_items = overflowed ? (uint64_t)(scan_hi - scan_lo) : cnt;
     n_items = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)n_items) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(n_items >> 32)) << 32);
@@ -384,6 +394,7 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     auto load_block = [&](uint64_t first) -> uint32_t {
         const uint64_t idx = first + lane;
         if (idx >= n_items) return kNoId;
+        if (bucket && first == 0 && c_lo == 0) return early_ids;
         if (seed) return a.plane_perm[seed_first + idx];   // (kNoId on the padding of a cell's last tile: skipped like an absent candidate)
         return overflowed ? (uint32_t)(scan_lo + (int64_t)idx) : a.cand_row[(size_t)t * a.cand_cap + c_lo + idx];
     };
@@ -451,7 +462,6 @@ __global__ void __launch_bounds__(64 * kRescoreTasksPerWG) RescoreKernel(Rescore
     float4 v[kRescoreSub / 2];
     uint32_t block_rows = load_block(0), next_block_rows = load_block(64);
     uint32_t row = round_rows(block_rows, 0), cur_row = row;   // the round being fetched / evaluated
-    const float4 q0 = c4l < (int)ld4 ? reinterpret_cast<const float4*>(q)[c4l] : make_float4(0.f, 0.f, 0.f, 0.f);   // the query's group of chunk 0
     fetch(v, row, 0, 0);
     const uint64_t n_subs = (n_items + kRescoreSub - 1) / kRescoreSub;
     for (uint64_t sr = 0; sr < n_subs; ++sr) {
