@@ -79,7 +79,7 @@ enum {
                                           Results are the same bits as without the flag.  (Measured, profiles/r05/overlap_race.md: kernels of
                                           different calls then share compute units; until the matrix-core kernels were given their SIMDs to
                                           themselves that cost about one call in 500 a neighbour at d <= 64 — none ever at 96 / 128 dimensions.
-                                          Since then: one such call in 48 000 at d = 64, none elsewhere.  One stream — no flag — has never
+                                          Since then: one such call in 280 000 at d = 64, none elsewhere.  One stream — no flag — has never
                                           shown any.) */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
