@@ -337,12 +337,12 @@ def test_overlapped_stream_of_batches_many_cells(orc, gp, monkeypatch, rest_item
 
 
 def test_overlapped_pipelines_at_64_dimensions_repeat_the_plain_call():
-    """tools/overlap_race_probe.py, short: 120 overlapped pipelines of 6 batches at 64 dimensions (filter kernels that once left room on their SIMDs for
+    """tools/overlap_race_probe.py, short: 60 overlapped pipelines of 6 batches at 64 dimensions (filter kernels that once left room on their SIMDs for
     other launches' wavefronts — before FilterKernelCells took the whole register file about one pipeline in 30 returned a list that missed neighbours,
     profiles/r05/overlap_race.md), every batch the plain call's bits.  (In its own process: the probe sets the store's options through the environment.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlap_race_probe.py"), "--d", "64", "--depth", "1", "--rest-items", "0", "--repeats", "120"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlap_race_probe.py"), "--d", "64", "--depth", "1", "--rest-items", "0", "--repeats", "60"],
                        capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "120 repeats x 6 batches" in r.stdout and ": 0 events" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "60 repeats x 6 batches" in r.stdout and ": 0 events" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
