@@ -251,8 +251,11 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 // short kernels of another call's front beside them) about one call in 500 lost a task's candidates — traced to single accumulator registers of
 // a co-resident CellDistKernel wavefront, lanes 48 - 63, holding other values than the same call made alone (the table entries it then wrote
 // differed, the cell tests and 8-bit thresholds built on them pruned rows of the true top-k); never at 128 dimensions, where the filter kernels
-// use 256 registers anyway, and gone (0 events in 10 000 pipelines against 12 - 99 per 2 500) once they do so everywhere.  The hunt, with the
-// experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe: tools/overlap_race_probe.py.
+// use 256 registers anyway, and gone (0 events in 10 000 pipelines against 12 - 99 per 2 500) once they do so everywhere.  Outside the product the
+// instruction is named: a wavefront beside a wavefront of another kernel that issues v_mfma_i32_32x32x32_i8 ends with wrong lanes 48 - 63 — every time in
+// tools/microbench/coresidency_repro.hip, never beside bf16 / f16 matrix instructions or vector code, never among wavefronts of the int8 kernel itself.
+// The hunt, with the experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe:
+// tools/overlap_race_probe.py.
 __device__ __forceinline__ void TakeWholeRegisterFile() { asm volatile("" ::: "v255"); }
 
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
