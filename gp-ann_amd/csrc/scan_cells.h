@@ -1319,6 +1319,9 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
     item = nxt;
     nxt = after;
     }   // next item
+    // (no wavefront of the workgroup leaves — and frees its registers for another launch's wavefront — while a sibling on the same SIMD may still
+    // issue matrix instructions: TakeWholeRegisterFile, common.h.  What follows the barrier is the queue's flush and the counters: no matrix work.)
+    __syncthreads();
     flush_queue();
     if (a.work && (threadIdx.x & 63) == 0 && my_tiles) {
         atomicAdd(&a.work[0], (unsigned long long)my_products);
