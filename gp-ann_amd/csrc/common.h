@@ -254,6 +254,7 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 // use 256 registers anyway, and gone (0 events in 10 000 pipelines against 12 - 99 per 2 500) once they do so everywhere.  Outside the product the
 // instruction is named: a wavefront beside a wavefront of another kernel that issues v_mfma_i32_32x32x32_i8 ends with wrong lanes 48 - 63 — every time in
 // tools/microbench/coresidency_repro.hip, never beside bf16 / f16 matrix instructions or vector code, never among wavefronts of the int8 kernel itself.
+// (FilterKernelCells also keeps its wavefronts together to the end: a barrier after the last work item.)
 // The hunt, with the experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe:
 // tools/overlap_race_probe.py.
 __device__ __forceinline__ void TakeWholeRegisterFile() { asm volatile("" ::: "v255"); }
