@@ -3,7 +3,7 @@
 # suite (a parent pytest process holding a GPU context, DistributedBench children with 2-3 ranks sharing the GPU and RCCL set-up / tear-down
 # right before the reference's QueryAttribution driver) — instead of the stand-alone harness, which never showed it.  Every router call runs
 # with GPANN_ROUTER_VERIFY + STRICT (conftest) and GPANN_ROUTER_PROBE=1: each bound block is run twice and every bit of the two runs compared.
-#   tools/stress_suite_context.sh OUT_DIR PAIR_LOOPS CONCURRENT_PROCS CONCURRENT_RUNS [FULL_SUITES] [LEGACY_MEMSET]
+#   tools/stress_suite_context.sh OUT_DIR PAIR_LOOPS CONCURRENT_PROCS CONCURRENT_RUNS [FULL_SUITES] [LEGACY_MEMSET] [PROBE_PIPELINES, 0 = none]
 # LEGACY_MEMSET=1 (round 5): every router handle sets its bound blocks up the way rounds 1-3 did — three runtime memsets + a fill launch
 # (GPANN_ROUTER_LEGACY_MEMSET, csrc/router.hip EnqueueBound) instead of one BoundInitKernel.  All three historical events predate the kernel; if
 # the event lives in the runtime's memsets it shows in this variant under the probe and nowhere else.
@@ -52,6 +52,15 @@ for p in $(seq 1 "$PROCS"); do
     tail -1 "$OUT/qa_conc_$p.log" | tee -a "$OUT/summary.txt"
     grep -c "router report\|failed:" "$OUT/qa_conc_$p.log" >> "$OUT/summary.txt"
 done
+# phase D (round 5): the overlapped pipeline at 64 dimensions, thousands of times (tools/overlap_race_probe.py; profiles/r05/overlap_race.md) — and
+# the reproducer of the int8 matrix instruction's effect on co-resident wavefronts, if it has been built
+PROBE=${7:-4000}
+if [ "$PROBE" != 0 ]; then
+    echo "== phase D: overlap probe, $PROBE pipelines at d = 64 (one call ahead) and d = 128" | tee -a "$OUT/summary.txt"
+    timeout 900 python3 tools/overlap_race_probe.py --d 64 --depth 1 --rest-items 0 --repeats "$PROBE" > "$OUT/probe_d64.log" 2>&1; tail -1 "$OUT/probe_d64.log" | tee -a "$OUT/summary.txt"
+    timeout 900 python3 tools/overlap_race_probe.py --d 128 --depth 1 --rest-items 0 --repeats "$PROBE" > "$OUT/probe_d128.log" 2>&1; tail -1 "$OUT/probe_d128.log" | tee -a "$OUT/summary.txt"
+    if [ -x tools/microbench/coresidency_repro ]; then (cd tools/microbench && timeout 300 ./coresidency_repro 5) > "$OUT/coresidency_repro.txt" 2>&1; grep -v "^  config" "$OUT/coresidency_repro.txt" | tee -a "$OUT/summary.txt"; fi
+fi
 echo "total wall $(( $(date +%s) - t0 )) s; suite-level events: $events; report file: $(test -s "$GPANN_VERIFY_REPORT" && wc -l < "$GPANN_VERIFY_REPORT" || echo 0) lines" | tee -a "$OUT/summary.txt"
 ls "$OUT" | grep -c "\.bin$" | sed 's/^/binary dumps: /' | tee -a "$OUT/summary.txt"
 exit 0
