@@ -36,6 +36,18 @@ _live_comm = []   # the communicator of this process, for the exit path of a fai
 _live_turns = []  # the timed loop's collective schedule (Turnstile), for the same exit path
 
 
+def best_single_step_seconds(step_fn, barrier_fn, n=5, clock=time.perf_counter):
+    """The shortest of n single steps, each closed by barrier_fn: what the choice among router configurations goes by.  (A mean lets one host hiccup
+    decide: a 19 ms outlier in a 4.6 ms step once handed the timed loop to a configuration 2.6x slower.)"""
+    best = float("inf")
+    for _ in range(n):
+        t0 = clock()
+        step_fn()
+        barrier_fn()
+        best = min(best, clock() - t0)
+    return best
+
+
 class Turnstile:
     """ONE launch order, the same on every rank, for the collectives of the timed loop's TWO communicators (the route-ahead thread's probe
     all-gathers, this thread's slot exchanges).  Each communicator alone is driven by one thread in one order — but two communicators on one GPU
@@ -683,12 +695,7 @@ def main():
         barrier()
         # the BEST of five single steps: the choice of the timed configuration must not hang on one host hiccup (a box was seen to spend 19 ms in a
         # step that takes 4.6 — averaged over two steps, as this trial used to be, that handed the timed loop to the 100k-centroid router: 1.1M QPS for 2.9M)
-        trial = float("inf")
-        for _ in range(5):
-            t0 = time.perf_counter()
-            step()
-            barrier()
-            trial = min(trial, time.perf_counter() - t0)
+        trial = best_single_step_seconds(step, barrier, 5)
         if multi:
             trial = comm.max_double(trial)
         candidates.append(dict(index_budget=index_budget, router=router, tree=tree, train_s=router_train_s, nprobe=nprobe, recall_curve=recall_curve,
