@@ -888,6 +888,8 @@ def main():
                 t_step = time.perf_counter()
             if pending is not None:
                 md, mi, _ = pending.result()
+            if record is not None:
+                record["last_buf"] = (count - 1) % depth     # the buffer set the last step's lists went to
             return md, mi
         nxt = router_pool.submit(route_job, 0, turn) if route_ahead and count else None
         for it in range(count):
@@ -906,6 +908,8 @@ def main():
             note(t_step, r_ms, s_ms, rst)
         if pending is not None:
             md, mi, _ = pending.result()
+        if record is not None and count:
+            record["last_buf"] = (count - 1) & 1
         return md, mi
 
     run_steps(args.warmup, None)
@@ -977,7 +981,7 @@ def main():
     recall = float(np.count_nonzero(md <= kth[:, None])) / (nq * k)
     qps = nq * args.steps / elapsed
     # what the merge of the last step had to drop: ids that came back from more than one probed shard (overlapping shards only)
-    last_ids = np.sort(host_out[(nq, nprobe, (args.steps - 1) % (3 if scan_overlap else 2))][1].numpy().view(np.uint32).reshape(nq, -1), axis=1)
+    last_ids = np.sort(host_out[(nq, nprobe, rec.get("last_buf", 0))][1].numpy().view(np.uint32).reshape(nq, -1), axis=1)
     dup_ids = int(np.count_nonzero((last_ids[:, 1:] == last_ids[:, :-1]) & (last_ids[:, 1:] != 0xFFFFFFFF)))
     slot_entries = int(np.count_nonzero(last_ids != 0xFFFFFFFF))
 

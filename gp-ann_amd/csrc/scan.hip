@@ -648,6 +648,84 @@ static std::vector<FilterGroup> PlanFilterGroups(uint32_t tb, uint32_t group_tas
     return out;
 }
 
+// The FilterKernelCells instances a store's passes launch (its k-steps and metric pick them): both bf16 planes / hi plane only, and — a store with an
+// 8-bit plane — the rest pass, the sample pass under a symbol of its own (TAG 1: the rest pass keeps rocprofv3's per-kernel statistics to itself; one row
+// tile per unit: its items are the 20-odd tiles of a cell's front) and the rest pass of a call that runs BESIDE other calls (TAG 2, GPANN_SCAN_OVERLAP:
+// the same code under a third symbol, so that the statistics keep launches that share the chip apart from the ones that have it to themselves).
+struct FilterKernelSet {
+    const void *fn = nullptr, *fn_hi = nullptr, *fn_q8 = nullptr, *fn_q8_sample = nullptr, *fn_q8_beside = nullptr;
+};
+static bool PickFilterKernels(bool l2, uint32_t KS, bool use_q8, uint32_t KS8, FilterKernelSet* out) {
+    FilterKernelSet f;
+    switch (KS) {
+#define GPANN_PICK(KS_)                                                                                                                                   \
+    case KS_:                                                                                                                                             \
+        f.fn_hi = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 1>;    \
+        if constexpr (KS_ <= 8) f.fn = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 0> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 0>; \
+        else f.fn = f.fn_hi;                                                                                                                              \
+        break;
+        GPANN_PICK(2) GPANN_PICK(4) GPANN_PICK(6) GPANN_PICK(7) GPANN_PICK(8) GPANN_PICK(10) GPANN_PICK(13) GPANN_PICK(16)
+#undef GPANN_PICK
+        default: return false;
+    }
+    if (use_q8) {
+        switch (KS8) {
+#define GPANN_PICK8(KS_)                                                                                                                       \
+    case KS_:                                                                                                                                  \
+        f.fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 2, 8>; \
+        f.fn_q8_sample = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 1, KS_, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 1, KS_, 2, 8, 1>; \
+        f.fn_q8_beside = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 2, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 2, KS_, 2, 8>; \
+        break;
+            GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
+#undef GPANN_PICK8
+            default: break;
+        }
+    }
+    *out = f;
+    return true;
+}
+static bool StoreUsesQ8(const gpann_shards* s) {
+    const auto& C = s->cells;
+    return C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || s->opt.U32("GPANN_FILTER_Q8", 1) != 0);
+}
+
+// GPANN_SCAN_OVERLAP rests on one property of the BUILT kernels: every matrix-core kernel is allocated all 256 architectural vector registers, so two of
+// its wavefronts fill a SIMD's register file and no wavefront of another launch is ever resident beside them (common.h TakeWholeRegisterFile: a
+// wavefront that shared a SIMD with another kernel's v_mfma_i32_32x32x32_i8 wavefront was measured to end with wrong registers,
+// profiles/r05/overlap_race.md).  tests/test_capi_exports.py checks the code objects of the shipped library; this is the same question asked of the
+// RUNTIME about the very kernels this store launches, once per store, before its first overlapped call: a library built by another compiler, or with the
+// claim edited away, runs its calls one after the other on the caller's stream instead (same results, no sharing of compute units) and says so once.
+static bool OverlapKernelsOwnTheirSimds(gpann_shards* s) {
+    if (s->overlap_kernels_state == 0) {
+        FilterKernelSet f;
+        bool ok = PickFilterKernels(s->metric == GPANN_METRIC_L2, s->cells.plane_ks, StoreUsesQ8(s), s->cells.q8_ks, &f);
+        int least = 256;
+        if (ok) {
+            for (const void* fn : {f.fn, f.fn_hi, f.fn_q8, f.fn_q8_sample, f.fn_q8_beside}) {
+                if (!fn) continue;
+                hipFuncAttributes attr{};
+                if (hipFuncGetAttributes(&attr, fn) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ok = false;
+                    break;
+                }
+                least = std::min(least, attr.numRegs);
+            }
+        }
+        s->overlap_kernels_regs = ok ? least : 0;
+        s->overlap_kernels_state = ok && least >= 256 ? 1 : 2;
+    }
+    // (GPANN_OVERLAP_ASSUME_SHARED_SIMDS: test hook — behave as if a kernel of this build left room beside itself)
+    const bool ok = s->overlap_kernels_state == 1 && s->opt.U32("GPANN_OVERLAP_ASSUME_SHARED_SIMDS", 0) == 0;
+    if (!ok && !s->overlap_refusal_said) {
+        s->overlap_refusal_said = true;
+        fprintf(stderr, "[gpann] GPANN_SCAN_OVERLAP is ignored for this store: a matrix-core kernel of this build is allocated %d vector registers, not 256 — "
+                        "wavefronts of other launches could run beside it (csrc/common.h TakeWholeRegisterFile); its calls run one after the other instead\n",
+                s->overlap_kernels_regs);
+    }
+    return ok;
+}
+
 // The MFMA-filtered pipeline (cells.hip, scan_cells.h, scan_filter.h):
 //   tasks of a shard ordered by nearest cell -> stage 0 (exact, first rows of the shard in store order: a random sample of it)
 //   -> head pass (the first tiles of every task's nearest cell) -> main pass (every cell the bound cannot exclude), each followed
@@ -698,7 +776,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const bool wide = KS > 8;   // beyond 128 dimensions: hi-plane passes only, 4 query tiles per group
     // the rest pass on the 8-bit plane (scan_cells.h MODE 2) when the store has one: a quarter of the fp32 bytes per row instead of half
     // (a store with compact hi planes has no bf16 tiles for the rest pass: the knob is ignored there)
-    const bool use_q8 = C.q8_planes != nullptr && C.q8_ks >= 1 && C.q8_ks <= 8 && (C.hi_compact || s->opt.U32("GPANN_FILTER_Q8", 1) != 0);
+    const bool use_q8 = StoreUsesQ8(s);
     const uint32_t KS8 = C.q8_ks, QT8 = 8;
     // (never the head pass: an 8-bit pass gives a task candidates only from the cells NeedKernel marked for it — its per-(task, cell) thresholds —
     // while the later passes skip a segment for a whole query tile once the tile has run on it; the head pass marks one cell per task, the bf16
@@ -1091,19 +1169,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     ra.task_nq = d_task_nq;
     ra.shard_rmax = s->d_shard_rmax;
     ra.seed_hi_only = 0;
-    // the kernel for this store's k-steps: both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
-    const void *fn = nullptr, *fn_hi = nullptr;
-    switch (KS) {
-#define GPANN_PICK(KS_)                                                                                                                                   \
-    case KS_:                                                                                                                                             \
-        fn_hi = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 1>;      \
-        if constexpr (KS_ <= 8) fn = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 0> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 0>; \
-        else fn = fn_hi;                                                                                                                                  \
-        break;
-        GPANN_PICK(2) GPANN_PICK(4) GPANN_PICK(6) GPANN_PICK(7) GPANN_PICK(8) GPANN_PICK(10) GPANN_PICK(13) GPANN_PICK(16)
-#undef GPANN_PICK
-        default: GPANN_REQUIRE(false, "no filter kernel for this number of k-steps");
-    }
+    // the kernels for this store's k-steps (PickFilterKernels): both planes (the shard-sample and head passes, up to 8 k-steps) and hi plane only
+    FilterKernelSet fks;
+    GPANN_REQUIRE(PickFilterKernels(l2, KS, use_q8, KS8, &fks), "no filter kernel for this number of k-steps");
+    const void *fn = fks.fn, *fn_hi = fks.fn_hi;
     // the sample and rest passes (all but the small head pass) read only the hi plane of the points: half the HBM bytes and two of
     // the three products for a slightly looser bound (rest pass 10.1 -> 6.1 ms on the NS workload, 40% more candidates).  A store
     // built with GPANN_FILTER_LO_ROWS=all has a lo tile for every tile: GPANN_FILTER_HI_ONLY=0 then keeps all three products everywhere,
@@ -1113,25 +1182,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     const size_t glds = FilterLdsBytes((size_t)QT * KS * 2048);
     GPANN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     GPANN_HIP_TRY(hipFuncSetAttribute(fn_hi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    // the sample pass under a symbol of its own (TAG 1: the rest pass keeps rocprofv3's per-kernel statistics to itself) and with one row tile per
-    // unit of work: its items are the 20-odd tiles of a cell's front — three rounds of 8 tiles instead of two of 16, the second a fifth full
-    // (TAG 2: the rest pass of a call that runs BESIDE other calls, GPANN_SCAN_OVERLAP — the same code under a symbol of its own, so that rocprofv3's
-    // per-kernel statistics keep the launches that share the chip apart from the ones that have it to themselves)
-    const void *fn_q8 = nullptr, *fn_q8_sample = nullptr, *fn_q8_beside = nullptr;
+    // (the 8-bit passes: the sample pass under a symbol of its own with one row tile per unit — three rounds of 8 tiles instead of two of 16, the second
+    // a fifth full — and the overlapped rest pass under a third: FilterKernelSet)
+    const void *fn_q8 = fks.fn_q8, *fn_q8_sample = fks.fn_q8_sample, *fn_q8_beside = fks.fn_q8_beside;
     uint32_t q8_unit_tiles = (uint32_t)FilterUnitTiles(2, (int)KS8), q8_waves = (uint32_t)FilterWaves(2, (int)KS8);
     size_t glds8 = 0;
     if (use_q8) {
-        switch (KS8) {
-#define GPANN_PICK8(KS_)                                                                                                                       \
-    case KS_:                                                                                                                                  \
-        fn_q8 = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 0, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 0, KS_, 2, 8>; \
-        fn_q8_sample = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 1, KS_, 2, 8, 1> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 1, KS_, 2, 8, 1>; \
-        fn_q8_beside = l2 ? (const void*)FilterKernelCells<GPANN_METRIC_L2, 2, KS_, 2, 8> : (const void*)FilterKernelCells<GPANN_METRIC_MIPS, 2, KS_, 2, 8>; \
-        break;
-            GPANN_PICK8(1) GPANN_PICK8(2) GPANN_PICK8(3) GPANN_PICK8(4) GPANN_PICK8(5) GPANN_PICK8(6) GPANN_PICK8(7) GPANN_PICK8(8)
-#undef GPANN_PICK8
-            default: break;
-        }
         // (16 wavefronts of 128 registers per workgroup, one row tile per unit, were measured on the 128-dimension kernel: no faster on the NS rest
         // pass nor on the uniform cloud's — profiles/r03/q8_kernel_variants.md)
         glds8 = FilterLdsBytes((size_t)QT8 * KS8 * 2048, (int)q8_waves);
@@ -1173,9 +1229,11 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, s->device);
     // GPANN_SCAN_OVERLAP: the front of this call shares the chip with the rest pass of the call before it (and its own rest pass with the front of
     // the next).  A filter launch takes whole CUs (one 512-thread workgroup with ~all of a CU's registers and most of its LDS), so the two sides are
-    // kept apart by their GRID sizes: the front's filter launches start at most front_cus workgroups; the rest pass either rest_cus persistent ones
-    // (GPANN_OVERLAP_REST_ITEMS=0) or — the default — as many workgroups as its items need, each leaving after rest_items items: the rest stream has
-    // the lower priority, so a CU it gives up goes to the front when the front has a workgroup waiting and back to the rest pass when it has not.
+    // kept apart by their GRID sizes: the front's filter launches start at most front_cus workgroups; the rest pass rest_cus PERSISTENT ones — the
+    // product's default, GPANN_OVERLAP_REST_ITEMS=0 — or, GPANN_OVERLAP_REST_ITEMS=n, as many workgroups as its items need, each leaving after n
+    // items (CellFilterArgs::wg_item_budget): the rest stream has the lower priority, so a CU it gives up goes to the front when the front has a
+    // workgroup waiting and back to the rest pass when it has not.  (Measured no better than the fixed split, profiles/r05/NOTES.md; the budget path is
+    // kept covered by tests/test_gpu_filter.py's rest_items cases and tools/overlap_race_probe.py --rest-items.)
     // Defaults (NS sweeps, profiles/r05/NOTES.md): a store whose rest pass streams gigabytes — 160 persistent rest workgroups, 96 for a front's filter
     // launches (the rest pass is HBM-bound: on 160 of 256 CUs it loses a fifth of its speed and the fronts get what they need); a small store (its
     // planes below 4 GB: the step is its launches, not its bytes) — no partition at all, every launch may take the whole chip.
@@ -1519,7 +1577,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     // deferred): the call's work goes to the handle's own streams; the caller's stream only orders its start
     hipStream_t st = st_caller, st_rest = st_caller, st_tail = st_caller;
     if ((flags & GPANN_SCAN_OVERLAP) && (flags & GPANN_SCAN_DEFER) && (flags & GPANN_QUERIES_ON_DEVICE) && FilterWanted(s, k) && s->ld == s->d &&
-        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0) {
+        (reinterpret_cast<uintptr_t>(queries) & 15u) == 0 && OverlapKernelsOwnTheirSimds(s)) {
         GPANN_TRY(OverlapStreams(s));
         GPANN_HIP_TRY(hipEventRecord(CS(s).ev_x[0], st_caller));
         // (a front stream per slot: the fronts of the calls in flight run side by side; 1: one after the other)
@@ -1586,6 +1644,7 @@ static gpann_status ScanToDevice(gpann_shards* s, const float* queries, uint32_t
     c.filter_passes_timed = 0;
     c.rest_begin_recorded = false;
     c.filtered = false;
+    c.overlapped = st_rest != st_caller;   // (the call runs on the store's own streams)
     c.dirty_cap = 0;
     c.d_queries = d_queries;
     c.nq = nq;
@@ -1622,6 +1681,7 @@ static void FillStats(gpann_shards* s, const gpann_shards::CallState& c, bool fi
     const ScanPlan& plan = c.plan;
     s->stats = gpann_scan_stats{};
     s->stats.filtered = filtered ? 1 : 0;
+    s->stats.overlapped = filtered && c.overlapped ? 1u : 0u;
     s->stats.pairs = plan.pairs;
     s->stats.algorithmic_bytes = plan.pairs * s->d * 4ull + (uint64_t)c.T * c.k * 8ull;
     s->stats.tasks = c.T;
@@ -1953,6 +2013,14 @@ gpann_status gpann_ground_truth(gpann_shards* s_all, const float* points, uint64
 gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out) {
     GPANN_REQUIRE(s != nullptr && out != nullptr, "null argument");
     *out = s->stats;
+    return GPANN_OK;
+}
+
+// (the struct only ever grows at its end: a caller compiled against an older or newer header passes ITS sizeof and gets the fields both sides know)
+gpann_status gpann_scan_last_stats_sized(const gpann_shards* s, void* out, size_t out_size) {
+    GPANN_REQUIRE(s != nullptr && out != nullptr, "null argument");
+    std::memset(out, 0, out_size);
+    std::memcpy(out, &s->stats, std::min(out_size, sizeof(gpann_scan_stats)));
     return GPANN_OK;
 }
 

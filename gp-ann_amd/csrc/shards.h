@@ -176,6 +176,7 @@ struct gpann_shards {
         // what the completion of the call (CompleteCall: at once, or in gpann_scan_finish) needs to know
         bool pending = false;            // enqueued, not completed yet
         bool filtered = false;           // the filtered pipeline ran (its counters are on their way to pin_words)
+        bool overlapped = false;         // GPANN_SCAN_OVERLAP took effect: the call's work went to the store's own streams
         uint32_t dirty_cap = 0;
         const float* d_queries = nullptr;   // the device queries the kernels read (for the exact redo of an overflowed call)
         uint32_t nq = 0, k = 0, nprobe = 0, T = 0;
@@ -210,6 +211,9 @@ struct gpann_shards {
     // the runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and a front that lands in the rest
     // pass's queue waits for it — INTEGRATION.md)
     hipStream_t st_front[kCallSlots] = {nullptr, nullptr, nullptr}, st_rest = nullptr, st_tail = nullptr;
+    int overlap_kernels_state = 0;   // 0: not asked yet, 1: this store's matrix-core kernels take whole SIMDs (overlap allowed), 2: they do not (scan.hip OverlapKernelsOwnTheirSimds)
+    int overlap_kernels_regs = 0;    // the fewest vector registers the runtime reports for one of them (0: the question failed)
+    bool overlap_refusal_said = false;
 };
 
 namespace gpann {

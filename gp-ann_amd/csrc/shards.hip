@@ -103,6 +103,7 @@ static const Knob kKnobs[] = {
     {"GPANN_OVERLAP_SPLIT_MAX_PRODUCTS", 'C', "GPANN_SCAN_OVERLAP: the CU split applies while the previous call ran at most this many (query tile, row tile) products per rest-pass row tile (default 3: an HBM-bound rest pass)"},
     {"GPANN_OVERLAP_PACE", 'C', "GPANN_SCAN_OVERLAP: 0 = a call's front may start at once (default 1: not before the rest pass of the call two before it has started)"},
     {"GPANN_OVERLAP_FRONT_STREAMS", 'C', "GPANN_SCAN_OVERLAP: 1 = the fronts of the calls in flight one after the other, 3 (default) = side by side, a stream per call slot"},
+    {"GPANN_OVERLAP_ASSUME_SHARED_SIMDS", 'C', "test hook: 1 = GPANN_SCAN_OVERLAP behaves as if a matrix-core kernel of this build had fewer than 256 vector registers (the flag is ignored, calls run one after the other)"},
     {"GPANN_DEBUG_Q8_NO_CAND", 'C', "measurement aid, WRONG RESULTS: the 8-bit passes find no candidate"},
     // router
     {"GPANN_ROUTER_MODE", 'C', "walk | dense: force the tree walk / the distance table + replay (default: by tree size and budget)"},
@@ -177,7 +178,8 @@ extern "C" {
 
 const char* gpann_last_error(void) { return g_last_error.c_str(); }
 
-const char* gpann_version(void) { return "gpann-hip 0.1 (gfx950)"; }
+const char* gpann_version(void) { return "gpann-hip 0.6 (gfx950)"; }
+uint32_t gpann_abi_version(void) { return GPANN_ABI_VERSION; }
 
 uint32_t gpann_option_count(void) { return (uint32_t)(sizeof(kKnobs) / sizeof(kKnobs[0])); }
 const char* gpann_option_name(uint32_t i) { return i < gpann_option_count() ? kKnobs[i].name : nullptr; }

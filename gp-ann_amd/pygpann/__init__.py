@@ -26,7 +26,7 @@ _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 
 EXPORTS = [
-    "gpann_last_error", "gpann_version", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_build_filter", "gpann_shards_info",
+    "gpann_last_error", "gpann_version", "gpann_abi_version", "gpann_scan_last_stats_sized", "gpann_device_count", "gpann_shards_create", "gpann_shards_destroy", "gpann_shards_build_filter", "gpann_shards_info",
     "gpann_shards_export", "gpann_shards_export_range", "gpann_scan_buckets", "gpann_scan_merged", "gpann_shard_search_hits", "gpann_ground_truth",
     "gpann_scan_last_stats", "gpann_scan_finish", "gpann_shards_set_scan_mode", "gpann_router_create", "gpann_router_destroy", "gpann_router_train", "gpann_kmeans", "gpann_router_info", "gpann_router_get_stats", "gpann_router_export", "gpann_router_query_batch", "gpann_router_query_batch_top", "gpann_router_frequency_query_batch", "gpann_merge_dedup",
     "gpann_synth_rows_device", "gpann_nearest_centroid_device",
@@ -47,7 +47,7 @@ class ScanStats(C.Structure):
                 ("scan_ms", C.c_float), ("merge_ms", C.c_float), ("filter_ms", C.c_float), ("filter_dirty_tasks", C.c_uint32),
                 ("filter_rows", C.c_uint64), ("filter_rest_rows", C.c_uint64), ("filter_rest_ms", C.c_float), ("filter_rest_hi_only", C.c_uint32),
                 ("filter_two_plane_rows", C.c_uint64), ("filter_seed_rows", C.c_uint64),
-                ("filter_rest_row_bytes", C.c_uint32), ("reserved3", C.c_uint32),
+                ("filter_rest_row_bytes", C.c_uint32), ("overlapped", C.c_uint32),
                 ("filter_mfma_bf16", C.c_uint64), ("filter_mfma_i8", C.c_uint64), ("filter_rest_mfma_i8", C.c_uint64)]
 
 
@@ -104,6 +104,8 @@ def lib():
     L.gpann_ground_truth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, _f32p]
     L.gpann_scan_last_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats)]
+    L.gpann_scan_last_stats_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.gpann_abi_version.restype = C.c_uint32
     L.gpann_scan_finish.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.gpann_shards_set_scan_mode.argtypes = [C.c_void_p, C.c_int]
     L.gpann_router_create.argtypes = [C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, _f32p, C.c_int,
@@ -266,8 +268,9 @@ class Shards:
                             defer=False, host_out=False, overlap=False):
         """Same with queries resident on the device (raw pointer) and the outputs on the device (raw pointers) or — host_out — in host
         arrays given by address (pinned ones for an asynchronous copy); asynchronous unless timed.  defer: GPANN_SCAN_DEFER — the call only
-        enqueues its work and finish() completes it; one more call may be issued before that.  overlap (with defer): GPANN_SCAN_OVERLAP — the
-        call runs on the handle's own two streams, its front beside the previous call's rest pass; results are in place after finish()."""
+        enqueues its work and finish() completes it; two more calls may be issued before that (the handle has three call slots).  overlap (with
+        defer): GPANN_SCAN_OVERLAP — the call runs on the handle's own streams (a front stream per slot, one rest stream, one tail stream), its front
+        beside the rest pass of the calls before it; results are in place after finish(); stats()["overlapped"] says whether the flag took effect."""
         probes = _np(probes, np.int32)
         stride = probes.shape[1]
         ms = C.c_float(0)
@@ -308,7 +311,7 @@ class Shards:
 
     def stats(self):
         st = ScanStats()
-        _check(lib().gpann_scan_last_stats(self.h, C.byref(st)))
+        _check(lib().gpann_scan_last_stats_sized(self.h, C.byref(st), C.sizeof(st)))   # (sized: this binding and the library may be of different revisions)
         return {f: getattr(st, f) for f, _ in ScanStats._fields_}
 
 

@@ -76,11 +76,18 @@ enum {
                                           the third — so that the fronts of calls i + 1, i + 2 run BESIDE the rest pass of call i and the rest
                                           passes follow each other without a gap (every call in flight owns its device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
                                           is issued); its results are in place when gpann_scan_finish returns, NOT when `stream` has drained.
-                                          Results are the same bits as without the flag.  (Measured, profiles/r05/overlap_race.md: kernels of
-                                          different calls then share compute units; until the matrix-core kernels were given their SIMDs to
-                                          themselves that cost about one call in 500 a neighbour at d <= 64 — none ever at 96 / 128 dimensions.
-                                          Since then: one such call in 280 000 at d = 64, none elsewhere.  One stream — no flag — has never
-                                          shown any.) */
+                                          What the flag may NOT change is the result: every list entry is still the canonical distance of a real row.
+                                          It rests on a property of the built kernels that the library checks for itself: kernels of different calls then
+                                          share compute units, and a wavefront that shares a SIMD with ANOTHER launch's v_mfma_i32_32x32x32_i8 wavefront
+                                          was measured to end with wrong vector registers (profiles/r05/overlap_race.md; reproducer
+                                          tools/microbench/coresidency_repro.hip).  Every matrix-core kernel of this library is therefore allocated all 256
+                                          vector registers and keeps its wavefronts together to the end — nothing of another launch ever runs on its
+                                          SIMDs (checked on the code objects by tests/test_capi_exports.py and, for the kernels a store launches, asked of
+                                          the runtime before its first overlapped call: a build without the property IGNORES this flag and says so on
+                                          stderr).  Before that rule about one overlapped call in 500 lost a neighbour at d <= 64 (never at 96 / 128
+                                          dimensions, where the kernels need 256 registers anyway); with it the long-run stress of
+                                          profiles/r06/overlap_stress.md is the evidence on record.  gpann_scan_stats.overlapped says whether the
+                                          flag took effect for a call. */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
                                           with the plain exact scan should the data have defeated the filter, statistics, timing).  TWO further
@@ -106,6 +113,11 @@ typedef struct gpann_router gpann_router;   /* device-resident flattened k-means
 /* thread-local, human-readable description of the last failure in the calling thread */
 const char* gpann_last_error(void);
 const char* gpann_version(void);
+/* ABI revision of this header; gpann_abi_version() is the library's.  It is raised whenever an exported signature or the layout of a struct a caller
+ * allocates changes (6: gpann_scan_stats ends with the matrix-core issue counters, reserved3 became `overlapped`, gpann_scan_last_stats_sized added).
+ * A caller that may meet a library of another revision compares the two and reads gpann_scan_stats through gpann_scan_last_stats_sized. */
+#define GPANN_ABI_VERSION 6u
+uint32_t gpann_abi_version(void);
 
 /* Options.  Every knob that changes what a call does is a named option of the HANDLE (string values; names with or without the GPANN_
  * prefix).  A handle takes a snapshot of the process environment's GPANN_* variables when it is created — so a deployment's defaults can
@@ -203,12 +215,15 @@ typedef struct gpann_scan_stats {
     uint64_t filter_two_plane_rows; /* of filter_rows: rows streamed by the launches that read both planes (shard-sample and head passes) */
     uint64_t filter_seed_rows;   /* rows evaluated exactly for the first lists (filter mode: tasks x seed rows) */
     uint32_t filter_rest_row_bytes; /* bytes the rest pass reads per row: 32 x k-steps (bf16 hi plane) or 32 x ceil(d / 32) (8-bit plane) + the norm word */
-    uint32_t reserved3;
+    uint32_t overlapped;         /* 1 if GPANN_SCAN_OVERLAP took effect: the call's device work ran on the store's own streams, beside other calls */
     uint64_t filter_mfma_bf16;   /* v_mfma_f32_32x32x16_bf16 wave-instructions the filter kernels ISSUED (32 x 32 x 16 x 2 flop each), counted by the kernels */
     uint64_t filter_mfma_i8;     /* v_mfma_i32_32x32x32_i8 wave-instructions issued (32 x 32 x 32 x 2 integer ops each): H.P' of every product + L.P' where it was not skipped */
     uint64_t filter_rest_mfma_i8;/* of filter_mfma_i8: the rest pass alone (0 when it ran on the bf16 plane) */
 } gpann_scan_stats;
-gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);
+gpann_status gpann_scan_last_stats(const gpann_shards* s, gpann_scan_stats* out);   /* writes sizeof(gpann_scan_stats) of THIS header's revision */
+/* The same for a caller whose header may be of another revision than the library: gpann_scan_stats only ever grows at its end, so the first
+ * min(out_size, the library's size) bytes are the fields both sides know; the rest of `out` is zeroed.  Pass sizeof(gpann_scan_stats). */
+gpann_status gpann_scan_last_stats_sized(const gpann_shards* s, void* out, size_t out_size);
 
 /* Scan mode of a store: 0 = exact VALU scan of every row (default); 1 = the same exact results with a matrix-core
  * pre-filter (bf16x3 MFMA bound + exact re-scoring of the candidates, gp-ann_amd/csrc/scan_filter.h).  Both modes return

@@ -132,3 +132,20 @@ def test_matrix_core_kernels_claim_their_simds():
                 name = re.search(r"\)\s*(\w+)\s*\(|void\s+(?:__launch_bounds__\([^)]*\)\s*)?(\w+)\s*\(", body)
                 assert "TakeWholeRegisterFile();" in body[: body.index("__builtin_amdgcn_mfma_")], f"{fn}: a matrix-core kernel without TakeWholeRegisterFile() ({name.group(0)[:60] if name else '?'})"
     assert found >= 2    # FilterKernelCells, RouterBoundKernel
+
+
+def test_matrix_core_kernels_are_allocated_the_whole_register_file():
+    """the BUILT library, not the source text: every symbol of every gfx950 code object in libgpann_hip.so whose disassembly holds a matrix instruction is
+    a kernel with vgpr_count 256 and 512-thread workgroups (tools/kernel_resources.py --check-matrix-kernels) — the property GPANN_SCAN_OVERLAP's
+    exactness rests on (profiles/r05/overlap_race.md), which a compiler change or a new template instance could silently take away"""
+    import importlib.util
+    import pygpann
+    pygpann.build()
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ok, bad = kr.check_matrix_kernels(pygpann.LIB_PATH)
+    assert not bad, "\n".join(bad)
+    mnemonics = {m for _, _, ms in ok for m in ms}
+    assert "v_mfma_i32_32x32x32_i8" in mnemonics and "v_mfma_f32_32x32x16_bf16" in mnemonics   # (the check saw the filter and the router kernels)
+    assert len(ok) >= 60

@@ -329,6 +329,7 @@ def test_overlapped_stream_of_batches_many_cells(orc, gp, monkeypatch, rest_item
         wi[cut] = 0xFFFFFFFF
         assert np.array_equal(got_i, wi) and np.array_equal(got_d, wd.view(np.uint32)), (rest_items, i)
         assert stats[i]["filtered"] == 1 and stats[i]["tasks"] == nq * nprobe and stats[i]["filter_rest_rows"] > 0, stats[i]
+        assert stats[i]["overlapped"] == 1, stats[i]      # the runtime reports 256 vector registers for this store's matrix-core kernels: the flag took effect
     for p in q_dev:
         ok(hip.hipFree(p))
     for h in h_ids + h_dist:
@@ -346,3 +347,65 @@ def test_overlapped_pipelines_at_64_dimensions_repeat_the_plain_call():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlap_race_probe.py"), "--d", "64", "--depth", "1", "--rest-items", "0", "--repeats", "60"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "60 repeats x 6 batches" in r.stdout and ": 0 events" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_overlap_flag_is_ignored_when_matrix_kernels_would_share_simds(orc, gp, capfd):
+    """GPANN_SCAN_OVERLAP asks the runtime, per store, whether every matrix-core kernel it launches is allocated all 256 vector registers
+    (scan.hip OverlapKernelsOwnTheirSimds) — the property its exactness rests on (profiles/r05/overlap_race.md).  With the test hook that makes the answer
+    "no" the same pipeline of deferred calls runs on the caller's stream (stats.overlapped 0, one line on stderr), with the same bits; taking the hook
+    away brings the overlap back on the same handle."""
+    C, hip, ok = _hip()
+    rng = np.random.default_rng(77)
+    n, d, S, nq, k, nprobe = 60000, 64, 2, 300, 10, 2
+    pts = make_mixture(orc, n, d, n_centers=24)
+    clusters = random_clusters(rng, n, S, overlap=0.0)
+    batches = [make_mixture(orc, nq, d, seed=900 + i, n_centers=24) for i in range(3)]
+    probes = np.stack([rng.permutation(S)[:nprobe] for _ in range(nq)]).astype(np.int32)
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.set_scan_mode(1)
+    st = C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(st)))
+    nb = nq * nprobe * k * 4
+    q_dev, h_ids, h_dist = [], [], []
+    for q in batches:
+        p = C.c_void_p()
+        ok(hip.hipMalloc(C.byref(p), C.c_size_t(q.nbytes)))
+        ok(hip.hipMemcpy(p, q.ctypes.data_as(C.c_void_p), C.c_size_t(q.nbytes), 1))
+        q_dev.append(p)
+        for lst in (h_ids, h_dist):
+            h = C.c_void_p()
+            ok(hip.hipHostMalloc(C.byref(h), C.c_size_t(nb), 0))
+            lst.append(h)
+    ok(hip.hipDeviceSynchronize())
+
+    def host_view(h):
+        return np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_uint32)), shape=(nq * nprobe * k,)).reshape(nq, nprobe, k).copy()
+
+    def pipeline():
+        stats = []
+        for i in range(len(batches)):
+            shards.scan_buckets_device(q_dev[i].value, nq, k, probes, nprobe, h_ids[i].value, h_dist[i].value, st.value, defer=True, host_out=True, overlap=True)
+        for i in range(len(batches)):
+            shards.finish()
+            stats.append(shards.stats())
+        return stats, [(host_view(h_ids[i]), host_view(h_dist[i])) for i in range(len(batches))]
+
+    want = [shards.scan_buckets(q, k, probes, nprobe) for q in batches]
+    capfd.readouterr()
+    shards.set_option("OVERLAP_ASSUME_SHARED_SIMDS", "1")
+    stats, got = pipeline()
+    err = capfd.readouterr().err
+    assert all(s_["overlapped"] == 0 and s_["filtered"] == 1 for s_ in stats), stats
+    assert err.count("GPANN_SCAN_OVERLAP is ignored for this store") == 1, err      # said once, not per call
+    for (gi, gd), (wi, wd, _) in zip(got, want):
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd.view(np.uint32))
+    shards.set_option("OVERLAP_ASSUME_SHARED_SIMDS", None)
+    stats, got = pipeline()
+    assert all(s_["overlapped"] == 1 and s_["filtered"] == 1 for s_ in stats), stats
+    for (gi, gd), (wi, wd, _) in zip(got, want):
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd.view(np.uint32))
+    for p in q_dev:
+        ok(hip.hipFree(p))
+    for h in h_ids + h_dist:
+        ok(hip.hipHostFree(h))
+    ok(hip.hipStreamDestroy(st))

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--nprobe", type=int, default=2)
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--repeats", type=int, default=100)
+    ap.add_argument("--seconds", type=float, default=0.0, help="run pipelines until this much time has passed (overrides --repeats)")
     ap.add_argument("--depth", type=int, default=2, help="calls begun ahead of the one being finished (the handle has three call slots)")
     ap.add_argument("--no-overlap", action="store_true", help="deferred calls without GPANN_SCAN_OVERLAP (the caller's stream only)")
     ap.add_argument("--no-for-merge", action="store_true", help="complete per-slot lists instead of GPANN_SCAN_FOR_MERGE")
@@ -111,7 +112,12 @@ def main():
 
     events = 0
     t0 = time.time()
-    for rep in range(args.repeats):
+    rep = -1
+    overlapped_calls = 0
+    while True:
+        rep += 1
+        if (time.time() - t0 >= args.seconds) if args.seconds > 0 else (rep >= args.repeats):
+            break
         for h in h_ids + h_dist:
             C.memset(h, 0xA5, nb)
         nbat = len(batches)
@@ -123,6 +129,7 @@ def main():
                 begin(i + args.depth)
             shards.finish()
             stats.append(shards.stats())
+            overlapped_calls += int(stats[-1].get("overlapped", 0))
         for i in range(nbat):
             got_i, got_d = host_view(h_ids[i]), host_view(h_dist[i])
             w_i, w_d = want[i]
@@ -147,7 +154,7 @@ def main():
             shards.finish()
             again = np.array_equal(host_view(h_ids[i]), w_i) and np.array_equal(host_view(h_dist[i]), w_d)
             print(f"    the same batch once more, alone with the flag: {'equal to the plain call' if again else 'DIFFERS again'}", flush=True)
-    print(f"[probe] {args.repeats} repeats x {len(batches)} batches in {time.time() - t0:.1f} s: {events} events", flush=True)
+    print(f"[probe] {rep} repeats x {len(batches)} batches in {time.time() - t0:.1f} s ({overlapped_calls} calls ran overlapped): {events} events", flush=True)
     shards.close()
     return 1 if events else 0
 

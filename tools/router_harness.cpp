@@ -108,9 +108,25 @@ int main(int argc, char** argv) {
     CHECK(gpann_router_query_batch(router, queries.data(), nq, search_budget, probes2.data(), nullptr, 0, nullptr, nullptr));
     gpann_router_stats st{};
     CHECK(gpann_router_get_stats(router, &st));
-    setenv("GPANN_ROUTER_BOUND", "0", 1);
+    // the third call is the CANONICAL route (every pair evaluated exactly).  The handle took its options from the environment when it was created and
+    // does not read the environment again: the knob is set on the handle, and read back so that a bound-against-bound comparison cannot pass for a check
+    CHECK(gpann_router_set_option(router, "ROUTER_BOUND", "0"));
+    {
+        char val[16] = {0};
+        CHECK(gpann_router_get_option(router, "ROUTER_BOUND", val, sizeof val));
+        if (std::strcmp(val, "0") != 0) {
+            fprintf(stderr, "HARNESS: ROUTER_BOUND reads back '%s', not 0\n", val);
+            return 2;
+        }
+    }
     std::vector<float> md((size_t)nq * S);
     CHECK(gpann_router_query_batch(router, queries.data(), nq, search_budget, probes3.data(), md.data(), 0, nullptr, nullptr));
+    gpann_router_stats st3{};
+    CHECK(gpann_router_get_stats(router, &st3));
+    if (st3.bound_calls != st.bound_calls) {   // (the reference call must not have gone through the path it is the reference for)
+        fprintf(stderr, "HARNESS: the canonical call ran %llu bound blocks\n", (unsigned long long)(st3.bound_calls - st.bound_calls));
+        return 2;
+    }
     size_t bad1 = 0, bad2 = 0;
     for (uint32_t q = 0; q < nq; ++q) {
         bad1 += std::memcmp(&probes[(size_t)q * S], &probes3[(size_t)q * S], S * 4) != 0;
