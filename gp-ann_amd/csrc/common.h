@@ -257,7 +257,14 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
 // (FilterKernelCells also keeps its wavefronts together to the end: a barrier after the last work item.)
 // The hunt, with the experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe:
 // tools/overlap_race_probe.py.
+#ifdef GPANN_EXPERIMENT_SHARED_SIMDS
+// (measurement builds only — `make -C gp-ann_amd experiment-shared-simds` -> lib_experiment/libgpann_hip.so, never the shipped library: the matrix-core
+// kernels keep their natural register counts, i.e. leave room on their SIMDs, so that tools/router_event_experiment.sh can put another process's
+// int8 matrix wavefronts beside RouterBoundKernel and see what its self-check then reports.  tests/test_capi_exports.py checks the SHIPPED code objects.)
+__device__ __forceinline__ void TakeWholeRegisterFile() {}
+#else
 __device__ __forceinline__ void TakeWholeRegisterFile() { asm volatile("" ::: "v255"); }
+#endif
 
 __device__ __forceinline__ bool PairLess(float d1, uint32_t i1, float d2, uint32_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); }
 // float <-> uint32 whose unsigned order is the float order (negative inner-product "distances" included): atomicMin on the keys

@@ -12,6 +12,8 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libgpann_hip.so")
+if os.environ.get("GPANN_HIP_LIBRARY"):   # another build of the same library: the co-tenancy-safe flavour (make cotenant-safe -> lib_cotenant/), or the measurement build of tools/router_event_experiment.sh
+    LIB_PATH = os.path.abspath(os.environ["GPANN_HIP_LIBRARY"])
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = range(6)
 METRIC_L2, METRIC_MIPS = 0, 1

@@ -149,3 +149,7 @@ def test_matrix_core_kernels_are_allocated_the_whole_register_file():
     mnemonics = {m for _, _, ms in ok for m in ms}
     assert "v_mfma_i32_32x32x32_i8" in mnemonics and "v_mfma_f32_32x32x16_bf16" in mnemonics   # (the check saw the filter and the router kernels)
     assert len(ok) >= 60
+    # ... and no packed fp32 arithmetic anywhere (Makefile: -target-feature -packed-fp32-ops): beside another kernel's or process's int8 matrix
+    # wavefronts it was measured to go wrong in lanes 48 - 63 — scalar fp32, the same IEEE operations, is not disturbed (profiles/r06/NOTES.md §2)
+    packed = kr.check_no_packed_fp32(pygpann.LIB_PATH)
+    assert not packed, "\n".join(packed[:10])

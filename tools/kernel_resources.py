@@ -2,7 +2,8 @@
 """Registers / spills / LDS of the gfx950 kernels in a built object file or shared library, from the code objects' metadata notes.
     python tools/kernel_resources.py [gp-ann_amd/build/scan.o | gp-ann_amd/lib/libgpann_hip.so] [name fragment ...]
     python tools/kernel_resources.py --check-matrix-kernels [gp-ann_amd/lib/libgpann_hip.so]
---check-matrix-kernels disassembles every code object and fails (exit 1) unless every symbol that holds a matrix instruction (v_mfma_*) is a
+--check-matrix-kernels disassembles every code object and fails (exit 1) if any symbol holds a packed fp32 instruction (v_pk_add/mul/fma_f32: the library
+is built without them, profiles/r06/NOTES.md §2) or unless every symbol that holds a matrix instruction (v_mfma_*) is a
 kernel that is allocated ALL 256 architectural vector registers: two such wavefronts fill a SIMD's register file, so no wavefront of another launch can
 run beside them (csrc/common.h TakeWholeRegisterFile; profiles/r05/overlap_race.md — a wavefront that shared a SIMD with another kernel's
 v_mfma_i32_32x32x32_i8 wavefront was measured to end with wrong registers).  tests/test_capi_exports.py runs the same check on the shipped library."""
@@ -66,8 +67,8 @@ def kernel_table(image):
     return rows
 
 
-def matrix_symbols(image):
-    """{symbol: set of matrix-instruction mnemonics in its body} of one code object (disassembly)"""
+def matrix_symbols(image, pattern=r"\b(v_(?:mfma|smfmac)_\w+)"):
+    """{symbol: set of matrix-instruction mnemonics in its body} of one code object (disassembly); `pattern`: another class of instruction"""
     with tempfile.NamedTemporaryFile(suffix=".co") as f:
         f.write(image)
         f.flush()
@@ -78,7 +79,7 @@ def matrix_symbols(image):
             if m:
                 sym = m.group(1)
                 continue
-            m = re.search(r"\b(v_(?:mfma|smfmac)_\w+)", line)
+            m = re.search(pattern, line)
             if m and sym:
                 found.setdefault(sym, set()).add(m.group(1))
         proc.wait()
@@ -104,6 +105,20 @@ def check_matrix_kernels(path):
     return ok, bad
 
 
+PACKED_FP32 = r"\b(v_pk_(?:add|mul|fma)_f32)\b"
+
+
+def check_no_packed_fp32(path):
+    """-> failure messages: symbols of the library that hold a packed fp32 instruction.  The library is built without them (Makefile HIPFLAGS:
+    -target-feature -packed-fp32-ops) because beside another kernel's or process's int8 matrix wavefronts a wavefront's packed fp32 arithmetic was
+    measured to go wrong in lanes 48 - 63 while scalar fp32 is not disturbed (profiles/r06/NOTES.md §2)."""
+    bad = []
+    for image in code_objects(path):
+        for sym, mnemonics in sorted(matrix_symbols(image, PACKED_FP32).items()):
+            bad.append(f"{sym}: packed fp32 instructions {sorted(mnemonics)} — the library is built with -target-feature -packed-fp32-ops")
+    return bad
+
+
 def main():
     args = sys.argv[1:]
     if args and args[0] == "--check-matrix-kernels":
@@ -112,9 +127,11 @@ def main():
         names = demangle([s for s, _, _ in ok]) if ok else {}
         for sym, v, mn in ok:
             print(f"ok   {v:>4}  {','.join(mn):<60} {names[sym][:120]}")
-        for msg in bad:
+        packed = check_no_packed_fp32(path)
+        for msg in bad + packed:
             print("FAIL", msg)
-        print(f"{len(ok)} matrix-core kernel instances with 256 vector registers, {len(bad)} failures")
+        print(f"{len(ok)} matrix-core kernel instances with 256 vector registers, {len(bad)} failures; {len(packed)} symbols with packed fp32 instructions")
+        bad = bad + packed
         sys.exit(1 if bad or not ok else 0)
     lib = args[0] if args and os.path.exists(args[0]) else "gp-ann_amd/build/scan.o"
     frags = [a for a in args if not os.path.exists(a)]
