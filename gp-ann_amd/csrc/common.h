@@ -243,20 +243,19 @@ __device__ __forceinline__ void AccumulateTail(float (&acc)[4][4], const float4 
     }
 }
 
-// lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15)
+// lexicographic (dist, id) < (dist2, id2): the order of std::pair<float,uint32_t> that TopN uses (src/topn.h:15): PairLess, below
 // A kernel that calls this is allocated all 256 architectural vector registers per wavefront: two of its wavefronts fill a SIMD's register
 // file, so no wavefront of ANOTHER launch can be resident on that SIMD beside them.  The matrix-core kernels (FilterKernelCells, RouterBoundKernel:
-// 512-thread workgroups, one per CU — nothing of their own is lost) call it because wavefronts of other launches that shared a SIMD with theirs
-// were seen to end with WRONG REGISTERS: with GPANN_SCAN_OVERLAP and 64-dimensional rows (filter kernels of 140 - 230 registers, room for the
-// short kernels of another call's front beside them) about one call in 500 lost a task's candidates — traced to single accumulator registers of
-// a co-resident CellDistKernel wavefront, lanes 48 - 63, holding other values than the same call made alone (the table entries it then wrote
-// differed, the cell tests and 8-bit thresholds built on them pruned rows of the true top-k); never at 128 dimensions, where the filter kernels
-// use 256 registers anyway, and gone (0 events in 10 000 pipelines against 12 - 99 per 2 500) once they do so everywhere.  Outside the product the
-// instruction is named: a wavefront beside a wavefront of another kernel that issues v_mfma_i32_32x32x32_i8 ends with wrong lanes 48 - 63 — every time in
-// tools/microbench/coresidency_repro.hip, never beside bf16 / f16 matrix instructions or vector code, never among wavefronts of the int8 kernel itself.
-// (FilterKernelCells also keeps its wavefronts together to the end: a barrier after the last work item.)
-// The hunt, with the experiments that ruled out streams, caches, LDS-DMA and the scalar cache: profiles/r05/overlap_race.md; the probe:
-// tools/overlap_race_probe.py.
+// 512-thread workgroups, one per CU — nothing of their own is lost) call it.  History: with GPANN_SCAN_OVERLAP and 64-dimensional rows (filter kernels
+// of 140 - 230 registers: room beside them for the short kernels of another call's front) about one call in 500 lost a task's candidates — traced to
+// single accumulator registers of a co-resident CellDistKernel wavefront, lanes 48 - 63 (round 5, profiles/r05/overlap_race.md); gone once the int8
+// kernels took their SIMDs whole and left them together (a barrier after the last work item): 0 events in 1.8 million overlapped calls
+// (profiles/r06/NOTES.md §1).  Round 6 named the victim's side: the RESULTS OF PACKED fp32 INSTRUCTIONS (v_pk_add/mul_f32 with an op_sel-broadcast
+// source that came from a load) go wrong in lanes 48 - 63 while ANOTHER kernel — or another PROCESS — issues gfx950's int8 matrix instructions
+// (v_mfma_i32_32x32x32_i8 / 16x16x64_i8) on the same SIMD; scalar fp32 instructions are not disturbed.  The library is therefore also built WITHOUT
+// packed fp32 (Makefile: -target-feature -packed-fp32-ops; same IEEE operations, same bits, no measurable cost) — beside an int8 neighbour process 186 of
+// 285 GPU tests failed before, 302 of 302 pass now (profiles/r06/NOTES.md §2; tools/microbench/coresidency_victims.hip, matrix_neighbour.hip).  Both
+// properties are checked on the built library: tools/kernel_resources.py --check-matrix-kernels, tests/test_capi_exports.py.
 #ifdef GPANN_EXPERIMENT_SHARED_SIMDS
 // (measurement builds only — `make -C gp-ann_amd experiment-shared-simds` -> lib_experiment/libgpann_hip.so, never the shipped library: the matrix-core
 // kernels keep their natural register counts, i.e. leave room on their SIMDs, so that tools/router_event_experiment.sh can put another process's

@@ -77,17 +77,15 @@ enum {
                                           passes follow each other without a gap (every call in flight owns its device workspaces).  `stream` only orders the call's START (the call waits for what `stream` holds when it
                                           is issued); its results are in place when gpann_scan_finish returns, NOT when `stream` has drained.
                                           What the flag may NOT change is the result: every list entry is still the canonical distance of a real row.
-                                          It rests on a property of the built kernels that the library checks for itself: kernels of different calls then
-                                          share compute units, and a wavefront that shares a SIMD with ANOTHER launch's v_mfma_i32_32x32x32_i8 wavefront
-                                          was measured to end with wrong vector registers (profiles/r05/overlap_race.md; reproducer
-                                          tools/microbench/coresidency_repro.hip).  Every matrix-core kernel of this library is therefore allocated all 256
-                                          vector registers and keeps its wavefronts together to the end — nothing of another launch ever runs on its
-                                          SIMDs (checked on the code objects by tests/test_capi_exports.py and, for the kernels a store launches, asked of
-                                          the runtime before its first overlapped call: a build without the property IGNORES this flag and says so on
-                                          stderr).  Before that rule about one overlapped call in 500 lost a neighbour at d <= 64 (never at 96 / 128
-                                          dimensions, where the kernels need 256 registers anyway); with it the long-run stress of
-                                          profiles/r06/overlap_stress.md is the evidence on record.  gpann_scan_stats.overlapped says whether the
-                                          flag took effect for a call. */
+                                          Kernels of different calls then share compute units, and on this part that needs two properties of the BUILT
+                                          library, both checked (tests/test_capi_exports.py on the code objects; the first also asked of the runtime
+                                          for the kernels a store launches — a build without it IGNORES this flag and says so on stderr):
+                                          every matrix-core kernel is allocated all 256 vector registers and leaves its SIMDs together (nothing of
+                                          another launch runs beside int8 matrix wavefronts), and the library contains no packed fp32 instruction (the
+                                          results of v_pk_*_f32 were measured to go wrong in lanes 48 - 63 beside another kernel's int8 matrix
+                                          instructions; scalar fp32 is not disturbed).  Round 5, before either: about one overlapped call in 500 lost a
+                                          neighbour at d <= 64; since: 0 events in 1.8 million overlapped calls (profiles/r06/NOTES.md).
+                                          gpann_scan_stats.overlapped says whether the flag took effect for a call. */
     GPANN_SCAN_DEFER = 1 << 6          /* gpann_scan_buckets: plan the call and ENQUEUE its work — uploads, kernels, the copies into host output
                                           arrays — then return; gpann_scan_finish completes it (waits, reads the pipeline's counters, redoes the call
                                           with the plain exact scan should the data have defeated the filter, statistics, timing).  TWO further

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Long-run stress of GPANN_SCAN_OVERLAP's exactness (profiles/r06/overlap_stress.md): tools/overlap_race_probe.py over the configurations in which
+# Long-run stress of GPANN_SCAN_OVERLAP's exactness (profiles/r06/NOTES.md §1): tools/overlap_race_probe.py over the configurations in which
 # round 5 saw wrong lists before the matrix-core kernels took whole SIMDs — 64 / 32 / 48 dimensions, one and two calls ahead, persistent and leaving
 # rest-pass workgroups, L2 and inner product — each for SECONDS (default 120) of back-to-back pipelines, every batch compared bit for bit with the plain call.
 #   bash tools/overlap_stress.sh [seconds per configuration] [output directory]
