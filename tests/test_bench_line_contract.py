@@ -1,5 +1,5 @@
 """SCHEMA check of committed artefacts (not behavioural coverage: tests/test_gpu_bench_line.py runs bench.py itself on a GPU and validates the line it prints).
-The committed bench lines (profiles/r03|r04/bench_*.json, each the single JSON line `python bench.py ...` printed on an MI355X) carry every field of the
+The committed bench lines (profiles/r03 … r06/bench_*.json, each the single JSON line `python bench.py ...` printed on an MI355X) carry every field of the
 measurement contract: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data /
 config.workload, the `roofline` object (bound, achieved, peak, unit, frac, traffic) and — where the CPU leg ran — `cpu_baseline`; and the self-checks
 of the run (filter mode == exact mode, GPU == CPU oracle) are recorded as true."""
@@ -12,7 +12,7 @@ import pytest
 from conftest import ROOT
 
 FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "bench_*.json")) +
-               glob.glob(os.path.join(ROOT, "profiles", "r05", "bench_*.json")))
+               glob.glob(os.path.join(ROOT, "profiles", "r05", "bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_*.json")))
 
 
 def _line(path):
@@ -45,7 +45,7 @@ def test_bench_line_has_the_contract_fields(path):
         assert c["kind"] in ("port", "reference") and c["results_match_gpu"] is True
 
 
-@pytest.mark.parametrize("rnd", ["r03", "r04", "r05"])
+@pytest.mark.parametrize("rnd", ["r03", "r04", "r05", "r06"])
 def test_the_default_line_is_the_metric_workload(rnd):
     path = os.path.join(ROOT, "profiles", rnd, "bench_ns_default.json")
     if not os.path.exists(path):

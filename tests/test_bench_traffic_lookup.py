@@ -22,7 +22,7 @@ def _bench():
 def test_traffic_of_the_ns_rest_pass_comes_from_the_newest_round():
     b = _bench()
     traffic, src = b.lookup_traffic(100_000_000, 128, 40, 1, "FilterKernelCells<", {"": 1}, largest_launch=True)
-    assert src is not None and src.startswith("profiles/r05/"), src      # (the newest committed pass of this workload)
+    assert src is not None and src.startswith("profiles/r06/"), src      # (the newest committed pass of this workload)
     # the rest pass reads about one int8 plane + norm word per row of the store: 100M x 132 B, give or take the pruned / repeated cells
     assert 10e9 < traffic < 15e9, traffic
     # and it is only reported for a run whose rest pass has to read the same bytes
