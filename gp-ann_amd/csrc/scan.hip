@@ -70,9 +70,9 @@ constexpr int kDC = 32;          // dims per staged chunk
 constexpr int kLdsStride = kDC + 4;   // floats; +4 keeps the 16 row addresses of a ds_read_b128 lane group on distinct banks
 constexpr int kThreads = 256;
 // The 64 point rows of a tile lie in LDS as 32 PAIRS (rows r and r + 16, r in [0,16) or [32,48)): [pair][dim][member], so that one
-// ds_read_b128 delivers two dimensions of both rows and every operation of the distance sequence is a packed (two-lane) fp32
-// instruction on a natural register pair — (x_a - q.x, x_b - q.x) and so on, the query operand broadcast by the instruction's op_sel.
-// (With one row per float4 the pairs had to be formed across dimensions: 32 v_mov per 192 packed operations.)
+// ds_read_b128 delivers two dimensions of both rows: the distance sequence runs on natural register pairs — (x_a - q.x, x_b - q.x) and so on
+// (common.h AccumulatePairs; scalar fp32 instructions since round 6, the library is built without the packed forms).
+// (With one row per float4 the pairs had to be formed across dimensions: 32 v_mov per 192 operations.)
 constexpr int kPairStride = 2 * kDC + 4;   // floats per pair row; +4: the 16 pair addresses of a lane group on distinct banks
 constexpr int kQueriesPerWave = kQT / 4;
 

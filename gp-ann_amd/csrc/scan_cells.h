@@ -1020,8 +1020,8 @@ __global__ void __launch_bounds__(64 * NW, 1) FilterKernelCells(CellFilterArgs a
         // 255 x 12582912 x s0 — Q8Threshold's e_bias covers the roundings at that magnitude)
         const float s0 = cell_scale * U[q0], b0 = BIAS ? __builtin_fmaf(kBias255, s0, Bq[Q8 ? q0 : 0]) : Bq[Q8 ? q0 : 0];
         uint32_t neg = 0;
-        // two accumulators per instruction: v_pk_fma_f32 / v_pk_add_f32 on register pairs (the matrix instruction's 16 result registers are
-        // consecutive) — 40 vector instructions per product instead of 64 (each element the same IEEE operation as before: same bits)
+        // written on pairs of accumulators (the matrix instruction's 16 result registers are consecutive); built without packed fp32 (Makefile) every
+        // element is one v_fma_f32 / v_sub_f32 — the same IEEE operation as the packed form computed per lane: same bits
         const f32x2 k254 = {254.0f, 254.0f}, s02 = {s0, s0}, b02 = {b0, b0};
 #pragma unroll
         for (int gg = 3; gg >= 0; --gg) {   // (accumulator 15 first: the last sign shifted in, accumulator 0's, is bit 0)
