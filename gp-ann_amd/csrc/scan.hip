@@ -108,7 +108,10 @@ __device__ __forceinline__ void ListInsert(float& ld_, uint32_t& lr_, float cd, 
 // (3 workgroups per CU: 164 VGPRs with the inner loop unrolled by 2.  A 4-workgroup budget — 128 VGPRs, no unrolling, 23 spills — measured
 // 6 % slower.)
 // (round 6, on scalar fp32 instructions — tools/exact_scan_timing.py, 8M x 128, 2048 queries: 3 workgroups / unroll 2 35.7 ms; 4 / 1 37.5; 3 / 4 35.9;
-// 2 / 4 42.2; 2 / 8 35.8; 3 / 1 36.3: the kernel is at the ceiling of its LDS-read mix whatever the occupancy)
+// 2 / 4 42.2; 2 / 8 35.8; 3 / 1 36.3.  A different kernel altogether — a wavefront owns 16 queries x 64 rows, the query values are SCALAR operands
+// (s_load_dwordx4, two blocks of eight in flight), a lane reads only its own row from LDS, no distance tile through LDS: 192 of 240 instructions of its
+// inner loop are arithmetic — ran the same store in 37.4 ms, same bits (profiles/r06/exact_kernel/).  Two unlike designs at 42 - 44 T lane-operations/s:
+// the limit is not this kernel's LDS mix.)
 template <int METRIC, int TAG>
 __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
     extern __shared__ float4 smem4[];
@@ -276,147 +279,6 @@ __global__ void __launch_bounds__(kThreads, 3) ScanTileKernel(ScanArgs a) {
         const uint32_t ql = wave * kQueriesPerWave + j;
         if (ql < u.task_count && lane < (int)k) {
             const size_t list = (size_t)a.task_part[u.task_begin + ql] + u.seg;
-            a.part_dist[list * k + lane] = list_d[j];
-            a.part_row[list * k + lane] = list_r[j];
-        }
-    }
-}
-
-// ---- the exact scan with the QUERIES IN SCALAR REGISTERS (round 6) --------------------------------------------------------------
-// ScanTileKernel's 4 x 4 register tile reads eight 16-byte operands from LDS per 192 vector instructions, four of them (the query rows) as
-// broadcast reads that use a quarter of the LDS' width: the kernel sits at the ceiling of that mix (0.63 of the vector ALUs' rate whatever the
-// occupancy or unrolling, tools/exact_scan_timing.py).  Here a wavefront owns 16 QUERIES x the tile's 64 ROWS, one row per lane: the 16 query rows are
-// the same for every lane, so their values are SCALAR operands (s_load_dwordx4 straight from the query array, no LDS, no vector register), a lane
-// reads nothing but its own row (one ds_read_b128 per group of four dimensions instead of eight), and its 16 accumulators are already what the
-// selection wants — lane = row, register = query — without the round trip of the 64 x 64 distance tile through LDS.  Same arithmetic per (query, row)
-// pair as AccumulateGroup / AccumulateTail (src/dist.cpp:17-52), so the same bits.
-constexpr int kRowQ = 16;   // queries per wavefront
-template <int METRIC>
-__device__ __forceinline__ float RowGroupStep(float r, const float4& p, const float4& q) {
-    if (METRIC == GPANN_METRIC_L2) {
-        const float d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
-        float t = d0 * d0 + d1 * d1;
-        t = t + d2 * d2;
-        t = t + d3 * d3;
-        return r + t;
-    }
-    r = r + q.x * p.x;
-    r = r + q.y * p.y;
-    r = r + q.z * p.z;
-    r = r + q.w * p.w;
-    return r;
-}
-template <int METRIC, int TAG>
-__global__ void __launch_bounds__(kThreads, 4) ScanRowKernel(ScanArgs a) {
-    extern __shared__ float4 smem4[];
-    float* sP = reinterpret_cast<float*>(smem4);   // [2][64 rows][36]: the tile's rows, one 32-dimension chunk at a time, double buffered
-    const int64_t u_row_begin = a.units[blockIdx.x].row_begin, u_row_end = a.units[blockIdx.x].row_end;
-    const uint32_t u_task_begin = a.units[blockIdx.x].task_begin, u_task_count = a.units[blockIdx.x].task_count, u_seg = a.units[blockIdx.x].seg;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: everything indexed by it is loaded by the scalar unit)
-    const uint32_t d = a.d, ld = a.ld, k = a.k;
-    const uint32_t full_groups = d >> 2;
-    const int tail = (int)(d & 3u);
-    const uint32_t nchunks = (ld + kDC - 1) / kDC;
-    // this wavefront's queries: element offsets of their rows in the query array (scalars)
-    uint32_t qoff[kRowQ];
-#pragma unroll
-    for (int j = 0; j < kRowQ; ++j) qoff[j] = a.task_query[u_task_begin + min((uint32_t)(wave * kRowQ + j), u_task_count - 1)] * ld;
-    const float* __restrict__ qbase = a.queries;
-
-    float list_d[kRowQ];
-    uint32_t list_r[kRowQ];
-#pragma unroll
-    for (int j = 0; j < kRowQ; ++j) {
-        list_d[j] = INFINITY;
-        list_r[j] = kNoId;
-    }
-    // staging role: float4 #st_c4 of rows st_row0 and st_row1 of the tile's chunk
-    const int st_row0 = tid >> 3, st_row1 = (tid + 256) >> 3, st_c4 = tid & 7;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t row0 = u_row_begin; row0 < u_row_end; row0 += kPT) {
-        float acc[kRowQ];
-#pragma unroll
-        for (int j = 0; j < kRowQ; ++j) acc[j] = 0.f;
-        const float* prow0 = a.points + (size_t)min(row0 + st_row0, u_row_end - 1) * ld;
-        const float* prow1 = a.points + (size_t)min(row0 + st_row1, u_row_end - 1) * ld;
-        {   // chunk 0 into buffer 0 (every wavefront has left the previous tile's last chunk: its iteration ended with a barrier)
-            const uint32_t c = 4u * st_c4;
-            const bool in = c < ld;
-            const float4 g0 = in ? *reinterpret_cast<const float4*>(prow0 + c) : zero4, g1 = in ? *reinterpret_cast<const float4*>(prow1 + c) : zero4;
-            *reinterpret_cast<float4*>(sP + st_row0 * kLdsStride + 4 * st_c4) = g0;
-            *reinterpret_cast<float4*>(sP + st_row1 * kLdsStride + 4 * st_c4) = g1;
-        }
-        __syncthreads();
-        for (uint32_t ch = 0; ch < nchunks; ++ch) {
-            float4 gp0 = zero4, gp1 = zero4;
-            if (ch + 1 < nchunks) {   // the next chunk's rows: on their way while this chunk is multiplied
-                const uint32_t c = (ch + 1) * kDC + 4u * st_c4;
-                if (c < ld) {
-                    gp0 = *reinterpret_cast<const float4*>(prow0 + c);
-                    gp1 = *reinterpret_cast<const float4*>(prow1 + c);
-                }
-            }
-            const float* my_row = sP + (ch & 1u) * (kPT * kLdsStride) + lane * kLdsStride;
-            const uint32_t g0 = ch * (kDC / 4);
-#pragma unroll
-            for (int g = 0; g < kDC / 4; ++g) {
-                const uint32_t G = g0 + g;
-                if (G < full_groups) {
-                    const float4 p = *reinterpret_cast<const float4*>(my_row + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < kRowQ; ++j) {
-                        const float4 q = *reinterpret_cast<const float4*>(qbase + qoff[j] + 4u * G);
-                        acc[j] = RowGroupStep<METRIC>(acc[j], p, q);
-                    }
-                } else if (G == full_groups && tail != 0) {
-                    const float4 p = *reinterpret_cast<const float4*>(my_row + 4 * g);
-#pragma unroll
-                    for (int j = 0; j < kRowQ; ++j) {
-                        const float* q = qbase + qoff[j] + 4u * G;
-                        float r = acc[j];
-                        r = TailStep<METRIC>(r, p.x, q[0]);
-                        if (tail > 1) r = TailStep<METRIC>(r, p.y, q[1]);
-                        if (tail > 2) r = TailStep<METRIC>(r, p.z, q[2]);
-                        acc[j] = r;
-                    }
-                }
-            }
-            if (ch + 1 < nchunks) {
-                float* dst = sP + ((ch + 1) & 1u) * (kPT * kLdsStride);
-                *reinterpret_cast<float4*>(dst + st_row0 * kLdsStride + 4 * st_c4) = gp0;
-                *reinterpret_cast<float4*>(dst + st_row1 * kLdsStride + 4 * st_c4) = gp1;
-            }
-            __syncthreads();
-        }
-        // selection: lane = row of the tile, accumulator j = this wavefront's query j
-        const uint32_t my_row_id = (uint32_t)(row0 + lane);
-        const bool row_valid = row0 + lane < u_row_end;
-#pragma unroll
-        for (int j = 0; j < kRowQ; ++j) {
-            const float v = METRIC == GPANN_METRIC_MIPS ? 1.0f - acc[j] : acc[j];   // src/dist.cpp:50-52
-            float td = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(list_d[j]), k - 1));
-            uint32_t tr = (uint32_t)__builtin_amdgcn_readlane((int)list_r[j], k - 1);
-            bool pass = row_valid && PairLess(v, my_row_id, td, tr);
-            unsigned long long mask = __ballot(pass);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                const float cd = __shfl(v, l);
-                const uint32_t cr = (uint32_t)(row0 + l);
-                ListInsert(list_d[j], list_r[j], cd, cr, k, lane);
-                td = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(list_d[j]), k - 1));
-                tr = (uint32_t)__builtin_amdgcn_readlane((int)list_r[j], k - 1);
-                pass = pass && lane > l && PairLess(v, my_row_id, td, tr);
-                mask = __ballot(pass);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kRowQ; ++j) {
-        const uint32_t ql = wave * kRowQ + j;
-        if (ql < u_task_count && lane < (int)k) {
-            const size_t list = (size_t)a.task_part[u_task_begin + ql] + u_seg;
             a.part_dist[list * k + lane] = list_d[j];
             a.part_row[list * k + lane] = list_r[j];
         }
@@ -748,16 +610,7 @@ static gpann_status RunExactStage(gpann_shards* s, ScanPlan& plan, const TaskArr
         const size_t lds = (size_t)(kQT * kLdsStride + (kPT / 2) * kPairStride + kQT * kPT) * sizeof(float);
         const dim3 grid((uint32_t)plan.units.size());
         const bool aux = (flags & GPANN_AUX_PASS) != 0;
-        if (s->opt.U32("GPANN_SCAN_ROW_KERNEL", 1) != 0) {   // the scalar-query kernel (ScanRowKernel)
-            const size_t rlds = (size_t)2 * kPT * kLdsStride * sizeof(float);
-            if (s->metric == GPANN_METRIC_L2) {
-                if (aux) hipLaunchKernelGGL((ScanRowKernel<GPANN_METRIC_L2, 1>), grid, dim3(kThreads), rlds, st, a);
-                else hipLaunchKernelGGL((ScanRowKernel<GPANN_METRIC_L2, 0>), grid, dim3(kThreads), rlds, st, a);
-            } else {
-                if (aux) hipLaunchKernelGGL((ScanRowKernel<GPANN_METRIC_MIPS, 1>), grid, dim3(kThreads), rlds, st, a);
-                else hipLaunchKernelGGL((ScanRowKernel<GPANN_METRIC_MIPS, 0>), grid, dim3(kThreads), rlds, st, a);
-            }
-        } else if (s->metric == GPANN_METRIC_L2) {
+        if (s->metric == GPANN_METRIC_L2) {
             if (aux) hipLaunchKernelGGL((ScanTileKernel<GPANN_METRIC_L2, 1>), grid, dim3(kThreads), lds, st, a);
             else hipLaunchKernelGGL((ScanTileKernel<GPANN_METRIC_L2, 0>), grid, dim3(kThreads), lds, st, a);
         } else {

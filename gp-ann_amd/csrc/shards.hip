@@ -95,7 +95,6 @@ static const Knob kKnobs[] = {
     {"GPANN_FILTER_HI_FROM_PASS", 'C', "first hi-plane-only pass (default 1)"},
     {"GPANN_RESCORE_PARTS", 'C', "wavefronts a heavy candidate bucket is split over (default: 2 .. 8 from the task count)"},
     {"GPANN_RESCORE_SPLIT_MIN", 'C', "candidates per piece of a split bucket (default 128)"},
-    {"GPANN_SCAN_ROW_KERNEL", 'C', "exact mode: 0 = the 4 x 4 register-tile kernel (ScanTileKernel) instead of the scalar-query kernel (ScanRowKernel, default)"},
     {"GPANN_SCAN_TARGET_UNITS", 'C', "exact mode: workgroups a launch is cut into (default 8192)"},
     {"GPANN_SCAN_MIN_SEG_ROWS", 'C', "exact mode: smallest row segment of a unit"},
     {"GPANN_OVERLAP_FRONT_CUS", 'C', "GPANN_SCAN_OVERLAP: workgroups of a front's filter launches (default 96; stores whose planes are below 4 GB: all CUs)"},

@@ -191,3 +191,4 @@ def test_back_to_back_untimed_device_calls_do_not_share_staged_tasks(orc, gp):
         hip.hipFree(b)
     hip.hipFree(q_dev)
     hip.hipStreamDestroy(st)
+
