@@ -192,3 +192,32 @@ def test_back_to_back_untimed_device_calls_do_not_share_staged_tasks(orc, gp):
     hip.hipFree(q_dev)
     hip.hipStreamDestroy(st)
 
+
+def test_scan_stats_sized_for_callers_of_another_abi_revision(orc, gp):
+    """gpann_scan_last_stats_sized: gpann_scan_stats only ever grows at its end, so a caller built against an older (shorter) or newer (longer) header
+    passes ITS sizeof and gets the fields both sides know — nothing written past its buffer, the unknown tail zeroed; gpann_abi_version() = the header's"""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n, d, S, nq, k = 3000, 32, 2, 40, 5
+    pts = make_mixture(orc, n, d)
+    clusters = random_clusters(rng, n, S)
+    queries = make_mixture(orc, nq, d, seed=556)
+    probes = np.tile(np.arange(S, dtype=np.int32), (nq, 1))
+    shards = gp.Shards(pts, clusters, 0, 0)
+    shards.scan_buckets(queries, k, probes, S)
+    full = shards.stats()
+    L = gp.lib()
+    assert L.gpann_abi_version() >= 6
+    size = C.sizeof(gp.ScanStats)
+    # an older caller: knows the struct up to filter_candidates (56 bytes); a guard word behind its buffer must stay untouched
+    buf = (C.c_uint8 * 64)(*([0xAB] * 64))
+    assert L.gpann_scan_last_stats_sized(shards.h, buf, C.c_size_t(56)) == 0
+    old = np.frombuffer(bytes(buf), dtype=np.uint64)
+    assert old[0] == full["pairs"] and old[2] == full["tasks"] and old[6] == full["filter_candidates"] and old[7] == 0xABABABABABABABAB
+    # a newer caller: a longer struct — the tail it knows and this library does not is zeroed
+    big = (C.c_uint8 * (size + 32))(*([0xCD] * (size + 32)))
+    assert L.gpann_scan_last_stats_sized(shards.h, big, C.c_size_t(size + 32)) == 0
+    raw = bytes(big)
+    st = gp.ScanStats.from_buffer_copy(raw[:size])
+    assert st.pairs == full["pairs"] and st.tasks == nq * S and raw[size:] == bytes(32)
+    shards.close()
