@@ -743,7 +743,7 @@ def main():
     # (several ranks: the scan is deferred the same way — into device arrays, two sets — and the exchange of batch i's slot lists (gather_slots,
     # the copies to the host) runs on a THIRD stream once its scan has been completed, next to the scan of batch i + 1)
     scan_ahead = route_ahead and os.environ.get("GPANN_BENCH_SCAN_AHEAD", "1") != "0"
-    # (round 5) ... on the handle's own two streams (GPANN_SCAN_OVERLAP): the passes before the rest pass of batch i + 1 — short launches that leave
+    # (round 5) ... on the handle's own streams (GPANN_SCAN_OVERLAP: a front stream per call slot, one rest stream, one tail stream): the passes before the rest pass of batch i + 1 — short launches that leave
     # most of the chip idle — run BESIDE the rest pass of batch i, which is bound by HBM and gives up compute units every few work items.
     # GPANN_BENCH_OVERLAP=0: both calls on one stream, batch i + 1 strictly behind batch i.
     scan_overlap = scan_ahead and os.environ.get("GPANN_BENCH_OVERLAP", "1") != "0"
@@ -1097,7 +1097,7 @@ def main():
     result["config"]["slot_lists"] = ("cut at the query's merge bound (GPANN_SCAN_FOR_MERGE): the merged neighbours are bit-identical to the merge of the "
                                       "complete QueryBucket lists" if merge_bound else "complete QueryBucket lists")
     result["config"]["pipeline"] = (("batches overlap: batch i+2 is routed (second stream), the scan of batch i+1 is planned and enqueued behind batch i (deferred "
-                                     "scan call" + (" on the store's own two streams: its passes before the rest pass run BESIDE the rest pass of batch i, GPANN_SCAN_OVERLAP"
+                                     "scan call" + (" on the store's own streams: its passes before the rest pass run BESIDE the rest pass of batch i, GPANN_SCAN_OVERLAP"
                                                     if scan_overlap else "") + ") and batch i-1 is merged on the host while batch i is scanned" if scan_ahead else
                                      "batches overlap: batch i+1 is routed (second stream) and batch i-1 merged (host) while batch i is scanned")
                                     if route_ahead else "batch i-1 is merged on the host while batch i is routed and scanned")
