@@ -764,7 +764,13 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // the first 1/16 of every needed cell, pass 2 = the rest of the cells still needed under the tightened k-th distance.
     // (GPANN_FILTER_HEAD_ROWS=0: no head pass — the seed lists go straight to the sample pass)
     // (the head pass multiplies both planes: it cannot reach past the rows that have a lo tile)
-    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(s->opt.U32("GPANN_FILTER_HEAD_ROWS", 512), cap_plan / 2) / kGTileRows,
+    // Small shards (on average fewer than GPANN_FILTER_SMALL_SHARD_ROWS rows; default 262144 = the shard size below which DefaultCellRows no longer
+    // shrinks the cells with the shard): no shard-sample and no head pass unless their knobs ask for them.  Both exist to tighten the k-th distances
+    // cheaply BEFORE the passes that stream the store, and each costs a set-up, a filter and a re-scoring launch — about 0.1 ms whatever the store's
+    // size.  On a store whose sample + rest passes take 0.3 ms together they cost more than they save (C2, 1M x 128 in 8 shards, 10k queries:
+    // 1.19 -> 1.02 ms per step, candidates 0.62M -> 0.94M; C3, 10M x 96 in 16 shards, is slower without them: profiles/r06/sweeps/small_store_passes.txt).
+    const bool small_shards = (uint64_t)s->rows < (uint64_t)s->opt.U32("GPANN_FILTER_SMALL_SHARD_ROWS", 262144) * (uint64_t)std::max<uint32_t>(1, s->S);
+    const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(s->opt.U32("GPANN_FILTER_HEAD_ROWS", small_shards ? 0 : 512), cap_plan / 2) / kGTileRows,
                                                                       C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles),
                                                    C.hi_compact ? 16u : 0xFFFFFFFFu);   // (compact hi planes keep 16 tiles of every cell at least)
     int64_t max_rows = 1;
@@ -885,7 +891,7 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     std::vector<uint32_t> stab((size_t)3 * G + 4, 0u);   // group_first [G] | group_count [G] | group_cursor [G] of that pass's lists
     uint32_t* d_stab = nullptr;
     CellItem* d_sitems = nullptr;
-    const bool shard_sample_pass = C.n_sample_tiles != 0 && s->opt.U32("GPANN_FILTER_SEED_ROWS", 128) != 0 && s->opt.U32("GPANN_FILTER_SHARD_SAMPLE", 1) != 0;
+    const bool shard_sample_pass = C.n_sample_tiles != 0 && s->opt.U32("GPANN_FILTER_SEED_ROWS", 128) != 0 && s->opt.U32("GPANN_FILTER_SHARD_SAMPLE", small_shards ? 0 : 1) != 0;
     if (shard_sample_pass) {
         const uint32_t piece = 32;   // row tiles per work item
         for (uint32_t g = 0; g < G; ++g) {

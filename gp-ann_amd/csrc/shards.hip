@@ -70,7 +70,7 @@ struct Knob {
 };
 static const Knob kKnobs[] = {
     // store build
-    {"GPANN_CELL_ROWS", 'B', "target rows per cell (default: rows per shard / 128, between 2048 and 32768)"},
+    {"GPANN_CELL_ROWS", 'B', "target rows per cell (default: rows per shard / 128, at most 32768; shards below 262144 rows: rows per shard / 256, at least 512)"},
     {"GPANN_FILTER_PLANES", 'B', "0: no planes / cells — the store offers the plain exact scan only"},
     {"GPANN_FILTER_LO_ROWS", 'B', "rows per cell that keep a bf16 lo tile (default 512; all: every row — allows GPANN_FILTER_HI_ONLY=0)"},
     {"GPANN_FILTER_HI_ROWS", 'B', "all: every tile keeps its bf16 hi tile although the store has the 8-bit plane"},
@@ -82,13 +82,14 @@ static const Knob kKnobs[] = {
     // scan calls
     {"GPANN_SCAN_MODE", 'C', "exact | filter: overrides gpann_shards_set_scan_mode"},
     {"GPANN_FILTER_CAND_CAP", 'C', "candidate bucket size per task (default: 1024 .. 16384 from the 6 GiB budget)"},
-    {"GPANN_FILTER_HEAD_ROWS", 'C', "rows of the head pass (default 512; 0: no head pass)"},
+    {"GPANN_FILTER_HEAD_ROWS", 'C', "rows of the head pass (default 512 — small shards, GPANN_FILTER_SMALL_SHARD_ROWS: 0; 0: no head pass)"},
     {"GPANN_FILTER_SAMPLE_DIV", 'C', "the sample pass covers 1 / n of a needed cell (default: 8 .. 64 from the bucket size)"},
     {"GPANN_FILTER_Q8_FROM_PASS", 'C', "first pass on the 8-bit plane: 1 sample (default), 2 rest"},
     {"GPANN_FILTER_Q8_L1", 'C', "0: no |q - c|_1 table — Cauchy-Schwarz on the squared distances"},
     {"GPANN_FILTER_SEG_TILES", 'C', "row tiles per work item (default: 16 .. 256 from the store size)"},
     {"GPANN_FILTER_SEED_ROWS", 'C', "rows of the nearest cell evaluated exactly for the first lists (default 128; 0: exact scan of the shard sample)"},
-    {"GPANN_FILTER_SHARD_SAMPLE", 'C', "0: no shard-sample pass"},
+    {"GPANN_FILTER_SHARD_SAMPLE", 'C', "0: no shard-sample pass, 1: with it (default 1 — small shards, GPANN_FILTER_SMALL_SHARD_ROWS: 0)"},
+    {"GPANN_FILTER_SMALL_SHARD_ROWS", 'C', "stores whose shards average fewer rows run without the shard-sample and head passes unless those knobs are set (default 262144; 0: never)"},
     {"GPANN_FILTER_SEED_ALL", 'C', "1: seed every task under the merge bound, not only a query's first slot"},
     {"GPANN_FILTER_SAMPLE_UNIT", 'C', "2: the sample pass on the rest pass's kernel (two row tiles per unit)"},
     {"GPANN_FILTER_HI_ONLY", 'C', "0: all three bf16 products in every pass (needs GPANN_FILTER_LO_ROWS=all)"},
@@ -164,14 +165,17 @@ gpann_status GetOption(const Options& o, const char* name, char* out, size_t cap
 
 using namespace gpann;
 
-// Target rows per cell (GPANN_CELL_ROWS overrides): about 128 cells per shard, between 2048 and 32768 rows.  Measured on the
+// Target rows per cell (GPANN_CELL_ROWS overrides): about 128 cells per shard, at most 32768 rows; shards below 262144 rows: about 256 cells, at least
+// 512 rows.  Measured on the
 // BASELINE.json shapes: 100M x 128 in 40 shards is flat between 16k and 32k rows (bigger cells stream rows for task groups that do not need
-// them, smaller ones add work items); 10M x 96 in 16 shards and 1M x 128 in 8 shards want 4k / 2k rows (their mixture components are that
-// small: larger cells mix components and their balls prune nothing).
+// them, smaller ones add work items); 10M x 96 in 16 shards is flat between 2k and 5k rows; 1M x 128 in 8 shards (mixture components of 977
+// rows: larger cells mix components and their balls prune nothing) 2048 rows 1.365 ms per step, 1024 1.242, 512 1.188, 384 1.188, 256 1.196
+// (profiles/r06/sweeps/small_store_passes.txt; until round 6 the floor was 2048).
 static uint32_t DefaultCellRows(const gpann_shards* s) {
     if (const char* cr = s->opt.Get("GPANN_CELL_ROWS")) return (uint32_t)std::max(64L, std::atol(cr));
     const uint64_t per_shard = s->rows / std::max<uint32_t>(1, s->S);
-    return (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(2048, per_shard / 128));
+    if (per_shard / 128 >= 2048) return (uint32_t)std::min<uint64_t>(32768, per_shard / 128);
+    return (uint32_t)std::max<uint64_t>(512, per_shard / 256);   // small shards (below 262144 rows): about 256 cells, not below 512 rows
 }
 
 extern "C" {

@@ -17,6 +17,7 @@ def test_bench_prints_a_line_that_meets_the_contract(tmp_path):
     env = dict(os.environ, GPANN_BENCH_CPU_QUERIES="200")
     env.pop("GPANN_ROUTER_VERIFY", None)      # (the timed configuration: the shipping path of the router, deferred scan calls)
     env.pop("GPANN_ROUTER_STRICT", None)
+    env.pop("GPANN_FILTER_SMALL_SHARD_ROWS", None)   # (... and the shipped pass structure for a store of this size)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--points", "400000", "--d", "64", "--shards", "6", "--nq", "1000", "--steps", "4", "--warmup", "2",
            "--router-budget", "3000", "--search-budget", "50000"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
@@ -48,7 +49,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment — how the driver starts it — must spawn the two ranks itself
     (bench.py spawn_ranks) and print rank 0's ONE line; here both ranks share the one GPU over the TCP backend."""
     env = dict(os.environ, GPANN_BENCH_FORCE_DEVICE="0", GPANN_COMM_WAIT_S="120")
-    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPANN_COMM_PORT", "GPANN_ROUTER_VERIFY", "GPANN_ROUTER_STRICT"):
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPANN_COMM_PORT", "GPANN_ROUTER_VERIFY", "GPANN_ROUTER_STRICT", "GPANN_FILTER_SMALL_SHARD_ROWS"):
         env.pop(name, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "tcp", "--points", "400000", "--d", "64", "--shards", "6", "--nq", "1000",
            "--steps", "3", "--warmup", "1", "--router-budget", "3000", "--no-cpu-baseline", "--no-exact-compare"]

@@ -113,11 +113,13 @@ def _run_config(orc, gp, n, d, nq, S, k, nprobe, metric, index_budget, search_bu
     return recall
 
 
-def test_c1_100k_x_128(orc, gp):
+def test_c1_100k_x_128(orc, gp, monkeypatch):
+    monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)   # the shipped defaults for a store of this size (conftest.py switches the small-shard rule off)
     _run_config(orc, gp, 100_000, 128, 1000, 4, 10, 2, 0, 5000, 5000, sample=1000)   # every query against the oracle
 
 
-def test_c2_sift1m_shape(orc, gp):
+def test_c2_sift1m_shape(orc, gp, monkeypatch):
+    monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)   # the shipped defaults: 125k rows per shard = small shards
     r = _run_config(orc, gp, 1_000_000, 128, 10_000, 8, 10, 2, 0, 20_000, 50_000, sample=200)
     assert r > 0.9
 

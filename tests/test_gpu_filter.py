@@ -120,6 +120,7 @@ def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, mo
     clusters = [rng.permutation(n).astype(np.uint32)]
     queries = make_mixture(orc, nq, d, seed=556, n_centers=16)
     probes = np.zeros((nq, 1), np.int32)
+    monkeypatch.setenv("GPANN_CELL_ROWS", "2048")          # (the geometry the caps below were chosen for: the default for a store of this size until round 6)
     monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "200")     # expected fill ~ k * 26000 / 4096 = 63 + tail
     st = _check(orc, gp, pts, clusters, queries, probes, 1, k, 0, expect_filtered=None)
     assert st["filtered"] == 0 or st["filter_dirty_tasks"] >= 1, st

@@ -33,6 +33,8 @@ def test_random_configuration(orc, gp, seed, monkeypatch):
     monkeypatch.setenv("GPANN_CELL_ROWS", str(int(rng.choice([64, 300, 1500]))))
     if rng.integers(0, 4) == 0:
         monkeypatch.setenv("GPANN_FILTER_CAND_CAP", "64")          # buckets overflow: dirty tasks / whole-call fallback
+    if seed % 2 == 1:
+        monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)   # the library's default for stores of this size: no shard-sample, no head pass
     pts = make_mixture(orc, n, d, n_centers=int(rng.integers(1, 12)), sigma=float(rng.choice([0.05, 0.35, 1.0])))
     if rng.integers(0, 3) == 0:
         pts += np.float32(rng.normal(0, 50))                       # far from the origin
