@@ -33,6 +33,7 @@ void SetLastError(const char* fmt, ...);
         hipError_t _e = (expr);                                                                               \
         if (_e != hipSuccess) {                                                                               \
             ::gpann::SetLastError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* the runtime keeps a failed launch as the thread's "last error": consumed here, or the NEXT call's check reports it */ \
             return _e == hipErrorOutOfMemory ? GPANN_ERR_OOM : GPANN_ERR_HIP;                                 \
         }                                                                                                     \
     } while (0)

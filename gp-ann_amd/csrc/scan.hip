@@ -1386,10 +1386,12 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             CellFilterArgs f8 = fa;
             f8.image = q8_image;
             // (the rest pass beside another call's front: workgroups that leave after rest_items items, as many as the item capacity can need)
-            uint64_t grid8 = std::min<uint64_t>((uint64_t)pass_cus, items_cap);
+            // (at least one workgroup: a call whose tasks all sit on shards WITHOUT cells — an empty or a three-row shard probed by a single query — has
+            // no work item at all, and a launch of zero workgroups is an invalid configuration; the one workgroup finds every list empty and leaves)
+            uint64_t grid8 = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pass_cus, items_cap));
             if (pass == 2 && rest_items != 0) {
                 f8.wg_item_budget = rest_items;
-                grid8 = std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus);
+                grid8 = std::max<uint64_t>(1, std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus));
             }
             void* kargs8[] = {&f8};
             GPANN_HIP_TRY(hipLaunchKernel(pass == 2 && overlap ? fn_q8_beside : (pass == 2 || sample_wide) ? fn_q8 : fn_q8_sample, dim3((uint32_t)grid8), dim3(64 * q8_waves),
@@ -1397,10 +1399,10 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
             if (pass == 2) plan.filter_rest_row_bytes = 32u * KS8 + 4u;
         } else {
             CellFilterArgs fb = fa;
-            uint64_t gridb = std::min<uint64_t>((uint64_t)pass_cus, items_cap);
+            uint64_t gridb = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pass_cus, items_cap));
             if (pass == 2 && rest_items != 0 && hi_pass) {   // (the two-plane kernel has no item budget: persistent workgroups, all CUs — a store without hi-only passes)
                 fb.wg_item_budget = rest_items;
-                gridb = std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus);
+                gridb = std::max<uint64_t>(1, std::min<uint64_t>(items_cap, (items_cap + rest_items - 1) / rest_items + (uint64_t)n_cus));
             }
             void* kargsb[] = {&fb};
             GPANN_HIP_TRY(hipLaunchKernel(hi_pass ? fn_hi : fn, dim3((uint32_t)gridb), dim3(64 * kFWaves), kargsb, glds, st));

@@ -133,6 +133,37 @@ def test_filtered_scan_single_bucket_overflow_is_rescanned_in_kernel(orc, gp, mo
         st = _check(orc, gp, pts, clusters, queries[:700], probes[:700], 3, k, metric, expect_filtered=None)
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("small_rule", ["0", None])
+def test_call_whose_tasks_all_sit_on_shards_without_cells(orc, gp, monkeypatch, metric, small_rule):
+    """one or two queries that probe only an empty shard and a three-row shard: no (task group, cell) block exists, the filter passes have no work item —
+    found by the fuzz test's longer run in round 6 (seeds 276 / 330 / 471: the filter launch was given ZERO workgroups, GPANN_ERR_HIP "invalid configuration
+    argument", and the failed launch stayed behind as the thread's last HIP error: the next gpann_shards_create failed too)"""
+    if small_rule is None:
+        monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("GPANN_FILTER_SMALL_SHARD_ROWS", small_rule)
+    monkeypatch.setenv("GPANN_CELL_ROWS", "1500")
+    rng = np.random.default_rng(276)
+    n, d, k = 3267, 100, 33
+    pts = make_mixture(orc, n, d, n_centers=1, sigma=1.0) + np.float32(37.0)
+    clusters = [np.arange(3, n, dtype=np.uint32), np.zeros(0, np.uint32), np.arange(3, dtype=np.uint32), rng.permutation(n)[:500].astype(np.uint32)]
+    ivf = orc.ivf_build(pts, clusters)
+    shards = gp.Shards(pts, clusters, metric, 0)
+    for probes in (np.array([[2, 1]], np.int32), np.array([[1, 2], [2, -1]], np.int32), np.array([[1, -1]], np.int32), np.array([[2, 0], [1, 3]], np.int32)):
+        nq = len(probes)
+        queries = make_mixture(orc, nq, d, seed=556, n_centers=1, sigma=1.0) + np.float32(37.0)
+        wd, wi, _ = orc.ivf_query_bucket_batch(ivf, queries, k, probes, 2, metric, nthreads=2)
+        for mode in (1, 0, 1):
+            shards.set_scan_mode(mode)
+            ids, dist, _ = shards.scan_buckets(queries, k, probes, 2)
+            assert np.array_equal(ids, wi), (probes.tolist(), mode)
+            assert np.array_equal(dist.view(np.uint32), wd.view(np.uint32)), (probes.tolist(), mode)
+    shards.close()
+    again = gp.Shards(pts, clusters, metric, 0)      # (... and the thread is left without a stale HIP error)
+    again.close()
+
+
 def test_filter_without_precomputed_planes(orc, gp, monkeypatch):
     """GPANN_FILTER_PLANES=0: a store without bf16 planes / cells offers only the plain exact scan; asking for filter mode
     must silently give the exact answer"""
