@@ -2012,6 +2012,8 @@ gpann_status gpann_ground_truth(gpann_shards* s_all, const float* points, uint64
         temp = true;
     } else {
         GPANN_REQUIRE(s->S == 1, "ground truth needs a 1-shard store over all points");
+        // (rows in another order would break ties by ROW where ComputeGroundTruth, recall.h:25-39, breaks them by point id)
+        GPANN_REQUIRE(s->ids_in_order, "ground truth needs a store whose row i is point i (ids 0 .. n-1 in order)");
     }
     std::vector<int32_t> probes(nq, 0);
     gpann_status st = gpann_scan_buckets(s, queries, nq, k, probes.data(), 1, 1, out_ids, out_dist, nullptr,

@@ -85,6 +85,7 @@ struct gpann_shards {
     uint32_t ld = 0;     // row stride in floats (d rounded up to 4; pad floats are zero and never enter the arithmetic)
     uint32_t S = 0;
     uint64_t rows = 0;   // sum of shard sizes
+    bool ids_in_order = false;   // row i holds point i for every row (what gpann_ground_truth asks of a store it is handed: ties are then broken by id)
     float* points = nullptr;         // [rows][ld]   HBM, shard-contiguous
     uint32_t* permutation = nullptr; // [rows]       row -> global id
     int64_t* d_offsets = nullptr;    // [S+1]        device copy

@@ -221,7 +221,11 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     GPANN_REQUIRE(rows < 0xFFFFFFFFull, "total rows must fit the reference's 32-bit row index (inverted_index.h:9)");
     GPANN_REQUIRE(rows == 0 || ids_concat != nullptr, "ids_concat null");
     for (uint32_t b = 0; b < S; ++b) GPANN_REQUIRE(shard_offsets[b] <= shard_offsets[b + 1], "shard_offsets not monotone");
-    for (uint64_t i = 0; i < rows; ++i) GPANN_REQUIRE(ids_concat[i] < n, "point id out of range");
+    bool ids_in_order = true;
+    for (uint64_t i = 0; i < rows; ++i) {
+        GPANN_REQUIRE(ids_concat[i] < n, "point id out of range");
+        ids_in_order = ids_in_order && ids_concat[i] == i;
+    }
     GPANN_TRY(EnsureDevice(device));
 
     auto* s = new gpann_shards();
@@ -232,6 +236,7 @@ gpann_status gpann_shards_create(const float* points, uint64_t n, uint32_t d, in
     s->ld = RoundUp4(d);
     s->S = S;
     s->rows = rows;
+    s->ids_in_order = ids_in_order;
     s->offsets.assign(shard_offsets, shard_offsets + S + 1);
     auto fail = [&](gpann_status st) {
         gpann_shards_destroy(s);

@@ -186,7 +186,8 @@ gpann_status gpann_shard_search_hits(gpann_shards* s, const float* queries, uint
 
 /* ComputeGroundTruth: exact k-NN of every query over ALL n points, ids are global point ids, ascending (dist, id).
  * points: host|device.  Requires nothing to be resident; builds a temporary 1-shard store unless `s_all` (a store
- * created with S = 1 and ids = 0..n-1) is passed, in which case `points` may be NULL. */
+ * created with S = 1 and ids = 0..n-1 IN ORDER: another row order would break ties by row, not by id, and is refused with GPANN_ERR_INVALID) is
+ * passed, in which case `points` may be NULL. */
 gpann_status gpann_ground_truth(gpann_shards* s_all, const float* points, uint64_t n, uint32_t d, int metric, const float* queries,
                                 uint32_t nq, uint32_t k, uint32_t* out_ids, float* out_dist, int device, int flags, void* stream,
                                 float* elapsed_ms);

@@ -104,5 +104,12 @@ def test_random_entry_point_configuration(orc, gp, seed, monkeypatch):
                 assert np.array_equal(ids2, wi) and np.array_equal(_bits(dist2), _bits(wd)), ("ground truth over a store", cfg)
             finally:
                 store.close()
+            if seed % 8 == 0:      # a store in another row order is refused (it would break ties by row, not by id), not answered differently
+                shuffled = gp.Shards(pts, [rng.permutation(n).astype(np.uint32)], metric, 0)
+                try:
+                    with pytest.raises(gp.GpannError):
+                        gp.ground_truth(None, queries, k, metric, store=shuffled)
+                finally:
+                    shuffled.close()
     finally:
         shards.close()
