@@ -769,7 +769,14 @@ static gpann_status RunCellFilteredScan(gpann_shards* s, ScanPlan& plan, const T
     // cheaply BEFORE the passes that stream the store, and each costs a set-up, a filter and a re-scoring launch — about 0.1 ms whatever the store's
     // size.  On a store whose sample + rest passes take 0.3 ms together they cost more than they save (C2, 1M x 128 in 8 shards, 10k queries:
     // 1.19 -> 1.02 ms per step, candidates 0.62M -> 0.94M; C3, 10M x 96 in 16 shards, is slower without them: profiles/r06/sweeps/small_store_passes.txt).
-    const bool small_shards = (uint64_t)s->rows < (uint64_t)s->opt.U32("GPANN_FILTER_SMALL_SHARD_ROWS", 262144) * (uint64_t)std::max<uint32_t>(1, s->S);
+    // ... where the cells prune: on a cloud without structure (one blob, overlapping components) every row reaches the matrix cores whatever the thresholds, the
+    // two passes' tighter k-th distances then save more re-scoring than their launches cost (C2-size store, one blob: 2.33M QPS without them, 2.73M with;
+    // sigma 0.8: 4.86M / 5.11M), so the rule applies only while the previous filtered call of the store sent at most GPANN_FILTER_SMALL_SHARD_MAX_SHARE per
+    // cent (default 50) of the (task, row) pairs it was asked for to the matrix cores — C2: 17 %, the blob: 104 % (pairs of all passes over the pairs asked
+    // for).  A store's first call has no history and takes the rule.  (Like the CU split of overlapped calls, this is a choice between pass structures
+    // that return the same bits.)
+    const bool cells_prune = s->filter_pair_share < 0.0 || s->filter_pair_share * 100.0 <= (double)s->opt.U32("GPANN_FILTER_SMALL_SHARD_MAX_SHARE", 50);
+    const bool small_shards = cells_prune && (uint64_t)s->rows < (uint64_t)s->opt.U32("GPANN_FILTER_SMALL_SHARD_ROWS", 262144) * (uint64_t)std::max<uint32_t>(1, s->S);
     const uint32_t head_tiles = std::min<uint32_t>(std::min<uint32_t>(std::min<uint32_t>(s->opt.U32("GPANN_FILTER_HEAD_ROWS", small_shards ? 0 : 512), cap_plan / 2) / kGTileRows,
                                                                       C.plane_ks > 8 ? 0xFFFFFFFFu : C.lo_head_tiles),
                                                    C.hi_compact ? 16u : 0xFFFFFFFFu);   // (compact hi planes keep 16 tiles of every cell at least)
@@ -1766,6 +1773,8 @@ static gpann_status CompleteCall(gpann_shards* s, int slot, float* elapsed_ms) {
     c.stage_in_flight = false;
     bool overflow = false;
     if (c.filtered) CollectFilterCounters(c, &overflow);
+    if (c.filtered && !overflow && c.plan.pairs != 0)   // (what the next call's small-shard rule goes by: RunCellFilteredScan)
+        s->filter_pair_share = (double)c.plan.filter_pairs / (double)c.plan.pairs;
     if (c.filtered && !overflow && c.plan.filter_rest_rows != 0)   // (what the next overlapped call's CU split goes by: RunCellFilteredScan)
         s->rest_products_per_tile = ((double)c.plan.filter_pairs / 1024.0) / ((double)c.plan.filter_rest_rows / (double)kGTileRows);
     if (overflow) {

@@ -202,6 +202,7 @@ struct gpann_shards {
         }
     } cs[kCallSlots];
     int cur = 0;
+    double filter_pair_share = -1.0;   // (task, row) pairs the last completed filtered call sent to the matrix cores / pairs its caller asked for (< 0: none yet): how well the cells prune — the small-shard rule of RunCellFilteredScan goes by it
     double rest_products_per_tile = 0.0;   // (query tile, row tile) products per row tile of the last completed filtered call (0: none yet) — all passes' products over the rest pass's tiles
     gpann_scan_stats stats{};
     // GPANN_SCAN_OVERLAP: the handle's own streams (created at the first such call): a front stream per call slot (high priority: short,

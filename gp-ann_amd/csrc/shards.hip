@@ -89,7 +89,8 @@ static const Knob kKnobs[] = {
     {"GPANN_FILTER_SEG_TILES", 'C', "row tiles per work item (default: 16 .. 256 from the store size)"},
     {"GPANN_FILTER_SEED_ROWS", 'C', "rows of the nearest cell evaluated exactly for the first lists (default 128; 0: exact scan of the shard sample)"},
     {"GPANN_FILTER_SHARD_SAMPLE", 'C', "0: no shard-sample pass, 1: with it (default 1 — small shards, GPANN_FILTER_SMALL_SHARD_ROWS: 0)"},
-    {"GPANN_FILTER_SMALL_SHARD_ROWS", 'C', "stores whose shards average fewer rows run without the shard-sample and head passes unless those knobs are set (default 262144; 0: never)"},
+    {"GPANN_FILTER_SMALL_SHARD_ROWS", 'C', "stores whose shards average fewer rows run without the shard-sample and head passes unless those knobs are set (default 262144; 0: never) — while the cells prune: GPANN_FILTER_SMALL_SHARD_MAX_SHARE"},
+    {"GPANN_FILTER_SMALL_SHARD_MAX_SHARE", 'C', "the small-shard rule applies while the store's previous filtered call sent at most this percentage of the (task, row) pairs it was asked for to the matrix cores (default 50; a first call has no history and takes the rule)"},
     {"GPANN_FILTER_SEED_ALL", 'C', "1: seed every task under the merge bound, not only a query's first slot"},
     {"GPANN_FILTER_SAMPLE_UNIT", 'C', "2: the sample pass on the rest pass's kernel (two row tiles per unit)"},
     {"GPANN_FILTER_HI_ONLY", 'C', "0: all three bf16 products in every pass (needs GPANN_FILTER_LO_ROWS=all)"},

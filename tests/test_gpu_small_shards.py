@@ -4,7 +4,7 @@ Stores whose shards average fewer than GPANN_FILTER_SMALL_SHARD_ROWS rows (defau
 that read both bf16 planes (`gpann_scan_stats.filter_two_plane_rows`) — unless GPANN_FILTER_SHARD_SAMPLE / GPANN_FILTER_HEAD_ROWS ask for them, and cells go
 down to 512 rows (csrc/scan.hip RunCellFilteredScan, csrc/shards.hip DefaultCellRows: rows per shard / 256; measured on the C2 shape: profiles/r06/sweeps/small_store_passes.txt).
 Whatever the pass structure, ids and distances are the oracle's bits.  tests/conftest.py switches the rule off for the session, so every test here sets
-it explicitly."""
+it explicitly.  The rule also looks at how well the cells pruned in the store's previous call (GPANN_FILTER_SMALL_SHARD_MAX_SHARE)."""
 import numpy as np
 import pytest
 
@@ -31,6 +31,7 @@ def _scan(shards, queries, k, probes, nprobe, wd, wi, tag):
 @pytest.mark.parametrize("metric,d", [(0, 128), (0, 64), (1, 96), (0, 200), (1, 200)])
 def test_small_shards_skip_the_two_plane_passes_by_default(orc, gp, monkeypatch, metric, d):
     monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)   # the library's default rule
+    monkeypatch.setenv("GPANN_FILTER_SMALL_SHARD_MAX_SHARE", "100000")    # (this test is about the size rule alone: whatever the previous call's pruning was)
     rng = np.random.default_rng(900 + d + metric)
     n, S, nq, k, nprobe = 120000, 4, 500, 10, 2
     pts = make_mixture(orc, n, d, n_centers=48)
@@ -63,6 +64,7 @@ def test_small_shards_skip_the_two_plane_passes_by_default(orc, gp, monkeypatch,
 
 def test_the_rule_is_about_the_average_shard(orc, gp, monkeypatch):
     monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)
+    monkeypatch.setenv("GPANN_FILTER_SMALL_SHARD_MAX_SHARE", "100000")    # (this test is about the size rule alone: whatever the previous call's pruning was)
     rng = np.random.default_rng(77)
     n, S, nq, k, d = 60000, 3, 200, 10, 64
     pts = make_mixture(orc, n, d, n_centers=16)
@@ -78,6 +80,35 @@ def test_the_rule_is_about_the_average_shard(orc, gp, monkeypatch):
     shards.set_option("FILTER_SMALL_SHARD_ROWS", str(n // S + 1))    # ... below 20001: small
     assert _scan(shards, queries, k, probes, 2, wd, wi, "below the bound")["filter_two_plane_rows"] == 0
     shards.close()
+
+
+def test_the_rule_holds_only_while_the_cells_prune(orc, gp, monkeypatch):
+    """a store's first filtered call takes the rule; from then on it applies while the previous call sent at most GPANN_FILTER_SMALL_SHARD_MAX_SHARE per cent of
+    the (task, row) pairs it was asked for to the matrix cores: a clustered cloud keeps it, one blob — every row reaches the matrix cores — gets the two passes
+    back from its second call on (their tighter thresholds save more re-scoring than their launches cost: profiles/r06/sweeps/small_store_passes.txt)"""
+    monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_ROWS", raising=False)
+    monkeypatch.delenv("GPANN_FILTER_SMALL_SHARD_MAX_SHARE", raising=False)
+    rng = np.random.default_rng(80)
+    n, S, nq, k, d = 160000, 2, 600, 10, 64
+    for centers, sigma, keeps in ((160, 0.2, True), (1, 1.0, False)):
+        pts = make_mixture(orc, n, d, n_centers=centers, sigma=sigma)
+        part = rng.integers(0, S, size=n)
+        clusters = [np.flatnonzero(part == b).astype(np.uint32) for b in range(S)]
+        queries = make_mixture(orc, nq, d, seed=562, n_centers=centers, sigma=sigma)
+        probes = np.stack([rng.permutation(S)[:1] for _ in range(nq)]).astype(np.int32)
+        wd, wi = _want(orc, pts, clusters, queries, k, probes, 1, 0)
+        shards = gp.Shards(pts, clusters, 0, 0)
+        shards.set_scan_mode(1)
+        st = _scan(shards, queries, k, probes, 1, wd, wi, ("first call", centers))
+        assert st["filter_two_plane_rows"] == 0, st            # no history: the rule
+        share = st["filter_pairs"] / st["pairs"]
+        assert (share <= 0.5) == keeps, (centers, share)          # (what the test's two clouds are chosen for)
+        for rep in range(2):
+            st = _scan(shards, queries, k, probes, 1, wd, wi, ("later call", centers, rep))
+            assert (st["filter_two_plane_rows"] == 0) == keeps, (centers, rep, st)
+        shards.set_option("FILTER_SMALL_SHARD_MAX_SHARE", "100000")   # the share is an option of the handle like the size
+        assert _scan(shards, queries, k, probes, 1, wd, wi, ("share lifted", centers))["filter_two_plane_rows"] == 0
+        shards.close()
 
 
 def test_small_shards_without_structure_and_with_overflowing_buckets(orc, gp, monkeypatch):
