@@ -40,3 +40,34 @@ if __name__ == "__main__":
         cand = cand8 * frac / res[8]
         plane = 89.2e6 * (128 * bits / 8 + 4)
         print(f"bits {bits}: rest-pass plane {plane / 1e9:.2f} GB, candidates ~{cand / 1e6:.1f}M = {cand * 512 / 1e9:.2f} GB of rows to re-score -> {(plane + cand * 512) / 1e9:.2f} GB")
+
+
+def error_terms():
+    """Second question (same model, 8 bits): how much tighter than the product's (s/2)|q - c|_1 would the Cauchy-Schwarz term |q - c|_2 * max_row |e|_2 be,
+    with the cell's LARGEST row error norm known at build time (not the worst case (s/2) sqrt(d) that GPANN_FILTER_Q8_L1=0 falls back to)?"""
+    rng = np.random.default_rng(7)
+    d, n, nq, k, sigma = 128, 97656, 256, 10, 0.35
+    P = (rng.standard_normal((n, d)) * sigma)
+    Q = (rng.standard_normal((nq, d)) * sigma)
+    pn = (P ** 2).sum(1)
+    G = Q @ P.T
+    D = (Q ** 2).sum(1)[:, None] - 2 * G + pn[None, :]
+    tau = np.partition(D, k - 1, axis=1)[:, k - 1]
+    s = np.abs(P).max() / 127
+    Pq = np.rint(P / s) * s
+    e = P - Pq
+    Gq = Q @ Pq.T
+    qn = (Q ** 2).sum(1)
+    terms = {"(s/2)|q|_1 (the product)": (s / 2) * np.abs(Q).sum(1),
+             "|q|_2 (s/2) sqrt(d) (worst case)": np.sqrt(qn) * (s / 2) * np.sqrt(d),
+             "|q|_2 max_row|e|_2 (per cell, known at build)": np.sqrt(qn) * np.sqrt((e ** 2).sum(1).max()),
+             "0 (no quantisation error at all)": np.zeros(nq)}
+    for name, E in terms.items():
+        lower = qn[:, None] - 2 * (Gq + E[:, None]) + pn[None, :]
+        if name.startswith("0"):
+            lower = D
+        print(f"error term {name}: mean 2E = {2 * E.mean():.3f}, candidate fraction {(lower <= tau[:, None]).mean():.2e}")
+
+
+if __name__ == "__main__":
+    error_terms()
